@@ -1,0 +1,572 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE - runs only in the build container).
+
+Imports the reference implementation from /root/reference (read-only, never copied), runs
+small seeded cases of every hot-path function listed in SURVEY.md section 8(a) on CPU and
+stores inputs + expected outputs as small .npz fixtures under tests/golden/.
+
+The reference never travels to the GPU box: only these fixtures do.  Noise tensors drawn
+through ``torch.randn_like`` are captured so that the oracle restatement and the HIP path
+can be fed the identical epsilon ("eps injection").
+
+Usage:  python oracle/make_golden.py [--out tests/golden]
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+import config as ref_config          # noqa: E402
+import prior_model as ref_prior      # noqa: E402
+import test_model as ref_test        # noqa: E402
+import utils as ref_utils            # noqa: E402
+
+torch.set_num_threads(4)
+
+# ----------------------------------------------------------------------------------------
+# mini presets: same code paths as the reference presets (config.py:28-137) at fixture size
+# ----------------------------------------------------------------------------------------
+def presets():
+    c = ref_config.configs
+    p = {}
+    p["cifar"] = dict(c["cifar"])
+    p["protein"] = dict(c["protein"])
+    p["patch2d"] = dict(c["kodak"], pixel_sizes=[32, 32], patch_nums=[2, 2],
+                        hierarchical_patch_nums={"level2": [1, 2], "level3": [2, 2]})
+    p["patch1d"] = dict(c["audio"], pixel_sizes=[160], patch_nums=[4],
+                        hierarchical_patch_nums={"level2": [2], "level3": [4]})
+    p["patch3d"] = dict(c["video"], pixel_sizes=[24, 16, 16], patch_nums=[1, 2, 2],
+                        hierarchical_patch_nums={"level2": [1, 1, 2], "level3": [1, 2, 2]})
+    n_inr = {"cifar": 3, "protein": 3, "patch2d": 8, "patch1d": 8, "patch3d": 8}
+    return p, n_inr
+
+
+def jsonable(cfg):
+    return json.dumps(cfg, sort_keys=True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def fourier_inputs(pixel_sizes, fourier_dim):
+    """data/image.py:24-27 (same three lines in audio/video/protein loaders)."""
+    datum = torch.zeros(1, *pixel_sizes)
+    coords, _ = ref_utils.to_grid_coordinates_and_features(datum)
+    dd = len(pixel_sizes)
+    w = torch.exp(torch.linspace(0, np.log(1024), fourier_dim // (2 * dd)))
+    inp = torch.matmul(coords.unsqueeze(-1), w.unsqueeze(0)).view(*coords.shape[:-1], -1)
+    inp = torch.cat([torch.cos(np.pi * inp), torch.sin(np.pi * inp)], dim=-1)
+    return coords, inp
+
+
+class NoiseTap:
+    """Records every tensor produced by torch.randn_like while active."""
+
+    def __init__(self):
+        self.log = []
+        self._orig = torch.randn_like
+
+    def __enter__(self):
+        def tapped(t, *a, **k):
+            out = self._orig(t, *a, **k)
+            self.log.append(out.detach().clone())
+            return out
+        torch.randn_like = tapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig
+
+
+def build_prior(cfg, n, seed=42):
+    m = ref_prior.PriorBNNmodel(in_dim=cfg["input_dim"], hidden_dims=cfg["hidden_dims"],
+                                out_dim=cfg["output_dim"], train_size=n,
+                                data_dim=cfg["data_dim"], pixel_sizes=cfg["pixel_sizes"],
+                                upsample_factors=cfg["upsample_factors"],
+                                latent_dim=cfg["latent_dim"], patch=cfg["patch"],
+                                patch_nums=cfg["patch_nums"],
+                                hierarchical_patch_nums=cfg["hierarchical_patch_nums"],
+                                random_seed=seed, device="cpu")
+    return m
+
+
+def build_maps(cfg, dims, seed_a=123, seed_u=124):
+    torch.manual_seed(seed_a)
+    lt = ref_prior.LinearTransform(dims)
+    torch.manual_seed(seed_u)
+    up = ref_prior.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"])
+    return lt, up
+
+
+def priors_for(m, patch, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    s0 = float(torch.nn.functional.softplus(torch.tensor(-2.0)) / 6)
+
+    def mk(shape):
+        loc = 0.01 * torch.randn(shape, generator=g)
+        sc = s0 * (1 + 0.2 * torch.rand(shape, generator=g))
+        return loc, sc
+    pl, ps = mk(m.loc.shape[1:])
+    ll, ls = mk(m.lpe_loc.shape[1:])
+    if patch:
+        hl, hs = mk(m.h_loc.shape[1:])
+        hhl, hhs = mk(m.hh_loc.shape[1:])
+    else:
+        hl = hs = hhl = hhs = None
+    return [pl, ps, ll, ls, hl, hs, hhl, hhs]
+
+
+def tnp(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def stats(t):
+    a = t.detach().double()
+    return np.array([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()])
+
+
+def put(d, key, val):
+    if val is not None:
+        store(d, key, val)
+
+
+FULL_LIMIT = 40000
+
+
+class Bag(dict):
+    """dict that routes big float arrays through store() (subsample + checksums)."""
+
+    def __setitem__(self, k, v):
+        if isinstance(v, np.ndarray) and v.dtype.kind == "f" and v.size > FULL_LIMIT \
+                and not k.endswith(("__sub",)):
+            store(self, k, v)
+        else:
+            if isinstance(v, np.ndarray) and v.dtype == np.int64 and v.size > 64:
+                v = v.astype(np.int32)
+            super().__setitem__(k, v)
+
+
+def store(d, key, arr):
+    """Store small arrays whole; large ones as a strided subsample + moment checksums."""
+    if arr is None:
+        return
+    arr = np.asarray(arr)
+    if arr.size <= FULL_LIMIT or arr.dtype.kind not in "f":
+        dict.__setitem__(d, key, arr)
+        return
+    flat = arr.reshape(-1)
+    stride = int(np.ceil(arr.size / 12000)) | 1
+    dict.__setitem__(d, key + "__sub", flat[::stride].copy())
+    d[key + "__stride"] = np.array(stride)
+    d[key + "__shape"] = np.array(arr.shape)
+    f64 = flat.astype(np.float64)
+    d[key + "__stats"] = np.array([f64.sum(), np.abs(f64).sum(), (f64 * f64).sum()])
+
+
+def store_noise(d, prefix, seed, log, keep_full):
+    """Noise = torch.manual_seed(seed) followed by randn of these shapes, in this order."""
+    d[prefix + "_seed"] = np.array(seed)
+    d[prefix + "_shapes"] = np.array(json.dumps([list(e.shape) for e in log]))
+    d[prefix + "_stats"] = np.stack([stats(e) for e in log])
+    if keep_full:
+        for i, e in enumerate(log):
+            d[f"{prefix}{i}"] = tnp(e)
+
+
+# ----------------------------------------------------------------------------------------
+def gen_synthetic(out):
+    d = {}
+    for name, px, f in [("cifar", [32, 32], 16), ("audio", [800], 16), ("video", [24, 16, 16], 18),
+                        ("protein", [96], 16), ("kodak", [64, 64], 16)]:
+        coords, x = fourier_inputs(px, f)
+        d[f"{name}_pixel_sizes"] = np.array(px)
+        d[f"{name}_fourier_dim"] = np.array(f)
+        xs = tnp(x)
+        if xs.size <= 20000:
+            d[f"{name}_X"] = xs
+            d[f"{name}_coords"] = tnp(coords)
+        else:
+            d[f"{name}_X_rows"] = xs[::37]
+            d[f"{name}_coords_rows"] = tnp(coords)[::37]
+        d[f"{name}_X_stats"] = stats(x)
+        d[f"{name}_X_sha"] = np.array(sha(xs))
+    np.savez_compressed(os.path.join(out, "synthetic.npz"), **d)
+
+
+def gen_prior_cases(out):
+    P, NI = presets()
+    for name, cfg in P.items():
+        n = NI[name]
+        d = Bag({"cfg": np.array(jsonable(cfg)), "n": np.array(n)})
+        small = name in ("cifar", "protein")
+        m = build_prior(cfg, n)
+        # A1: init parity (seed 42)
+        d["init_loc"] = tnp(m.loc)
+        d["init_lpe_loc"] = tnp(m.lpe_loc)
+        if cfg["patch"]:
+            d["init_h_loc"] = tnp(m.h_loc)
+            d["init_hh_loc"] = tnp(m.hh_loc)
+        # make log-scales non-trivial
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            m.log_scale.add_(0.7 * torch.randn(m.log_scale.shape, generator=g))
+            m.lpe_log_scale.add_(0.7 * torch.randn(m.lpe_log_scale.shape, generator=g))
+            if cfg["patch"]:
+                m.h_log_scale.add_(0.7 * torch.randn(m.h_log_scale.shape, generator=g))
+                m.hh_log_scale.add_(0.7 * torch.randn(m.hh_log_scale.shape, generator=g))
+        for k in ["log_scale", "lpe_log_scale", "h_log_scale", "hh_log_scale"]:
+            if hasattr(m, k):
+                d["p_" + k] = tnp(getattr(m, k))
+        lt, up = build_maps(cfg, m.dims)
+        d["A_stats"] = np.stack([stats(a) for a in lt.A])
+        d["up_stats"] = np.stack([stats(p) for p in up.parameters()])
+        _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
+        torch.manual_seed(5)
+        y = torch.rand(n, x.shape[0], cfg["output_dim"])
+        d["X"] = tnp(x)
+        d["Y"] = tnp(y)
+        X = x[None].repeat(n, 1, 1)
+        pri = priors_for(m, cfg["patch"])
+        for k, v in zip(["pl", "ps", "ll", "ls", "hl", "hs", "hhl", "hhs"], pri):
+            put(d, "prior_" + k, tnp(v))
+
+        # A3-A6 forward with captured noise
+        torch.manual_seed(1000)
+        with NoiseTap() as tap, torch.no_grad():
+            yhat = m.forward(X, lt, up)
+        store_noise(d, "fwd_eps", 1000, tap.log, small)
+        d["fwd_yhat"] = tnp(yhat)
+        # intermediate: pe and h_w (re-run helper functions with the same noise)
+        with torch.no_grad():
+            lpe = m.lpe_loc + m.st(m.lpe_log_scale) * tap.log[0]
+            pe = ref_utils.map_lpe_to_inr_inputs(up, lpe[None], m.latent_dim, m.pixel_sizes,
+                                                 m.upsample_factors, m.patch, m.patch_nums,
+                                                 m.data_dim)[:, 0]
+        d["fwd_pe"] = tnp(pe)
+        # A7 KL
+        with torch.no_grad():
+            d["kl"] = np.array(m.calculate_kl(*pri).item())
+
+        # A8: 3 Adam steps, mappings trained / frozen
+        for tm in (True, False):
+            m2 = build_prior(cfg, n)
+            with torch.no_grad():
+                for k in ["log_scale", "lpe_log_scale", "h_log_scale", "hh_log_scale"]:
+                    if hasattr(m, k):
+                        getattr(m2, k).copy_(getattr(m, k))
+            lt2, up2 = build_maps(cfg, m.dims)
+            torch.manual_seed(2000)
+            with NoiseTap() as tap2:
+                mse, klv, elbo = m2.train(3, 2e-4, X, y, *pri, lt2, up2, 1e-4,
+                                          training_mappings=tm)
+            tag = "tm1" if tm else "tm0"
+            store_noise(d, f"{tag}_eps", 2000, tap2.log, False)
+            d[f"{tag}_ret"] = np.array([mse, klv])
+            d[f"{tag}_elbo"] = np.array(elbo)
+            for k in ["loc", "log_scale", "lpe_loc", "lpe_log_scale", "h_loc", "h_log_scale",
+                      "hh_loc", "hh_log_scale"]:
+                if hasattr(m2, k):
+                    d[f"{tag}_{k}"] = tnp(getattr(m2, k))
+            d[f"{tag}_A_stats"] = np.stack([stats(a) for a in lt2.A])
+            d[f"{tag}_A0_rows"] = tnp(lt2.A[0][:4])
+            d[f"{tag}_A3"] = tnp(lt2.A[-1])
+            d[f"{tag}_up_stats"] = np.stack([stats(p) for p in up2.parameters()])
+            d[f"{tag}_conv3_w"] = tnp(up2.conv3.weight)
+
+        # A9: prior refit expressions (main_prior_training.py:157-172 evaluated on m2)
+        with torch.no_grad():
+            def refit(loc, ls):
+                pl_ = loc.clone().detach().mean(0)
+                ps_ = ((m2.st(ls.clone().detach()) ** 2).mean(0) + loc.clone().detach().var(0)) ** 0.5
+                return pl_, ps_
+            a, b = refit(m2.loc, m2.log_scale)
+            d["refit_loc"], d["refit_scale"] = tnp(a), tnp(b)
+            a, b = refit(m2.lpe_loc, m2.lpe_log_scale)
+            d["refit_lpe_loc"], d["refit_lpe_scale"] = tnp(a), tnp(b)
+            if cfg["patch"]:
+                a, b = refit(m2.h_loc, m2.h_log_scale)
+                d["refit_h_loc"], d["refit_h_scale"] = tnp(a), tnp(b)
+                a, b = refit(m2.hh_loc, m2.hh_log_scale)
+                d["refit_hh_loc"], d["refit_hh_scale"] = tnp(a), tnp(b)
+        np.savez_compressed(os.path.join(out, f"prior_{name}.npz"), **d)
+        print("prior", name, "ok", flush=True)
+
+
+def gen_grouping(out):
+    """A10: get_grouping_by_kl on synthetic fp32 bit-weights (exact integer outputs)."""
+    d = {}
+    rng = np.random.RandomState(3)
+    for tag, D, scale in [("a", 3779, 0.06), ("b", 515, 3.0), ("c", 64, 9.0)]:
+        w = (rng.gamma(0.7, scale, size=D)).astype(np.float32)
+        if tag == "c":
+            w[5] = 17.5  # single element above the 16-bit cap
+        r = ref_prior.get_grouping_by_kl(w.copy())
+        names = ["group_idx", "start", "end", "group2param", "param2group", "n_groups",
+                 "group_kls", "weights"]
+        d[f"{tag}_in"] = w
+        for k, v in zip(names, r):
+            d[f"{tag}_{k}"] = np.asarray(v)
+    # and through get_grouping (KL in bits, mean over rows)
+    g = torch.Generator().manual_seed(9)
+    ql = 0.02 * torch.randn(6, 300, generator=g)
+    qs = 0.003 + 0.01 * torch.rand(6, 300, generator=g)
+    pl = 0.005 * torch.randn(300, generator=g)
+    ps = 0.02 + 0.01 * torch.rand(300, generator=g)
+    r = ref_prior.get_grouping(ql, qs, pl, ps)
+    for k, v in zip(["ql", "qs", "pl", "ps"], [ql, qs, pl, ps]):
+        d["g_" + k] = tnp(v)
+    for k, v in zip(names, r):
+        d[f"g_{k}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(out, "grouping.npz"), **d)
+    print("grouping ok", flush=True)
+
+
+def gen_tables(out):
+    """A15/A16: Gumbel recurrence and Sobol-normal candidate tables (seed 42)."""
+    d = {}
+
+    class Stub:
+        pass
+    s = Stub()
+    s.bit_per_group = 16
+    s.random_seed = 42
+    ref_test.TestBNNmodel.get_gumbel_sample(s)
+    g = s.g_samples.numpy()
+    d["gumbel_head"] = g[:512]
+    d["gumbel_tail"] = g[-512:]
+    d["gumbel_sha"] = np.array(sha(g))
+    d["gumbel_stats"] = np.array([g.sum(), np.abs(g).sum()])
+    os.makedirs(os.path.join(out, "tables"), exist_ok=True)
+    np.save(os.path.join(out, "tables", "gumbel_seed42_f64.npy"), g)
+    for gs in range(1, 13):
+        t = ref_test.TestBNNmodel.get_sobol_normal_sample(s, gs, 65536)
+        a = t.numpy()
+        assert a.dtype == np.float64
+        a32 = a.astype(np.float32)
+        assert np.array_equal(a32.astype(np.float64), a), "table not fp32-representable"
+        d[f"sobol_g{gs}_sha"] = np.array(sha(a))
+        d[f"sobol_g{gs}_head"] = a[:64]
+        if gs in (3, 5):
+            np.save(os.path.join(out, "tables", f"sobol_normal_g{gs}_seed42_f32.npy"), a32)
+    d["versions"] = np.array(json.dumps({"torch": torch.__version__, "numpy": np.__version__,
+                                          "scipy": __import__("scipy").__version__}))
+    np.savez_compressed(os.path.join(out, "tables.npz"), **d)
+    print("tables ok", flush=True)
+
+
+def build_test_model(cfg, name, n, pm, pri, lt, up, initial_beta=1e-5):
+    """Mirror of main_compression.py:49-146 on in-memory priors."""
+    q_loc = torch.cat([pm.loc.flatten(start_dim=1), pm.lpe_loc.flatten(start_dim=1)], -1)
+    q_scale = torch.cat([pm.st(pm.log_scale).flatten(start_dim=1),
+                         pm.st(pm.lpe_log_scale).flatten(start_dim=1)], -1)
+    p_loc = torch.cat([pri[0].flatten(), pri[2].flatten()])
+    p_scale = torch.cat([pri[1].flatten(), pri[3].flatten()])
+    with torch.no_grad():
+        G = ref_prior.get_grouping(q_loc, q_scale, p_loc, p_scale)
+    avg_ls = torch.cat([pm.log_scale.detach().mean(0), pm.lpe_log_scale.detach().mean(0).flatten()])
+    kw = {}
+    groups = {"": G}
+    if cfg["patch"]:
+        with torch.no_grad():
+            Gh = ref_prior.get_grouping(pm.h_loc, pm.st(pm.h_log_scale), pri[4], pri[5])
+            Ghh = ref_prior.get_grouping(pm.hh_loc, pm.st(pm.hh_log_scale), pri[6], pri[7])
+        groups["h_"] = Gh
+        groups["hh_"] = Ghh
+
+    def inv_st(s):
+        return torch.log(torch.exp(s * 6) - 1)
+    p2g = G[4]
+    kw.update(p_loc=p_loc[p2g], p_log_scale=inv_st(p_scale)[p2g], init_log_scale=avg_ls[p2g],
+              param_to_group=p2g, group_to_param=G[3], n_groups=G[5], group_start_index=G[1],
+              group_end_index=G[2], group_idx=G[0])
+    if cfg["patch"]:
+        for pre, Gx, pl_, ps_, als in [("h_", Gh, pri[4], pri[5], pm.h_log_scale.detach().mean(0)),
+                                       ("hh_", Ghh, pri[6], pri[7], pm.hh_log_scale.detach().mean(0))]:
+            q = Gx[4]
+            kw.update({pre + "p_loc": pl_[q], pre + "p_log_scale": inv_st(ps_)[q],
+                       pre + "init_log_scale": als[q], pre + "param_to_group": q,
+                       pre + "group_to_param": Gx[3], pre + "n_groups": Gx[5],
+                       pre + "group_start_index": Gx[1], pre + "group_end_index": Gx[2],
+                       pre + "group_idx": Gx[0]})
+    tm = ref_test.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n,
+                               cfg["upsample_factors"], cfg["latent_dim"], cfg["data_dim"],
+                               cfg["pixel_sizes"], cfg["patch"], cfg["patch_nums"],
+                               cfg["hierarchical_patch_nums"], name if name in ("cifar", "protein") else
+                               {"patch2d": "kodak", "patch1d": "audio", "patch3d": "video"}[name],
+                               linear_transform=lt, upsample_net=up, device="cpu",
+                               initial_beta=initial_beta, **kw)
+    return tm, groups, kw
+
+
+def gen_test_cases(out):
+    P, NI = presets()
+    for name in ["cifar", "patch2d", "patch1d"]:
+        cfg = P[name]
+        n = {"cifar": 4, "patch2d": 8, "patch1d": 8}[name]  # 2 datapoints for the patched presets
+        d = Bag({"cfg": np.array(jsonable(cfg)), "n": np.array(n)})
+        pm = build_prior(cfg, n)
+        lt, up = build_maps(cfg, pm.dims)
+        _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
+        torch.manual_seed(5)
+        y = torch.rand(n, x.shape[0], cfg["output_dim"])
+        X = x[None].repeat(n, 1, 1)
+        d["X"], d["Y"] = tnp(x), tnp(y)
+        # a short prior fit so that the KLs / groups are non-degenerate
+        s0 = float(torch.nn.functional.softplus(torch.tensor(-2.0)) / 6)
+        pri = [torch.zeros(pm.loc.shape[1]), torch.ones(pm.loc.shape[1]) * s0,
+               torch.zeros(pm.lpe_loc.shape[1:]), torch.ones(pm.lpe_loc.shape[1:]) * s0]
+        if cfg["patch"]:
+            pri += [torch.zeros(pm.h_loc.shape[1]), torch.ones(pm.h_loc.shape[1]) * s0,
+                    torch.zeros(pm.hh_loc.shape[1]), torch.ones(pm.hh_loc.shape[1]) * s0]
+        else:
+            pri += [None] * 4
+        torch.manual_seed(77)
+        pm.train(30, 2e-3, X, y, *pri, lt, up, 1e-6, training_mappings=False)
+        with torch.no_grad():
+            # tighten the posteriors so that groups hold a handful of parameters each
+            pm.log_scale.sub_(1.0)
+            pm.lpe_log_scale.sub_(1.0)
+        for k in ["loc", "log_scale", "lpe_loc", "lpe_log_scale", "h_loc", "h_log_scale", "hh_loc",
+                  "hh_log_scale"]:
+            if hasattr(pm, k):
+                d["pm_" + k] = tnp(getattr(pm, k))
+        for k, v in zip(["pl", "ps", "ll", "ls", "hl", "hs", "hhl", "hhs"], pri):
+            put(d, "prior_" + k, tnp(v))
+        tm, groups, kw = build_test_model(cfg, name, n, pm, pri, lt, up)
+        for pre, G in groups.items():
+            for k, v in zip(["group_idx", "start", "end", "group2param", "param2group", "n_groups",
+                             "group_kls", "weights"], G):
+                d[f"{pre}G_{k}"] = np.asarray(v)
+        for k, v in kw.items():
+            if torch.is_tensor(v):
+                d["kw_" + k] = tnp(v)
+        d["bpp"] = np.array(tm.bpp)
+        if cfg["patch"]:
+            d["perm_x_g2p"] = tm.permute_patch_x_g2p.astype(np.int16)
+            d["h_perm_x_g2p"] = tm.h_permute_patch_x_g2p.astype(np.int16)
+        # perturb the test posteriors so rows differ
+        g = torch.Generator().manual_seed(21)
+        with torch.no_grad():
+            tm.loc.add_(0.004 * torch.randn(tm.loc.shape, generator=g))
+            tm.log_scale.add_(0.3 * torch.randn(tm.log_scale.shape, generator=g))
+            if cfg["patch"]:
+                tm.h_loc.add_(0.004 * torch.randn(tm.h_loc.shape, generator=g))
+                tm.hh_loc.add_(0.004 * torch.randn(tm.hh_loc.shape, generator=g))
+        d["t_loc"], d["t_log_scale"] = tnp(tm.loc), tnp(tm.log_scale)
+        if cfg["patch"]:
+            d["t_h_loc"], d["t_h_log_scale"] = tnp(tm.h_loc), tnp(tm.h_log_scale)
+            d["t_hh_loc"], d["t_hh_log_scale"] = tnp(tm.hh_loc), tnp(tm.hh_log_scale)
+        # A12 predict, S=1 and S=5
+        for S in (1, 5):
+            with NoiseTap() as tap, torch.no_grad():
+                yp = tm.predict(X, random_seed=3, sample_size=S)
+            d[f"pred_S{S}"] = tnp(yp)
+            store_noise(d, f"pred_S{S}_eps", 3, tap.log, False)
+        # A13 / A14
+        with torch.no_grad():
+            d["kl_beta_weighted"] = np.array(tm.calculate_kl().item())
+        r = tm.update_annealing_factors(update=False)
+        if cfg["patch"]:
+            d["kls"], d["h_kls"], d["hh_kls"] = r
+        else:
+            d["kls"] = r
+        d["beta_before"] = tnp(tm.kl_beta)
+        tm.update_annealing_factors(update=True)
+        d["beta_after"] = tnp(tm.kl_beta)
+        if cfg["patch"]:
+            d["h_beta_after"] = tnp(tm.h_kl_beta)
+            d["hh_beta_after"] = tnp(tm.hh_kl_beta)
+        # A17/A18: encode a few groups (level-1) and record index, sample and top-2 margin
+        enc = []
+        for row, grp in [(0, 0), (1, 3), (n - 1, int(tm.n_groups) - 1), (2, 7)]:
+            i, z, lw = tm.sample_group(row, grp, 65536)
+            top2 = torch.topk(lw, 2).values
+            enc.append((row, grp, i, float(top2[0] - top2[1])))
+            d[f"enc_{row}_{grp}_z"] = tnp(z)
+            d[f"enc_{row}_{grp}_lw_head"] = tnp(lw[:256])
+            d[f"enc_{row}_{grp}_lw_max"] = np.array(lw.max().item())
+        d["enc_table"] = np.array(enc, dtype=np.float64)
+        if cfg["patch"]:
+            i, z, lw = tm.h_sample_group(0, 1, 65536)
+            d["h_enc_0_1"] = np.array([i])
+            d["h_enc_0_1_z"] = tnp(z)
+            i, z, lw = tm.hh_sample_group(0, 2, 65536)
+            d["hh_enc_0_2"] = np.array([i])
+            d["hh_enc_0_2_z"] = tnp(z)
+        # A19: 3 training epochs (S=5), beta update at epoch 0
+        opt = torch.optim.Adam(tm.parameters(), lr=2e-4)
+        with NoiseTap() as tap:
+            tm.train(X, y, 3, opt, False, sample_size=5)
+        # the reference reseeds with the epoch number each step (test_model.py:285,623)
+        store_noise(d, "train_eps", -1, tap.log, False)
+        d["train_loc"], d["train_log_scale"] = tnp(tm.loc), tnp(tm.log_scale)
+        d["train_beta"] = tnp(tm.kl_beta)
+        if cfg["patch"]:
+            d["train_h_loc"], d["train_hh_loc"] = tnp(tm.h_loc), tnp(tm.hh_loc)
+            d["train_h_log_scale"], d["train_hh_log_scale"] = tnp(tm.h_log_scale), tnp(tm.hh_log_scale)
+        np.savez_compressed(os.path.join(out, f"test_{name}.npz"), **d)
+        print("test", name, "ok", flush=True)
+
+        # A20/A21 mini end-to-end (only for cifar and patch1d: cheap)
+        if name in ("cifar", "patch1d"):
+            e = Bag({"cfg": d["cfg"], "n": d["n"]})
+            tm2, _, _ = build_test_model(cfg, name, n, pm, pri, lt, up)
+            import io
+            import contextlib
+            with contextlib.redirect_stderr(io.StringIO()):
+                tm2.optimize_posteriors(X, y, n_epochs=12, lr=2e-4, verbose=False)
+                e["opt_loc"], e["opt_log_scale"] = tnp(tm2.loc), tnp(tm2.log_scale)
+                e["opt_beta"] = tnp(tm2.kl_beta)
+                dist = tm2.compress_posteriors(X, y, n_epochs_finetune=2, h_n_epochs_finetune=2,
+                                               hh_n_epochs_finetune=2, verbose=False, lr=2e-4,
+                                               fine_tune_gap=1)
+            e["distortion"] = np.asarray(dist)
+            e["idx"] = tm2.compressed_idx_groupwise
+            e["final_sample"] = tnp(tm2.compressed_sample)
+            if cfg["patch"]:
+                e["h_idx"] = tm2.h_compressed_idx_groupwise
+                e["hh_idx"] = tm2.hh_compressed_idx_groupwise
+            with torch.no_grad():
+                e["final_pred"] = tnp(tm2.predict(X))
+            np.savez_compressed(os.path.join(out, f"e2e_{name}.npz"), **e)
+            print("e2e", name, "ok", flush=True)
+
+
+def gen_metrics(out):
+    d = {}
+    rng = np.random.RandomState(0)
+    a = rng.rand(4, 1024, 3).astype(np.float32)
+    b = (a + 0.05 * rng.randn(4, 1024, 3)).astype(np.float32)
+    d["a"], d["b"] = a, b
+    for ds in ["cifar", "kodak", "video", "audio", "protein"]:
+        d["m_" + ds] = np.asarray(ref_utils.metric(a, b, ds))
+    np.savez_compressed(os.path.join(out, "metrics.npz"), **d)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    todo = a.only.split(",") if a.only else ["synthetic", "prior", "grouping", "tables", "test", "metrics"]
+    if "synthetic" in todo:
+        gen_synthetic(a.out)
+    if "metrics" in todo:
+        gen_metrics(a.out)
+    if "grouping" in todo:
+        gen_grouping(a.out)
+    if "tables" in todo:
+        gen_tables(a.out)
+    if "prior" in todo:
+        gen_prior_cases(a.out)
+    if "test" in todo:
+        gen_test_cases(a.out)
+    print("done")
