@@ -1,0 +1,203 @@
+/*
+ * librcb_hip  --  C ABI of the MI355X (gfx950) kernels behind the RECOMBINER per-datapoint
+ * INR training hot path.
+ *
+ * The reference (cambridge-mlg/RECOMBINER) is pure PyTorch and has no FFI of its own; each entry
+ * point below replaces a sequence of torch ops on the reference's hot path and cites it
+ * (file:line relative to the reference root).  Conventions:
+ *   - plain device pointers + explicit sizes; the caller (PyTorch, or any HIP host) allocates
+ *     every buffer including outputs; nothing is allocated, freed or synchronised inside;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - return value: 0 = ok, < 0 = argument/shape error (RCB_ERR_*), > 0 = hipError_t;
+ *   - no global mutable state besides the thread-local last-error string; re-entrant per stream;
+ *   - fp32 tensors are row-major and contiguous unless a stride argument says otherwise.
+ */
+#ifndef RCB_H_
+#define RCB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCB_VERSION 100
+#define RCB_OK 0
+#define RCB_ERR_ARG (-1)
+#define RCB_ERR_SHAPE (-2)
+#define RCB_ERR_UNSUPPORTED (-3)
+
+typedef void* rcb_stream_t;
+
+int rcb_version(void);
+const char* rcb_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3 + K4: batched SIREN coordinate-MLP, one workgroup per (INR, sample).
+ * Replaces prior_model.py:168-179 (+121-127) and test_model.py:347-355 (+269-280): per layer
+ * `x = x @ W + b; x = sin(30 x)` with per-INR weights, and the MSE term prior_model.py:237 /
+ * test_model.py:625-627.
+ *
+ * Input features of layer 0 are the concatenation [xf | pe] (prior_model.py:155): `xf` is the
+ * Fourier embedding [*, P, F] (row stride xf_inr_stride between INRs, 0 = one grid shared by all
+ * INRs), `pe` the upsampled positional encodings [G, P, E] (E may be 0 with pe = NULL).
+ * `wvec` row g holds the layer vectors back to back, each `[bias(out) | W(in,out) row-major]`
+ * (prior_model.py:125-126); rows are w_row_stride floats apart.  G = N*S; sample s of INR n is
+ * row g = n*S + s; targets / xf are indexed by n = g / S.
+ * Hidden width must be 32, 1..4 hidden layers, out_dim <= 32, F + E <= 64.
+ * precision: 0 = fp32 MFMA (exact fp32 products), 1 = bf16 operands / fp32 accumulate.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_rows;        /* G = N * S workgroups                                   */
+  int32_t samples;       /* S                                                       */
+  int32_t n_pix;         /* P                                                       */
+  int32_t fourier_dim;   /* F                                                       */
+  int32_t pe_dim;        /* E                                                       */
+  int32_t n_hidden;      /* number of hidden layers                                 */
+  int32_t hidden;        /* hidden width (32)                                       */
+  int32_t out_dim;       /* C                                                       */
+  int64_t xf_inr_stride; /* floats between INRs in xf; 0 = shared grid              */
+  int64_t w_row_stride;  /* floats between rows of wvec and of dwvec                */
+  float   w0;            /* sine frequency (30)                                     */
+  int32_t precision;     /* 0 fp32, 1 bf16                                          */
+} rcb_siren_desc;
+
+/* y_out[G, P, C] = MLP(x)                                                           */
+int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
+                  float* y_out, rcb_stream_t stream);
+
+/* Given dy[G, P, C]: dwvec[G, :] (same layout/stride as wvec) and, if dpe != NULL, dpe[G, P, E].
+ * The forward pass is recomputed in registers; no activations are read from memory.            */
+int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
+                  const float* dy, float* dwvec, float* dpe, rcb_stream_t stream);
+
+/* Fused training pass: sse[g] = sum_{p,c} (y - target[g/S])^2 and the gradients of
+ * dy_scale * sse[g] with respect to wvec row g and pe row g (dpe may be NULL).  With
+ * dy_scale = 1/(S*P*C) this is the reference's `mean((y_hat - y)**2) * N` term.              */
+int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, const float* pe,
+                       const float* wvec, const float* target, float dy_scale, float* sse,
+                       float* dwvec, float* dpe, rcb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1 + K10: reparameterised sampling of the latent vector of every (INR, sample) from a 1- or
+ * 3-level factorised Gaussian posterior.  Replaces utils.py:142-198, prior_model.py:140-145 and
+ * the mask/permutation gathers test_model.py:289-298,320-330.
+ *
+ *   out[n, s, d] = sum_levels  mu_L(n, d) + sigma_L(n, d) * eps_L[n, s, d]
+ *   mu    = loc * (1 - m) + enc_sample * m          sigma = softplus(log_scale)/6 * (1 - m) + 1e-15 * m
+ * evaluated at source element (r, j):  j = col_map ? col_map[d] : d;  r0 = row_map ? row_map[n] : n;
+ * r = row_perm ? row_perm[r0 * cols + j] : r0.  A level contributes to d < cols_out only.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* loc;        /* [rows, cols]                                          */
+  const float* log_scale;  /* [rows, cols]                                          */
+  const float* enc_sample; /* nullable [rows, cols]                                 */
+  const float* enc_mask;   /* nullable [rows, cols] (0/1)                           */
+  const int32_t* row_map;  /* nullable [N]                                          */
+  const int32_t* row_perm; /* nullable [rows, cols]                                 */
+  const int32_t* col_map;  /* nullable [cols_out]                                   */
+  const float* eps;        /* [N, S, cols_out]                                      */
+  int32_t rows, cols, cols_out;
+} rcb_level;
+
+int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t samples,
+                    int32_t out_cols, float* out, rcb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5 + K6 + K7: KL( N(loc, softplus(log_scale)/6) || N(p_loc, p_scale) ) per element
+ * (torch.distributions.kl._kl_normal_normal as used at prior_model.py:191-199, test_model.py:357-377,
+ * 384-402), reduced per row and optionally per (row, group) segment.
+ *   kl_row[r]      = sum_j w(r,j) * kl(r,j),  w = beta[r, group_idx[j]] if beta != NULL else 1
+ *   kl_group[r,g]  = sum_{j in [seg_start[g], seg_end[g])} kl(r,j)        (unweighted, fp64)
+ * p_scale_is_log: p_scale holds log-scales to be passed through softplus/6 (test_model.py:358).
+ * ------------------------------------------------------------------------------------------- */
+int rcb_gauss_kl(const float* loc, const float* log_scale, const float* p_loc, const float* p_scale,
+                 int32_t p_scale_is_log, int32_t rows, int32_t cols, const float* beta,
+                 const int32_t* group_idx, int32_t n_groups, const int32_t* seg_start,
+                 const int32_t* seg_end, double* kl_row, double* kl_group, rcb_stream_t stream);
+
+/* K8: per-group beta annealing (test_model.py:404-413): groups above 16+upper bits get
+ * beta *= (1+step), groups at or below 16-lower bits beta /= (1+step), clamp [0, 1e4]; encoded
+ * groups (done != 0) keep their beta.                                                          */
+int rcb_beta_update(const double* kl_group, float* beta, const uint8_t* done, int32_t rows,
+                    int32_t n_groups, double bits, double upper, double lower, double step,
+                    rcb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1-bwd + K5-bwd + K11: one pass over a level's parameters that (a) gathers the gradient of the
+ * sampled latents back to (loc, log_scale), (b) adds the analytic gradient of kl_weight * KL, and
+ * (c) either writes the gradients (g_loc / g_log_scale != NULL) or applies one Adam step in place
+ * (torch.optim.Adam defaults, prior_model.py:224-250, test_model.py:633-635).
+ *
+ * d_out[N, S, cols_out] is the gradient w.r.t. rcb_reparam_fwd's output.  Members of source row r0
+ * (the INRs n with row_map[n] == r0) are member_idx[member_ptr[r0] .. member_ptr[r0+1]) (NULL =
+ * identity).  row_perm_inv / col_inv are the inverse permutations of row_perm / col_map.
+ * kl weight: kl_scalar * (beta ? beta[r, group_idx[j]] : 1).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  float lr, beta1, beta2, eps;
+  int32_t step;            /* 1-based step count t                                  */
+} rcb_adam_cfg;
+
+typedef struct {
+  float* loc;              /* [rows, cols] (updated in place when adam != NULL)     */
+  float* log_scale;
+  const float* enc_mask;   /* nullable                                              */
+  const float* p_loc;      /* [cols]                                                */
+  const float* p_scale;    /* [cols]                                                */
+  int32_t p_scale_is_log;
+  const float* beta;       /* nullable [rows, n_groups]                             */
+  const int32_t* group_idx;/* nullable [cols]                                       */
+  int32_t n_groups;
+  float kl_scalar;
+  const float* d_out;      /* [N, S, cols_out] ; nullable (KL-only)                 */
+  const float* eps;        /* [N, S, cols_out]                                      */
+  const int32_t* member_ptr;   /* nullable [rows+1]                                 */
+  const int32_t* member_idx;   /* nullable                                          */
+  const int32_t* row_perm_inv; /* nullable [rows, cols]                             */
+  const int32_t* col_inv;      /* nullable [cols] : d of source column j            */
+  int32_t rows, cols, cols_out, samples;
+  float* g_loc;            /* nullable outputs [rows, cols]                         */
+  float* g_log_scale;
+  float* m_loc; float* v_loc; float* m_ls; float* v_ls;   /* Adam state            */
+} rcb_level_bwd;
+
+int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream);
+
+/* K11: Adam on a flat fp32 array (shared mappings A / conv weights).                          */
+int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const rcb_adam_cfg* cfg,
+                  rcb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172).
+ * For x = loc[rows, cols]: sum[j], m2[j] = sum_r (x - mean_j)^2, and sig2[j] = sum_r sigma(r,j)^2
+ * with sigma = softplus(log_scale)/6, all fp64.  Shards are merged on the host (Chan).
+ * ------------------------------------------------------------------------------------------- */
+int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, double* sum,
+                    double* m2, double* sig2, rcb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9: A* / relative-entropy-coding candidate scoring (test_model.py:501-533, 586-595), batched
+ * over jobs.  Job b encodes columns [start[b], start[b]+glen[b]) of row row[b]:
+ *   z_k   = p_loc + p_scale * xi_k                     (fp64; xi = table for group length glen)
+ *   logw_k = sum_j logN(z_kj; loc, scale) - logN(z_kj; p_loc, p_scale) + gumbel[k]
+ *   idx   = first argmax_k logw_k ;  z_out = z_idx
+ * loc/scale/p_loc/p_scale are fp32 (scale = softplus(log_scale)/6 precomputed by the caller),
+ * tables[g] points to a [K, g] fp64 row-major table (or NULL if unused), gumbel is [K] fp64.
+ * Outputs: idx[b] (int32), z_out[b, max_glen] fp64, best[b, 2] = (max, runner-up) log-weights;
+ * logw_job0 (nullable, [K]) receives all log-weights of job 0 for testing.
+ * ------------------------------------------------------------------------------------------- */
+int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, const float* p_loc,
+                         const float* p_scale, const double* const* tables, int32_t max_glen,
+                         const double* gumbel, int32_t n_candidates, const int32_t* job_row,
+                         const int32_t* job_start, const int32_t* job_glen, int32_t n_jobs,
+                         int32_t* idx, double* z_out, double* best, double* logw_job0,
+                         rcb_stream_t stream);
+
+/* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
+int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCB_H_ */

@@ -124,7 +124,7 @@ def priors_for(m, patch, seed=7):
 
 
 def tnp(t):
-    return None if t is None else t.detach().cpu().numpy()
+    return None if t is None else t.detach().cpu().numpy().copy()   # copy: never alias live parameters
 
 
 def stats(t):

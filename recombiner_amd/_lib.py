@@ -1,0 +1,97 @@
+"""ctypes binding of librcb_hip.so (include/rcb.h).  The product has no CPU fallback: if the
+library is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librcb_hip.so")
+
+EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
+           "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
+           "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale"]
+
+
+class RcbError(RuntimeError):
+    pass
+
+
+class SirenDesc(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("samples", C.c_int32), ("n_pix", C.c_int32), ("fourier_dim", C.c_int32),
+                ("pe_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
+                ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
+                ("precision", C.c_int32)]
+
+
+class Level(C.Structure):
+    _fields_ = [("loc", C.c_void_p), ("log_scale", C.c_void_p), ("enc_sample", C.c_void_p),
+                ("enc_mask", C.c_void_p), ("row_map", C.c_void_p), ("row_perm", C.c_void_p),
+                ("col_map", C.c_void_p), ("eps", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("cols_out", C.c_int32)]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int32)]
+
+
+class LevelBwd(C.Structure):
+    _fields_ = [("loc", C.c_void_p), ("log_scale", C.c_void_p), ("enc_mask", C.c_void_p), ("p_loc", C.c_void_p),
+                ("p_scale", C.c_void_p), ("p_scale_is_log", C.c_int32), ("beta", C.c_void_p),
+                ("group_idx", C.c_void_p), ("n_groups", C.c_int32), ("kl_scalar", C.c_float),
+                ("d_out", C.c_void_p), ("eps", C.c_void_p), ("member_ptr", C.c_void_p),
+                ("member_idx", C.c_void_p), ("row_perm_inv", C.c_void_p), ("col_inv", C.c_void_p),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("cols_out", C.c_int32), ("samples", C.c_int32),
+                ("g_loc", C.c_void_p), ("g_log_scale", C.c_void_p), ("m_loc", C.c_void_p), ("v_loc", C.c_void_p),
+                ("m_ls", C.c_void_p), ("v_ls", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RcbError(f"{LIB_PATH} not found: run `python -m recombiner_amd.build` (no CPU fallback exists)")
+        lib = C.CDLL(LIB_PATH)
+        lib.rcb_last_error_string.restype = C.c_char_p
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RcbError(f"{LIB_PATH} does not export {name}")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rcb_last_error_string().decode(errors="replace")
+        raise RcbError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, allow_none=False):
+    """device pointer of a contiguous CUDA tensor (or NULL when allowed)."""
+    if t is None:
+        if allow_none:
+            return C.c_void_p(0)
+        raise RcbError("null tensor")
+    if not t.is_cuda:
+        raise RcbError("tensor must live on the GPU (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RcbError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RcbError(f"expected {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def addr(t, dtype=None):
+    """integer address for structure fields (None -> NULL)."""
+    if t is None:
+        return None
+    return ptr(t, dtype).value

@@ -1,0 +1,422 @@
+// Elementwise / reduction kernels of the variational-posterior path (HBM-bound):
+//   reparameterised sampling (K1/K10), Gaussian KL + segment sums (K5-K7), beta annealing (K8),
+//   fused reparam-bwd + KL-bwd + Adam (K1'/K5'/K11), flat Adam (K11), column moments (K12).
+// All arithmetic that feeds a parity check is written un-fused (mul, then add) like the torch
+// CPU ops it replaces.
+#include <stdarg.h>
+
+#include "rcb_common.h"
+
+#pragma clang fp contract(off)
+
+namespace rcb {
+char* last_error_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace rcb
+
+using namespace rcb;
+
+extern "C" int rcb_version(void) { return RCB_VERSION; }
+extern "C" const char* rcb_last_error_string(void) { return last_error_buf(); }
+
+// ------------------------------------------------------------------------------------------
+// softplus/6
+// ------------------------------------------------------------------------------------------
+__global__ void softplus_scale_kernel(const float* __restrict__ ls, float* __restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = st_f32(ls[i]);
+}
+
+extern "C" int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream) {
+  RCB_REQUIRE(log_scale && scale && n >= 0, RCB_ERR_ARG, "softplus_scale: null pointer");
+  if (n == 0) return RCB_OK;
+  int grid = cdiv(n, 256);
+  if (grid > 4096) grid = 4096;
+  softplus_scale_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(log_scale, scale, n);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 / K10 reparam forward
+// ------------------------------------------------------------------------------------------
+struct ReparamArgs {
+  rcb_level lv[3];
+  int n_levels, n_inr, samples, out_cols;
+  float* out;
+};
+
+__device__ __forceinline__ void level_mu_sigma(const rcb_level& L, int n, int d, float& mu, float& sig) {
+  int j = L.col_map ? L.col_map[d] : d;
+  int r = L.row_map ? L.row_map[n] : n;
+  if (L.row_perm) r = L.row_perm[(long long)r * L.cols + j];
+  long long o = (long long)r * L.cols + j;
+  float loc = L.loc[o];
+  float s = st_f32(L.log_scale[o]);
+  if (L.enc_mask) {
+    float m = L.enc_mask[o];
+    float z = L.enc_sample[o];
+    // loc*(1-m) + z*m ; st*(1-m) + 1e-15*m   (test_model.py:289-290)
+    loc = __fadd_rn(__fmul_rn(loc, 1.0f - m), __fmul_rn(z, m));
+    s = __fadd_rn(__fmul_rn(s, 1.0f - m), __fmul_rn(1e-15f, m));
+  }
+  mu = loc;
+  sig = s;
+}
+
+__global__ void reparam_fwd_kernel(ReparamArgs a) {
+  int n = blockIdx.x;
+  int d = blockIdx.y * blockDim.x + threadIdx.x;
+  if (d >= a.out_cols) return;
+  float mu[3], sg[3];
+  bool on[3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    on[l] = l < a.n_levels && d < a.lv[l].cols_out;
+    mu[l] = 0.f;
+    sg[l] = 0.f;
+    if (on[l]) level_mu_sigma(a.lv[l], n, d, mu[l], sg[l]);
+  }
+  for (int s = 0; s < a.samples; ++s) {
+    long long row = (long long)n * a.samples + s;
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      if (on[l]) {
+        float e = a.lv[l].eps[row * a.lv[l].cols_out + d];
+        float v = __fadd_rn(mu[l], __fmul_rn(sg[l], e));
+        acc = (l == 0) ? v : __fadd_rn(acc, v);
+      }
+    }
+    a.out[row * a.out_cols + d] = acc;
+  }
+}
+
+extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t samples,
+                               int32_t out_cols, float* out, rcb_stream_t stream) {
+  RCB_REQUIRE(levels && out, RCB_ERR_ARG, "reparam_fwd: null pointer");
+  RCB_REQUIRE(n_levels >= 1 && n_levels <= 3, RCB_ERR_ARG, "reparam_fwd: n_levels=%d", n_levels);
+  RCB_REQUIRE(n_inr > 0 && samples > 0 && out_cols > 0, RCB_ERR_SHAPE, "reparam_fwd: empty shape");
+  ReparamArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int l = 0; l < n_levels; ++l) {
+    a.lv[l] = levels[l];
+    RCB_REQUIRE(a.lv[l].loc && a.lv[l].log_scale && a.lv[l].eps, RCB_ERR_ARG, "reparam_fwd: level %d null", l);
+    RCB_REQUIRE(a.lv[l].cols_out <= out_cols && a.lv[l].cols_out > 0, RCB_ERR_SHAPE, "reparam_fwd: level %d cols_out", l);
+    RCB_REQUIRE((a.lv[l].enc_mask == nullptr) == (a.lv[l].enc_sample == nullptr), RCB_ERR_ARG, "reparam_fwd: mask/sample");
+    RCB_REQUIRE(a.lv[l].col_map || a.lv[l].cols_out <= a.lv[l].cols, RCB_ERR_SHAPE, "reparam_fwd: level %d cols", l);
+  }
+  RCB_REQUIRE(a.lv[0].cols_out == out_cols, RCB_ERR_SHAPE, "reparam_fwd: level 0 must cover all columns");
+  a.n_levels = n_levels;
+  a.n_inr = n_inr;
+  a.samples = samples;
+  a.out_cols = out_cols;
+  a.out = out;
+  dim3 grid(n_inr, cdiv(out_cols, 256));
+  RCB_REQUIRE(grid.y <= 65535, RCB_ERR_SHAPE, "reparam_fwd: too many columns");
+  reparam_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5-K7 Gaussian KL with row and (row, group) reductions
+// ------------------------------------------------------------------------------------------
+struct KlArgs {
+  const float *loc, *ls, *p_loc, *p_scale;
+  int p_is_log, rows, cols;
+  const float* beta;
+  const int* group_idx;
+  int n_groups;
+  const int *seg_start, *seg_end;
+  double* kl_row;
+  double* kl_group;
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ void __launch_bounds__(256) kl_rows_kernel(KlArgs a) {
+  __shared__ double sm[4];
+  int r = blockIdx.x;
+  const float* loc = a.loc + (long long)r * a.cols;
+  const float* ls = a.ls + (long long)r * a.cols;
+  double acc = 0.0;
+  if (a.seg_start == nullptr) {
+    for (int j = threadIdx.x; j < a.cols; j += 256) {
+      float sp = a.p_is_log ? st_f32(a.p_scale[j]) : a.p_scale[j];
+      float k = kl_elem_f32(loc[j], st_f32(ls[j]), a.p_loc[j], sp);
+      if (a.beta) k = __fmul_rn(k, a.beta[(long long)r * a.n_groups + a.group_idx[j]]);
+      acc += (double)k;
+    }
+  } else {
+    // parameters are stored in group order: group g is the contiguous segment [start, end)
+    for (int g = threadIdx.x; g < a.n_groups; g += 256) {
+      int s = a.seg_start[g], e = a.seg_end[g];
+      double gs = 0.0;
+      for (int j = s; j < e; ++j) {
+        float sp = a.p_is_log ? st_f32(a.p_scale[j]) : a.p_scale[j];
+        gs += (double)kl_elem_f32(loc[j], st_f32(ls[j]), a.p_loc[j], sp);  // np.bincount order
+      }
+      if (a.kl_group) a.kl_group[(long long)r * a.n_groups + g] = gs;
+      double w = a.beta ? (double)a.beta[(long long)r * a.n_groups + g] : 1.0;
+      acc += w * gs;
+    }
+  }
+  double tot = block_sum_256(acc, sm);
+  if (threadIdx.x == 0 && a.kl_row) a.kl_row[r] = tot;
+}
+
+extern "C" int rcb_gauss_kl(const float* loc, const float* log_scale, const float* p_loc, const float* p_scale,
+                            int32_t p_scale_is_log, int32_t rows, int32_t cols, const float* beta,
+                            const int32_t* group_idx, int32_t n_groups, const int32_t* seg_start,
+                            const int32_t* seg_end, double* kl_row, double* kl_group, rcb_stream_t stream) {
+  RCB_REQUIRE(loc && log_scale && p_loc && p_scale, RCB_ERR_ARG, "gauss_kl: null input");
+  RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "gauss_kl: empty shape %d x %d", rows, cols);
+  RCB_REQUIRE(kl_row || kl_group, RCB_ERR_ARG, "gauss_kl: no output requested");
+  RCB_REQUIRE(!beta || (group_idx && n_groups > 0), RCB_ERR_ARG, "gauss_kl: beta needs group_idx");
+  RCB_REQUIRE((seg_start == nullptr) == (seg_end == nullptr), RCB_ERR_ARG, "gauss_kl: segments");
+  RCB_REQUIRE(!kl_group || seg_start, RCB_ERR_ARG, "gauss_kl: kl_group needs segments");
+  KlArgs a{loc, log_scale, p_loc, p_scale, p_scale_is_log, rows, cols, beta, group_idx, n_groups,
+           seg_start, seg_end, kl_row, kl_group};
+  kl_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 beta annealing
+// ------------------------------------------------------------------------------------------
+__global__ void beta_update_kernel(const double* kl, float* beta, const uint8_t* done, long long n, double hi,
+                                   double lo, float factor) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (done && done[i]) return;
+  double bits = kl[i] / 0.6931471805599453;  // kls / np.log(2.)
+  float b = beta[i];
+  b = __fmul_rn(b, bits > hi ? factor : 1.0f);
+  b = __fdiv_rn(b, bits <= lo ? factor : 1.0f);
+  b = fminf(fmaxf(b, 0.0f), 10000.0f);
+  beta[i] = b;
+}
+
+extern "C" int rcb_beta_update(const double* kl_group, float* beta, const uint8_t* done, int32_t rows,
+                               int32_t n_groups, double bits, double upper, double lower, double step,
+                               rcb_stream_t stream) {
+  RCB_REQUIRE(kl_group && beta, RCB_ERR_ARG, "beta_update: null pointer");
+  RCB_REQUIRE(rows > 0 && n_groups > 0, RCB_ERR_SHAPE, "beta_update: empty shape");
+  long long n = (long long)rows * n_groups;
+  beta_update_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(kl_group, beta, done, n, bits + upper,
+                                                                   bits - lower, (float)(1.0 + step));
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused reparam-bwd + KL-bwd (+ Adam)
+// ------------------------------------------------------------------------------------------
+struct AdamScalars {
+  float w1;         // 1 - beta1
+  float beta2;      // beta2
+  float w2;         // 1 - beta2
+  float step_size;  // lr / (1 - beta1^t)
+  float bc2_sqrt;   // sqrt(1 - beta2^t)
+  float eps;
+  int enabled;
+};
+
+static AdamScalars make_adam(const rcb_adam_cfg* c) {
+  AdamScalars s;
+  memset(&s, 0, sizeof(s));
+  if (!c) return s;
+  double bc1 = 1.0 - pow((double)c->beta1, (double)c->step);
+  double bc2 = 1.0 - pow((double)c->beta2, (double)c->step);
+  s.w1 = (float)(1.0 - (double)c->beta1);
+  s.beta2 = c->beta2;
+  s.w2 = (float)(1.0 - (double)c->beta2);
+  s.step_size = (float)((double)c->lr / bc1);
+  s.bc2_sqrt = (float)sqrt(bc2);
+  s.eps = c->eps;
+  s.enabled = 1;
+  return s;
+}
+
+// torch.optim.Adam single step (default flags), operation order as in torch/optim/adam.py
+__device__ __forceinline__ void adam_apply(float& p, float g, float& m, float& v, const AdamScalars& s) {
+  m = __fadd_rn(m, __fmul_rn(s.w1, __fsub_rn(g, m)));                    // exp_avg.lerp_(grad, 1-beta1)
+  v = __fadd_rn(__fmul_rn(v, s.beta2), __fmul_rn(__fmul_rn(s.w2, g), g));  // mul_(beta2).addcmul_(g, g, 1-beta2)
+  float denom = __fadd_rn(__fdiv_rn(sqrtf(v), s.bc2_sqrt), s.eps);
+  p = __fadd_rn(p, __fmul_rn(-s.step_size, __fdiv_rn(m, denom)));        // addcdiv_(exp_avg, denom, -step_size)
+}
+
+struct PostBwdArgs {
+  rcb_level_bwd L;
+  AdamScalars adam;
+};
+
+__global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
+  const rcb_level_bwd& L = a.L;
+  int r = blockIdx.x;
+  int j = blockIdx.y * blockDim.x + threadIdx.x;
+  if (j >= L.cols) return;
+  long long o = (long long)r * L.cols + j;
+  float loc = L.loc[o];
+  float ls = L.log_scale[o];
+  float sig = st_f32(ls);
+  float g_mu = 0.f, g_sig = 0.f;
+  int d = L.col_inv ? L.col_inv[j] : j;
+  if (L.d_out && d < L.cols_out) {
+    int r0 = L.row_perm_inv ? L.row_perm_inv[o] : r;
+    int mb = L.member_ptr ? L.member_ptr[r0] : r0;
+    int me = L.member_ptr ? L.member_ptr[r0 + 1] : r0 + 1;
+    for (int q = mb; q < me; ++q) {
+      int n = L.member_idx ? L.member_idx[q] : q;
+      for (int s = 0; s < L.samples; ++s) {
+        long long e = ((long long)n * L.samples + s) * L.cols_out + d;
+        float go = L.d_out[e];
+        g_mu += go;
+        g_sig += go * L.eps[e];
+      }
+    }
+    if (L.enc_mask) {
+      float keep = 1.0f - L.enc_mask[o];
+      g_mu *= keep;
+      g_sig *= keep;
+    }
+  }
+  float w = L.kl_scalar;
+  if (L.beta) w *= L.beta[(long long)r * L.n_groups + L.group_idx[j]];
+  if (w != 0.0f) {
+    float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
+    float inv_var_p = 1.0f / (sp * sp);
+    g_mu += w * ((loc - L.p_loc[j]) * inv_var_p);
+    g_sig += w * (sig * inv_var_p - 1.0f / sig);
+  }
+  float g_ls = g_sig * dst_f32(ls);
+  if (a.adam.enabled) {
+    float m1 = L.m_loc[o], v1 = L.v_loc[o], m2 = L.m_ls[o], v2 = L.v_ls[o];
+    adam_apply(loc, g_mu, m1, v1, a.adam);
+    adam_apply(ls, g_ls, m2, v2, a.adam);
+    L.loc[o] = loc;
+    L.log_scale[o] = ls;
+    L.m_loc[o] = m1;
+    L.v_loc[o] = v1;
+    L.m_ls[o] = m2;
+    L.v_ls[o] = v2;
+  }
+  if (L.g_loc) L.g_loc[o] = g_mu;
+  if (L.g_log_scale) L.g_log_scale[o] = g_ls;
+}
+
+extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream) {
+  RCB_REQUIRE(lv, RCB_ERR_ARG, "posterior_bwd: null level");
+  RCB_REQUIRE(lv->loc && lv->log_scale && lv->p_loc && lv->p_scale, RCB_ERR_ARG, "posterior_bwd: null tensor");
+  RCB_REQUIRE(lv->rows > 0 && lv->cols > 0 && lv->cols <= 65535 * 256, RCB_ERR_SHAPE, "posterior_bwd: shape %d x %d", lv->rows, lv->cols);
+  RCB_REQUIRE(!lv->d_out || (lv->eps && lv->samples > 0 && lv->cols_out > 0), RCB_ERR_ARG, "posterior_bwd: d_out needs eps");
+  RCB_REQUIRE((lv->member_ptr == nullptr) == (lv->member_idx == nullptr), RCB_ERR_ARG, "posterior_bwd: members");
+  RCB_REQUIRE(!lv->beta || (lv->group_idx && lv->n_groups > 0), RCB_ERR_ARG, "posterior_bwd: beta needs group_idx");
+  RCB_REQUIRE(adam || (lv->g_loc && lv->g_log_scale), RCB_ERR_ARG, "posterior_bwd: neither adam nor grad outputs");
+  RCB_REQUIRE(!adam || (lv->m_loc && lv->v_loc && lv->m_ls && lv->v_ls && adam->step >= 1), RCB_ERR_ARG,
+              "posterior_bwd: adam state missing");
+  PostBwdArgs a;
+  a.L = *lv;
+  a.adam = make_adam(adam);
+  dim3 grid(lv->rows, cdiv(lv->cols, 256));
+  posterior_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+__global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, long long n, AdamScalars s) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_apply(pi, g[i], mi, vi, s);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+extern "C" int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const rcb_adam_cfg* cfg,
+                             rcb_stream_t stream) {
+  RCB_REQUIRE(p && g && m && v && cfg, RCB_ERR_ARG, "adam_flat: null pointer");
+  RCB_REQUIRE(cfg->step >= 1, RCB_ERR_ARG, "adam_flat: step must be >= 1");
+  if (n == 0) return RCB_OK;
+  int grid = cdiv(n, 256);
+  if (grid > 8192) grid = 8192;
+  adam_flat_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, make_adam(cfg));
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K12 column moments (shifted sums in fp64, fp64 atomics across row chunks)
+// ------------------------------------------------------------------------------------------
+constexpr int kMomRowsPerBlock = 256;
+
+__global__ void __launch_bounds__(256) col_moments_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
+                                                          int rows, int cols, double* s1, double* s2, double* sg) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  int r0 = blockIdx.y * kMomRowsPerBlock;
+  int r1 = min(rows, r0 + kMomRowsPerBlock);
+  double shift = (double)loc[j];  // row 0 as the shift
+  double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    double x = (double)loc[(long long)r * cols + j] - shift;
+    a1 += x;
+    a2 += x * x;
+    float s = st_f32(ls[(long long)r * cols + j]);
+    a3 += (double)__fmul_rn(s, s);
+  }
+  atomicAdd(&s1[j], a1);
+  atomicAdd(&s2[j], a2);
+  atomicAdd(&sg[j], a3);
+}
+
+__global__ void col_moments_finalize(const float* loc, int rows, int cols, double* s1, double* s2) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  double a1 = s1[j], a2 = s2[j];
+  s2[j] = a2 - a1 * a1 / (double)rows;          // M2
+  s1[j] = a1 + (double)rows * (double)loc[j];   // sum
+}
+
+extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, double* sum,
+                               double* m2, double* sig2, rcb_stream_t stream) {
+  RCB_REQUIRE(loc && log_scale && sum && m2 && sig2, RCB_ERR_ARG, "col_moments: null pointer");
+  RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "col_moments: empty shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if ((e = hipMemsetAsync(sum, 0, sizeof(double) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  if ((e = hipMemsetAsync(m2, 0, sizeof(double) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  if ((e = hipMemsetAsync(sig2, 0, sizeof(double) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  int row_blocks = cdiv(rows, kMomRowsPerBlock);
+  RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "col_moments: too many rows");
+  dim3 grid(cdiv(cols, 256), row_blocks);
+  col_moments_kernel<<<grid, 256, 0, st>>>(loc, log_scale, rows, cols, sum, m2, sig2);
+  RCB_LAUNCH_CHECK();
+  col_moments_finalize<<<cdiv(cols, 256), 256, 0, st>>>(loc, rows, cols, sum, m2);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}

@@ -1,0 +1,390 @@
+"""Tensor-level wrappers over the C ABI (include/rcb.h) + autograd glue.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic of the
+hot path runs in librcb_hip.so.  Every wrapper raises if the library is missing or a tensor is
+not on the GPU -- there is no CPU fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdamCfg, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
+
+f32 = torch.float32
+f64 = torch.float64
+i32 = torch.int32
+
+
+# ----------------------------------------------------------------------------------------------
+# SIREN MLP (K3 + K4)
+# ----------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class SirenMeta:
+    """Static geometry of one batched-MLP launch."""
+    samples: int
+    n_pix: int
+    fourier_dim: int
+    pe_dim: int
+    n_hidden: int
+    hidden: int
+    out_dim: int
+    w0: float = 30.0
+    precision: int = 0
+
+    @property
+    def d_net(self):
+        dims = [self.fourier_dim + self.pe_dim] + [self.hidden] * self.n_hidden + [self.out_dim]
+        return sum(dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1))
+
+
+def _xf_stride(xf, meta, n_inr):
+    """xf is [P,F] (shared), or [N,P,F] possibly an expanded (stride-0) view."""
+    P, F = meta.n_pix, meta.fourier_dim
+    if xf.dim() == 2:
+        if tuple(xf.shape) != (P, F) or not xf.is_contiguous():
+            raise RcbError(f"xf must be contiguous [{P},{F}], got {tuple(xf.shape)}")
+        return 0
+    if tuple(xf.shape) != (n_inr, P, F):
+        raise RcbError(f"xf must be [{n_inr},{P},{F}], got {tuple(xf.shape)}")
+    if xf.stride(1) != F or xf.stride(2) != 1:
+        raise RcbError("xf rows must be contiguous")
+    if xf.stride(0) not in (0, P * F):
+        raise RcbError("unsupported xf stride")
+    return int(xf.stride(0))
+
+
+def _siren_desc(meta: SirenMeta, wvec, xf):
+    if wvec.dim() != 2 or wvec.stride(1) != 1:
+        raise RcbError("wvec must be 2-D with unit column stride")
+    G = wvec.shape[0]
+    if wvec.shape[1] != meta.d_net:
+        raise RcbError(f"wvec has {wvec.shape[1]} columns, geometry needs {meta.d_net}")
+    if G % meta.samples:
+        raise RcbError("rows of wvec must be a multiple of samples")
+    d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
+                  meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
+                  meta.precision)
+    return d, G
+
+
+def _dev_ptr_strided(t):
+    if not t.is_cuda or t.dtype != f32:
+        raise RcbError("expected an fp32 GPU tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _check_pe(pe, G, meta):
+    if meta.pe_dim == 0:
+        return
+    if pe is None or tuple(pe.shape) != (G, meta.n_pix, meta.pe_dim):
+        raise RcbError(f"pe must be [{G},{meta.n_pix},{meta.pe_dim}]")
+
+
+def siren_fwd(xf, pe, wvec, meta: SirenMeta):
+    lib = _lib.load()
+    d, G = _siren_desc(meta, wvec, xf)
+    _check_pe(pe, G, meta)
+    y = torch.empty(G, meta.n_pix, meta.out_dim, device=wvec.device, dtype=f32)
+    check(lib.rcb_siren_fwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, f32, True), _dev_ptr_strided(wvec),
+                            ptr(y), stream_ptr()), "rcb_siren_fwd")
+    return y
+
+
+def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True):
+    lib = _lib.load()
+    d, G = _siren_desc(meta, wvec, xf)
+    _check_pe(pe, G, meta)
+    if tuple(dy.shape) != (G, meta.n_pix, meta.out_dim):
+        raise RcbError("dy shape mismatch")
+    dw = torch.empty(G, wvec.stride(0), device=wvec.device, dtype=f32)[:, :meta.d_net]
+    dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
+    check(lib.rcb_siren_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, f32, True), _dev_ptr_strided(wvec),
+                            ptr(dy.contiguous(), f32), _dev_ptr_strided(dw), ptr(dpe, f32, True), stream_ptr()),
+          "rcb_siren_bwd")
+    return dw, dpe
+
+
+def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True):
+    """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None)."""
+    lib = _lib.load()
+    d, G = _siren_desc(meta, wvec, xf)
+    _check_pe(pe, G, meta)
+    N = G // meta.samples
+    if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
+        raise RcbError(f"target must be [{N},{meta.n_pix},{meta.out_dim}], got {tuple(target.shape)}")
+    sse = torch.empty(G, device=wvec.device, dtype=f32)
+    dw = torch.empty(G, wvec.stride(0), device=wvec.device, dtype=f32)[:, :meta.d_net]
+    dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
+    check(lib.rcb_siren_loss_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, f32, True), _dev_ptr_strided(wvec),
+                                 ptr(target, f32), C.c_float(dy_scale), ptr(sse), _dev_ptr_strided(dw),
+                                 ptr(dpe, f32, True), stream_ptr()), "rcb_siren_loss_bwd")
+    return sse, dw, dpe
+
+
+class SirenFn(torch.autograd.Function):
+    """y[G,P,C] = SIREN(xf | pe ; wvec) with gradients for pe and wvec."""
+
+    @staticmethod
+    def forward(ctx, xf, pe, wvec, meta):
+        ctx.meta = meta
+        ctx.save_for_backward(xf, pe, wvec)
+        return siren_fwd(xf, pe.contiguous() if pe is not None else None, wvec, meta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, pe, wvec = ctx.saved_tensors
+        dw, dpe = siren_bwd(xf, pe.contiguous() if pe is not None else None, wvec, dy, ctx.meta,
+                            want_dpe=ctx.needs_input_grad[1])
+        return None, dpe, dw, None
+
+
+# ----------------------------------------------------------------------------------------------
+# posterior levels (K1 / K10 and their backward)
+# ----------------------------------------------------------------------------------------------
+class LevelSpec:
+    """Device-side description of one level of the factorised Gaussian posterior together with the
+    index maps that scatter it onto INRs (hierarchy) and un-permute it (test-time grouping)."""
+
+    def __init__(self, loc, log_scale, cols_out, n_inr, row_map=None, row_perm=None, col_map=None,
+                 enc_sample=None, enc_mask=None):
+        self.loc, self.log_scale = loc, log_scale
+        self.rows, self.cols = loc.shape[0], loc.shape[1]
+        self.cols_out, self.n_inr = int(cols_out), int(n_inr)
+        dev = loc.device
+        self.enc_sample, self.enc_mask = enc_sample, enc_mask
+
+        def dev_i32(a):
+            if a is None:
+                return None
+            return torch.as_tensor(np.ascontiguousarray(a), dtype=i32).to(dev).contiguous()
+        self.row_map = dev_i32(row_map)
+        self.row_perm = dev_i32(row_perm)
+        self.col_map = dev_i32(col_map)
+        # inverses for the backward gather
+        self.member_ptr = self.member_idx = self.row_perm_inv = self.col_inv = None
+        if row_map is not None:
+            rm = np.asarray(row_map)
+            order = np.argsort(rm, kind="stable")
+            counts = np.bincount(rm, minlength=self.rows)
+            self.member_ptr = dev_i32(np.r_[0, np.cumsum(counts)])
+            self.member_idx = dev_i32(order)
+        if row_perm is not None:
+            rp = np.asarray(row_perm)
+            inv = np.empty_like(rp)
+            cols = np.arange(rp.shape[1])[None, :].repeat(rp.shape[0], 0)
+            inv[rp, cols] = np.arange(rp.shape[0])[:, None]
+            self.row_perm_inv = dev_i32(inv)
+        if col_map is not None:
+            cm = np.asarray(col_map)
+            inv = np.full(self.cols, 2 ** 30, dtype=np.int64)   # columns not produced: d >= cols_out
+            inv[cm] = np.arange(cm.shape[0])
+            self.col_inv = dev_i32(inv)
+
+    def c_fwd(self, eps):
+        if tuple(eps.shape[-1:]) != (self.cols_out,):
+            raise RcbError("eps last dim must equal cols_out")
+        return Level(addr(self.loc.detach(), f32), addr(self.log_scale.detach(), f32), addr(self.enc_sample, f32),
+                     addr(self.enc_mask, f32), addr(self.row_map, i32), addr(self.row_perm, i32),
+                     addr(self.col_map, i32), addr(eps, f32), self.rows, self.cols, self.cols_out)
+
+
+def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], samples: int):
+    """out[N, S, cols_out(level 0)] (rcb_reparam_fwd)."""
+    lib = _lib.load()
+    n = levels[0].n_inr
+    cols = levels[0].cols_out
+    arr = (Level * len(levels))(*[lv.c_fwd(e) for lv, e in zip(levels, eps)])
+    for e, lv in zip(eps, levels):
+        if tuple(e.shape) != (n, samples, lv.cols_out) or not e.is_contiguous():
+            raise RcbError(f"eps must be contiguous [{n},{samples},{lv.cols_out}], got {tuple(e.shape)}")
+    out = torch.empty(n, samples, cols, device=levels[0].loc.device, dtype=f32)
+    check(lib.rcb_reparam_fwd(arr, len(levels), n, samples, cols, ptr(out), stream_ptr()), "rcb_reparam_fwd")
+    return out
+
+
+def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: float, d_out, eps, samples: int,
+                  beta=None, group_idx=None, n_groups=0, adam: Optional[AdamCfg] = None, state=None,
+                  want_grads=False):
+    """Fused gradient gather + KL gradient (+ Adam).  Returns (g_loc, g_log_scale) when requested."""
+    lib = _lib.load()
+    g_loc = g_ls = None
+    if want_grads:
+        g_loc = torch.empty_like(lv.loc)
+        g_ls = torch.empty_like(lv.log_scale)
+    if adam is not None and state is None:
+        raise RcbError("adam step needs state")
+    s = state or {}
+    b = LevelBwd(addr(lv.loc.detach(), f32), addr(lv.log_scale.detach(), f32), addr(lv.enc_mask, f32),
+                 addr(p_loc, f32), addr(p_scale, f32), int(bool(p_is_log)), addr(beta, f32), addr(group_idx, i32),
+                 int(n_groups), float(kl_scalar), addr(d_out, f32), addr(eps, f32), addr(lv.member_ptr, i32),
+                 addr(lv.member_idx, i32), addr(lv.row_perm_inv, i32), addr(lv.col_inv, i32), lv.rows, lv.cols,
+                 lv.cols_out, int(samples), addr(g_loc, f32), addr(g_ls, f32), addr(s.get("m_loc"), f32),
+                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32))
+    if d_out is not None and tuple(d_out.shape) != (lv.n_inr, samples, lv.cols_out):
+        raise RcbError(f"d_out must be [{lv.n_inr},{samples},{lv.cols_out}], got {tuple(d_out.shape)}")
+    check(lib.rcb_posterior_bwd(C.byref(b), C.byref(adam) if adam is not None else None, stream_ptr()),
+          "rcb_posterior_bwd")
+    return g_loc, g_ls
+
+
+class ReparamFn(torch.autograd.Function):
+    """Differentiable sampling: inputs (loc_0, log_scale_0, loc_1, ...) -> out[N,S,D]."""
+
+    @staticmethod
+    def forward(ctx, levels, eps, samples, *params):
+        ctx.levels, ctx.eps, ctx.samples = levels, eps, samples
+        return reparam_fwd(levels, eps, samples)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_out = d_out.contiguous()
+        grads = []
+        for lv, e in zip(ctx.levels, ctx.eps):
+            d = d_out if lv.cols_out == d_out.shape[-1] else d_out[..., :lv.cols_out].contiguous()
+            zeros = torch.zeros(lv.cols, device=d.device, dtype=f32)
+            ones = torch.ones(lv.cols, device=d.device, dtype=f32)
+            g = posterior_bwd(lv, zeros, ones, False, 0.0, d, e, ctx.samples, want_grads=True)
+            grads += list(g)
+        return (None, None, None, *grads)
+
+
+def sample_levels(levels: Sequence[LevelSpec], eps, samples):
+    params = []
+    for lv in levels:
+        params += [lv.loc, lv.log_scale]
+    return ReparamFn.apply(tuple(levels), tuple(eps), samples, *params)
+
+
+# ----------------------------------------------------------------------------------------------
+# KL (K5 - K8)
+# ----------------------------------------------------------------------------------------------
+def gauss_kl(loc, log_scale, p_loc, p_scale, p_is_log=False, beta=None, group_idx=None, seg_start=None,
+             seg_end=None, want_rows=True, want_groups=False):
+    """-> (kl_row fp64 [rows] or None, kl_group fp64 [rows, G] or None)."""
+    lib = _lib.load()
+    loc2 = loc.detach().reshape(loc.shape[0], -1)
+    ls2 = log_scale.detach().reshape(loc.shape[0], -1)
+    rows, cols = loc2.shape
+    n_groups = int(seg_start.shape[0]) if seg_start is not None else (int(beta.shape[1]) if beta is not None else 0)
+    kl_row = torch.empty(rows, device=loc.device, dtype=f64) if want_rows else None
+    kl_group = torch.empty(rows, n_groups, device=loc.device, dtype=f64) if want_groups else None
+    pl, ps = p_loc.reshape(-1), p_scale.reshape(-1)
+    if pl.numel() != cols or ps.numel() != cols:
+        raise RcbError("prior shape mismatch")
+    check(lib.rcb_gauss_kl(ptr(loc2, f32), ptr(ls2, f32), ptr(pl, f32), ptr(ps, f32), int(bool(p_is_log)), rows,
+                           cols, ptr(beta, f32, True), ptr(group_idx, i32, True), n_groups,
+                           ptr(seg_start, i32, True), ptr(seg_end, i32, True), ptr(kl_row, f64, True),
+                           ptr(kl_group, f64, True), stream_ptr()), "rcb_gauss_kl")
+    return kl_row, kl_group
+
+
+class GaussKLFn(torch.autograd.Function):
+    """sum_{r,j} w(r,j) KL(N(loc, st(log_scale)) || N(p_loc, p_scale)) as a 0-d fp32 tensor."""
+
+    @staticmethod
+    def forward(ctx, loc, log_scale, p_loc, p_scale, p_is_log, beta, group_idx, seg_start, seg_end):
+        ctx.save_for_backward(loc, log_scale, p_loc, p_scale)
+        ctx.aux = (p_is_log, beta, group_idx, seg_start, seg_end)
+        rows, _ = gauss_kl(loc, log_scale, p_loc, p_scale, p_is_log, beta, group_idx, seg_start, seg_end)
+        return rows.sum().to(f32)
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, log_scale, p_loc, p_scale = ctx.saved_tensors
+        p_is_log, beta, group_idx, seg_start, seg_end = ctx.aux
+        shape = loc.shape
+        l2 = loc.detach().reshape(shape[0], -1)
+        s2 = log_scale.detach().reshape(shape[0], -1)
+        lv = LevelSpec(l2, s2, l2.shape[1], l2.shape[0])
+        n_groups = int(beta.shape[1]) if beta is not None else 0
+        gl, gs = posterior_bwd(lv, p_loc.reshape(-1).contiguous(), p_scale.reshape(-1).contiguous(), p_is_log, 1.0,
+                               None, None, 1, beta=beta, group_idx=group_idx, n_groups=n_groups, want_grads=True)
+        return gl.reshape(shape) * g, gs.reshape(shape) * g, None, None, None, None, None, None, None
+
+
+def beta_update(kl_group, beta, done_u8, bits=16.0, upper=0.0, lower=0.4, step=0.05):
+    lib = _lib.load()
+    rows, G = beta.shape
+    check(lib.rcb_beta_update(ptr(kl_group, f64), ptr(beta, f32), ptr(done_u8, torch.uint8, True), rows, G,
+                              C.c_double(bits), C.c_double(upper), C.c_double(lower), C.c_double(step),
+                              stream_ptr()), "rcb_beta_update")
+
+
+# ----------------------------------------------------------------------------------------------
+# Adam, moments, REC, softplus
+# ----------------------------------------------------------------------------------------------
+def adam_cfg(lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    return AdamCfg(float(lr), float(beta1), float(beta2), float(eps), int(step))
+
+
+def adam_flat(p, g, m, v, cfg: AdamCfg):
+    lib = _lib.load()
+    if not (p.is_contiguous() and g.is_contiguous()):
+        raise RcbError("adam_flat needs contiguous tensors")
+    check(lib.rcb_adam_flat(ptr(p.detach(), f32), ptr(g, f32), ptr(m, f32), ptr(v, f32), C.c_int64(p.numel()),
+                            C.byref(cfg), stream_ptr()), "rcb_adam_flat")
+
+
+def col_moments(loc, log_scale):
+    """-> (sum, m2, sum sigma^2) fp64 [cols] over the rows of loc (rcb_col_moments)."""
+    lib = _lib.load()
+    l2 = loc.detach().reshape(loc.shape[0], -1)
+    s2 = log_scale.detach().reshape(loc.shape[0], -1)
+    rows, cols = l2.shape
+    out = torch.empty(3, cols, device=loc.device, dtype=f64)
+    check(lib.rcb_col_moments(ptr(l2, f32), ptr(s2, f32), rows, cols, ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                              stream_ptr()), "rcb_col_moments")
+    return out[0], out[1], out[2]
+
+
+def softplus_scale(log_scale):
+    lib = _lib.load()
+    out = torch.empty_like(log_scale)
+    check(lib.rcb_softplus_scale(ptr(log_scale.detach(), f32), ptr(out), C.c_int64(out.numel()), stream_ptr()),
+          "rcb_softplus_scale")
+    return out
+
+
+def rec_score_argmax(loc, scale, p_loc, p_scale, tables: dict, gumbel, job_row, job_start, job_glen,
+                     want_logw0=False):
+    """Batched A* scoring.  tables: {group_len: fp64 [K, g] GPU tensor}.  job_* are host int arrays.
+    -> (idx int32 [B] (GPU), z fp64 [B, max_g] (GPU), best fp64 [B,2] (GPU), logw0 or None)."""
+    lib = _lib.load()
+    job_row = np.asarray(job_row, dtype=np.int32)
+    job_start = np.asarray(job_start, dtype=np.int32)
+    job_glen = np.asarray(job_glen, dtype=np.int32)
+    B = int(job_row.shape[0])
+    rows, cols = loc.shape
+    K = int(gumbel.shape[0])
+    if B == 0:
+        raise RcbError("rec_score_argmax: no jobs")
+    max_g = int(job_glen.max())
+    if job_glen.min() < 1 or max_g > 32:
+        raise RcbError("group length outside 1..32")
+    if (job_row < 0).any() or (job_row >= rows).any() or (job_start < 0).any() or (job_start + job_glen > cols).any():
+        raise RcbError("job outside the parameter matrix")
+    tab = (C.c_void_p * (max_g + 1))()
+    for g in range(max_g + 1):
+        tab[g] = None
+    for g in np.unique(job_glen):
+        t = tables.get(int(g))
+        if t is None or tuple(t.shape) != (K, int(g)) or t.dtype != f64:
+            raise RcbError(f"missing / malformed candidate table for group length {int(g)}")
+        tab[int(g)] = ptr(t, f64).value
+    dev = loc.device
+    jr = torch.from_numpy(job_row).to(dev)
+    js = torch.from_numpy(job_start).to(dev)
+    jg = torch.from_numpy(job_glen).to(dev)
+    idx = torch.empty(B, device=dev, dtype=i32)
+    z = torch.zeros(B, max_g, device=dev, dtype=f64)
+    best = torch.empty(B, 2, device=dev, dtype=f64)
+    logw0 = torch.empty(K, device=dev, dtype=f64) if want_logw0 else None
+    check(lib.rcb_rec_score_argmax(ptr(loc.detach(), f32), ptr(scale, f32), cols, ptr(p_loc, f32), ptr(p_scale, f32),
+                                   tab, max_g, ptr(gumbel, f64), K, ptr(jr, i32), ptr(js, i32), ptr(jg, i32), B,
+                                   ptr(idx), ptr(z), ptr(best), ptr(logw0, f64, True), stream_ptr()),
+          "rcb_rec_score_argmax")
+    return idx, z, best, logw0

@@ -1,0 +1,129 @@
+"""Helpers shared by the parity tests: fixture loading, compact-array checks, input rebuilds."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_cpu as O  # noqa: E402  (oracle = checker only)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def cfg_of(d):
+    return json.loads(str(d["cfg"]))
+
+
+def has(d, key):
+    return key in d.files or (key + "__sub") in d.files
+
+
+def check(d, key, actual, rtol=1e-5, atol=1e-6, what=""):
+    """Compare ``actual`` with fixture entry ``key`` stored whole or as subsample+moments."""
+    a = actual.detach().cpu().numpy() if torch.is_tensor(actual) else np.asarray(actual)
+    if key in d.files:
+        exp = d[key]
+        assert a.shape == exp.shape, (key, a.shape, exp.shape)
+        np.testing.assert_allclose(a, exp, rtol=rtol, atol=atol, err_msg=f"{what}{key}")
+        return
+    sub, stride = d[key + "__sub"], int(d[key + "__stride"])
+    assert tuple(a.shape) == tuple(d[key + "__shape"]), (key, a.shape)
+    flat = a.reshape(-1)
+    np.testing.assert_allclose(flat[::stride], sub, rtol=rtol, atol=atol, err_msg=f"{what}{key} (subsample)")
+    f64 = flat.astype(np.float64)
+    got = np.array([f64.sum(), np.abs(f64).sum(), (f64 * f64).sum()])
+    exp = d[key + "__stats"]
+    n = flat.size
+    tol = np.array([atol * n + rtol * exp[1], atol * n + rtol * exp[1], 2 * (atol * exp[1] + rtol * exp[2]) + 1e-30])
+    assert np.all(np.abs(got - exp) <= tol), (key, got, exp, tol)
+
+
+def regen_noise(d, prefix, seed=None):
+    """Noise tensors = torch.manual_seed(seed) then randn(shape) in the recorded order; the
+    recorded moments pin the regeneration."""
+    shapes = json.loads(str(d[prefix + "_shapes"]))
+    seed = int(d[prefix + "_seed"]) if seed is None else seed
+    torch.manual_seed(seed)
+    out = [torch.randn(tuple(s)) for s in shapes]
+    st = d[prefix + "_stats"]
+    for e, s in zip(out, st):
+        a = e.double()
+        got = np.array([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()])
+        np.testing.assert_allclose(got, s, rtol=1e-9, atol=1e-9)
+    return out
+
+
+def regen_noise_per_epoch(d, prefix, n_epochs):
+    """Test-time training reseeds with the epoch index before every step."""
+    shapes = json.loads(str(d[prefix + "_shapes"]))
+    per = len(shapes) // n_epochs
+    out, k = [], 0
+    for ep in range(n_epochs):
+        torch.manual_seed(ep)
+        out.append([torch.randn(tuple(s)) for s in shapes[k:k + per]])
+        k += per
+    st = d[prefix + "_stats"]
+    flat = [e for ep in out for e in ep]
+    for e, s in zip(flat, st):
+        a = e.double()
+        np.testing.assert_allclose(np.array([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()]), s,
+                                   rtol=1e-9, atol=1e-9)
+    return out
+
+
+def t(d, key):
+    return torch.from_numpy(np.array(d[key])) if key in d.files else None
+
+
+def prior_inputs(d):
+    """Rebuild the inputs of a prior_<name>.npz case with the oracle's own constructors."""
+    cfg = cfg_of(d)
+    geo = O.Geometry.from_config(cfg)
+    n = int(d["n"])
+    p = O.init_prior_params(geo, n, seed=42)
+    for k in ["log_scale", "lpe_log_scale", "h_log_scale", "hh_log_scale"]:
+        if ("p_" + k) in d.files:
+            p[k] = t(d, "p_" + k).clone()
+    A = O.make_linear_transform(geo.dims, seed=123)
+    up = O.UpsampleNet(geo.data_dim, geo.paddings, geo.layerwise_scale_factors, seed=124)
+    X = t(d, "X")
+    if X is None:  # stored as subsample + moments: rebuild and verify
+        X = O.fourier_features(cfg["pixel_sizes"], cfg["fourier_dim"])
+        check(d, "X", X, rtol=0, atol=1e-6)
+    Y = t(d, "Y")
+    if Y is None:
+        torch.manual_seed(5)
+        Y = torch.rand(n, X.shape[0], cfg["output_dim"])
+        check(d, "Y", Y, rtol=0, atol=0)
+    pri = [t(d, "prior_" + k) for k in ["pl", "ps", "ll", "ls", "hl", "hs", "hhl", "hhs"]]
+    return cfg, geo, n, p, A, up, X, Y, pri
+
+
+def stats_of(tensors):
+    out = []
+    for a in tensors:
+        a = a.detach().double()
+        out.append([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()])
+    return np.array(out)
+
+
+def level_kwargs(d, pre=""):
+    return dict(p_loc=t(d, f"kw_{pre}p_loc"), p_log_scale=t(d, f"kw_{pre}p_log_scale"),
+                init_log_scale=t(d, f"kw_{pre}init_log_scale"),
+                group_idx=d[f"{pre}G_group_idx"].astype(np.int64),
+                group_start_index=d[f"{pre}G_start"].astype(np.int64),
+                group_end_index=d[f"{pre}G_end"].astype(np.int64),
+                group_to_param=d[f"{pre}G_group2param"].astype(np.int64),
+                param_to_group=d[f"{pre}G_param2group"].astype(np.int64),
+                n_groups=int(d[f"{pre}G_n_groups"]))
+
+
+DATASET_OF = {"cifar": "cifar", "protein": "protein", "patch2d": "kodak", "patch1d": "audio", "patch3d": "video"}
