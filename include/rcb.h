@@ -116,6 +116,11 @@ int rcb_gauss_kl(const float* loc, const float* log_scale, const float* p_loc, c
                  const int32_t* group_idx, int32_t n_groups, const int32_t* seg_start,
                  const int32_t* seg_end, double* kl_row, double* kl_group, rcb_stream_t stream);
 
+/* Per-parameter KL summed over rows, out[j] = sum_r kl(r, j) (fp64): the statistic behind
+ * get_grouping (prior_model.py:264-271); q_scale holds sigma (or log-scales if q_scale_is_log).  */
+int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32_t q_scale_is_log, const float* p_loc,
+                        const float* p_scale, int32_t rows, int32_t cols, double* out, rcb_stream_t stream);
+
 /* K8: per-group beta annealing (test_model.py:404-413): groups above 16+upper bits get
  * beta *= (1+step), groups at or below 16-lower bits beta /= (1+step), clamp [0, 1e4]; encoded
  * groups (done != 0) keep their beta.                                                          */

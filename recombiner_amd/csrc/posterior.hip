@@ -420,3 +420,40 @@ extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// per-parameter KL summed over rows (get_grouping, prior_model.py:264-271), fp64
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kl_colsum_kernel(const float* __restrict__ loc, const float* __restrict__ sc,
+                                                        int q_is_log, const float* __restrict__ p_loc,
+                                                        const float* __restrict__ p_scale, int rows, int cols,
+                                                        double* out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  int r0 = blockIdx.y * kMomRowsPerBlock;
+  int r1 = min(rows, r0 + kMomRowsPerBlock);
+  float mp = p_loc[j], sp = p_scale[j];
+  double acc = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    float s = sc[(long long)r * cols + j];
+    if (q_is_log) s = st_f32(s);
+    acc += (double)kl_elem_f32(loc[(long long)r * cols + j], s, mp, sp);
+  }
+  atomicAdd(&out[j], acc);
+}
+
+extern "C" int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32_t q_scale_is_log, const float* p_loc,
+                                   const float* p_scale, int32_t rows, int32_t cols, double* out,
+                                   rcb_stream_t stream) {
+  RCB_REQUIRE(loc && q_scale && p_loc && p_scale && out, RCB_ERR_ARG, "kl_colsum: null pointer");
+  RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "kl_colsum: empty shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * cols, st);
+  if (e != hipSuccess) return fail((int)e, "memset");
+  int row_blocks = cdiv(rows, kMomRowsPerBlock);
+  RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "kl_colsum: too many rows");
+  dim3 grid(cdiv(cols, 256), row_blocks);
+  kl_colsum_kernel<<<grid, 256, 0, st>>>(loc, q_scale, q_scale_is_log, p_loc, p_scale, rows, cols, out);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}

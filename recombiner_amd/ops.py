@@ -306,6 +306,19 @@ class GaussKLFn(torch.autograd.Function):
         return gl.reshape(shape) * g, gs.reshape(shape) * g, None, None, None, None, None, None, None
 
 
+def gauss_kl_colsum(loc, q_scale, p_loc, p_scale, q_is_log=False):
+    """-> fp64 [cols]: sum over rows of the elementwise KL."""
+    lib = _lib.load()
+    l2 = loc.detach().reshape(loc.shape[0], -1).contiguous()
+    s2 = q_scale.detach().reshape(loc.shape[0], -1).contiguous()
+    rows, cols = l2.shape
+    out = torch.empty(cols, device=loc.device, dtype=f64)
+    check(lib.rcb_gauss_kl_colsum(ptr(l2, f32), ptr(s2, f32), int(bool(q_is_log)), ptr(p_loc.reshape(-1).contiguous(), f32),
+                                  ptr(p_scale.reshape(-1).contiguous(), f32), rows, cols, ptr(out), stream_ptr()),
+          "rcb_gauss_kl_colsum")
+    return out
+
+
 def beta_update(kl_group, beta, done_u8, bits=16.0, upper=0.0, lower=0.4, step=0.05):
     lib = _lib.load()
     rows, G = beta.shape

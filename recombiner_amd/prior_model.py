@@ -1,0 +1,329 @@
+"""Prior-learning model on MI355X: per-INR variational posteriors, batched SIREN forward/backward,
+ELBO/KL, Adam -- the call surface of the reference's prior_model.py (same class / function names,
+argument order and return values, cited per member) on top of hand-written HIP kernels.
+
+Where the reference chains torch ops through autograd, `train()` here runs one fused pipeline per
+step: sample (K1) -> upsample net (torch/MIOpen for now) -> A-transform GEMMs -> fused SIREN
+fwd+MSE+bwd (K3/K4) -> GEMM backward -> fused reparam-bwd + KL-bwd + Adam (K1'/K5'/K11).
+`forward()` / `calculate_kl()` stay autograd-capable through custom Functions so user code written
+against the reference API keeps working.  There is no CPU fallback.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .ops import LevelSpec, SirenMeta
+from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs
+
+
+class LinearTransform(nn.Module):
+    """Shared per-layer square maps A[l] (L_l x L_l), init U(-1,1)/L_l  (prior_model.py:16-21)."""
+
+    def __init__(self, net_dims):
+        super().__init__()
+        mats = []
+        for i in range(1, len(net_dims)):
+            L = net_dims[i] * (net_dims[i - 1] + 1)
+            mats.append((torch.rand(L, L) * 2 - 1) / L)
+        self.A = nn.ParameterList(mats)
+
+
+class Upsample(nn.Module):
+    """Latent grid -> per-pixel encodings: 3 x (nearest upsample, conv), 128 -> 64 -> 64 -> 16 channels,
+    kernels 5/3/3, LeakyReLU(0.01) after the first two convs  (prior_model.py:23-59).  Submodule names
+    match the reference so state dicts / pickles interchange."""
+
+    def __init__(self, kernel_dim, paddings, layerwise_scale_factors):
+        super().__init__()
+        conv = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}[kernel_dim]
+        layerwise_scale_factors = [tuple(s) if isinstance(s, (list, tuple)) else s for s in layerwise_scale_factors]
+        self.up1 = nn.Upsample(scale_factor=layerwise_scale_factors[0])
+        self.conv1 = conv(128, 64, 5, padding=paddings[0])
+        self.conv2 = conv(64, 64, 3, padding=paddings[1])
+        self.conv3 = conv(64, 16, 3, padding=paddings[2])
+        self.act1 = nn.LeakyReLU()
+        self.up2 = nn.Upsample(scale_factor=layerwise_scale_factors[1])
+        self.act2 = nn.LeakyReLU()
+        self.up3 = nn.Upsample(scale_factor=layerwise_scale_factors[2])
+
+    def forward(self, x):
+        x = self.act1(self.conv1(self.up1(x)))
+        x = self.act2(self.conv2(self.up2(x)))
+        return self.conv3(self.up3(x))
+
+
+def _zeros_state(t):
+    return torch.zeros_like(t, memory_format=torch.contiguous_format)
+
+
+class PriorBNNmodel(nn.Module):
+    """Training-set posteriors + batched INR evaluation (prior_model.py:62-262)."""
+
+    def __init__(self, in_dim, hidden_dims, out_dim, train_size, data_dim, pixel_sizes, upsample_factors,
+                 latent_dim, patch, patch_nums, hierarchical_patch_nums, random_seed=42, device="cuda",
+                 init_log_scale=-4, c=6., w0=30.):
+        super().__init__()
+        self.random_seed, self.device = random_seed, device
+        self.n_layers = len(hidden_dims) + 1
+        self.dims = [in_dim] + list(hidden_dims) + [out_dim]
+        self.patch, self.w0 = patch, float(w0)
+        self.st = lambda x: F.softplus(x, beta=1, threshold=20) / 6
+        self.data_dim, self.train_size, self.latent_dim = data_dim, train_size, latent_dim
+        self.pixel_sizes, self.upsample_factors = pixel_sizes, upsample_factors
+        self.patch_nums, self.hierarchical_patch_nums = patch_nums, hierarchical_patch_nums
+        self.net_params_list, self.cum_param_sizes = count_net_params(in_dim, hidden_dims, out_dim)
+        D = int(self.cum_param_sizes[-1])
+        if len(set(hidden_dims)) != 1:
+            raise ValueError("hidden layers must share one width")
+
+        # A1: same CPU-generator draw order as the reference (loc, h_loc, hh_loc, lpe_loc), then moved
+        torch.manual_seed(random_seed)
+        w_std = np.sqrt(c / hidden_dims[-1]) / w0
+
+        def uni(rows):
+            return nn.Parameter((torch.rand(rows, D) * w_std * 2 - w_std).to(device))
+
+        def const(rows):
+            return nn.Parameter((torch.zeros(rows, D) + init_log_scale).to(device))
+        self.loc, self.log_scale = uni(train_size), const(train_size)
+        if patch:
+            r2 = train_size // int(np.prod(hierarchical_patch_nums["level2"]))
+            r3 = train_size // int(np.prod(hierarchical_patch_nums["level3"]))
+            self.h_loc, self.h_log_scale = uni(r2), const(r2)
+            self.hh_loc, self.hh_log_scale = uni(r3), const(r3)
+        lat = [pixel_sizes[i] // upsample_factors[i] for i in range(data_dim)]
+        self.lpe_loc = nn.Parameter((torch.randn(train_size, *lat, latent_dim) * 0.1).to(device))
+        self.lpe_log_scale = nn.Parameter((torch.zeros(train_size, *lat, latent_dim) + init_log_scale).to(device))
+        self._lat = lat
+        self._d_net, self._d_lpe = D, int(np.prod(lat)) * latent_dim
+        self._maps = hierarchy_row_maps(train_size, patch_nums, hierarchical_patch_nums, data_dim) if patch else None
+        self._levels_cache = None
+        self.noise_source = None     # optional callable(shape) -> standard normal GPU tensor (eps injection)
+        self.precision = 0           # 0 = fp32 MFMA, 1 = bf16 operands (throughput mode)
+        self.dp_group = None         # torch.distributed group for sharded training of the shared mappings
+
+    # ---- level descriptions ------------------------------------------------------------------------
+    def _levels(self):
+        """LevelSpecs of the latent-weight hierarchy [level1, (level2, level3)] and of the lpe."""
+        c = self._levels_cache
+        if c is None or c["dev"] != self.loc.device:
+            N, D = self.train_size, self._d_net
+            net = [LevelSpec(self.loc, self.log_scale, D, N)]
+            if self.patch:
+                net.append(LevelSpec(self.h_loc, self.h_log_scale, D, N, row_map=self._maps[0]))
+                net.append(LevelSpec(self.hh_loc, self.hh_log_scale, D, N, row_map=self._maps[1]))
+            c = {"dev": self.loc.device, "net": net}
+            self._levels_cache = c
+        lpe = LevelSpec(self.lpe_loc.view(self.train_size, -1), self.lpe_log_scale.view(self.train_size, -1),
+                        self._d_lpe, self.train_size)
+        return c["net"], lpe
+
+    def _noise(self, shape):
+        if self.noise_source is not None:
+            e = self.noise_source(tuple(shape))
+            return e.to(self.loc.device, torch.float32).reshape(shape).contiguous()
+        return torch.randn(shape, device=self.loc.device, dtype=torch.float32)
+
+    def _meta(self, x, pe_dim, samples=1):
+        return SirenMeta(samples=samples, n_pix=x.shape[-2], fourier_dim=x.shape[-1], pe_dim=pe_dim,
+                         n_hidden=self.n_layers - 1, hidden=self.dims[1], out_dim=self.dims[-1], w0=self.w0,
+                         precision=self.precision)
+
+    def _layer_slices(self):
+        cum = self.cum_param_sizes
+        return [(0 if i == 0 else int(cum[i - 1]), int(cum[i])) for i in range(self.n_layers)]
+
+    # ---- reference API: helpers ----------------------------------------------------------------------
+    def group_to_layer(self, params, layer_idx):
+        lo, hi = self._layer_slices()[layer_idx]
+        return params[..., lo:hi]
+
+    def layer_to_weight(self, in_dim, out_dim, layer_param):
+        bias = layer_param[:, :out_dim]
+        weights = layer_param[:, out_dim:].reshape(-1, in_dim, out_dim)
+        return weights, bias
+
+    # ---- reference API: forward (autograd-capable) -----------------------------------------------------
+    def forward(self, x, linear_transform, upsample_net, gradient_through_A=True):
+        """x [N, P, F] (or [P, F] shared grid) -> y_hat [N, P, C]  (prior_model.py:129-179).
+        Noise draw order as in the reference: lpe, level 1, level 2, level 3."""
+        assert x.shape[0] == self.train_size or x.dim() == 2
+        N = self.train_size
+        net, lpe_lv = self._levels()
+        e_lpe = self._noise((N, 1, self._d_lpe))
+        lpe = ops.sample_levels([lpe_lv], [e_lpe], 1)                       # [N,1,Dlpe]
+        lpe = lpe.reshape(N, *self._lat, self.latent_dim)[None]
+        pe = map_lpe_to_inr_inputs(upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
+                                   self.patch, self.patch_nums, self.data_dim)[:, 0]
+        eps = [self._noise((N, 1, self._d_net)) for _ in net]
+        h_w = ops.sample_levels(net, eps, 1)[:, 0]                          # [N, D_net]
+        parts = []
+        for idx, (lo, hi) in enumerate(self._layer_slices()):
+            A = linear_transform.A[idx] if gradient_through_A else linear_transform.A[idx].detach()
+            parts.append(h_w[:, lo:hi] @ A)
+        wvec = torch.cat(parts, -1)
+        return ops.SirenFn.apply(x, pe.contiguous(), wvec, self._meta(x, pe.shape[-1]))
+
+    def calculate_kl(self, prior_loc, prior_scale, prior_lpe_loc, prior_lpe_scale, prior_h_loc, prior_h_scale,
+                     prior_hh_loc, prior_hh_scale):
+        """Sum of elementwise Gaussian KLs over all levels (prior_model.py:181-200) -> 0-d tensor."""
+        def one(loc, ls, pl, ps):
+            return ops.GaussKLFn.apply(loc, ls, pl.contiguous(), ps.contiguous(), False, None, None, None, None)
+        kl = one(self.loc, self.log_scale, prior_loc, prior_scale)
+        kl = kl + one(self.lpe_loc, self.lpe_log_scale, prior_lpe_loc, prior_lpe_scale)
+        if self.patch:
+            kl = kl + one(self.h_loc, self.h_log_scale, prior_h_loc, prior_h_scale)
+            kl = kl + one(self.hh_loc, self.hh_log_scale, prior_hh_loc, prior_hh_scale)
+        return kl
+
+    def _kl_value(self, priors):
+        """fp64 0-d KL on device, no autograd."""
+        tot = None
+        pairs = [(self.loc, self.log_scale, priors[0], priors[1]),
+                 (self.lpe_loc, self.lpe_log_scale, priors[2], priors[3])]
+        if self.patch:
+            pairs += [(self.h_loc, self.h_log_scale, priors[4], priors[5]),
+                      (self.hh_loc, self.hh_log_scale, priors[6], priors[7])]
+        for loc, ls, pl, ps in pairs:
+            r, _ = ops.gauss_kl(loc, ls, pl.contiguous(), ps.contiguous())
+            tot = r.sum() if tot is None else tot + r.sum()
+        return tot
+
+    # ---- reference API: train (fused pipeline) -----------------------------------------------------------
+    def train(self, n_epoch, lr, x, y, prior_loc, prior_scale, prior_lpe_loc, prior_lpe_scale, prior_h_loc,
+              prior_h_scale, prior_hh_loc, prior_hh_scale, linear_transform, upsample_net, kl_beta,
+              training_mappings=True, verbose=False):
+        """n_epoch Adam steps on loss = mean((y_hat-y)^2)*N + kl_beta*KL with a fresh Adam
+        (prior_model.py:202-262).  Returns (MSE_last/N, KL/N, ELBO list).  NB: shadows nn.Module.train
+        exactly like the reference does."""
+        dev = self.loc.device
+        x = x.to(dev)
+        y = y.to(dev).contiguous()
+        N = y.shape[0]
+        P, Cc = y.shape[1], y.shape[2]
+        priors = [prior_loc, prior_scale, prior_lpe_loc, prior_lpe_scale, prior_h_loc, prior_h_scale,
+                  prior_hh_loc, prior_hh_scale]
+        priors = [None if p is None else p.detach().to(dev, torch.float32).contiguous() for p in priors]
+        net, lpe_lv = self._levels()
+        net_priors = [(priors[0], priors[1])] + ([(priors[4], priors[5]), (priors[6], priors[7])] if self.patch else [])
+
+        def st4(lv):
+            return {k: _zeros_state(lv.loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+        net_state = [st4(lv) for lv in net]
+        lpe_state = st4(lpe_lv)
+        A = [a for a in linear_transform.A]
+        conv = [p for p in upsample_net.parameters()]
+        if training_mappings:
+            map_state = [(_zeros_state(p), _zeros_state(p)) for p in A + conv]
+        slices = self._layer_slices()
+        mse_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
+        elbo_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
+        D = self._d_net
+        world = 1
+        if self.dp_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world = torch.distributed.get_world_size(self.dp_group)
+        rng = range(n_epoch)
+        if verbose:
+            from tqdm import tqdm
+            rng = tqdm(rng)
+        for i in rng:
+            cfg = ops.adam_cfg(lr, i + 1)
+            # ---- sample ---------------------------------------------------------------------------------
+            e_lpe = self._noise((N, 1, self._d_lpe))
+            lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
+            lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
+            with torch.enable_grad():
+                pe = map_lpe_to_inr_inputs(upsample_net, lpe_t, self.latent_dim, self.pixel_sizes,
+                                           self.upsample_factors, self.patch, self.patch_nums, self.data_dim)[:, 0]
+                pe_c = pe.contiguous()
+            eps = [self._noise((N, 1, D)) for _ in net]
+            h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
+            # ---- A transform (dense GEMMs) --------------------------------------------------------------
+            wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
+            for (lo, hi), a in zip(slices, A):
+                wvec[:, lo:hi] = torch.mm(h_w[:, lo:hi], a.detach())
+            # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
+            meta = self._meta(x, pe_c.shape[-1])
+            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
+            kl = self._kl_value(priors)
+            mse = sse.sum(dtype=torch.float64) / (P * Cc)
+            mse_buf[i] = mse
+            elbo_buf[i] = -(mse + kl * float(kl_beta))
+            # ---- backward through the shared mappings ------------------------------------------------------
+            inputs = [lpe_t] + (conv if training_mappings else [])
+            g_in = torch.autograd.grad(pe_c, inputs, dpe)
+            d_lpe = g_in[0].reshape(N, 1, self._d_lpe).contiguous()
+            dh = torch.empty(N, D, device=dev, dtype=torch.float32)
+            gA = []
+            for (lo, hi), a in zip(slices, A):
+                dh[:, lo:hi] = torch.mm(dw[:, lo:hi], a.detach().t())
+                if training_mappings:
+                    gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
+            # ---- fused posterior update -------------------------------------------------------------------
+            dh3 = dh.view(N, 1, D)
+            for lv, (pl, ps), e, stt in zip(net, net_priors, eps, net_state):
+                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt)
+            ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), d_lpe,
+                              e_lpe, 1, adam=cfg, state=lpe_state)
+            if training_mappings:
+                grads = gA + [g.contiguous() for g in g_in[1:]]
+                if world > 1:
+                    flat = torch.cat([g.reshape(-1) for g in grads])
+                    torch.distributed.all_reduce(flat, group=self.dp_group)
+                    out, k = [], 0
+                    for g in grads:
+                        out.append(flat[k:k + g.numel()].view_as(g))
+                        k += g.numel()
+                    grads = out
+                for p, g, (m, v) in zip(A + conv, grads, map_state):
+                    ops.adam_flat(p.data, g.contiguous(), m, v, cfg)
+        kl_final = self._kl_value(priors)
+        mse_h = mse_buf.cpu()
+        elbo_h = elbo_buf.cpu().tolist()
+        return float(mse_h[-1]) / N, float(kl_final.item()) / N, elbo_h
+
+
+# ------------------------------------------------------------------------------------------------------
+# grouping (prior_model.py:264-316) -- host side, as in the reference
+# ------------------------------------------------------------------------------------------------------
+def get_grouping(q_loc, q_scale, prior_loc, prior_scale):
+    """Mean-over-rows KL in bits per parameter (HIP reduction), then greedy packing on the host."""
+    rows = q_loc.shape[0]
+    colsum = ops.gauss_kl_colsum(q_loc, q_scale, prior_loc, prior_scale, q_is_log=False)
+    weights = (colsum / np.log(2.) / rows).to(torch.float32).cpu().numpy()
+    return get_grouping_by_kl(weights)
+
+
+def group_parameters(parameters, weights, max_weight=16):
+    """Sequential greedy packing; the running sum keeps the dtype of `weights` (fp32 in practice)."""
+    groups = [[parameters[0]]]
+    run = weights[0]
+    for i in range(1, len(parameters)):
+        if run + weights[i] > max_weight:
+            groups.append([parameters[i]])
+            run = weights[i]
+        else:
+            groups[-1].append(parameters[i])
+            run = run + weights[i]
+    return groups
+
+
+def get_grouping_by_kl(kls_bits):
+    """-> (group_idx, group_start_index, group_end_index, group2param, param2group, n_groups,
+    group_kls, weights) with the fixed np.random.seed(0) shuffle (prior_model.py:273-299)."""
+    D = kls_bits.shape[0]
+    np.random.seed(0)
+    order = np.random.choice(D, D, False)
+    np.random.seed(None)
+    result = group_parameters(np.arange(D)[order], kls_bits[order])
+    sizes = np.array([len(g) for g in result])
+    n_groups = len(result)
+    param2group = np.concatenate([np.asarray(g) for g in result])
+    group2param = np.argsort(param2group)
+    group_idx = np.repeat(np.arange(n_groups), sizes).astype(int)
+    end = np.cumsum(sizes)
+    start = end - sizes
+    group_kls = np.array([sum(kls_bits[j] for j in g) for g in result])
+    return group_idx, start, end, group2param, param2group, n_groups, group_kls, kls_bits

@@ -1,0 +1,141 @@
+"""Host-side helpers of the hot path: layer bookkeeping, patch stitching around the upsampling
+net, synthetic coordinate inputs, metrics.  Mirrors the helper surface of the reference's
+utils.py (names and argument meaning); the arithmetic-heavy helper of the reference
+(`map_hierarchical_model_to_int_weights`, utils.py:122-198) is replaced by the HIP sampling
+kernel (`ops.sample_levels` over `LevelSpec` index maps built by `hierarchy_row_maps`).
+"""
+import numpy as np
+import torch
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter bookkeeping (utils.py:216-232)
+# ---------------------------------------------------------------------------------------------
+def count_layer_params(in_dim, out_dim):
+    return in_dim * out_dim + out_dim
+
+
+def count_net_params(in_dim, hidden_dims, out_dim):
+    dims = [in_dim] + list(hidden_dims) + [out_dim]
+    n_params = [count_layer_params(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
+    return n_params, np.cumsum(n_params)
+
+
+# ---------------------------------------------------------------------------------------------
+# hierarchy index maps (utils.py:151-185 expressed as gathers)
+# ---------------------------------------------------------------------------------------------
+def hierarchy_row_maps(n_inr, patch_nums, hierarchical_patch_nums, data_dim):
+    """patch n -> row of the level-2 posterior, row of the level-3 posterior."""
+    ppd = int(np.prod(patch_nums))
+    l2 = hierarchical_patch_nums["level2"]
+    ngrp = [patch_nums[i] // l2[i] for i in range(data_dim)]
+    n = np.arange(n_inr)
+    datum, local = n // ppd, n % ppd
+    pos = np.unravel_index(local, patch_nums)
+    grp = np.ravel_multi_index(tuple(pos[i] // l2[i] for i in range(data_dim)), ngrp)
+    return (datum * int(np.prod(ngrp)) + grp).astype(np.int64), datum.astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+# latent positional encodings -> per-pixel inputs (utils.py:4-120)
+# ---------------------------------------------------------------------------------------------
+def map_lpe_to_inr_inputs(upsample_net, latent_pe, latent_dim, pixel_sizes, upsample_factors, patch, patch_nums,
+                          data_dim):
+    """latent_pe [S, N, ...] -> pe [N, S, P, C_out] (channel-last, P row-major over the pixel grid).
+    Patched presets: the latent grids of all patches of a datapoint are stitched into one grid,
+    upsampled together, and cut back into patches."""
+    S, N = latent_pe.shape[:2]
+    lat = [pixel_sizes[i] // upsample_factors[i] for i in range(data_dim)]
+    z = latent_pe.reshape(S, N, *lat, -1)
+    assert z.shape[-1] == latent_dim
+    if not patch:
+        o = upsample_net(z.reshape(S * N, *lat, latent_dim).movedim(-1, 1)).movedim(1, -1)
+        pe = o.reshape(S, N, -1, o.shape[-1])
+    else:
+        pn = list(patch_nums)
+        nd = N // int(np.prod(pn))
+        z = z.reshape(S, nd, *pn, *lat, latent_dim)
+        inter = [2 + i + j * data_dim for i in range(data_dim) for j in range(2)]
+        z = z.permute([0, 1] + inter + [2 + 2 * data_dim])
+        z = z.reshape(S * nd, *[pn[i] * lat[i] for i in range(data_dim)], latent_dim)
+        o = upsample_net(z.movedim(-1, 1)).movedim(1, -1)
+        ch = o.shape[-1]
+        split = [v for i in range(data_dim) for v in (pn[i], pixel_sizes[i])]
+        o = o.reshape(S, nd, *split, ch)
+        back = [2 + 2 * i for i in range(data_dim)] + [3 + 2 * i for i in range(data_dim)]
+        pe = o.permute([0, 1] + back + [2 + 2 * data_dim]).reshape(S, N, -1, ch)
+    return pe.permute(1, 0, 2, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic coordinate inputs (utils.py:265-297 + data/image.py:24-27)
+# ---------------------------------------------------------------------------------------------
+def make_coord_grid(shape, range, device=None):
+    axes = []
+    for i, s in enumerate(shape):
+        lo, hi = range[i] if isinstance(range[0], (list, tuple)) else range
+        axes.append(lo + (hi - lo) * ((0.5 + torch.arange(s, device=device)) / s))
+    return torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1)
+
+
+def to_grid_coordinates_and_features(datum):
+    """datum [C, *spatial] -> (coords [P, dd] in (-1,1), features [P, C])."""
+    sp = datum.shape[1:]
+    coords = make_coord_grid(sp, (-1, 1), device=datum.device).view(-1, len(sp))
+    return coords, datum.reshape(datum.shape[0], -1).T
+
+
+def fourier_embed(coords, feature_size):
+    """cat(cos(pi v), sin(pi v)), v = coords (x) exp(linspace(0, ln 1024, F/(2 dd)))."""
+    dd = coords.shape[-1]
+    w = torch.exp(torch.linspace(0, np.log(1024), feature_size // (2 * dd), device=coords.device))
+    v = torch.matmul(coords.unsqueeze(-1), w.unsqueeze(0)).view(*coords.shape[:-1], -1)
+    return torch.cat([torch.cos(np.pi * v), torch.sin(np.pi * v)], dim=-1)
+
+
+def synthetic_inputs(pixel_sizes, fourier_dim, n_inr, out_dim, seed=0):
+    """Benchmark inputs: X[P,F] from the coordinate grid, Y ~ U[0,1) [N,P,C] (CPU RNG)."""
+    coords, _ = to_grid_coordinates_and_features(torch.zeros(1, *pixel_sizes))
+    X = fourier_embed(coords, fourier_dim)
+    g = torch.Generator().manual_seed(seed)
+    Y = torch.rand(n_inr, X.shape[0], out_dim, generator=g)
+    return X, Y
+
+
+# ---------------------------------------------------------------------------------------------
+# metrics (utils.py:200-260) -- host numpy, as in the reference
+# ---------------------------------------------------------------------------------------------
+def _round8(c):
+    return np.round(np.clip(c, 0, 1) * 255) / 255
+
+
+def PSNR(original, compressed, round, max_value=1):
+    if round:
+        compressed = _round8(compressed)
+    mse = np.mean((original - compressed) ** 2)
+    return (20 * np.log10(max_value / np.sqrt(mse))).item()
+
+
+def batch_PSNR(original, compressed, round, max_value=1):
+    b = original.shape[0]
+    if round:
+        compressed = _round8(compressed)
+    mse = np.mean((original.reshape(b, -1) - compressed.reshape(b, -1)) ** 2, axis=-1)
+    return 20 * np.log10(max_value / np.sqrt(mse))
+
+
+def batch_RMSD(original, compressed, scale_factor):
+    b = original.shape[0]
+    return (((original * scale_factor - compressed * scale_factor) ** 2).reshape(b, -1).mean(-1) * 3) ** 0.5
+
+
+def metric(original, compressed, dataset):
+    if dataset == "cifar":
+        return batch_PSNR(original, compressed, round=True, max_value=1)
+    if dataset in ("kodak", "video"):
+        return PSNR(original, compressed, round=True, max_value=1)
+    if dataset == "audio":
+        return PSNR(original, compressed, round=False, max_value=1)
+    if dataset == "protein":
+        return batch_RMSD(original, compressed, scale_factor=25)
+    raise ValueError(dataset)

@@ -1,0 +1,317 @@
+"""GPU parity tests: every C-ABI kernel against the CPU oracle on seeded inputs (run with -m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN, O, cfg_of, check, load, prior_inputs, regen_noise, t
+
+pytestmark = pytest.mark.gpu
+
+from recombiner_amd import ops  # noqa: E402
+from recombiner_amd.ops import LevelSpec, SirenMeta  # noqa: E402
+
+DEV = "cuda"
+
+
+def g(x):
+    return None if x is None else x.to(DEV).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------
+# SIREN MLP
+# ---------------------------------------------------------------------------------------------------
+def _siren_case(F, E, n_hidden, C, P, N, S, seed):
+    gen = torch.Generator().manual_seed(seed)
+    in0 = F + E
+    dims = [in0] + [32] * n_hidden + [C]
+    D = sum(dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1))
+    xf = torch.rand(P, F, generator=gen) * 2 - 1
+    pe = torch.randn(N * S, P, E, generator=gen) * 0.5
+    # weights with the magnitude the A-transform produces for SIREN-initialised latents
+    wv = (torch.rand(N * S, D, generator=gen) * 2 - 1) * (np.sqrt(6 / 32) / 30) * 3.0
+    y = torch.rand(N, P, C, generator=gen)
+    return dims, D, xf, pe, wv, y
+
+
+def _oracle_mlp(dims, xf, pe, wv, S):
+    """plain fp32 torch: x @ W + b, sin(30 x)  (same layer-vector layout)."""
+    G, P = pe.shape[0], pe.shape[1]
+    x = torch.cat([xf[None].expand(G, -1, -1), pe], -1)
+    lo = 0
+    nl = len(dims) - 1
+    for l in range(nl):
+        n = dims[l + 1] * (dims[l] + 1)
+        v = wv[:, lo:lo + n]
+        b = v[:, :dims[l + 1]].unsqueeze(1)
+        W = v[:, dims[l + 1]:].reshape(G, dims[l], dims[l + 1])
+        x = x @ W + b
+        if l != nl - 1:
+            x = torch.sin(30.0 * x)
+        lo += n
+    return x
+
+
+SIREN_CASES = [
+    dict(F=16, E=16, n_hidden=3, C=3, P=1024, N=3, S=1),     # cifar
+    dict(F=16, E=16, n_hidden=3, C=1, P=800, N=2, S=1),      # audio (P = 25 tiles)
+    dict(F=18, E=16, n_hidden=3, C=3, P=192, N=2, S=1),      # video input width 34
+    dict(F=16, E=16, n_hidden=3, C=3, P=96, N=2, S=5),       # protein, S = 5 samples
+    dict(F=16, E=16, n_hidden=2, C=3, P=100, N=2, S=1),      # ragged P (not a multiple of 32), 2 hidden
+    dict(F=16, E=16, n_hidden=1, C=3, P=64, N=1, S=1),
+    dict(F=16, E=16, n_hidden=4, C=3, P=64, N=1, S=1),
+]
+
+
+@pytest.mark.parametrize("case", SIREN_CASES)
+def test_siren_fwd_bwd_loss(case):
+    S, N, P, C = case["S"], case["N"], case["P"], case["C"]
+    dims, D, xf, pe, wv, y = _siren_case(seed=1, **case)
+    meta = SirenMeta(samples=S, n_pix=P, fourier_dim=case["F"], pe_dim=case["E"], n_hidden=case["n_hidden"], hidden=32,
+                     out_dim=C)
+    assert meta.d_net == D
+    # ---- oracle with autograd
+    pe_r, wv_r = pe.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+    y_ref = _oracle_mlp(dims, xf, pe_r, wv_r, S)
+    tgt = y.repeat_interleave(S, 0)
+    scale = 1.0 / (S * P * C)
+    loss = ((y_ref - tgt) ** 2).sum() * scale
+    loss.backward()
+    # ---- forward
+    y_hip = ops.siren_fwd(g(xf), g(pe), g(wv), meta)
+    assert rel_err(y_hip, y_ref.detach()) < 2e-5
+    # ---- fused loss + backward
+    sse, dw, dpe = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    sse_ref = ((y_ref.detach() - tgt) ** 2).sum((1, 2))
+    assert rel_err(sse, sse_ref) < 2e-5
+    assert rel_err(dw, wv_r.grad) < 1e-4, rel_err(dw, wv_r.grad)
+    assert rel_err(dpe, pe_r.grad) < 1e-4
+    # ---- plain backward with an arbitrary dy
+    gen = torch.Generator().manual_seed(3)
+    dy = torch.randn(N * S, P, C, generator=gen)
+    pe_r.grad = None
+    wv_r.grad = None
+    y_ref2 = _oracle_mlp(dims, xf, pe_r, wv_r, S)
+    y_ref2.backward(dy)
+    dw2, dpe2 = ops.siren_bwd(g(xf), g(pe), g(wv), g(dy), meta)
+    assert rel_err(dw2, wv_r.grad) < 1e-4
+    assert rel_err(dpe2, pe_r.grad) < 1e-4
+    # determinism: two launches give bitwise identical gradients
+    sse_b, dw_b, dpe_b = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
+
+
+def test_siren_per_inr_coordinates_and_strided_rows():
+    """xf given per INR ([N,P,F]) and wvec rows with a padded stride."""
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=64, N=3, S=1)
+    dims, D, xf, pe, wv, y = _siren_case(seed=5, **case)
+    meta = SirenMeta(1, 64, 16, 16, 3, 32, 3)
+    xfn = torch.stack([xf, xf * 0.5, -xf])
+    ref = torch.stack([_oracle_mlp(dims, xfn[i], pe[i:i + 1], wv[i:i + 1], 1)[0] for i in range(3)])
+    wpad = torch.zeros(3, D + 5)
+    wpad[:, :D] = wv
+    y_hip = ops.siren_fwd(g(xfn), g(pe), g(wpad)[:, :D], meta)
+    assert rel_err(y_hip, ref) < 2e-5
+
+
+def test_siren_rejects_bad_arguments():
+    meta = SirenMeta(1, 64, 16, 16, 3, 32, 3)
+    xf = torch.zeros(64, 16, device=DEV)
+    pe = torch.zeros(2, 64, 16, device=DEV)
+    with pytest.raises(ops.RcbError):
+        ops.siren_fwd(xf, pe, torch.zeros(2, 100, device=DEV), meta)             # wrong d_net
+    with pytest.raises(ops.RcbError):
+        ops.siren_fwd(xf.cpu(), pe, torch.zeros(2, meta.d_net, device=DEV), meta)  # CPU tensor: no fallback
+    bad = SirenMeta(1, 64, 16, 16, 3, 48, 3)
+    with pytest.raises(ops.RcbError):
+        ops.siren_fwd(xf, pe, torch.zeros(2, bad.d_net, device=DEV), bad)          # unsupported width
+
+
+# ---------------------------------------------------------------------------------------------------
+# reparam / posterior
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["patch2d", "patch1d", "patch3d", "cifar"])
+def test_reparam_fwd_and_posterior_grads(name):
+    d = load(f"prior_{name}.npz")
+    cfg, geo, n, p, A, up, X, Y, pri = prior_inputs(d)
+    D = geo.d_net
+    S = 3
+    torch.manual_seed(9)
+    noise = O.Noise()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    hl = pr.get("h_loc")
+    hw_ref = O.sample_latent_weights(geo, pr["loc"], O.st(pr["log_scale"]), hl,
+                                     O.st(pr["h_log_scale"]) if hl is not None else None, pr.get("hh_loc"),
+                                     O.st(pr["hh_log_scale"]) if hl is not None else None, S, noise)
+    levels = [LevelSpec(g(p["loc"]), g(p["log_scale"]), D, n)]
+    if geo.patch:
+        m2, m3 = geo.level_maps(n)
+        levels.append(LevelSpec(g(p["h_loc"]), g(p["h_log_scale"]), D, n, row_map=m2.numpy()))
+        levels.append(LevelSpec(g(p["hh_loc"]), g(p["hh_log_scale"]), D, n, row_map=m3.numpy()))
+    eps = [g(e) for e in noise.drawn]
+    out = ops.reparam_fwd(levels, eps, S)
+    assert torch.equal(out.cpu(), hw_ref.detach()), rel_err(out, hw_ref.detach())   # un-fused fp32: bit exact
+    # gradients of sum(out * G) + beta*KL
+    gen = torch.Generator().manual_seed(2)
+    Gm = torch.randn(n, S, D, generator=gen)
+    beta = 0.37
+    keys = [("loc", "log_scale", 0, 1)] + ([("h_loc", "h_log_scale", 4, 5), ("hh_loc", "hh_log_scale", 6, 7)] if geo.patch else [])
+    kl = sum(O.gauss_kl_elem(pr[a], O.st(pr[b]), pri[i], pri[j]).sum() for a, b, i, j in keys)
+    ((hw_ref * Gm).sum() + beta * kl).backward()
+    for lv, (a, b, i, j), e in zip(levels, keys, eps):
+        gl, gs = ops.posterior_bwd(lv, g(pri[i]), g(pri[j]), False, beta, g(Gm), e, S, want_grads=True)
+        assert rel_err(gl, pr[a].grad) < 2e-5
+        assert rel_err(gs, pr[b].grad) < 2e-5
+
+
+def test_adam_matches_torch():
+    gen = torch.Generator().manual_seed(4)
+    p0 = torch.randn(1000, generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4)
+    p = g(p0.clone())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn(1000, generator=gen) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=gen)))
+        ref.grad = gr.clone()
+        opt.step()
+        ops.adam_flat(p, g(gr), m, v, ops.adam_cfg(2e-4, step))
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_posterior_adam_step_matches_autograd_adam():
+    """fused grad + KL + Adam == torch autograd + torch.optim.Adam on the same loss."""
+    gen = torch.Generator().manual_seed(6)
+    n, D, S = 5, 300, 2
+    loc = 0.02 * torch.randn(n, D, generator=gen)
+    ls = -4 + 0.5 * torch.randn(n, D, generator=gen)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    ps = 0.02 + 0.01 * torch.rand(D, generator=gen)
+    eps = torch.randn(n, S, D, generator=gen)
+    Gm = torch.randn(n, S, D, generator=gen) * 1e-3
+    rl, rs = loc.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    opt = torch.optim.Adam([rl, rs], lr=2e-4)
+    dl, ds = g(loc.clone()), g(ls.clone())
+    lv = LevelSpec(dl, ds, D, n)
+    state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+    for step in range(1, 4):
+        out = rl[:, None] + O.st(rs)[:, None] * eps
+        loss = (out * Gm).sum() + 1e-3 * O.gauss_kl_elem(rl, O.st(rs), pl, ps).sum()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ops.posterior_bwd(lv, g(pl), g(ps), False, 1e-3, g(Gm), g(eps), S, adam=ops.adam_cfg(2e-4, step), state=state)
+    np.testing.assert_allclose(dl.cpu().numpy(), rl.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ds.cpu().numpy(), rs.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------
+# KL family, annealing, moments
+# ---------------------------------------------------------------------------------------------------
+def test_gauss_kl_rows_groups_and_beta_update():
+    d = load("test_cifar.npz")
+    loc, ls = t(d, "t_loc"), t(d, "t_log_scale")
+    pl, pls = t(d, "kw_p_loc"), t(d, "kw_p_log_scale")
+    gi = d["G_group_idx"].astype(np.int32)
+    st_, en_ = d["G_start"].astype(np.int32), d["G_end"].astype(np.int32)
+    beta = t(d, "beta_before")
+    rows, groups = ops.gauss_kl(g(loc), g(ls), g(pl), g(pls), True, beta=g(beta), group_idx=g(torch.from_numpy(gi)),
+                                seg_start=g(torch.from_numpy(st_)), seg_end=g(torch.from_numpy(en_)), want_groups=True)
+    np.testing.assert_allclose(groups.cpu().numpy(), d["kls"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(rows.sum().item(), float(d["kl_beta_weighted"]), rtol=2e-5)
+    # unweighted, no segments
+    rows2, _ = ops.gauss_kl(g(loc), g(ls), g(pl), g(pls), True)
+    np.testing.assert_allclose(rows2.cpu().numpy(), d["kls"].sum(1), rtol=2e-5)
+    # beta update from the golden KLs (identical inputs -> identical decisions)
+    b = g(beta.clone())
+    done = torch.zeros_like(b, dtype=torch.uint8)
+    done[0, 3] = 1
+    ops.beta_update(g(torch.from_numpy(d["kls"])), b, done)
+    exp = d["beta_after"].copy()
+    exp[0, 3] = d["beta_before"][0, 3]
+    np.testing.assert_array_equal(b.cpu().numpy(), exp)
+
+
+def test_col_moments_and_kl_colsum():
+    gen = torch.Generator().manual_seed(8)
+    rows, cols = 700, 517
+    loc = 0.3 + 0.02 * torch.randn(rows, cols, generator=gen)
+    ls = -4 + torch.randn(rows, cols, generator=gen)
+    s, m2, sg = ops.col_moments(g(loc), g(ls))
+    np.testing.assert_allclose((s / rows).cpu().numpy(), loc.double().mean(0).numpy(), rtol=1e-9)
+    np.testing.assert_allclose((m2 / (rows - 1)).cpu().numpy(), loc.double().var(0).numpy(), rtol=1e-7)
+    np.testing.assert_allclose((sg / rows).cpu().numpy(), (O.st(ls) ** 2).double().mean(0).numpy(), rtol=1e-5)
+    mu, sig = O.refit_prior(loc, ls)
+    sig_h = torch.sqrt(sg / rows + m2 / (rows - 1)).float().cpu()
+    np.testing.assert_allclose(sig_h.numpy(), sig.numpy(), rtol=1e-5)
+    pl = 0.3 + 0.01 * torch.randn(cols, generator=gen)
+    ps = 0.02 + 0.01 * torch.rand(cols, generator=gen)
+    cs = ops.gauss_kl_colsum(g(loc), g(O.st(ls)), g(pl), g(ps))
+    ref = O.gauss_kl_elem(loc, O.st(ls), pl, ps).double().sum(0)
+    np.testing.assert_allclose(cs.cpu().numpy(), ref.numpy(), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# REC scoring: exact index selection
+# ---------------------------------------------------------------------------------------------------
+def test_rec_score_exact_against_golden_encodes():
+    d = load("test_cifar.npz")
+    loc, ls = t(d, "t_loc"), t(d, "t_log_scale")
+    pl, pls = t(d, "kw_p_loc"), t(d, "kw_p_log_scale")
+    st_, en_ = d["G_start"], d["G_end"]
+    gum = torch.from_numpy(np.load(os.path.join(GOLDEN, "tables", "gumbel_seed42_f64.npy")))
+    enc = d["enc_table"]
+    rows = enc[:, 0].astype(int)
+    grps = enc[:, 1].astype(int)
+    starts = st_[grps]
+    lens = en_[grps] - st_[grps]
+    tables = {}
+    for gl in np.unique(lens):
+        tables[int(gl)] = g(O.sobol_normal_table(int(gl)))
+    scale = O.st(ls)            # identical fp32 inputs for both sides
+    pscale = O.st(pls)
+    # put the first golden encode as job 0 so that its log-weights can be compared too
+    idx, z, best, lw0 = ops.rec_score_argmax(g(loc), g(scale), g(pl), g(pscale), tables, g(gum), rows, starts, lens,
+                                             want_logw0=True)
+    idx = idx.cpu().numpy()
+    assert np.array_equal(idx, enc[:, 2].astype(int)), (idx, enc[:, 2])
+    margins = (best[:, 0] - best[:, 1]).cpu().numpy()
+    np.testing.assert_allclose(margins, enc[:, 3], rtol=1e-6, atol=1e-9)
+    r0, g0 = rows[0], grps[0]
+    np.testing.assert_allclose(lw0[:256].cpu().numpy(), d[f"enc_{r0}_{g0}_lw_head"], rtol=0, atol=2e-6)
+    for b, (r, gr) in enumerate(zip(rows, grps)):
+        zz = z[b, :lens[b]].cpu().numpy()
+        np.testing.assert_allclose(zz, d[f"enc_{r}_{gr}_z"], rtol=1e-15, atol=0)
+
+
+def test_rec_score_batch_vs_oracle_random():
+    """many (row, group) jobs of mixed length against the fp64 oracle: all indices equal."""
+    gen = torch.Generator().manual_seed(10)
+    N, D = 16, 400
+    loc = 0.02 * torch.randn(N, D, generator=gen)
+    scale = 0.002 + 0.004 * torch.rand(N, D, generator=gen)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    ps = 0.015 + 0.01 * torch.rand(D, generator=gen)
+    gum = torch.from_numpy(O.gumbel_table(42))
+    lens_all = [3, 5]
+    tabs_cpu = {3: torch.from_numpy(np.load(os.path.join(GOLDEN, "tables", "sobol_normal_g3_seed42_f32.npy")).astype(np.float64)),
+                5: torch.from_numpy(np.load(os.path.join(GOLDEN, "tables", "sobol_normal_g5_seed42_f32.npy")).astype(np.float64))}
+    jobs = []
+    rs = np.random.RandomState(0)
+    for _ in range(48):
+        gl = lens_all[rs.randint(2)]
+        jobs.append((rs.randint(N), rs.randint(D - gl), gl))
+    jr, js, jg = map(np.array, zip(*jobs))
+    idx, z, best, _ = ops.rec_score_argmax(g(loc), g(scale), g(pl), g(ps), {k: g(v) for k, v in tabs_cpu.items()}, g(gum),
+                                           jr, js, jg)
+    idx = idx.cpu().numpy()
+    for b, (r, s, gl) in enumerate(jobs):
+        i, zi, lw = O.rec_score(tabs_cpu[gl], loc[r, s:s + gl], scale[r, s:s + gl], pl[s:s + gl], ps[s:s + gl], gum)
+        assert idx[b] == i, (b, idx[b], i)
+        np.testing.assert_allclose(z[b, :gl].cpu().numpy(), zi.numpy(), rtol=1e-15)

@@ -1,0 +1,123 @@
+"""GPU parity of the prior-time model (PriorBNNmodel / get_grouping) against reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import O, cfg_of, check, load, prior_inputs, regen_noise, stats_of, t
+
+pytestmark = pytest.mark.gpu
+
+from recombiner_amd import prior_model as PM  # noqa: E402
+
+DEV = "cuda"
+CASES = ["cifar", "protein", "patch2d", "patch1d", "patch3d"]
+
+
+def build(d):
+    cfg = cfg_of(d)
+    n = int(d["n"])
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"],
+                         cfg["pixel_sizes"], cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"],
+                         cfg["patch_nums"], cfg["hierarchical_patch_nums"], random_seed=42, device=DEV)
+    torch.manual_seed(123)
+    lt = PM.LinearTransform(m.dims).to(DEV)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    return cfg, n, m, lt, up
+
+
+def feed(m, eps_list):
+    q = [e.clone() for e in eps_list]
+    m.noise_source = lambda shape: q.pop(0)
+    return q
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_init_forward_kl(name):
+    d = load(f"prior_{name}.npz")
+    cfg, n, m, lt, up = build(d)
+    # A1 / A2 / A3 init parity (CPU generator draws, identical order)
+    assert np.array_equal(m.loc.detach().cpu().numpy(), d["init_loc"])
+    assert np.array_equal(m.lpe_loc.detach().cpu().numpy(), d["init_lpe_loc"])
+    if cfg["patch"]:
+        assert np.array_equal(m.h_loc.detach().cpu().numpy(), d["init_h_loc"])
+        assert np.array_equal(m.hh_loc.detach().cpu().numpy(), d["init_hh_loc"])
+    np.testing.assert_allclose(stats_of([a.cpu() for a in lt.A]), d["A_stats"], rtol=1e-12)
+    np.testing.assert_allclose(stats_of([p.cpu() for p in up.parameters()]), d["up_stats"], rtol=1e-12)
+    _, geo, _, p, A, upo, X, Y, pri = prior_inputs(d)
+    with torch.no_grad():
+        for k in ["log_scale", "lpe_log_scale", "h_log_scale", "hh_log_scale"]:
+            if k in p:
+                getattr(m, k).copy_(p[k].to(DEV))
+    feed(m, regen_noise(d, "fwd_eps"))
+    with torch.no_grad():
+        y = m.forward(X.to(DEV)[None].expand(n, -1, -1), lt, up)
+    check(d, "fwd_yhat", y, rtol=2e-4, atol=2e-5)
+    prg = [None if q is None else q.to(DEV) for q in pri]
+    with torch.no_grad():
+        kl = m.calculate_kl(*prg).item()
+    np.testing.assert_allclose(kl, float(d["kl"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tm", [True, False])
+def test_train_3_steps(name, tm):
+    """fused pipeline == reference autograd + Adam after 3 steps (A8), incl. the shared mappings."""
+    d = load(f"prior_{name}.npz")
+    cfg, n, m, lt, up = build(d)
+    _, geo, _, p, A, upo, X, Y, pri = prior_inputs(d)
+    with torch.no_grad():
+        for k in ["log_scale", "lpe_log_scale", "h_log_scale", "hh_log_scale"]:
+            if k in p:
+                getattr(m, k).copy_(p[k].to(DEV))
+    tag = "tm1" if tm else "tm0"
+    feed(m, regen_noise(d, f"{tag}_eps"))
+    prg = [None if q is None else q.to(DEV) for q in pri]
+    mse, kl, elbo = m.train(3, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *prg, lt, up, 1e-4,
+                            training_mappings=tm)
+    np.testing.assert_allclose([mse, kl], d[f"{tag}_ret"], rtol=2e-4)
+    np.testing.assert_allclose(elbo, d[f"{tag}_elbo"], rtol=2e-4)
+    # Adam moves every parameter by ~lr per step whatever the gradient scale: compare absolutely
+    for k in ["loc", "log_scale", "lpe_loc", "lpe_log_scale", "h_loc", "h_log_scale", "hh_loc", "hh_log_scale"]:
+        if hasattr(m, k):
+            check(d, f"{tag}_{k}", getattr(m, k), rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(lt.A[-1].detach().cpu().numpy(), d[f"{tag}_A3"], rtol=1e-3, atol=3e-5)
+    np.testing.assert_allclose(up.conv3.weight.detach().cpu().numpy(), d[f"{tag}_conv3_w"], rtol=1e-3, atol=3e-5)
+
+
+def test_autograd_path_matches_fused_path():
+    """forward()/calculate_kl() + torch autograd + torch.optim.Adam == train() (same noise)."""
+    d = load("prior_cifar.npz")
+    _, geo, _, p, A, upo, X, Y, pri = prior_inputs(d)
+    prg = [None if q is None else q.to(DEV) for q in pri]
+    res = []
+    for mode in ("fused", "autograd"):
+        cfg, n, m, lt, up = build(d)
+        feed(m, regen_noise(d, "tm1_eps"))
+        x = X.to(DEV)[None].expand(n, -1, -1)
+        y = Y.to(DEV)
+        if mode == "fused":
+            m.train(3, 2e-4, x, y, *prg, lt, up, 1e-4, training_mappings=True)
+        else:
+            opt = torch.optim.Adam(list(m.parameters()) + list(lt.parameters()) + list(up.parameters()), 2e-4)
+            for _ in range(3):
+                yh = m.forward(x, lt, up)
+                loss = torch.mean((yh - y) ** 2) * n + m.calculate_kl(*prg) * 1e-4
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+        res.append([m.loc.detach().clone(), m.log_scale.detach().clone(), m.lpe_loc.detach().clone(),
+                    lt.A[0].detach().clone(), up.conv1.weight.detach().clone()])
+    for a, b in zip(*res):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_get_grouping_matches_golden():
+    d = load("grouping.npz")
+    r = PM.get_grouping(t(d, "g_ql").to(DEV), t(d, "g_qs").to(DEV), t(d, "g_pl").to(DEV), t(d, "g_ps").to(DEV))
+    names = ["group_idx", "start", "end", "group2param", "param2group", "n_groups", "group_kls", "weights"]
+    for k, v in zip(names, r):
+        if k in ("group_kls", "weights"):
+            np.testing.assert_allclose(np.asarray(v), d[f"g_{k}"], rtol=1e-5)
+        else:
+            assert np.array_equal(np.asarray(v), d[f"g_{k}"]), k

@@ -1,0 +1,98 @@
+"""CPU tests of the product's host logic and of the C-ABI library surface (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import O, ROOT, cfg_of, check, load, prior_inputs, regen_noise
+
+from recombiner_amd import _lib, config, ops, utils
+from recombiner_amd import prior_model as PM
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rcb.h")).read()
+    declared = sorted(set(re.findall(r"\b(rcb_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 14
+    assert os.path.exists(_lib.LIB_PATH), "librcb_hip.so not built (python -m recombiner_amd.build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/rcb.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+    assert _lib.load().rcb_version() == 100
+
+
+def test_product_refuses_cpu_tensors():
+    with pytest.raises(_lib.RcbError):
+        ops.softplus_scale(torch.zeros(4))
+
+
+def test_configs_match_reference_presets():
+    for name in ("cifar", "protein"):
+        assert config.configs[name] == cfg_of(load(f"prior_{name}.npz"))
+    assert config.configs["kodak"]["hierarchical_patch_nums"] == {"level2": [4, 4], "level3": [8, 12]}
+    assert config.configs["video"]["layerwise_scale_factors"] == [(6, 4, 4), 2, 2] or \
+        config.configs["video"]["layerwise_scale_factors"] == [[6, 4, 4], 2, 2]
+    assert config.configs["audio"]["patch_nums"] == [60]
+
+
+def test_grouping_host_logic_exact():
+    d = load("grouping.npz")
+    names = ["group_idx", "start", "end", "group2param", "param2group", "n_groups", "group_kls", "weights"]
+    for tag in "abc":
+        r = PM.get_grouping_by_kl(d[f"{tag}_in"].copy())
+        for k, v in zip(names, r):
+            if k in ("group_kls", "weights"):
+                np.testing.assert_allclose(np.asarray(v), d[f"{tag}_{k}"], rtol=1e-6)
+            else:
+                assert np.array_equal(np.asarray(v), d[f"{tag}_{k}"]), (tag, k)
+
+
+def test_metrics_and_synthetic_inputs():
+    d = load("metrics.npz")
+    for ds in ["cifar", "kodak", "video", "audio", "protein"]:
+        np.testing.assert_allclose(np.asarray(utils.metric(d["a"], d["b"], ds)), d["m_" + ds], rtol=1e-6)
+    s = load("synthetic.npz")
+    for name in ["cifar", "audio", "protein"]:
+        X, Y = utils.synthetic_inputs(list(s[f"{name}_pixel_sizes"]), int(s[f"{name}_fourier_dim"]), 2, 3)
+        np.testing.assert_allclose(X.numpy(), s[f"{name}_X"], atol=1e-6)
+        assert Y.shape == (2, X.shape[0], 3) and float(Y.min()) >= 0 and float(Y.max()) < 1
+
+
+@pytest.mark.parametrize("name", ["cifar", "protein", "patch2d", "patch1d", "patch3d"])
+def test_patch_stitching_and_row_maps(name):
+    d = load(f"prior_{name}.npz")
+    cfg, geo, n, p, A, up, X, Y, pri = prior_inputs(d)
+    eps = regen_noise(d, "fwd_eps")
+    lpe = p["lpe_loc"] + O.st(p["lpe_log_scale"]) * eps[0]
+    torch.manual_seed(124)
+    net = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"])
+    with torch.no_grad():
+        pe = utils.map_lpe_to_inr_inputs(net, lpe[None], cfg["latent_dim"], cfg["pixel_sizes"], cfg["upsample_factors"],
+                                         cfg["patch"], cfg["patch_nums"], cfg["data_dim"])[:, 0]
+    check(d, "fwd_pe", pe, rtol=1e-5, atol=1e-6)
+    if cfg["patch"]:
+        m2, m3 = utils.hierarchy_row_maps(n, cfg["patch_nums"], cfg["hierarchical_patch_nums"], cfg["data_dim"])
+        o2, o3 = geo.level_maps(n)
+        assert np.array_equal(m2, o2.numpy()) and np.array_equal(m3, o3.numpy())
+
+
+def test_level_spec_inverse_maps():
+    rows, cols, n = 4, 7, 12
+    rm = np.repeat(np.arange(rows), 3)
+    perm = np.stack([np.random.RandomState(c).permutation(rows) for c in range(cols)], 1)
+    cm = np.random.RandomState(1).permutation(cols)[:5]
+    lv = ops.LevelSpec(torch.zeros(rows, cols), torch.zeros(rows, cols), 5, n, row_map=rm, row_perm=perm, col_map=cm)
+    mp, mi = lv.member_ptr.numpy(), lv.member_idx.numpy()
+    for r in range(rows):
+        assert set(mi[mp[r]:mp[r + 1]]) == set(np.flatnonzero(rm == r))
+    inv = lv.row_perm_inv.numpy()
+    for j in range(cols):
+        assert np.array_equal(perm[inv[:, j], j], np.arange(rows))
+    ci = lv.col_inv.numpy()
+    for dcol, j in enumerate(cm):
+        assert ci[j] == dcol
+    assert (ci[np.setdiff1d(np.arange(cols), cm)] >= 5).all()
