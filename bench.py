@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-datapoint INR training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* is one full training step of PriorBNNmodel.train on one batch of synthetic CIFAR-shaped
+signals per GPU: sample posteriors -> upsample net -> A-transform -> batched SIREN forward, MSE,
+backward -> KL -> Adam for every per-INR parameter and for the shared mappings
+(training_mappings=True, the reference default, main_prior_training.py:114-132).  Workload =
+BASELINE.json configs[1]: CIFAR-10 32x32, 4096 INRs per GPU, 3x32 SIREN.  Datapoints shard across
+GPUs (weak scaling); the only per-step collective is the gradient sum of the shared mappings.
+
+Prints ONE JSON line on rank 0.  `value` = INRs trained per second for the whole job at the
+reference schedule (55 100 Adam steps per INR, main_prior_training.py:106-107,132); the raw
+INR-steps/s is reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_INR = 200 + 549 * 100   # reference schedule
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inrs", type=int, default=4096, help="INRs per GPU")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seconds_target=15.0):
+    """The CPU oracle (op-for-op restatement of the reference, golden-pinned) timed on the host
+    cores on a bounded sample of the same workload: N=256 CIFAR INRs, training_mappings=True."""
+    from oracle import ref_cpu as O
+    from recombiner_amd import utils
+    n = 256
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    geo = O.Geometry.from_config(cfg)
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
+    p = O.init_prior_params(geo, n, seed=42)
+    A = O.make_linear_transform(geo.dims, seed=123)
+    up = O.UpsampleNet(geo.data_dim, geo.paddings, geo.layerwise_scale_factors, seed=124)
+    s0 = 0.0211547
+    lat = geo.latent_grid
+    pri = [torch.zeros(geo.d_net), torch.full((geo.d_net,), s0), torch.zeros(*lat, 128), torch.full((*lat, 128), s0)] + [None] * 4
+    Xn = X[None].repeat(n, 1, 1)
+    O.prior_train(geo, p, Xn, Y, pri, A, up, 1, 2e-4, 1e-8, True, O.Noise())    # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        O.prior_train(geo, p, Xn, Y, pri, A, up, 2, 2e-4, 1e-8, True, O.Noise())
+        steps += 2
+        el = time.perf_counter() - t0
+        if el > seconds_target or steps >= 40:
+            break
+    inr_steps = n * steps / el
+    return {"value": inr_steps / STEPS_PER_INR, "unit": "INRs trained/s", "inr_steps_per_sec": inr_steps,
+            "cores": threads, "kind": "port",
+            "sample": f"oracle prior_train, CIFAR preset, N={n} INRs, {steps} Adam steps, training_mappings=True, "
+                      f"torch CPU fp32, {threads} threads"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from recombiner_amd import config, ops, utils
+    from recombiner_amd import prior_model as PM
+    cfg = config.configs["cifar"]
+    n = a.inrs
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=rank)
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"],
+                         cfg["pixel_sizes"], cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"],
+                         cfg["patch_nums"], cfg["hierarchical_patch_nums"], random_seed=42 + rank, device=dev)
+    m.precision = 1 if a.precision == "bf16" else 0
+    torch.manual_seed(123)
+    lt = PM.LinearTransform(m.dims).to(dev)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(dev)
+    torch.manual_seed(1000 + rank)
+    s0 = 0.0211547
+    D = m._d_net
+    pri = [torch.zeros(D, device=dev), torch.full((D,), s0, device=dev), torch.zeros(2, 2, 128, device=dev),
+           torch.full((2, 2, 128), s0, device=dev), None, None, None, None]
+    Xd = X.to(dev)[None].expand(n, -1, -1)     # one coordinate grid shared by every INR (stride-0 view)
+    Yd = Y.to(dev)
+    tm = not a.frozen_mappings
+
+    def run(k):
+        return m.train(k, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=tm)
+
+    def fence():
+        if ws > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        run(a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(a.steps)
+    fence()
+    el = time.perf_counter() - t0
+    if ws > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        el = float(tt.item())
+
+    # ---- roofline of the hot-path kernel (fused SIREN fwd + MSE + bwd), measured live ----------
+    roof = None
+    if rank == 0:
+        meta = m._meta(Xd, 16)
+        pe = torch.randn(n, 1024, 16, device=dev) * 0.1
+        wv = (torch.rand(n, D, device=dev) * 2 - 1) * 0.02
+        for _ in range(2):
+            ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta)
+        reps = 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record()
+            ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta)
+            e1.record()
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+        dims = m.dims
+        flops = 6.0 * 1024 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n   # fwd + 2x bwd
+        peak = 2500.0 if m.precision == 1 else 157.3
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"kernel": "siren_kernel<MODE_LOSS> (rcb_siren_loss_bwd)", "bound": "mfma", "achieved": round(ach, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "avg_launch_ms": round(ms, 4), "alg_flops_per_launch": flops,
+                "share_of_step": round(ms / (el / a.steps * 1e3), 4)}
+    cpu = None
+    if rank == 0 and ws == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg)
+    if rank == 0:
+        inr_steps = n * ws * a.steps / el
+        out = {"metric": "INRs trained/sec (whole node), CIFAR-10 32x32", "value": inr_steps / STEPS_PER_INR,
+               "unit": "INRs trained/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if m.precision == 0 else "bf16", "data": "synthetic",
+               "inr_steps_per_sec": inr_steps, "steps_per_inr_reference_schedule": STEPS_PER_INR,
+               "config": {"workload": f"CIFAR-10 32x32, {n} INRs/GPU, 3x32 SIREN (in 32 = 16 Fourier + 16 upsampled pe), "
+                                      f"S=1, training_mappings={tm}, Adam lr 2e-4", "inrs_per_gpu": n,
+                          "parallelism": f"datapoint-sharded x{ws}"},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if ws > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

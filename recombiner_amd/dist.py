@@ -1,0 +1,86 @@
+"""Datapoint sharding across GPUs (one process per GPU, torch.distributed; backend "nccl" = RCCL
+over xGMI on ROCm, "gloo" in CPU tests).
+
+The per-INR losses are independent given the shared (A, Upsample, prior), so INRs shard
+embarrassingly: whole datapoints (all patches of an image / clip) stay on one rank.  The only
+cross-INR reductions of the reference are
+  * the closed-form prior refit, main_prior_training.py:157-172  (mean / unbiased var over INRs),
+  * the scalar KL that drives the beta rule, main_prior_training.py:136-154,
+  * the per-parameter mean KL behind get_grouping, prior_model.py:268-270,
+and, only when the shared mappings are trained, the per-step gradient sum of A / Upsample
+(handled inside PriorBNNmodel.train).  Each is a small all-reduce of fp64 sufficient statistics.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+
+def world(group=None) -> Tuple[int, int]:
+    if td.is_available() and td.is_initialized():
+        return td.get_rank(group), td.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(n_datapoints: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block of whole datapoints for `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(n_datapoints, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def merge_moments(count: torch.Tensor, total: torch.Tensor, m2: torch.Tensor, sig2: torch.Tensor, group=None):
+    """Chan et al. pairwise merge of per-shard (n, sum, M2, sum sigma^2) via one all-gather-free
+    all-reduce: with mean_k = sum_k / n_k,
+        N = sum n_k ; S = sum sum_k ; M2 = sum M2_k + sum n_k (mean_k - S/N)^2
+    computed as  sum M2_k + sum sum_k^2 / n_k  -  S^2 / N  in fp64."""
+    rank, ws = world(group)
+    if ws == 1:
+        return count, total, m2, sig2
+    n = count.to(torch.float64).reshape(1).to(total.device)
+    pack = torch.cat([n, total, m2 + total * total / n, sig2])
+    td.all_reduce(pack, group=group)
+    cols = total.numel()
+    N = pack[0]
+    S = pack[1:1 + cols]
+    M2 = pack[1 + cols:1 + 2 * cols] - S * S / N
+    SG = pack[1 + 2 * cols:]
+    return N.reshape(()), S, M2, SG
+
+
+def prior_from_moments(count, total, m2, sig2, out_shape=None):
+    """mu_p = mean(mu_q); sigma_p = sqrt(mean(sigma_q^2) + var_unbiased(mu_q))  (main_prior_training.py:157-172)."""
+    n = float(count)
+    mu = (total / n).to(torch.float32)
+    sig = torch.sqrt(sig2 / n + m2 / (n - 1.0)).to(torch.float32)
+    if out_shape is not None:
+        mu, sig = mu.reshape(out_shape), sig.reshape(out_shape)
+    return mu, sig
+
+
+def refit_prior(loc: torch.Tensor, log_scale: torch.Tensor, group=None):
+    """Prior refit over *all* ranks' INRs for one parameter tensor [rows, ...]."""
+    from . import ops
+    s, m2, sg = ops.col_moments(loc, log_scale)
+    cnt = torch.tensor(float(loc.shape[0]), dtype=torch.float64, device=loc.device)
+    n, s, m2, sg = merge_moments(cnt, s, m2, sg, group)
+    return prior_from_moments(n, s, m2, sg, loc.shape[1:])
+
+
+def allreduce_scalar(v: torch.Tensor, group=None) -> torch.Tensor:
+    rank, ws = world(group)
+    if ws > 1:
+        v = v.clone()
+        td.all_reduce(v, group=group)
+    return v
+
+
+def grouping_weights(kl_colsum: torch.Tensor, n_rows_local: int, group=None) -> np.ndarray:
+    """mean-over-INRs KL in bits per parameter across ranks -> fp32 numpy weights for get_grouping_by_kl."""
+    rank, ws = world(group)
+    pack = torch.cat([kl_colsum.to(torch.float64), torch.tensor([float(n_rows_local)], dtype=torch.float64,
+                                                                device=kl_colsum.device)])
+    if ws > 1:
+        td.all_reduce(pack, group=group)
+    return (pack[:-1] / np.log(2.) / pack[-1]).to(torch.float32).cpu().numpy()

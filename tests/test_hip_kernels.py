@@ -156,7 +156,7 @@ def test_reparam_fwd_and_posterior_grads(name):
         levels.append(LevelSpec(g(p["hh_loc"]), g(p["hh_log_scale"]), D, n, row_map=m3.numpy()))
     eps = [g(e) for e in noise.drawn]
     out = ops.reparam_fwd(levels, eps, S)
-    assert torch.equal(out.cpu(), hw_ref.detach()), rel_err(out, hw_ref.detach())   # un-fused fp32: bit exact
+    assert rel_err(out, hw_ref.detach()) < 1e-6     # un-fused fp32; softplus differs by <= 1 ulp CPU vs GPU
     # gradients of sum(out * G) + beta*KL
     gen = torch.Generator().manual_seed(2)
     Gm = torch.randn(n, S, D, generator=gen)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import O, cfg_of, check, load, prior_inputs, regen_noise, stats_of, t
+from golden_util import O, assert_close_mostly, cfg_of, check, load, prior_inputs, regen_noise, stats_of, t
 
 pytestmark = pytest.mark.gpu
 
@@ -81,8 +81,8 @@ def test_train_3_steps(name, tm):
     for k in ["loc", "log_scale", "lpe_loc", "lpe_log_scale", "h_loc", "h_log_scale", "hh_loc", "hh_log_scale"]:
         if hasattr(m, k):
             check(d, f"{tag}_{k}", getattr(m, k), rtol=1e-4, atol=3e-5)
-    np.testing.assert_allclose(lt.A[-1].detach().cpu().numpy(), d[f"{tag}_A3"], rtol=1e-3, atol=3e-5)
-    np.testing.assert_allclose(up.conv3.weight.detach().cpu().numpy(), d[f"{tag}_conv3_w"], rtol=1e-3, atol=3e-5)
+    assert_close_mostly(lt.A[-1], d[f"{tag}_A3"], rtol=1e-3, atol=3e-5, what="A3")
+    assert_close_mostly(up.conv3.weight, d[f"{tag}_conv3_w"], rtol=1e-3, atol=3e-5, what="conv3")
 
 
 def test_autograd_path_matches_fused_path():
