@@ -47,7 +47,11 @@ def cpu_baseline(cfg, seconds_target=15.0):
     from oracle import ref_cpu as O
     from recombiner_amd import utils
     n = 256
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))      # the GPU box grants 16 host cores per GPU
     torch.set_num_threads(threads)
     geo = O.Geometry.from_config(cfg)
     X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
