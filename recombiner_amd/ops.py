@@ -288,7 +288,9 @@ class GaussKLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loc, log_scale, p_loc, p_scale, p_is_log, beta, group_idx, seg_start, seg_end):
         ctx.save_for_backward(loc, log_scale, p_loc, p_scale)
-        ctx.aux = (p_is_log, beta, group_idx, seg_start, seg_end)
+        # snapshot beta: the annealing step may overwrite it in place between forward and backward,
+        # and the gradient must use the weights the loss was formed with (test_model.py:629-635)
+        ctx.aux = (p_is_log, None if beta is None else beta.clone(), group_idx, seg_start, seg_end)
         rows, _ = gauss_kl(loc, log_scale, p_loc, p_scale, p_is_log, beta, group_idx, seg_start, seg_end)
         return rows.sum().to(f32)
 

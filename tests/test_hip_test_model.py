@@ -1,0 +1,160 @@
+"""GPU parity of the test-time model (TestBNNmodel: predict / KL / annealing / A* coding / training /
+mini end-to-end compression) against reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import DATASET_OF, O, cfg_of, check, level_kwargs, load, regen_noise, regen_noise_per_epoch, t
+
+pytestmark = pytest.mark.gpu
+
+from recombiner_amd import prior_model as PM  # noqa: E402
+from recombiner_amd import test_model as TM   # noqa: E402
+
+DEV = "cuda"
+NAMES = ["cifar", "patch2d", "patch1d"]
+
+
+def build(d, name):
+    cfg = cfg_of(d)
+    n = int(d["n"])
+    torch.manual_seed(123)
+    dims = [cfg["input_dim"]] + cfg["hidden_dims"] + [cfg["output_dim"]]
+    lt = PM.LinearTransform(dims).to(DEV)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    kw = {}
+    for pre in ([""] + (["h_", "hh_"] if cfg["patch"] else [])):
+        k = level_kwargs(d, pre)
+        kw.update({pre + a: b for a, b in k.items()})
+    m = TM.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["upsample_factors"],
+                        cfg["latent_dim"], cfg["data_dim"], cfg["pixel_sizes"], cfg["patch"], cfg["patch_nums"],
+                        cfg["hierarchical_patch_nums"], DATASET_OF[name], linear_transform=lt, upsample_net=up,
+                        device=DEV, initial_beta=1e-5, **kw)
+    return cfg, n, m
+
+
+def set_post(d, cfg, m):
+    with torch.no_grad():
+        m.loc.copy_(t(d, "t_loc").to(DEV))
+        m.log_scale.copy_(t(d, "t_log_scale").to(DEV))
+        if cfg["patch"]:
+            m.h_loc.copy_(t(d, "t_h_loc").to(DEV))
+            m.h_log_scale.copy_(t(d, "t_h_log_scale").to(DEV))
+            m.hh_loc.copy_(t(d, "t_hh_loc").to(DEV))
+            m.hh_log_scale.copy_(t(d, "t_hh_log_scale").to(DEV))
+
+
+def feed(m, eps):
+    q = [e.clone() for e in eps]
+    m.noise_source = lambda kind, shape: q.pop(0)
+
+
+def feed_epochs(m, per_epoch):
+    q = [e.clone() for ep in per_epoch for e in ep]
+    m.noise_source = lambda kind, shape: q.pop(0)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_init_predict_kl_anneal(name):
+    d = load(f"test_{name}.npz")
+    cfg, n, m = build(d, name)
+    np.testing.assert_allclose(m.bpp, float(d["bpp"]), rtol=1e-12)
+    if cfg["patch"]:
+        assert np.array_equal(m.permute_patch_x_g2p, d["perm_x_g2p"].astype(np.int64))
+        assert np.array_equal(m.h_permute_patch_x_g2p, d["h_perm_x_g2p"].astype(np.int64))
+    set_post(d, cfg, m)
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    for S in (1, 5):
+        feed(m, regen_noise(d, f"pred_S{S}_eps"))
+        with torch.no_grad():
+            yp = m.predict(X, random_seed=None, sample_size=S)
+        check(d, f"pred_S{S}", yp, rtol=2e-4, atol=2e-5)
+    with torch.no_grad():
+        np.testing.assert_allclose(m.calculate_kl().item(), float(d["kl_beta_weighted"]), rtol=2e-5)
+    r = m.update_annealing_factors(False)
+    arrs = r if cfg["patch"] else (r,)
+    for a, k in zip(arrs, ["kls", "h_kls", "hh_kls"]):
+        np.testing.assert_allclose(a, d[k], rtol=2e-5, atol=1e-9)
+    np.testing.assert_array_equal(m.kl_beta.cpu().numpy(), d["beta_before"])
+    m.update_annealing_factors(True)
+    got = m.kl_beta.cpu().numpy()
+    # decisions sit on fp32 KLs that differ by ulps between CPU and GPU: allow a vanishing fraction of flips
+    assert (got != d["beta_after"]).mean() < 2e-3
+    if cfg["patch"]:
+        assert (m.h_kl_beta.cpu().numpy() != d["h_beta_after"]).mean() < 2e-3
+        assert (m.hh_kl_beta.cpu().numpy() != d["hh_beta_after"]).mean() < 2e-3
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_sample_group_selects_reference_index(name):
+    d = load(f"test_{name}.npz")
+    cfg, n, m = build(d, name)
+    set_post(d, cfg, m)
+    for row, grp, idx, margin in d["enc_table"]:
+        row, grp = int(row), int(grp)
+        i, z, lw = m.sample_group(row, grp, 65536)
+        # sigma = softplus(log_scale)/6 is evaluated on the GPU here (<= 1 ulp from the CPU value): the
+        # index must agree whenever the reference's top-2 margin is not itself at rounding level
+        if margin > 1e-3:
+            assert i == int(idx), (row, grp, i, idx, margin)
+            np.testing.assert_allclose(z.cpu().numpy(), d[f"enc_{row}_{grp}_z"], rtol=1e-12)
+            np.testing.assert_allclose(lw[:256].cpu().numpy(), d[f"enc_{row}_{grp}_lw_head"], rtol=0, atol=1e-3)
+    if cfg["patch"]:
+        i, z, _ = m.h_sample_group(0, 1, 65536)
+        assert i == int(d["h_enc_0_1"][0])
+        i, z, _ = m.hh_sample_group(0, 2, 65536)
+        assert i == int(d["hh_enc_0_2"][0])
+        np.testing.assert_allclose(z.cpu().numpy(), d["hh_enc_0_2_z"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("path", ["fused", "autograd"])
+def test_train_3_epochs(name, path):
+    d = load(f"test_{name}.npz")
+    cfg, n, m = build(d, name)
+    set_post(d, cfg, m)
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    Y = t(d, "Y").to(DEV)
+    m.update_annealing_factors(True)          # the golden run did this before training
+    feed_epochs(m, regen_noise_per_epoch(d, "train_eps", 3))
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    if path == "autograd":
+        m._fresh = lambda o: False             # force the generic autograd + optimizer.step() path
+    m.train(X, Y, 3, opt, False, sample_size=5)
+    check(d, "train_loc", m.loc, rtol=1e-4, atol=3e-5)
+    check(d, "train_log_scale", m.log_scale, rtol=1e-4, atol=3e-5)
+    assert (np.abs(m.kl_beta.cpu().numpy() - d["train_beta"]) > 1e-6 * d["train_beta"]).mean() < 2e-3
+    if cfg["patch"]:
+        check(d, "train_h_loc", m.h_loc, rtol=1e-4, atol=3e-5)
+        check(d, "train_hh_log_scale", m.hh_log_scale, rtol=1e-4, atol=3e-5)
+
+
+def test_end_to_end_cifar_first_rounds():
+    """optimise 12 epochs, then 6 encode rounds with 2 fine-tune epochs each, with the torch GPU
+    generator replaced by the reference's CPU noise stream; compare encoded indices with the
+    reference run (golden e2e_cifar.npz)."""
+    d = load("test_cifar.npz")
+    e = load("e2e_cifar.npz")
+    cfg, n, m = build(d, "cifar")
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    Y = t(d, "Y").to(DEV)
+    Dt, D = m._l1.D, m._d_net
+
+    def cpu_stream(kind, shape):     # the reference draws on the CPU generator after torch.manual_seed(epoch)
+        return torch.randn(shape)
+    m.noise_source = cpu_stream
+    m.optimize_posteriors(X, Y, n_epochs=12, lr=2e-4, verbose=False)
+    check(e, "opt_loc", m.loc, rtol=1e-4, atol=3e-5)
+    rounds = 6
+    lv = m._l1
+    for r in range(rounds):
+        m._encode_round(lv, True, r)
+        m.train(X, Y, 2, torch.optim.Adam(m.parameters(), lr=2e-4), False)
+    done = lv.mask_groupwise
+    assert done.sum() == rounds * n
+    ref_done = e["idx"] != 0
+    same_groups = (done & ref_done).sum() / done.sum()
+    agree = (lv.idx_groupwise[done] == e["idx"][done]).mean()
+    print("e2e agreement: groups", same_groups, "indices", agree)
+    assert agree >= 0.9, agree
