@@ -1,0 +1,41 @@
+// Declarations shared by the fp32 and bf16 SIREN kernels.
+#pragma once
+#include "rcb_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace rcb {
+
+constexpr int HID = 32;      // hidden width
+constexpr int TS = 36;       // LDS tile row stride in floats (32 + 4 pad: conflict-free b128 reads)
+constexpr int MAXL = 5;      // max linear layers
+
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_LOSS = 2 };
+
+struct SirenArgs {
+  const float* xf;
+  const float* pe;
+  const float* wvec;
+  const float* yin;   // MODE_LOSS: target [N,P,C];  MODE_BWD: dy [G,P,C]
+  float* yout;        // MODE_FWD: [G,P,C]
+  float* sse;         // MODE_LOSS: [G]
+  float* dwvec;       // [G, w_stride]
+  float* dpe;         // [G,P,E] or null
+  long long xf_stride, w_stride;
+  int G, S, P, F, E, C;
+  int dnet, wt_total, tile_base, smem_floats;
+  float k_hi, k_lo;   // w0 / (2 pi) split in two floats
+  float w0, dy_scale;
+};
+
+// row of accumulator register r for lane half h (32x32 MFMA C/D layout)
+__device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+
+int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);
+
+}  // namespace rcb

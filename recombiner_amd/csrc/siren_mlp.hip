@@ -19,38 +19,9 @@
 
 using namespace rcb;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "siren_common.h"
 
 namespace {
-
-constexpr int HID = 32;      // hidden width
-constexpr int TS = 36;       // LDS tile row stride in floats (32 + 4 pad: conflict-free b128 reads)
-constexpr int MAXL = 5;      // max linear layers
-
-enum { MODE_FWD = 0, MODE_BWD = 1, MODE_LOSS = 2 };
-
-struct SirenArgs {
-  const float* xf;
-  const float* pe;
-  const float* wvec;
-  const float* yin;   // MODE_LOSS: target [N,P,C];  MODE_BWD: dy [G,P,C]
-  float* yout;        // MODE_FWD: [G,P,C]
-  float* sse;         // MODE_LOSS: [G]
-  float* dwvec;       // [G, w_stride]
-  float* dpe;         // [G,P,E] or null
-  long long xf_stride, w_stride;
-  int G, S, P, F, E, C;
-  int dnet, wt_total, tile_base, smem_floats;
-  float k_hi, k_lo;   // w0 / (2 pi) split in two floats
-  float w0, dy_scale;
-};
-
-// row of accumulator register r for lane half h (32x32 MFMA C/D layout)
-__device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
 
 // sin / cos of w0*z with a two-float range reduction in revolutions
 template <bool FAST>
@@ -346,6 +317,7 @@ __global__ void __launch_bounds__(256) siren_kernel(SirenArgs a) {
   }
 }
 
+
 template <int NH, int KS0, int NB0, int MODE>
 int launch(const SirenArgs& a, size_t smem_bytes, hipStream_t st) {
   static bool attr_done = false;
@@ -404,7 +376,7 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d->fourier_dim % 2 == 0 && d->pe_dim % 2 == 0, RCB_ERR_UNSUPPORTED, "siren: odd feature dims");
   RCB_REQUIRE(d->n_rows > 0 && d->samples > 0 && d->n_pix > 0 && d->n_rows % d->samples == 0, RCB_ERR_SHAPE,
               "siren: rows=%d samples=%d pix=%d", d->n_rows, d->samples, d->n_pix);
-  RCB_REQUIRE(d->precision == 0, RCB_ERR_UNSUPPORTED, "siren: precision %d not built", d->precision);
+  RCB_REQUIRE(d->precision == 0 || d->precision == 1, RCB_ERR_UNSUPPORTED, "siren: precision %d not built", d->precision);
   memset(&a, 0, sizeof(a));
   a.G = d->n_rows;
   a.S = d->samples;
@@ -433,6 +405,7 @@ extern "C" int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const flo
   a.pe = pe;
   a.wvec = wvec;
   a.yout = y_out;
+  if (d->precision == 1) return siren_bf16_dispatch(MODE_FWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_FWD>(d, a, (hipStream_t)stream);
 }
 
@@ -448,6 +421,7 @@ extern "C" int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const flo
   a.yin = dy;
   a.dwvec = dwvec;
   a.dpe = dpe;
+  if (d->precision == 1) return siren_bf16_dispatch(MODE_BWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_BWD>(d, a, (hipStream_t)stream);
 }
 
@@ -466,5 +440,6 @@ extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, cons
   a.dwvec = dwvec;
   a.dpe = dpe;
   a.dy_scale = dy_scale;
+  if (d->precision == 1) return siren_bf16_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
   return dispatch<MODE_LOSS>(d, a, (hipStream_t)stream);
 }

@@ -1,0 +1,507 @@
+// bf16-operand SIREN kernel: v_mfma_f32_32x32x16_bf16, fp32 accumulate, hardware sin/cos.
+//
+// Same dataflow as the fp32 kernel (siren_mlp.hip): one workgroup per (INR, sample), pixel on the
+// lane, chained 32x32 accumulators so activations never leave registers in the forward and
+// data-gradient chains.  Specifics of this path:
+//   * geometry (F, E, C, hidden layers) is a template parameter: all layer offsets, predicates and
+//     LDS addresses are compile-time, the tile loop has no divergent branch except the tail store;
+//   * one 32x32x16 MFMA consumes 16 k-values; for an accumulator tile used as the next B operand,
+//     k-slot (step s, lane half h, element j) is tile row fk(s,h,j) = 16 s + 8 (j>>2) + 4 h + (j&3),
+//     i.e. registers 8s..8s+7 of the lane, converted pairwise to bf16.  The weight (A) fragments
+//     are pre-swizzled once per INR into LDS in exactly that k order (one ds_read_b128 per MFMA),
+//     for the forward (W^T) and the data-gradient (W) orientation;
+//   * weight gradient (contraction over pixels = lanes): the [pixel][feature] bf16 image of a tile is
+//     written with four 8-byte stores per lane (64-byte rows, XOR-swizzled chunks: conflict-free) and read back
+//     transposed with ds_read_b64_tr_b16 (4 per operand), 2 MFMAs per layer per 32 pixels;
+//   * bias gradients: v_dot2c_f32_bf16 of the transposed dZ fragment against ones;
+//   * sin and cos are kept as packed bf16 (8 VGPRs per layer each).
+#include "siren_common.h"
+
+using namespace rcb;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ constexpr int fk(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+template <int NH, int F, int E, int C>
+struct Geo {
+  static constexpr int NL = NH + 1;
+  static constexpr int IN0 = F + E;
+  static constexpr int K0S = (cmax(F, E) + 7) / 8;
+  static constexpr int NB0 = (IN0 + 31) / 32;
+  static constexpr int NFA = K0S + 2 * NH;
+  static constexpr int NFB = 2 * NH + 1;
+  __host__ __device__ static constexpr int lin(int l) { return l == 0 ? IN0 : HID; }
+  __host__ __device__ static constexpr int lout(int l) { return l == NL - 1 ? C : HID; }
+  __host__ __device__ static constexpr int off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += lout(i) * (lin(i) + 1);
+    return o;
+  }
+  static constexpr int DNET = off(NL);
+  // LDS map (bytes)
+  static constexpr int FR_OFF = ((DNET * 4 + 15) / 16) * 16;
+  static constexpr int TILE_OFF = FR_OFF + (NFA + NFB) * 1024;
+  static constexpr int TSA = 32;                   // bufA row stride (bf16 elements), XOR-swizzled 8-byte chunks
+  static constexpr int TSBB = 32 * NB0;            // bufB row stride
+  static constexpr int WAVE_TILE = 32 * (TSA + TSBB) * 2;   // bytes per wave
+  static constexpr int LDS_MAIN = TILE_OFF + 4 * WAVE_TILE;
+  // cross-wave reduction scratch: per wave, layer l stored [out][in] with row stride 33 (+ bias row)
+  __host__ __device__ static constexpr int roff(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += lout(i) * (32 * (i == 0 ? NB0 : 1) + 1) + 32;
+    return o;
+  }
+  static constexpr int RED_WAVE = roff(NL);
+  static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4);
+};
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sum8_bf16(bf16x8 v, float acc) {
+  const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x2 pr = {v[2 * i], v[2 * i + 1]};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, acc, false);
+  }
+  return acc;
+}
+
+// pack registers 8s..8s+7 of an accumulator tile into the bf16 B-operand of k-step s
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[8 * s + j];
+  return o;
+}
+
+// element offset of feature f of pixel row `pix` in a swizzled [pixel][feature] image: the 8-byte chunk
+// index (f >> 2) has its low 3 bits XORed with (pix >> 1) & 7  -> conflict-free 8-byte row writes
+// (16 consecutive pixels, same chunk) and conflict-free ds_read_b64_tr_b16 (4 rows x 8 chunks)
+__device__ __forceinline__ int swz(int pix, int f, int stride) {
+  const int c = f >> 2;
+  return pix * stride + ((((c & 7) ^ ((pix >> 1) & 7)) | (c & ~7)) << 2) + (f & 3);
+}
+
+// transposed operand read: 8 pixels (16 s + 8 h + 0..7) of feature column (lane & 31) from a
+// [pixel][feature] image with row stride `stride` elements, feature block offset `fcol`
+__device__ __forceinline__ bf16x8 read_tr(const __bf16* img, int stride, int s, int lane, int fcol) {
+  const int h = lane >> 5, fb = (lane >> 4) & 1, i = lane & 15, q4 = i >> 2, p4 = i & 3;
+  union { s16x4 v[2]; bf16x8 b; } u;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const __bf16* ptr = img + swz(16 * s + 8 * h + 4 * w + q4, fcol + 16 * fb + 4 * p4, stride);
+    u.v[w] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  }
+  return u.b;
+}
+
+template <int NH, int F, int E, int C, int MODE>
+__global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
+  using G = Geo<NH, F, E, C>;
+  constexpr int NL = G::NL, IN0 = G::IN0, K0S = G::K0S, NB0 = G::NB0, NFA = G::NFA, NFB = G::NFB, DNET = G::DNET;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int q = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x;
+  const int n = g / a.S;
+  const int P = a.P;
+
+  float* wl = smem;
+  uint4* frags = reinterpret_cast<uint4*>(smem_raw + G::FR_OFF);
+  __bf16* bufA = reinterpret_cast<__bf16*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
+  __bf16* bufB = bufA + 32 * G::TSA;
+
+  // ---- stage weights, build MFMA A-fragments, clear the zero padding of bufB ---------------------
+  {
+    const float* src = a.wvec + (long long)g * a.w_stride;
+    for (int i = tid; i < DNET; i += 256) wl[i] = src[i];
+    if (32 * NB0 > IN0) {
+      for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (__bf16)0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < (NFA + NFB) * 64; e += 256) {
+      const int slot = e >> 6, ln = e & 63;
+      const int fq = ln & 31, fh = ln >> 5;
+      union { bf16x8 v; uint4 u; } fr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float w = 0.f;
+        if (slot < K0S) {
+          int kk = 8 * slot + j;
+          int row = (fh == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
+          if (row >= 0) w = wl[G::off(0) + HID + row * HID + fq];
+        } else if (slot < NFA) {
+          int l = 1 + (slot - K0S) / 2, st = (slot - K0S) & 1;
+          int no = (l == NL - 1) ? C : HID;
+          int o = 0;
+          for (int i = 0; i < l; ++i) o += G::lout(i) * (G::lin(i) + 1);
+          if (fq < no) w = wl[o + no + fk(st, fh, j) * no + fq];
+        } else {
+          int b = slot - NFA;
+          if (b == 0) {
+            int oo = fk(0, fh, j);
+            if (oo < C) w = wl[G::off(NL - 1) + C + fq * C + oo];
+          } else if (b < 1 + 2 * (NH - 1)) {
+            int l = (NH - 1) - (b - 1) / 2, st = (b - 1) & 1;
+            int o = 0;
+            for (int i = 0; i < l; ++i) o += G::lout(i) * (G::lin(i) + 1);
+            w = wl[o + HID + fq * HID + fk(st, fh, j)];
+          } else {
+            int st = (b - 1 - 2 * (NH - 1));
+            if (fq < E) w = wl[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
+          }
+        }
+        fr.v[j] = (__bf16)w;
+      }
+      frags[e] = fr.u;
+    }
+    __syncthreads();
+  }
+  auto FA = [&](int slot) -> bf16x8 {
+    union { bf16x8 v; uint4 u; } fr;
+    fr.u = frags[slot * 64 + lane];
+    return fr.v;
+  };
+
+  f32x16 gW[NL + NB0 - 1];
+  float gb[NL];
+  float sse_local = 0.f;
+  if (MODE != MODE_FWD) {
+#pragma unroll
+    for (int i = 0; i < NL + NB0 - 1; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gW[i][r] = 0.f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) gb[l] = 0.f;
+  }
+  const float kk0 = a.k_hi;
+  const float w0 = a.w0;
+  constexpr int KH0 = F, KH1 = E;
+
+  const int ntiles = (P + 31) >> 5;
+  constexpr bool VEC4 = (F % 4 == 0) && (E % 4 == 0) && (F % 8 == 0) && (E % 8 == 0);
+  // raw fp32 input rows of the NEXT tile are fetched while the current tile computes (HBM/L2 latency
+  // is otherwise exposed at only 2 waves per SIMD)
+  float4 raw[2 * K0S];
+  auto fetch = [&](int tile) {
+    const int pp = tile * 32 + q;
+    const int pcl = pp < P ? pp : P - 1;
+    const float* src = (h == 0) ? (a.xf + (long long)n * a.xf_stride + (long long)pcl * F)
+                                : (a.pe + ((long long)g * P + pcl) * E);
+    const int kh = (h == 0) ? KH0 : KH1;
+#pragma unroll
+    for (int s = 0; s < K0S; ++s) {
+      if (VEC4) {
+        if (8 * s + 8 <= kh) {
+          raw[2 * s] = *reinterpret_cast<const float4*>(src + 8 * s);
+          raw[2 * s + 1] = *reinterpret_cast<const float4*>(src + 8 * s + 4);
+        } else {
+          raw[2 * s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          raw[2 * s + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          float2 w2 = make_float2(0.f, 0.f);
+          if (8 * s + j + 1 < kh) w2 = *reinterpret_cast<const float2*>(src + 8 * s + j);
+          v[j] = w2.x;
+          v[j + 1] = w2.y;
+        }
+        raw[2 * s] = make_float4(v[0], v[1], v[2], v[3]);
+        raw[2 * s + 1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+  };
+  if (wave < ntiles) fetch(wave);
+  for (int t = wave; t < ntiles; t += 4) {
+    const int p = t * 32 + q;
+    const bool valid = p < P;
+    const int pc = valid ? p : P - 1;                       // clamped: loads never leave the arrays
+    // ---- layer-0 input fragments (from the prefetched rows), then prefetch the next tile -------------
+    bf16x8 xin[K0S];
+#pragma unroll
+    for (int s = 0; s < K0S; ++s) {
+      const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
+      xin[s][0] = (__bf16)v0.x; xin[s][1] = (__bf16)v0.y; xin[s][2] = (__bf16)v0.z; xin[s][3] = (__bf16)v0.w;
+      xin[s][4] = (__bf16)v1.x; xin[s][5] = (__bf16)v1.y; xin[s][6] = (__bf16)v1.z; xin[s][7] = (__bf16)v1.w;
+    }
+    fetch(t + 4 < ntiles ? t + 4 : t);
+    // targets / upstream gradient of this tile, issued early
+    float yv[16];
+    if (MODE != MODE_FWD) {
+      const long long ybase = ((MODE == MODE_LOSS ? (long long)n : (long long)g) * P + pc) * C;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        yv[r] = 0.f;
+        if (rho(r, 0) < C || rho(r, 1) < C) {
+          const int row = rho(r, h);
+          yv[r] = a.yin[ybase + (row < C ? row : 0)];
+        }
+      }
+    }
+    // ---- forward ----------------------------------------------------------------------------------
+    bf16x8 S[NH][2], Cs[NH][2];
+    f32x16 acc;
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+      const float* Bl = wl + G::off(l);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = Bl[rho(r, h)];
+      if (l == 0) {
+#pragma unroll
+        for (int s = 0; s < K0S; ++s) acc = mfma16(FA(s), xin[s], acc);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = mfma16(FA(K0S + 2 * (l - 1) + s), S[l - 1][s], acc);
+      }
+      f32x16 sv, cv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float tt = acc[r] * kk0;
+        tt = tt - rintf(tt);
+        sv[r] = __builtin_amdgcn_sinf(tt);
+        cv[r] = __builtin_amdgcn_cosf(tt);
+      }
+      S[l][0] = pack8(sv, 0);
+      S[l][1] = pack8(sv, 1);
+      if (MODE != MODE_FWD) {
+        Cs[l][0] = pack8(cv, 0);
+        Cs[l][1] = pack8(cv, 1);
+      }
+    }
+    {
+      const float* Bl = wl + G::off(NL - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] : 0.f) : 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc = mfma16(FA(K0S + 2 * (NH - 1) + s), S[NH - 1][s], acc);
+    }
+    if (MODE == MODE_FWD) {
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (rho(r, 0) < C || rho(r, 1) < C) {
+            int row = rho(r, h);
+            if (row < C) a.yout[((long long)g * P + p) * C + row] = acc[r];
+          }
+        }
+      }
+      continue;
+    }
+    // ---- output gradient (branch-free: selects on the prefetched targets) ---------------------------------
+    f32x16 dz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = 0.f;
+      if (rho(r, 0) < C || rho(r, 1) < C) {
+        const bool ok = valid && rho(r, h) < C;
+        if (MODE == MODE_LOSS) {
+          float diff = ok ? (acc[r] - yv[r]) : 0.f;
+          sse_local += diff * diff;
+          v = 2.0f * a.dy_scale * diff;
+        } else {
+          v = ok ? yv[r] : 0.f;
+        }
+      }
+      dz[r] = v;
+    }
+    // ---- backward ----------------------------------------------------------------------------------
+#pragma unroll
+    for (int l = NL - 1; l >= 0; --l) {
+      bf16x8 dzb[2] = {pack8(dz, 0), pack8(dz, 1)};
+      // (1) weight gradient: [pixel][feature] images -> transposed reads
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      {
+        union { bf16x8 v; bf16x4 hlf[2]; } u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u.v = dzb[s];
+          *reinterpret_cast<bf16x4*>(bufA + swz(q, 16 * s + 4 * h, G::TSA)) = u.hlf[0];
+          *reinterpret_cast<bf16x4*>(bufA + swz(q, 16 * s + 8 + 4 * h, G::TSA)) = u.hlf[1];
+        }
+        if (l > 0) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            u.v = S[l - 1][s];
+            *reinterpret_cast<bf16x4*>(bufB + swz(q, 16 * s + 4 * h, G::TSBB)) = u.hlf[0];
+            *reinterpret_cast<bf16x4*>(bufB + swz(q, 16 * s + 8 + 4 * h, G::TSBB)) = u.hlf[1];
+          }
+        } else {
+          // input image: half-wave 0 holds features [0,F), half-wave 1 features [F, F+E)
+          const int base = (h == 0) ? 0 : F;
+          const int kh = (h == 0) ? KH0 : KH1;
+#pragma unroll
+          for (int s = 0; s < K0S; ++s) {
+            union { bf16x8 v; bf16x2 pr[4]; bf16x4 hlf[2]; } x;
+            x.v = xin[s];
+            if (F % 4 == 0 && E % 4 == 0) {
+              if (8 * s + 4 <= kh) *reinterpret_cast<bf16x4*>(bufB + swz(q, base + 8 * s, G::TSBB)) = x.hlf[0];
+              if (8 * s + 8 <= kh) *reinterpret_cast<bf16x4*>(bufB + swz(q, base + 8 * s + 4, G::TSBB)) = x.hlf[1];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; j += 2)
+                if (8 * s + j + 1 < kh) *reinterpret_cast<bf16x2*>(bufB + swz(q, base + 8 * s + j, G::TSBB)) = x.pr[j >> 1];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      {
+        bf16x8 av[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) av[s] = read_tr(bufA, G::TSA, s, lane, 0);
+        gb[l] = sum8_bf16(av[0], gb[l]);
+        gb[l] = sum8_bf16(av[1], gb[l]);
+#pragma unroll
+        for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
+          const int gi = (l == 0) ? blk : (l + NB0 - 1);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) gW[gi] = mfma16(av[s], read_tr(bufB, G::TSBB, s, lane, 32 * blk), gW[gi]);
+        }
+      }
+      // (2) data gradient
+      if (l > 0) {
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+        if (l == NL - 1) {
+          dh = mfma16(FA(NFA + 0), dzb[0], dh);
+        } else {
+          constexpr int dummy = 0;
+          const int base = NFA + 1 + 2 * ((NH - 1) - l);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) dh = mfma16(FA(base + s), dzb[s], dh);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (w0 * (float)Cs[l - 1][r >> 3][r & 7]);
+      } else if (a.dpe != nullptr) {
+        f32x16 dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+        const int base = NFA + 1 + 2 * (NH - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dx = mfma16(FA(base + s), dzb[s], dx);
+        if (valid) {
+          float* dst = a.dpe + ((long long)g * P + p) * E;
+          if (E % 8 == 0) {
+#pragma unroll
+            for (int g4 = 0; g4 < E / 8; ++g4)
+              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4], dx[4 * g4 + 1], dx[4 * g4 + 2], dx[4 * g4 + 3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              int e = rho(r, h);
+              if (e < E) dst[e] = dx[r];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == MODE_FWD) return;
+
+  // ---- deterministic cross-wave reduction of the weight gradients -------------------------------------
+  // per wave scratch: layer l as [out o][in i] rows of stride (32*NBl + 1) (conflict-free for the
+  // lane = i writes and for the o-fastest reads below), followed by 32 bias slots
+  __syncthreads();
+  float* part = smem + wave * G::RED_WAVE;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int no = G::lout(l), ro = G::roff(l);
+    const int rs = 32 * ((l == 0) ? NB0 : 1) + 1;
+    float bt = gb[l] + __shfl_xor(gb[l], 32, 64);
+    if (h == 0) part[ro + no * rs + q] = bt;
+#pragma unroll
+    for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
+      const int gi = (l == 0) ? blk : (l + NB0 - 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rho(r, 0) < no || rho(r, 1) < no) {
+          int o = rho(r, h);
+          if (o < no) part[ro + o * rs + 32 * blk + q] = gW[gi][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float* dst = a.dwvec + (long long)g * a.w_stride;
+    for (int idx = tid; idx < DNET; idx += 256) {
+      int l = 0;
+#pragma unroll
+      for (int k = 1; k < NL; ++k) l += (idx >= G::off(k)) ? 1 : 0;
+      int ol = 0, no = 0, ro = 0, rs = 0;
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        if (k == l) { ol = G::off(k); no = G::lout(k); ro = G::roff(k); rs = 32 * ((k == 0) ? NB0 : 1) + 1; }
+      const int e = idx - ol;
+      int src;
+      if (e < no) {
+        src = ro + no * rs + e;                 // bias
+      } else {
+        const int i = (e - no) / no, o = (e - no) - i * no;
+        src = ro + o * rs + i;
+      }
+      dst[idx] = ((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src];
+    }
+  }
+  if (MODE == MODE_LOSS) {
+    float v = wave_sum(sse_local);
+    __syncthreads();
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    if (tid == 0) a.sse[g] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
+  }
+}
+
+template <int NH, int F, int E, int C, int MODE>
+int launch_one(const SirenArgs& a, hipStream_t st) {
+  using G = Geo<NH, F, E, C>;
+  static bool attr_done = false;
+  auto kfn = siren_bf16_kernel<NH, F, E, C, MODE>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return fail((int)e, "siren(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  kfn<<<a.G, 256, G::LDS_BYTES, st>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+template <int NH, int F, int E, int C>
+int launch_mode(int mode, const SirenArgs& a, hipStream_t st) {
+  if (mode == MODE_FWD) return launch_one<NH, F, E, C, MODE_FWD>(a, st);
+  if (mode == MODE_BWD) return launch_one<NH, F, E, C, MODE_BWD>(a, st);
+  return launch_one<NH, F, E, C, MODE_LOSS>(a, st);
+}
+
+}  // namespace
+
+namespace rcb {
+int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
+#define RCB_CASE(NHv, Fv, Ev, Cv) \
+  if (d->n_hidden == NHv && d->fourier_dim == Fv && d->pe_dim == Ev && d->out_dim == Cv) return launch_mode<NHv, Fv, Ev, Cv>(mode, a, st);
+  RCB_CASE(3, 16, 16, 3)   // cifar / kodak / protein
+  RCB_CASE(3, 16, 16, 1)   // audio
+  RCB_CASE(3, 18, 16, 3)   // video
+  RCB_CASE(2, 16, 16, 3)   // 2 hidden layers
+#undef RCB_CASE
+  return fail(RCB_ERR_UNSUPPORTED, "siren(bf16): geometry n_hidden=%d F=%d E=%d C=%d is not instantiated", d->n_hidden,
+              d->fourier_dim, d->pe_dim, d->out_dim);
+}
+}  // namespace rcb

@@ -107,6 +107,30 @@ def test_siren_fwd_bwd_loss(case):
     assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
 
 
+@pytest.mark.parametrize("case", [SIREN_CASES[0], SIREN_CASES[1], SIREN_CASES[2], SIREN_CASES[3], SIREN_CASES[4]])
+def test_siren_bf16_operands(case):
+    """bf16-operand / fp32-accumulate MFMA path against the fp32 oracle: bounded relative error
+    (operands carry 8 mantissa bits; accumulation, biases, loss and reductions are fp32)."""
+    S, N, P, C = case["S"], case["N"], case["P"], case["C"]
+    dims, D, xf, pe, wv, y = _siren_case(seed=1, **case)
+    meta = SirenMeta(samples=S, n_pix=P, fourier_dim=case["F"], pe_dim=case["E"], n_hidden=case["n_hidden"], hidden=32,
+                     out_dim=C, precision=1)
+    pe_r, wv_r = pe.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+    y_ref = _oracle_mlp(dims, xf, pe_r, wv_r, S)
+    tgt = y.repeat_interleave(S, 0)
+    scale = 1.0 / (S * P * C)
+    (((y_ref - tgt) ** 2).sum() * scale).backward()
+    y_hip = ops.siren_fwd(g(xf), g(pe), g(wv), meta)
+    sse, dw, dpe = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    e_y, e_w, e_p = rel_err(y_hip, y_ref.detach()), rel_err(dw, wv_r.grad), rel_err(dpe, pe_r.grad)
+    e_s = rel_err(sse, ((y_ref.detach() - tgt) ** 2).sum((1, 2)))
+    print("bf16 rel err: y %.2e  sse %.2e  dW %.2e  dpe %.2e" % (e_y, e_s, e_w, e_p))
+    # the test weights are 3x the SIREN init scale (phases up to ~10 rad), a stress case for 8-bit mantissas
+    assert e_y < 0.12 and e_s < 1e-2 and e_w < 0.12 and e_p < 0.15
+    sse_b, dw_b, dpe_b = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
+
+
 def test_siren_per_inr_coordinates_and_strided_rows():
     """xf given per INR ([N,P,F]) and wvec rows with a padded stride."""
     case = dict(F=16, E=16, n_hidden=3, C=3, P=64, N=3, S=1)
