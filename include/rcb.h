@@ -45,7 +45,8 @@ const char* rcb_last_error_string(void);
  * (prior_model.py:125-126); rows are w_row_stride floats apart.  G = N*S; sample s of INR n is
  * row g = n*S + s; targets / xf are indexed by n = g / S.
  * Hidden width must be 32, 1..4 hidden layers, out_dim <= 32, F + E <= 64.
- * precision: 0 = fp32 MFMA (exact fp32 products), 1 = bf16 operands / fp32 accumulate.
+ * precision: 0 = fp32 MFMA (exact fp32 products); 1 = bf16 operands, 2 = f16 operands (both fp32 accumulate;
+ * f16 carries gradients scaled by 2^10 internally).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int32_t n_rows;        /* G = N * S workgroups                                   */

@@ -376,7 +376,7 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d->fourier_dim % 2 == 0 && d->pe_dim % 2 == 0, RCB_ERR_UNSUPPORTED, "siren: odd feature dims");
   RCB_REQUIRE(d->n_rows > 0 && d->samples > 0 && d->n_pix > 0 && d->n_rows % d->samples == 0, RCB_ERR_SHAPE,
               "siren: rows=%d samples=%d pix=%d", d->n_rows, d->samples, d->n_pix);
-  RCB_REQUIRE(d->precision == 0 || d->precision == 1, RCB_ERR_UNSUPPORTED, "siren: precision %d not built", d->precision);
+  RCB_REQUIRE(d->precision >= 0 && d->precision <= 2, RCB_ERR_UNSUPPORTED, "siren: precision %d not built", d->precision);
   memset(&a, 0, sizeof(a));
   a.G = d->n_rows;
   a.S = d->samples;
@@ -405,7 +405,7 @@ extern "C" int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const flo
   a.pe = pe;
   a.wvec = wvec;
   a.yout = y_out;
-  if (d->precision == 1) return siren_bf16_dispatch(MODE_FWD, d, a, (hipStream_t)stream);
+  if (d->precision >= 1) return siren_bf16_dispatch(MODE_FWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_FWD>(d, a, (hipStream_t)stream);
 }
 
@@ -421,7 +421,7 @@ extern "C" int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const flo
   a.yin = dy;
   a.dwvec = dwvec;
   a.dpe = dpe;
-  if (d->precision == 1) return siren_bf16_dispatch(MODE_BWD, d, a, (hipStream_t)stream);
+  if (d->precision >= 1) return siren_bf16_dispatch(MODE_BWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_BWD>(d, a, (hipStream_t)stream);
 }
 
@@ -440,6 +440,6 @@ extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, cons
   a.dwvec = dwvec;
   a.dpe = dpe;
   a.dy_scale = dy_scale;
-  if (d->precision == 1) return siren_bf16_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
+  if (d->precision >= 1) return siren_bf16_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
   return dispatch<MODE_LOSS>(d, a, (hipStream_t)stream);
 }

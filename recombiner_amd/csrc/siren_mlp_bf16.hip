@@ -19,10 +19,31 @@
 
 using namespace rcb;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// 16-bit operand traits: bf16 (8-bit mantissa) or f16 (11-bit mantissa, gradients pre-scaled by 2^10
+// so that they stay in f16's normal range; everything downstream is linear in them and unscaled in fp32)
+template <typename T> struct Op16;
+template <> struct Op16<__bf16> {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr float GRAD_SCALE = 1.0f;
+  static constexpr float W_SCALE = 1.0f;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float dot2(v2 a, v2 b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+};
+template <> struct Op16<_Float16> {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr float GRAD_SCALE = 1024.0f;
+  // effective INR weights (h_w @ A) are ~1e-4: scaled by 2^10 into f16's normal range; the factor is
+  // folded into the sine argument / cosine multipliers, biases are pre-scaled in the accumulator
+  static constexpr float W_SCALE = 1024.0f;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float dot2(v2 a, v2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+};
 
 namespace {
 
@@ -62,25 +83,23 @@ struct Geo {
   static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4);
 };
 
-__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float sum8_bf16(bf16x8 v, float acc) {
-  const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+template <typename T>
+__device__ __forceinline__ float sum8_16(typename Op16<T>::v8 v, float acc) {
+  const typename Op16<T>::v2 ones = {(T)1.0f, (T)1.0f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    bf16x2 pr = {v[2 * i], v[2 * i + 1]};
-    acc = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, acc, false);
+    typename Op16<T>::v2 pr = {v[2 * i], v[2 * i + 1]};
+    acc = Op16<T>::dot2(pr, ones, acc);
   }
   return acc;
 }
 
-// pack registers 8s..8s+7 of an accumulator tile into the bf16 B-operand of k-step s
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
-  bf16x8 o;
+// pack registers 8s..8s+7 of an accumulator tile into the 16-bit B-operand of k-step s
+template <typename T>
+__device__ __forceinline__ typename Op16<T>::v8 pack8(const f32x16& v, int s) {
+  typename Op16<T>::v8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[8 * s + j];
+  for (int j = 0; j < 8; ++j) o[j] = (T)v[8 * s + j];
   return o;
 }
 
@@ -94,20 +113,26 @@ __device__ __forceinline__ int swz(int pix, int f, int stride) {
 
 // transposed operand read: 8 pixels (16 s + 8 h + 0..7) of feature column (lane & 31) from a
 // [pixel][feature] image with row stride `stride` elements, feature block offset `fcol`
-__device__ __forceinline__ bf16x8 read_tr(const __bf16* img, int stride, int s, int lane, int fcol) {
+template <typename T>
+__device__ __forceinline__ typename Op16<T>::v8 read_tr(const T* img, int stride, int s, int lane, int fcol) {
   const int h = lane >> 5, fb = (lane >> 4) & 1, i = lane & 15, q4 = i >> 2, p4 = i & 3;
-  union { s16x4 v[2]; bf16x8 b; } u;
+  union { s16x4 v[2]; typename Op16<T>::v8 b; } u;
 #pragma unroll
   for (int w = 0; w < 2; ++w) {
-    const __bf16* ptr = img + swz(16 * s + 8 * h + 4 * w + q4, fcol + 16 * fb + 4 * p4, stride);
+    const T* ptr = img + swz(16 * s + 8 * h + 4 * w + q4, fcol + 16 * fb + 4 * p4, stride);
     u.v[w] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
   }
   return u.b;
 }
 
-template <int NH, int F, int E, int C, int MODE>
+template <typename T, int NH, int F, int E, int C, int MODE>
 __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   using G = Geo<NH, F, E, C>;
+  using bf16x8 = typename Op16<T>::v8;
+  using bf16x4 = typename Op16<T>::v4;
+  using bf16x2 = typename Op16<T>::v2;
+  constexpr float GS = Op16<T>::GRAD_SCALE;
+  constexpr float WS = Op16<T>::W_SCALE;
   constexpr int NL = G::NL, IN0 = G::IN0, K0S = G::K0S, NB0 = G::NB0, NFA = G::NFA, NFB = G::NFB, DNET = G::DNET;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
@@ -120,15 +145,15 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 
   float* wl = smem;
   uint4* frags = reinterpret_cast<uint4*>(smem_raw + G::FR_OFF);
-  __bf16* bufA = reinterpret_cast<__bf16*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
-  __bf16* bufB = bufA + 32 * G::TSA;
+  T* bufA = reinterpret_cast<T*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
+  T* bufB = bufA + 32 * G::TSA;
 
   // ---- stage weights, build MFMA A-fragments, clear the zero padding of bufB ---------------------
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
     for (int i = tid; i < DNET; i += 256) wl[i] = src[i];
     if (32 * NB0 > IN0) {
-      for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (__bf16)0.f;
+      for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
     }
     __syncthreads();
     for (int e = tid; e < (NFA + NFB) * 64; e += 256) {
@@ -163,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
             if (fq < E) w = wl[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
           }
         }
-        fr.v[j] = (__bf16)w;
+        fr.v[j] = (T)(w * WS);
       }
       frags[e] = fr.u;
     }
@@ -186,8 +211,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) gb[l] = 0.f;
   }
-  const float kk0 = a.k_hi;
-  const float w0 = a.w0;
+  const float kk0 = a.k_hi * (1.0f / WS);
+  const float w0 = a.w0 * (1.0f / WS);
   constexpr int KH0 = F, KH1 = E;
 
   const int ntiles = (P + 31) >> 5;
@@ -235,8 +260,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #pragma unroll
     for (int s = 0; s < K0S; ++s) {
       const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
-      xin[s][0] = (__bf16)v0.x; xin[s][1] = (__bf16)v0.y; xin[s][2] = (__bf16)v0.z; xin[s][3] = (__bf16)v0.w;
-      xin[s][4] = (__bf16)v1.x; xin[s][5] = (__bf16)v1.y; xin[s][6] = (__bf16)v1.z; xin[s][7] = (__bf16)v1.w;
+      xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
+      xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
     }
     fetch(t + 4 < ntiles ? t + 4 : t);
     // targets / upstream gradient of this tile, issued early
@@ -259,13 +284,13 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     for (int l = 0; l < NH; ++l) {
       const float* Bl = wl + G::off(l);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = Bl[rho(r, h)];
+      for (int r = 0; r < 16; ++r) acc[r] = Bl[rho(r, h)] * WS;
       if (l == 0) {
 #pragma unroll
-        for (int s = 0; s < K0S; ++s) acc = mfma16(FA(s), xin[s], acc);
+        for (int s = 0; s < K0S; ++s) acc = Op16<T>::mfma(FA(s), xin[s], acc);
       } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc = mfma16(FA(K0S + 2 * (l - 1) + s), S[l - 1][s], acc);
+        for (int s = 0; s < 2; ++s) acc = Op16<T>::mfma(FA(K0S + 2 * (l - 1) + s), S[l - 1][s], acc);
       }
       f32x16 sv, cv;
 #pragma unroll
@@ -275,19 +300,24 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         sv[r] = __builtin_amdgcn_sinf(tt);
         cv[r] = __builtin_amdgcn_cosf(tt);
       }
-      S[l][0] = pack8(sv, 0);
-      S[l][1] = pack8(sv, 1);
+      S[l][0] = pack8<T>(sv, 0);
+      S[l][1] = pack8<T>(sv, 1);
       if (MODE != MODE_FWD) {
-        Cs[l][0] = pack8(cv, 0);
-        Cs[l][1] = pack8(cv, 1);
+        Cs[l][0] = pack8<T>(cv, 0);
+        Cs[l][1] = pack8<T>(cv, 1);
       }
     }
     {
       const float* Bl = wl + G::off(NL - 1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] : 0.f) : 0.f;
+      for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] * WS : 0.f) : 0.f;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acc = mfma16(FA(K0S + 2 * (NH - 1) + s), S[NH - 1][s], acc);
+      for (int s = 0; s < 2; ++s) acc = Op16<T>::mfma(FA(K0S + 2 * (NH - 1) + s), S[NH - 1][s], acc);
+      if (WS != 1.0f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rho(r, 0) < C || rho(r, 1) < C) acc[r] *= (1.0f / WS);
+      }
     }
     if (MODE == MODE_FWD) {
       if (valid) {
@@ -311,9 +341,9 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         if (MODE == MODE_LOSS) {
           float diff = ok ? (acc[r] - yv[r]) : 0.f;
           sse_local += diff * diff;
-          v = 2.0f * a.dy_scale * diff;
+          v = (2.0f * GS) * a.dy_scale * diff;
         } else {
-          v = ok ? yv[r] : 0.f;
+          v = ok ? yv[r] * GS : 0.f;
         }
       }
       dz[r] = v;
@@ -321,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     // ---- backward ----------------------------------------------------------------------------------
 #pragma unroll
     for (int l = NL - 1; l >= 0; --l) {
-      bf16x8 dzb[2] = {pack8(dz, 0), pack8(dz, 1)};
+      bf16x8 dzb[2] = {pack8<T>(dz, 0), pack8<T>(dz, 1)};
       // (1) weight gradient: [pixel][feature] images -> transposed reads
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       {
@@ -362,14 +392,14 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       {
         bf16x8 av[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) av[s] = read_tr(bufA, G::TSA, s, lane, 0);
-        gb[l] = sum8_bf16(av[0], gb[l]);
-        gb[l] = sum8_bf16(av[1], gb[l]);
+        for (int s = 0; s < 2; ++s) av[s] = read_tr<T>(bufA, G::TSA, s, lane, 0);
+        gb[l] = sum8_16<T>(av[0], gb[l]);
+        gb[l] = sum8_16<T>(av[1], gb[l]);
 #pragma unroll
         for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
           const int gi = (l == 0) ? blk : (l + NB0 - 1);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) gW[gi] = mfma16(av[s], read_tr(bufB, G::TSBB, s, lane, 32 * blk), gW[gi]);
+          for (int s = 0; s < 2; ++s) gW[gi] = Op16<T>::mfma(av[s], read_tr<T>(bufB, G::TSBB, s, lane, 32 * blk), gW[gi]);
         }
       }
       // (2) data gradient
@@ -378,12 +408,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = 0.f;
         if (l == NL - 1) {
-          dh = mfma16(FA(NFA + 0), dzb[0], dh);
+          dh = Op16<T>::mfma(FA(NFA + 0), dzb[0], dh);
         } else {
           constexpr int dummy = 0;
           const int base = NFA + 1 + 2 * ((NH - 1) - l);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) dh = mfma16(FA(base + s), dzb[s], dh);
+          for (int s = 0; s < 2; ++s) dh = Op16<T>::mfma(FA(base + s), dzb[s], dh);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (w0 * (float)Cs[l - 1][r >> 3][r & 7]);
@@ -393,18 +423,19 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         for (int r = 0; r < 16; ++r) dx[r] = 0.f;
         const int base = NFA + 1 + 2 * (NH - 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) dx = mfma16(FA(base + s), dzb[s], dx);
+        for (int s = 0; s < 2; ++s) dx = Op16<T>::mfma(FA(base + s), dzb[s], dx);
         if (valid) {
           float* dst = a.dpe + ((long long)g * P + p) * E;
           if (E % 8 == 0) {
 #pragma unroll
             for (int g4 = 0; g4 < E / 8; ++g4)
-              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4], dx[4 * g4 + 1], dx[4 * g4 + 2], dx[4 * g4 + 3]);
+              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
+                                                                             dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               int e = rho(r, h);
-              if (e < E) dst[e] = dx[r];
+              if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
             }
           }
         }
@@ -455,7 +486,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         const int i = (e - no) / no, o = (e - no) - i * no;
         src = ro + o * rs + i;
       }
-      dst[idx] = ((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src];
+      dst[idx] = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
     }
   }
   if (MODE == MODE_LOSS) {
@@ -467,11 +498,11 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   }
 }
 
-template <int NH, int F, int E, int C, int MODE>
+template <typename T, int NH, int F, int E, int C, int MODE>
 int launch_one(const SirenArgs& a, hipStream_t st) {
   using G = Geo<NH, F, E, C>;
   static bool attr_done = false;
-  auto kfn = siren_bf16_kernel<NH, F, E, C, MODE>;
+  auto kfn = siren_bf16_kernel<T, NH, F, E, C, MODE>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -483,19 +514,21 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
   return RCB_OK;
 }
 
-template <int NH, int F, int E, int C>
+template <typename T, int NH, int F, int E, int C>
 int launch_mode(int mode, const SirenArgs& a, hipStream_t st) {
-  if (mode == MODE_FWD) return launch_one<NH, F, E, C, MODE_FWD>(a, st);
-  if (mode == MODE_BWD) return launch_one<NH, F, E, C, MODE_BWD>(a, st);
-  return launch_one<NH, F, E, C, MODE_LOSS>(a, st);
+  if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, MODE_FWD>(a, st);
+  if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, MODE_BWD>(a, st);
+  return launch_one<T, NH, F, E, C, MODE_LOSS>(a, st);
 }
 
 }  // namespace
 
 namespace rcb {
 int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
-#define RCB_CASE(NHv, Fv, Ev, Cv) \
-  if (d->n_hidden == NHv && d->fourier_dim == Fv && d->pe_dim == Ev && d->out_dim == Cv) return launch_mode<NHv, Fv, Ev, Cv>(mode, a, st);
+#define RCB_CASE(NHv, Fv, Ev, Cv)                                                                   \
+  if (d->n_hidden == NHv && d->fourier_dim == Fv && d->pe_dim == Ev && d->out_dim == Cv)              \
+    return d->precision == 2 ? launch_mode<_Float16, NHv, Fv, Ev, Cv>(mode, a, st)                  \
+                             : launch_mode<__bf16, NHv, Fv, Ev, Cv>(mode, a, st);
   RCB_CASE(3, 16, 16, 3)   // cifar / kodak / protein
   RCB_CASE(3, 16, 16, 1)   // audio
   RCB_CASE(3, 18, 16, 3)   // video

@@ -1,0 +1,130 @@
+"""Sub-pixel ("phase") decomposition of the upsampling net (prior_model.py:23-59).
+
+Every stage of the reference net is  nearest-upsample(f) -> conv(k, pad) .  For output pixel f*i + a
+(phase a in [0, f)) kernel tap kk reads up-sampled coordinate f*i + a + kk - pad, i.e. SOURCE pixel
+i + floor((a + kk - pad) / f).  For the reference's (f, k, pad) = (4,5,2), (6,5,2), (2,3,1) every phase
+touches only TWO neighbouring source pixels per axis, so each stage is, per phase, a dense 2^d-tap
+convolution on the *small* source grid with pre-summed weights
+
+    Weff[phase][tap][ci][co] = sum_{kernel taps that land on that source pixel} W[co][ci][taps].
+
+This is exact (only the fp32 summation order changes) and needs 21 instead of 64 MFLOP per CIFAR
+INR; the up-sampled intermediates are never materialised.  Implemented here with plain tensor ops
+(window gathers + GEMMs) so that autograd supplies the backward; it works for 1-D, 2-D and 3-D nets.
+"""
+import itertools
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _axis_plan(f: int, k: int, pad: int):
+    """per-axis phase plan: window width w, left/right zero padding, per-phase window shift s[a]
+    and the 0/1 matrix R[a, t, kk] that folds kernel tap kk of phase a onto window tap t."""
+    lo = [min(math.floor((a + kk - pad) / f) for kk in range(k)) for a in range(f)]
+    hi = [max(math.floor((a + kk - pad) / f) for kk in range(k)) for a in range(f)]
+    w = max(h - l + 1 for l, h in zip(lo, hi))
+    pad_l = -min(lo)
+    pad_r = max(l + w - 1 for l in lo)
+    R = np.zeros([f, w, k], dtype=np.float32)
+    for a in range(f):
+        for kk in range(k):
+            o = math.floor((a + kk - pad) / f)
+            R[a, o - lo[a], kk] = 1.0
+    shift = [l + pad_l for l in lo]
+    return w, pad_l, max(pad_r, 0), shift, R
+
+
+class PhaseStage:
+    """one  nearest-upsample(f) -> conv(k, pad)  stage in phase form (channel-last tensors)."""
+
+    def __init__(self, factors, k, pad, dd):
+        self.dd = dd
+        self.f = [int(v) for v in (factors if isinstance(factors, (tuple, list)) else [factors] * dd)]
+        self.plans = [_axis_plan(f, k, pad) for f in self.f]
+        self.k = k
+
+    def eff_weight(self, W):
+        """W [Cout, Cin, *k] -> Weff [*taps, Cin, *phases, Cout]."""
+        dd = self.dd
+        Rs = [torch.from_numpy(p[4]).to(W.device, W.dtype) for p in self.plans]
+        letters = "abcdefghijklmnopqrstuvwxyz"
+        ph, tp, kk = letters[0:dd], letters[dd:2 * dd], letters[2 * dd:3 * dd]
+        o, i = "O", "I"
+        terms = [f"{ph[d]}{tp[d]}{kk[d]}" for d in range(dd)] + [f"{o}{i}{kk}"]
+        out = f"{tp}{i}{ph}{o}"
+        return torch.einsum(",".join(terms) + "->" + out, *Rs, W)
+
+    def forward(self, x, W, b):
+        """x [B, *g, Cin] -> [B, *(f*g), Cout]"""
+        dd = self.dd
+        B, g, Cin = x.shape[0], list(x.shape[1:-1]), x.shape[-1]
+        Cout = W.shape[0]
+        Weff = self.eff_weight(W)                                   # [*taps, Cin, *phases, Cout]
+        ws = [p[0] for p in self.plans]
+        pads = []
+        for p in reversed(self.plans):                              # F.pad lists the last dim first
+            pads += [p[1], p[2]]
+        xp = F.pad(x, [0, 0] + pads)                                # zero halo
+        for d in range(dd):
+            xp = xp.unfold(1 + d, ws[d], 1)                         # [B, *g', Cin, w0, w1, ..]
+        # -> [B, *g', w0.., Cin]
+        nd = xp.dim()
+        perm = [0] + list(range(1, 1 + dd)) + list(range(2 + dd, nd)) + [1 + dd]
+        col = xp.permute(perm)
+        K = int(np.prod(ws)) * Cin
+        out = x.new_empty([B] + [g[d] * self.f[d] for d in range(dd)] + [Cout])
+        # phases that share the same window shift along every axis are served by one GEMM
+        shifts = [sorted(set(p[3])) for p in self.plans]
+        for combo in itertools.product(*shifts):
+            sel = [[a for a in range(self.f[d]) if self.plans[d][3][a] == combo[d]] for d in range(dd)]
+            sl = (slice(None),) + tuple(slice(combo[d], combo[d] + g[d]) for d in range(dd))
+            A = col[sl].reshape(B * int(np.prod(g)), K)
+            idx = (Ellipsis,) + tuple(torch.as_tensor(s, device=x.device) for s in [])  # placeholder
+            Wsel = Weff
+            for d in range(dd):
+                Wsel = Wsel.index_select(dd + 1 + d, torch.as_tensor(sel[d], device=x.device))
+            nph = [len(s) for s in sel]
+            Y = (A @ Wsel.reshape(K, -1)).reshape([B] + g + nph + [Cout]) + b
+            # scatter the phases of this shift group into the interleaved output
+            ov = out.view([B] + [v for d in range(dd) for v in (g[d], self.f[d])] + [Cout])
+            # Y dims: B, g0..g_{d-1}, p0..p_{d-1}, C  ->  B, g0, p0, g1, p1, .., C
+            perm2 = [0] + [v for d in range(dd) for v in (1 + d, 1 + dd + d)] + [1 + 2 * dd]
+            Yp = Y.permute(perm2)
+            index = [slice(None)]
+            for d in range(dd):
+                index += [slice(None), slice(sel[d][0], sel[d][-1] + 1)]
+                assert sel[d] == list(range(sel[d][0], sel[d][-1] + 1))
+            index.append(slice(None))
+            ov[tuple(index)] = Yp
+        return out
+
+
+class UpsampleFast(torch.nn.Module):
+    """Drop-in evaluation of an `Upsample` module (same parameters, shared storage) in phase form.
+    Input/outputs are channel-FIRST like the reference module so it can replace it anywhere."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        dd = net.conv1.weight.dim() - 2
+        self.dd = dd
+        sf = [net.up1.scale_factor, net.up2.scale_factor, net.up3.scale_factor]
+        self.stages = [PhaseStage(sf[0], 5, int(net.conv1.padding[0]), dd),
+                       PhaseStage(sf[1], 3, int(net.conv2.padding[0]), dd),
+                       PhaseStage(sf[2], 3, int(net.conv3.padding[0]), dd)]
+        for st, conv in zip(self.stages, [net.conv1, net.conv2, net.conv3]):
+            for (w, pl, pr, shift, R), f in zip(st.plans, st.f):
+                if any(shift[a] > shift[a + 1] for a in range(f - 1)):
+                    raise ValueError("unsupported upsample/conv geometry")
+
+    def forward_channel_last(self, x):
+        n = self.net
+        x = F.leaky_relu(self.stages[0].forward(x, n.conv1.weight, n.conv1.bias), 0.01)
+        x = F.leaky_relu(self.stages[1].forward(x, n.conv2.weight, n.conv2.bias), 0.01)
+        return self.stages[2].forward(x, n.conv3.weight, n.conv3.bias)
+
+    def forward(self, x):
+        return self.forward_channel_last(x.movedim(1, -1)).movedim(-1, 1)

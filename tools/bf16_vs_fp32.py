@@ -1,0 +1,51 @@
+"""Trains the same INRs in fp32 and bf16-operand mode with identical noise; prints loss / PSNR gaps."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recombiner_amd import config, utils
+from recombiner_amd import prior_model as PM
+
+def smooth_targets(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 32), torch.linspace(-1, 1, 32), indexing="ij")
+    out = []
+    for _ in range(n):
+        img = torch.zeros(3, 32, 32)
+        for _ in range(6):
+            fx, fy, ph = (torch.rand(3, generator=g) * 6).tolist()
+            amp = torch.rand(3, 1, 1, generator=g) * 0.25
+            img += amp * torch.sin(fx * xx + fy * yy + ph)
+        out.append((img * 0.5 + 0.5).clamp(0, 1).reshape(3, -1).T)
+    return torch.stack(out)
+
+def run(precision, n, steps, lr):
+    cfg = config.configs["cifar"]
+    X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3)
+    Y = smooth_targets(n)
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                         cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device="cuda")
+    m.precision = precision
+    torch.manual_seed(123); lt = PM.LinearTransform(m.dims).cuda()
+    torch.manual_seed(124); up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    m.noise_source = lambda shape: torch.randn(shape, device="cuda", generator=gen)
+    D = m._d_net; s0 = 0.0211547
+    pri = [torch.zeros(D).cuda(), torch.full((D,), s0).cuda(), torch.zeros(2, 2, 128).cuda(), torch.full((2, 2, 128), s0).cuda()] + [None] * 4
+    mse, kl, elbo = m.train(steps, lr, X.cuda()[None].expand(n, -1, -1), Y.cuda(), *pri, lt, up, 1e-8, training_mappings=True)
+    return mse, kl, np.array(elbo)
+
+if __name__ == "__main__":
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    res = {}
+    for name, prec in (("fp32", 0), ("bf16", 1), ("f16", 2)):
+        ps = []
+        for rep in range(3):
+            r = run(prec, n, steps, 1e-3)
+            ps.append(10 * np.log10(1 / r[0]))
+        res[name] = ps
+        print("%-5s PSNR over 3 runs: %s  mean %.3f" % (name, " ".join("%.3f" % p for p in ps), np.mean(ps)), flush=True)
+    for name in ("bf16", "f16"):
+        print("gap %s - fp32: %.3f dB (fp32 run-to-run spread %.3f dB)" % (name, np.mean(res[name]) - np.mean(res["fp32"]),
+                                                                          max(res["fp32"]) - min(res["fp32"])))
