@@ -200,6 +200,25 @@ int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, con
                          int32_t* idx, double* z_out, double* best, double* logw_job0,
                          rcb_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * N1: the `nearest-upsample(2) -> conv3x3(pad 1)` stages of the upsampling net (prior_model.py:52-54:
+ * up2/conv2/act2, up3/conv3) in sub-pixel (phase) form, bf16 MFMA / fp32 accumulate, channel-last images,
+ * Cin = 64.  weff = kernel taps pre-summed per (phase, 2x2 window tap), fp32 [ty][tx][ci][a][b][co].
+ *   fwd  : y[b, 2i+a, 2j+b', co] = bias[co] + sum weff[ty,tx,ci,a,b',co] * x[b, i+a+ty-1, j+b'+tx-1, ci]
+ *          x: bf16 activations, or fp32 pre-activations (LeakyReLU(0.01) applied on load);
+ *          y: bf16 with LeakyReLU applied, or fp32 linear output.
+ *   dgrad: dx = (conv^T dy) * LeakyReLU'(x)   (sign taken from the stored activation / pre-activation)
+ *   wgrad: dweff += sum_b,i,j x (x) dy   (fp32 atomics; the caller zeroes dweff)
+ * Instantiated for (grid, cout) = (8, 64) [stage 2: fp32 pre-activation in, bf16 out] and (16, 16)
+ * [stage 3: bf16 in, fp32 out]; batch = number of images (INR x sample).
+ * ------------------------------------------------------------------------------------------- */
+int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, const float* bias, void* y,
+                   int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x, int32_t x_is_f32_preact,
+                     void* dx, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
+                     int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);
 

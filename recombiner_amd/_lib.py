@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "librcb_hip.so")
 
 EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
-           "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum"]
+           "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
+           "rcb_upconv_dgrad", "rcb_upconv_wgrad"]
 
 
 class RcbError(RuntimeError):

@@ -1,0 +1,493 @@
+// N1: the upsampling net's  nearest-upsample(2) -> conv3x3(pad 1)  stages in sub-pixel ("phase") form,
+// bf16 MFMA with fp32 accumulation.  Replaces prior_model.py:52-54 (up2/conv2/act2/up3/conv3) without
+// ever materialising the up-sampled intermediates.
+//
+// For output pixel (2i+a, 2j+b) only a 2x2 window of SOURCE pixels is touched:
+//     y[2i+a, 2j+b, co] = bias[co] + sum_{ty,tx in {0,1}} sum_ci  Weff[ty,tx,ci,a,b,co] * x[i+a+ty-1, j+b+tx-1, ci]
+// with Weff the kernel taps pre-summed per (phase, window tap) (host: upsample_fast.PhaseStage.eff_weight,
+// layout [ty][tx][ci][a][b][co] fp32).  All images are channel-last; Cin = 64.
+//
+// Three kernels, all with the *position on the MFMA lane* (the B / D column), channels on rows:
+//   forward : D[co, pos] += A[co, (tap,ci)] * B[(tap,ci), pos]    A = weight fragments (LDS), B gathered from x
+//   dgrad   : D[ci, pos] += A[ci, (combo,co)] * B[(combo,co), pos] A = transposed weight fragments, B gathered from dy
+//   wgrad   : D[ci, co]  += A[ci, pos] * B[pos, co]                per-INR images staged in LDS, transposed reads
+// LeakyReLU(0.01) is fused: forward applies it on load (fp32 pre-activation input) or in the epilogue;
+// dgrad multiplies by its derivative taken from the sign of the stored activation.
+#include "rcb_common.h"
+
+using namespace rcb;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CIN = 64;
+constexpr float SLOPE = 0.01f;
+
+__device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * SLOPE; }
+
+__host__ __device__ constexpr long long weff_index(int ty, int tx, int ci, int a, int b, int co, int cout) {
+  return ((((long long)(ty * 2 + tx) * CIN + ci) * 2 + a) * 2 + b) * cout + co;
+}
+
+union Frag {
+  bf16x8 v;
+  uint4 u;
+};
+
+// 8 consecutive channels of one pixel as a bf16 fragment; `ok` false -> zeros (halo)
+template <int MODE>  // 0: bf16 image, 1: fp32 pre-activation (LeakyReLU applied), 2: fp32 plain
+__device__ __forceinline__ bf16x8 load8(const void* base, long long elem_off, bool ok) {
+  Frag f;
+  if (MODE == 0) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + elem_off);
+    f.u = *p;
+    if (!ok) f.u = make_uint4(0, 0, 0, 0);
+  } else {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    float4 v0 = p[0], v1 = p[1];
+    float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = ok ? t[j] : 0.f;
+      if (MODE == 1) x = lrelu(x);
+      f.v[j] = (__bf16)x;
+    }
+  }
+  return f.v;
+}
+
+// raw (unconverted) 8-channel loads, so that the next gather can be in flight while the current
+// one feeds the matrix cores (explicit two-stage pipeline; hipcc otherwise hoists every gather of a
+// tile and spills)
+template <int MODE> struct Raw8;
+template <> struct Raw8<0> { uint4 u; };
+template <> struct Raw8<1> { float4 a, b; };
+template <> struct Raw8<2> { float4 a, b; };
+
+template <int MODE>
+__device__ __forceinline__ Raw8<MODE> raw_load(const void* base, long long elem_off) {
+  Raw8<MODE> r;
+  if constexpr (MODE == 0) {
+    r.u = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + elem_off);
+  } else {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    r.a = p[0];
+    r.b = p[1];
+  }
+  return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ bf16x8 raw_frag(const Raw8<MODE>& r, bool ok) {
+  Frag f;
+  if constexpr (MODE == 0) {
+    f.u = ok ? r.u : make_uint4(0, 0, 0, 0);
+  } else {
+    float t[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = ok ? t[j] : 0.f;
+      if (MODE == 1) x = lrelu(x);
+      f.v[j] = (__bf16)x;
+    }
+  }
+  return f.v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+  const void* x;
+  const float* weff;
+  const float* bias;
+  void* y;
+  int batch;
+};
+
+template <int COUT, int G, int IN_MODE, int OUT_F32>
+__global__ void __launch_bounds__(512) upconv_fwd_kernel(FwdArgs a) {
+  constexpr int MT = (COUT + 31) / 32;
+  constexpr int NF = 4 * 4 * 4 * MT;   // [phase][tap][kb][mt]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  for (int e = tid; e < NF * 64; e += 512) {
+    const int ln = e & 63, slot = e >> 6;
+    const int mt = slot % MT, kb = (slot / MT) & 3, t = (slot / (MT * 4)) & 3, p = slot / (MT * 16);
+    const int fq = ln & 31, fh = ln >> 5, co = 32 * mt + fq;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float w = 0.f;
+      if (co < COUT) w = a.weff[weff_index(t >> 1, t & 1, 16 * kb + 8 * fh + j, p >> 1, p & 1, co, COUT)];
+      f.v[j] = (__bf16)w;
+    }
+    frags[e] = f.u;
+  }
+  __syncthreads();
+  const int ntiles = a.batch * (G * G / 32);
+  for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+    const int pos = tile * 32 + q;
+    const int b = pos / (G * G), rem = pos - b * (G * G), i = rem / G, j = rem - i * G;
+    f32x16 acc[4][MT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
+    // 9 source neighbours, 4 channel blocks each; neighbour n+1 is fetched while n is consumed
+    Raw8<IN_MODE> cur[4], nxt[4];
+    bool ok_cur = false, ok_nxt = false;
+    auto issue = [&](int nb, Raw8<IN_MODE>(&dst)[4], bool& ok) {
+      const int dy = nb / 3 - 1, dx = nb % 3 - 1;
+      const int si = i + dy, sj = j + dx;
+      ok = si >= 0 && si < G && sj >= 0 && sj < G;
+      const long long pix = ((long long)b * G + (ok ? si : i)) * G + (ok ? sj : j);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) dst[kb] = raw_load<IN_MODE>(a.x, pix * CIN + 16 * kb + 8 * h);
+    };
+    issue(0, cur, ok_cur);
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+      if (nb + 1 < 9) issue(nb + 1, nxt, ok_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      const int dy = nb / 3 - 1, dx = nb % 3 - 1;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 bf = raw_frag<IN_MODE>(cur[kb], ok_cur);
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+          const int ty = dy + 1 - pa;
+          if (ty < 0 || ty > 1) continue;
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int tx = dx + 1 - pb;
+            if (tx < 0 || tx > 1) continue;
+            const int p = pa * 2 + pb, t = ty * 2 + tx;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              Frag fa;
+              fa.u = frags[(((p * 4 + t) * 4 + kb) * MT + mt) * 64 + lane];
+              acc[p][mt] = mfma16(fa.v, bf, acc[p][mt]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) cur[kb] = nxt[kb];
+      ok_cur = ok_nxt;
+    }
+    // epilogue: bias (+ LeakyReLU), scatter the four phases
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long long opix = ((long long)b * (2 * G) + 2 * i + (p >> 1)) * (2 * G) + 2 * j + (p & 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int co = 32 * mt + 8 * g4 + 4 * h;
+          if (32 * mt + 8 * g4 >= COUT) continue;
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] = acc[p][mt][4 * g4 + k] + a.bias[co + k];
+            if (!OUT_F32) v[k] = lrelu(v[k]);
+          }
+          if (OUT_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + co) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + co) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// data gradient
+// ------------------------------------------------------------------------------------------------
+struct DgradArgs {
+  const void* dy;
+  const float* weff;
+  const void* x;   // stored activation (bf16 post-LeakyReLU) or fp32 pre-activation: sign source
+  void* dx;
+  int batch;
+};
+
+template <int COUT, int G, int DY_F32, int X_F32>
+__global__ void __launch_bounds__(512) upconv_dgrad_kernel(DgradArgs a) {
+  constexpr int KB = COUT / 16;
+  constexpr int NF = 16 * KB * 2;      // [combo(ry,rx)][kb][mt]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  for (int e = tid; e < NF * 64; e += 512) {
+    const int ln = e & 63, slot = e >> 6;
+    const int mt = slot & 1, kb = (slot >> 1) % KB, combo = slot / (2 * KB);
+    const int ry = (combo >> 2) - 1, rx = (combo & 3) - 1;
+    // output row offset ry -> (phase a, window tap ty):  -1:(1,1)  0:(0,1)  1:(1,0)  2:(0,0)
+    const int pa = (ry & 1), ty = (ry <= 0) ? 1 : 0;
+    const int pb = (rx & 1), tx = (rx <= 0) ? 1 : 0;
+    const int fq = ln & 31, fh = ln >> 5, ci = 32 * mt + fq;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, ci, pa, pb, 16 * kb + 8 * fh + j, COUT)];
+    frags[e] = f.u;
+  }
+  __syncthreads();
+  const int ntiles = a.batch * (G * G / 32);
+  for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+    const int pos = tile * 32 + q;
+    const int b = pos / (G * G), rem = pos - b * (G * G), u = rem / G, v = rem - u * G;
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    // 16 output-pixel offsets (ry, rx) in [-1, 2]^2; offset n+1 is fetched while n is consumed
+    constexpr int DM = DY_F32 ? 2 : 0;
+    Raw8<DM> cur[KB], nxt[KB];
+    bool ok_cur = false, ok_nxt = false;
+    auto issue = [&](int n, Raw8<DM>(&dst)[KB], bool& ok) {
+      const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
+      const int oy = 2 * u + ry, ox = 2 * v + rx;
+      ok = oy >= 0 && oy < 2 * G && ox >= 0 && ox < 2 * G;
+      const long long pix = ((long long)b * (2 * G) + (ok ? oy : 2 * u)) * (2 * G) + (ok ? ox : 2 * v);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) dst[kb] = raw_load<DM>(a.dy, pix * COUT + 16 * kb + 8 * h);
+    };
+    issue(0, cur, ok_cur);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      if (n + 1 < 16) issue(n + 1, nxt, ok_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const bf16x8 bf = raw_frag<DM>(cur[kb], ok_cur);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          Frag fa;
+          fa.u = frags[((n * KB + kb) * 2 + mt) * 64 + lane];
+          acc[mt] = mfma16(fa.v, bf, acc[mt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
+      ok_cur = ok_nxt;
+    }
+    // epilogue: multiply by LeakyReLU'(x) and store
+    const long long xpix = (long long)pos * CIN;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int ci = 32 * mt + 8 * g4 + 4 * h;
+        float xs[4];
+        if (X_F32) {
+          float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.x) + xpix + ci);
+          xs[0] = t.x; xs[1] = t.y; xs[2] = t.z; xs[3] = t.w;
+        } else {
+          bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + ci);
+          xs[0] = (float)t[0]; xs[1] = (float)t[1]; xs[2] = (float)t[2]; xs[3] = (float)t[3];
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acc[mt][4 * g4 + k] * (xs[k] > 0.f ? 1.0f : SLOPE);
+        if (X_F32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dx) + xpix + ci) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* dweff;   // accumulated with fp32 atomics (caller zeroes)
+  int batch;
+};
+
+// transposed gather read: the 16-lane group supplies addresses of 4 "rows" (positions) x 4 chunks of 4 channels
+__device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+template <int COUT, int G, int X_F32, int DY_F32>
+__global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = (COUT + 31) / 32;
+  constexpr int HG = G + 2;             // halo grid
+  constexpr int OG = 2 * G;             // output grid
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* ximg = reinterpret_cast<__bf16*>(smem_raw);               // [HG*HG][64]
+  __bf16* dimg = ximg + HG * HG * CIN;                              // [OG*OG][COUT]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, fb = (lane >> 4) & 1, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+  for (int e = tid; e < HG * HG * CIN / 8; e += 512) reinterpret_cast<uint4*>(ximg)[e] = make_uint4(0, 0, 0, 0);
+  f32x16 acc[2][2][NT];   // [combo slot][mt][nt]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][mt][nt][r] = 0.f;
+  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+    __syncthreads();   // previous INR fully consumed (also orders the halo clear)
+    // stage x (interior of the halo image) and dy as bf16
+    for (int e = tid; e < G * G * (CIN / 8); e += 512) {
+      const int pix = e / (CIN / 8), c8 = e - pix * (CIN / 8);
+      const int i = pix / G, j = pix - i * G;
+      Frag f;
+      f.v = load8<X_F32 ? 1 : 0>(a.x, ((long long)b * G * G + pix) * CIN + 8 * c8, true);
+      *reinterpret_cast<uint4*>(ximg + ((i + 1) * HG + (j + 1)) * CIN + 8 * c8) = f.u;
+    }
+    for (int e = tid; e < OG * OG * (COUT / 8); e += 512) {
+      const int pix = e / (COUT / 8), c8 = e - pix * (COUT / 8);
+      Frag f;
+      f.v = load8<DY_F32 ? 2 : 0>(a.dy, ((long long)b * OG * OG + pix) * COUT + 8 * c8, true);
+      *reinterpret_cast<uint4*>(dimg + pix * COUT + 8 * c8) = f.u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int combo = 2 * wave + c;                 // 16 combos over 8 waves
+      const int p = combo >> 2, t = combo & 3;
+      const int pa = p >> 1, pb = p & 1, ty = t >> 1, tx = t & 1;
+      for (int pt = 0; pt < G * G / 32; ++pt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          union { s16x4 s[2]; bf16x8 v; } av[2], bv[NT];
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) {
+            const int pos = 32 * pt + 16 * ks + 8 * h + 4 * w2 + q4;
+            const int i = pos / G, j = pos - i * G;
+            const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb + tx)) * CIN + 16 * fb + 4 * p4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt].s[w2] = tr_read(xr + 32 * mt);
+            const __bf16* dr = dimg + ((2 * i + pa) * OG + (2 * j + pb)) * COUT + 4 * p4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt].s[w2] = tr_read(dr + ((COUT >= 32) ? (32 * nt + 16 * fb) : 0));
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = mfma16(av[mt].v, bv[nt].v, acc[c][mt][nt]);
+        }
+      }
+    }
+  }
+  // D[m = ci, n = co]: rows in registers, column on the lane
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int combo = 2 * wave + c;
+    const int p = combo >> 2, t = combo & 3;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = 32 * nt + (lane & 31);
+        if (co < COUT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ci = 32 * mt + rho(r, h);
+            atomicAdd(a.dweff + weff_index(t >> 1, t & 1, ci, p >> 1, p & 1, co, COUT), acc[c][mt][nt][r]);
+          }
+        }
+      }
+  }
+}
+
+template <typename K, typename A>
+int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& attr_done) {
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  kfn<<<grid, 512, smem, st>>>(args);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+int grid_for(int ntiles) {
+  int g = (ntiles + 7) / 8;
+  return g < 256 ? g : 256;
+}
+
+}  // namespace
+
+extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, const float* bias, void* y,
+                              int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream) {
+  RCB_REQUIRE(x && weff && bias && y, RCB_ERR_ARG, "upconv_fwd: null pointer");
+  RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_fwd: empty batch");
+  FwdArgs a{x, weff, bias, y, batch};
+  hipStream_t st = (hipStream_t)stream;
+  if (grid == 8 && cout == 64 && x_is_f32_preact && !y_is_f32_linear) {
+    static bool done = false;
+    return launch(upconv_fwd_kernel<64, 8, 1, 0>, a, grid_for(batch * 2), 4 * 4 * 4 * 2 * 1024, st, done);
+  }
+  if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear) {
+    static bool done = false;
+    return launch(upconv_fwd_kernel<16, 16, 0, 1>, a, grid_for(batch * 8), 4 * 4 * 4 * 1 * 1024, st, done);
+  }
+  return fail(RCB_ERR_UNSUPPORTED, "upconv_fwd: grid=%d cout=%d in_f32=%d out_f32=%d not instantiated", grid, cout,
+              x_is_f32_preact, y_is_f32_linear);
+}
+
+extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x,
+                                int32_t x_is_f32_preact, void* dx, int32_t batch, int32_t grid, int32_t cout,
+                                rcb_stream_t stream) {
+  RCB_REQUIRE(dy && weff && x && dx, RCB_ERR_ARG, "upconv_dgrad: null pointer");
+  RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_dgrad: empty batch");
+  DgradArgs a{dy, weff, x, dx, batch};
+  hipStream_t st = (hipStream_t)stream;
+  if (grid == 16 && cout == 16 && dy_is_f32 && !x_is_f32_preact) {
+    static bool done = false;
+    return launch(upconv_dgrad_kernel<16, 16, 1, 0>, a, grid_for(batch * 8), 16 * 1 * 2 * 1024, st, done);
+  }
+  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact) {
+    static bool done = false;
+    return launch(upconv_dgrad_kernel<64, 8, 0, 1>, a, grid_for(batch * 2), 16 * 4 * 2 * 1024, st, done);
+  }
+  return fail(RCB_ERR_UNSUPPORTED, "upconv_dgrad: grid=%d cout=%d not instantiated", grid, cout);
+}
+
+extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
+                                int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream) {
+  RCB_REQUIRE(x && dy && dweff, RCB_ERR_ARG, "upconv_wgrad: null pointer");
+  RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_wgrad: empty batch");
+  WgradArgs a{x, dy, dweff, batch};
+  hipStream_t st = (hipStream_t)stream;
+  int g = batch < 256 ? batch : 256;
+  if (grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32) {
+    static bool done = false;
+    return launch(upconv_wgrad_kernel<16, 16, 0, 1>, a, g, (18 * 18 * 64 + 32 * 32 * 16) * 2, st, done);
+  }
+  if (grid == 8 && cout == 64 && x_is_f32_preact && !dy_is_f32) {
+    static bool done = false;
+    return launch(upconv_wgrad_kernel<64, 8, 1, 0>, a, g, (10 * 10 * 64 + 16 * 16 * 64) * 2, st, done);
+  }
+  return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
+}

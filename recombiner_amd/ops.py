@@ -403,3 +403,37 @@ def rec_score_argmax(loc, scale, p_loc, p_scale, tables: dict, gumbel, job_row, 
                                    ptr(idx), ptr(z), ptr(best), ptr(logw0, f64, True), stream_ptr()),
           "rcb_rec_score_argmax")
     return idx, z, best, logw0
+
+
+# ----------------------------------------------------------------------------------------------
+# N1: phase-form upsampling stages (rcb_upconv_*)
+# ----------------------------------------------------------------------------------------------
+bf16 = torch.bfloat16
+
+
+def upconv_fwd(x, weff, bias, grid, cout, out_f32):
+    """x [B, g, g, 64] (fp32 pre-activation or bf16 activation) -> y [B, 2g, 2g, cout]."""
+    lib = _lib.load()
+    B = x.shape[0]
+    y = torch.empty(B, 2 * grid, 2 * grid, cout, device=x.device, dtype=f32 if out_f32 else bf16)
+    check(lib.rcb_upconv_fwd(ptr(x), int(x.dtype == f32), ptr(weff, f32), ptr(bias, f32), ptr(y), int(out_f32), B, grid,
+                             cout, stream_ptr()), "rcb_upconv_fwd")
+    return y
+
+
+def upconv_dgrad(dy, weff, x, grid, cout):
+    lib = _lib.load()
+    B = x.shape[0]
+    dx = torch.empty_like(x)
+    check(lib.rcb_upconv_dgrad(ptr(dy), int(dy.dtype == f32), ptr(weff, f32), ptr(x), int(x.dtype == f32), ptr(dx), B,
+                               grid, cout, stream_ptr()), "rcb_upconv_dgrad")
+    return dx
+
+
+def upconv_wgrad(x, dy, grid, cout):
+    lib = _lib.load()
+    B = x.shape[0]
+    dw = torch.zeros(2, 2, 64, 2, 2, cout, device=x.device, dtype=f32)
+    check(lib.rcb_upconv_wgrad(ptr(x), int(x.dtype == f32), ptr(dy), int(dy.dtype == f32), ptr(dw), B, grid, cout,
+                               stream_ptr()), "rcb_upconv_wgrad")
+    return dw

@@ -15,6 +15,7 @@ from torch import nn
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
+from .upsample_fast import hip_path_supported, upsample_cifar_hip
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs
 
 
@@ -120,6 +121,15 @@ class PriorBNNmodel(nn.Module):
                         self._d_lpe, self.train_size)
         return c["net"], lpe
 
+    def _pe(self, upsample_net, lpe):
+        """lpe [S, N, *lat, C] -> pe [N, S, P, 16]: hand-written phase-conv kernels in the 16-bit modes
+        where the geometry is instantiated, the nn.Module (MIOpen) otherwise."""
+        if self.precision != 0 and hip_path_supported(upsample_net, self.pixel_sizes, self.upsample_factors, self.patch,
+                                                      self.data_dim):
+            return upsample_cifar_hip(upsample_net, lpe)
+        return map_lpe_to_inr_inputs(upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
+                                     self.patch, self.patch_nums, self.data_dim)
+
     def _noise(self, shape):
         if self.noise_source is not None:
             e = self.noise_source(tuple(shape))
@@ -155,8 +165,7 @@ class PriorBNNmodel(nn.Module):
         e_lpe = self._noise((N, 1, self._d_lpe))
         lpe = ops.sample_levels([lpe_lv], [e_lpe], 1)                       # [N,1,Dlpe]
         lpe = lpe.reshape(N, *self._lat, self.latent_dim)[None]
-        pe = map_lpe_to_inr_inputs(upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
-                                   self.patch, self.patch_nums, self.data_dim)[:, 0]
+        pe = self._pe(upsample_net, lpe)[:, 0]
         eps = [self._noise((N, 1, self._d_net)) for _ in net]
         h_w = ops.sample_levels(net, eps, 1)[:, 0]                          # [N, D_net]
         parts = []
@@ -235,8 +244,7 @@ class PriorBNNmodel(nn.Module):
             lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
             lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
             with torch.enable_grad():
-                pe = map_lpe_to_inr_inputs(upsample_net, lpe_t, self.latent_dim, self.pixel_sizes,
-                                           self.upsample_factors, self.patch, self.patch_nums, self.data_dim)[:, 0]
+                pe = self._pe(upsample_net, lpe_t)[:, 0]
                 pe_c = pe.contiguous()
             eps = [self._noise((N, 1, D)) for _ in net]
             h_w = ops.reparam_fwd(net, eps, 1).view(N, D)

@@ -20,6 +20,7 @@ from torch.optim import Adam
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
+from .upsample_fast import hip_path_supported, upsample_cifar_hip
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs, metric
 
 LN2 = np.log(2.)
@@ -220,6 +221,13 @@ class TestBNNmodel(nn.Module):
         cum = self.cum_param_sizes
         return [(0 if i == 0 else int(cum[i - 1]), int(cum[i])) for i in range(self.n_layers)]
 
+    def _pe(self, lpe):
+        if self.precision != 0 and hip_path_supported(self.upsample_net, self.pixel_sizes, self.upsample_factors,
+                                                      self.patch, self.data_dim):
+            return upsample_cifar_hip(self.upsample_net, lpe)
+        return map_lpe_to_inr_inputs(self.upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
+                                     self.patch, self.patch_nums, self.data_dim)
+
     def _pe_from_sample(self, sample, S):
         N, D = self._n, self._d_net
         lat = [self.pixel_sizes[i] // self.upsample_factors[i] for i in range(self.data_dim)]
@@ -244,8 +252,7 @@ class TestBNNmodel(nn.Module):
         eps = self._draw_all(S)
         sample = self._forward_parts(x, S, eps, torch.is_grad_enabled())
         lpe = self._pe_from_sample(sample, S)
-        pe = map_lpe_to_inr_inputs(self.upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
-                                   self.patch, self.patch_nums, self.data_dim)           # [N,S,P,16]
+        pe = self._pe(lpe)                                                              # [N,S,P,16]
         h_w = sample[..., :D].reshape(N * S, D)
         parts = [h_w[:, lo:hi] @ self.linear_transform.A[i] for i, (lo, hi) in enumerate(self._layer_slices())]
         wvec = torch.cat(parts, -1)
@@ -435,8 +442,7 @@ class TestBNNmodel(nn.Module):
             sample = ops.reparam_fwd(specs, eps, S)                                   # [N,S,Dtot]
             lpe_t = self._pe_from_sample(sample, S).contiguous().requires_grad_(True)
             with torch.enable_grad():
-                pe = map_lpe_to_inr_inputs(self.upsample_net, lpe_t, self.latent_dim, self.pixel_sizes,
-                                           self.upsample_factors, self.patch, self.patch_nums, self.data_dim)
+                pe = self._pe(lpe_t)
                 pe_c = pe.reshape(N * S, P, pe.shape[-1]).contiguous()
             h_w = sample[..., :D].reshape(N * S, D)
             wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)

@@ -128,3 +128,84 @@ class UpsampleFast(torch.nn.Module):
 
     def forward(self, x):
         return self.forward_channel_last(x.movedim(1, -1)).movedim(-1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP path for the CIFAR-shaped net: 2x2 latent grid -> 8x8 -> 16x16 -> 32x32, 128 -> 64 -> 64 -> 16
+# ---------------------------------------------------------------------------------------------------
+def _stage1_maps(dev, dtype):
+    """My[y, s, k] = 1 iff kernel tap k of output row y (up-sampled 8x8 grid, pad 2) reads source row s."""
+    M = np.zeros([8, 2, 5], dtype=np.float32)
+    for y in range(8):
+        for k in range(5):
+            u = y + k - 2
+            if 0 <= u < 8:
+                M[y, u // 4, k] = 1.0
+    return torch.from_numpy(M).to(dev, dtype)
+
+
+def hip_path_supported(net, pixel_sizes, upsample_factors, patch, data_dim):
+    try:
+        ok = (data_dim == 2 and not patch and list(pixel_sizes) == [32, 32] and list(upsample_factors) == [16, 16]
+              and isinstance(net.conv1, torch.nn.Conv2d) and tuple(net.conv1.weight.shape) == (64, 128, 5, 5)
+              and tuple(net.conv2.weight.shape) == (64, 64, 3, 3) and tuple(net.conv3.weight.shape) == (16, 64, 3, 3)
+              and tuple(net.conv1.padding) == (2, 2) and tuple(net.conv2.padding) == (1, 1)
+              and tuple(net.conv3.padding) == (1, 1)
+              and [float(net.up1.scale_factor), float(net.up2.scale_factor), float(net.up3.scale_factor)] == [4., 2., 2.])
+    except (AttributeError, TypeError):
+        ok = False
+    return ok
+
+
+class _UpsampleCifarFn(torch.autograd.Function):
+    """lpe [B, 512] (channel-last 2x2x128) -> pe [B, 1024, 16].  Stage 1 is one dense GEMM against the
+    pre-summed 512 x 4096 weight (hipBLASLt); stages 2 and 3 are the rcb_upconv_* kernels."""
+
+    @staticmethod
+    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3):
+        from . import ops
+        B = lpe.shape[0]
+        M = _stage1_maps(lpe.device, torch.float32)
+        Weff1 = torch.einsum("ysk,xtl,oikl->stiyxo", M, M, W1).reshape(512, 4096)
+        z1 = torch.addmm(b1.repeat(64), lpe, Weff1).view(B, 8, 8, 64)
+        st = PhaseStage(2, 3, 1, 2)
+        Weff2 = st.eff_weight(W2).contiguous()
+        h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False)
+        Weff3 = st.eff_weight(W3).contiguous()
+        pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=True)
+        ctx.save_for_backward(lpe, Weff1, z1, Weff2, h2, Weff3)
+        return pe.view(B, 1024, 16)
+
+    @staticmethod
+    def backward(ctx, dpe):
+        from . import ops
+        lpe, Weff1, z1, Weff2, h2, Weff3 = ctx.saved_tensors
+        B = lpe.shape[0]
+        need_w = any(ctx.needs_input_grad[1:])
+        dpe = dpe.contiguous().view(B, 32, 32, 16)
+        dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16)                     # bf16 [B,16,16,64]
+        dz1 = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64)                      # fp32 [B,8,8,64]
+        dz1f = dz1.view(B, 4096)
+        dlpe = dz1f @ Weff1.t() if ctx.needs_input_grad[0] else None
+        if not need_w:
+            return dlpe, None, None, None, None, None, None
+        M = _stage1_maps(lpe.device, torch.float32)
+        R = torch.from_numpy(_axis_plan(2, 3, 1)[4]).to(lpe.device)
+        dWeff3 = ops.upconv_wgrad(h2, dpe, 16, 16)
+        dWeff2 = ops.upconv_wgrad(z1, dz2, 8, 64)
+        dWeff1 = (lpe.t() @ dz1f).view(2, 2, 128, 8, 8, 64)
+        dW1 = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, dWeff1)
+        dW2 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff2)
+        dW3 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff3)
+        db1 = dz1.sum((0, 1, 2))
+        db2 = dz2.sum((0, 1, 2), dtype=torch.float32)
+        db3 = dpe.sum((0, 1, 2))
+        return dlpe, dW1, db1, dW2, db2, dW3, db3
+
+
+def upsample_cifar_hip(net, lpe):
+    """lpe [S, N, 2, 2, 128] -> pe [N, S, 1024, 16] through the HIP phase-conv kernels."""
+    S, N = lpe.shape[:2]
+    pe = _UpsampleCifarFn.apply(lpe.reshape(S * N, 512), net.conv1.weight, net.conv1.bias, net.conv2.weight,
+                                net.conv2.bias, net.conv3.weight, net.conv3.bias)
+    return pe.view(S, N, 1024, 16).permute(1, 0, 2, 3)
