@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--inrs", type=int, default=4096, help="INRs per GPU")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
+                    help="bf16 = bf16 MFMA operands / fp32 accumulate / fp32 master weights (BASELINE config[1]); "
+                         "fp32 = exact-parity mode (fp32 MFMA, MIOpen upsample net)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
     return ap.parse_args()
@@ -152,7 +154,7 @@ def main():
         flops = 6.0 * 1024 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n   # fwd + 2x bwd
         peak = 2500.0 if m.precision == 1 else 157.3
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": "siren_kernel<MODE_LOSS> (rcb_siren_loss_bwd)", "bound": "mfma", "achieved": round(ach, 3),
+        roof = {"kernel": "fused SIREN fwd+MSE+bwd (rcb_siren_loss_bwd)", "bound": "mfma", "achieved": round(ach, 3),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "avg_launch_ms": round(ms, 4), "alg_flops_per_launch": flops,
                 "share_of_step": round(ms / (el / a.steps * 1e3), 4)}

@@ -26,6 +26,7 @@ extern "C" {
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
 #define RCB_ERR_UNSUPPORTED (-3)
+#define RCB_KL_SLOTS 1024
 
 typedef void* rcb_stream_t;
 
@@ -166,6 +167,8 @@ typedef struct {
   float* g_loc;            /* nullable outputs [rows, cols]                         */
   float* g_log_scale;
   float* m_loc; float* v_loc; float* m_ls; float* v_ls;   /* Adam state            */
+  double* kl_accum;        /* nullable [RCB_KL_SLOTS]: partial sums of the unweighted elementwise KL (before the
+                              update) are atomically added to the slots; their total is the KL           */
 } rcb_level_bwd;
 
 int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream);

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   const rcb_level_bwd& L = a.L;
   int r = blockIdx.x;
   int j = blockIdx.y * blockDim.x + threadIdx.x;
-  if (j >= L.cols) return;
+  const bool act = j < L.cols;     // tail lanes stay alive (clamped) so that the wave reduction is convergent
+  if (!act) j = L.cols - 1;
   long long o = (long long)r * L.cols + j;
   float loc = L.loc[o];
   float ls = L.log_scale[o];
@@ -304,6 +305,16 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   }
   float w = L.kl_scalar;
   if (L.beta) w *= L.beta[(long long)r * L.n_groups + L.group_idx[j]];
+  if (L.kl_accum) {   // unweighted KL of the parameters *before* this update (ELBO logging)
+    __shared__ double s_kl[4];
+    float spk = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
+    double kv = wave_sum(act ? (double)kl_elem_f32(loc, sig, L.p_loc[j], spk) : 0.0);
+    if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
+    __syncthreads();
+    // one atomic per block, spread over RCB_KL_SLOTS addresses (a single address serialises)
+    if (threadIdx.x == 0)
+      atomicAdd(L.kl_accum + ((blockIdx.x * 7 + blockIdx.y) & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
+  }
   if (w != 0.0f) {
     float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
     float inv_var_p = 1.0f / (sp * sp);
@@ -311,6 +322,7 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
     g_sig += w * (sig * inv_var_p - 1.0f / sig);
   }
   float g_ls = g_sig * dst_f32(ls);
+  if (!act) return;
   if (a.adam.enabled) {
     float m1 = L.m_loc[o], v1 = L.v_loc[o], m2 = L.m_ls[o], v2 = L.v_ls[o];
     adam_apply(loc, g_mu, m1, v1, a.adam);

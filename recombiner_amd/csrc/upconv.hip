@@ -431,9 +431,13 @@ int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& at
   return RCB_OK;
 }
 
-int grid_for(int ntiles) {
+// persistent grid: as many 512-thread workgroups per CU as the fragment LDS allows (max 2 by waves)
+int grid_for(int ntiles, size_t smem) {
+  int per_cu = (int)((160 * 1024) / (smem + 1024));
+  if (per_cu > 1) per_cu = 1;   // measured: a second resident workgroup per CU is slower (L2 / LDS contention)
+  if (per_cu < 1) per_cu = 1;
   int g = (ntiles + 7) / 8;
-  return g < 256 ? g : 256;
+  return g < 256 * per_cu ? g : 256 * per_cu;
 }
 
 }  // namespace
@@ -446,11 +450,11 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   hipStream_t st = (hipStream_t)stream;
   if (grid == 8 && cout == 64 && x_is_f32_preact && !y_is_f32_linear) {
     static bool done = false;
-    return launch(upconv_fwd_kernel<64, 8, 1, 0>, a, grid_for(batch * 2), 4 * 4 * 4 * 2 * 1024, st, done);
+    return launch(upconv_fwd_kernel<64, 8, 1, 0>, a, grid_for(batch * 2, 4 * 4 * 4 * 2 * 1024), 4 * 4 * 4 * 2 * 1024, st, done);
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear) {
     static bool done = false;
-    return launch(upconv_fwd_kernel<16, 16, 0, 1>, a, grid_for(batch * 8), 4 * 4 * 4 * 1 * 1024, st, done);
+    return launch(upconv_fwd_kernel<16, 16, 0, 1>, a, grid_for(batch * 8, 4 * 4 * 4 * 1 * 1024), 4 * 4 * 4 * 1 * 1024, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_fwd: grid=%d cout=%d in_f32=%d out_f32=%d not instantiated", grid, cout,
               x_is_f32_preact, y_is_f32_linear);
@@ -465,11 +469,11 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (grid == 16 && cout == 16 && dy_is_f32 && !x_is_f32_preact) {
     static bool done = false;
-    return launch(upconv_dgrad_kernel<16, 16, 1, 0>, a, grid_for(batch * 8), 16 * 1 * 2 * 1024, st, done);
+    return launch(upconv_dgrad_kernel<16, 16, 1, 0>, a, grid_for(batch * 8, 16 * 1 * 2 * 1024), 16 * 1 * 2 * 1024, st, done);
   }
   if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact) {
     static bool done = false;
-    return launch(upconv_dgrad_kernel<64, 8, 0, 1>, a, grid_for(batch * 2), 16 * 4 * 2 * 1024, st, done);
+    return launch(upconv_dgrad_kernel<64, 8, 0, 1>, a, grid_for(batch * 2, 16 * 4 * 2 * 1024), 16 * 4 * 2 * 1024, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_dgrad: grid=%d cout=%d not instantiated", grid, cout);
 }

@@ -208,7 +208,7 @@ def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], sample
 
 def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: float, d_out, eps, samples: int,
                   beta=None, group_idx=None, n_groups=0, adam: Optional[AdamCfg] = None, state=None,
-                  want_grads=False):
+                  want_grads=False, kl_accum=None):
     """Fused gradient gather + KL gradient (+ Adam).  Returns (g_loc, g_log_scale) when requested."""
     lib = _lib.load()
     g_loc = g_ls = None
@@ -223,7 +223,7 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  int(n_groups), float(kl_scalar), addr(d_out, f32), addr(eps, f32), addr(lv.member_ptr, i32),
                  addr(lv.member_idx, i32), addr(lv.row_perm_inv, i32), addr(lv.col_inv, i32), lv.rows, lv.cols,
                  lv.cols_out, int(samples), addr(g_loc, f32), addr(g_ls, f32), addr(s.get("m_loc"), f32),
-                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32))
+                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, f64))
     if d_out is not None and tuple(d_out.shape) != (lv.n_inr, samples, lv.cols_out):
         raise RcbError(f"d_out must be [{lv.n_inr},{samples},{lv.cols_out}], got {tuple(d_out.shape)}")
     check(lib.rcb_posterior_bwd(C.byref(b), C.byref(adam) if adam is not None else None, stream_ptr()),

@@ -228,7 +228,7 @@ class PriorBNNmodel(nn.Module):
             map_state = [(_zeros_state(p), _zeros_state(p)) for p in A + conv]
         slices = self._layer_slices()
         mse_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
-        elbo_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
+        kl_buf = torch.zeros(n_epoch, 1024, device=dev, dtype=torch.float64)     # RCB_KL_SLOTS partial sums per step
         D = self._d_net
         world = 1
         if self.dp_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -251,14 +251,11 @@ class PriorBNNmodel(nn.Module):
             # ---- A transform (dense GEMMs) --------------------------------------------------------------
             wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
             for (lo, hi), a in zip(slices, A):
-                wvec[:, lo:hi] = torch.mm(h_w[:, lo:hi], a.detach())
+                torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
             sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
-            kl = self._kl_value(priors)
-            mse = sse.sum(dtype=torch.float64) / (P * Cc)
-            mse_buf[i] = mse
-            elbo_buf[i] = -(mse + kl * float(kl_beta))
+            mse_buf[i] = sse.sum(dtype=torch.float64) / (P * Cc)
             # ---- backward through the shared mappings ------------------------------------------------------
             inputs = [lpe_t] + (conv if training_mappings else [])
             g_in = torch.autograd.grad(pe_c, inputs, dpe)
@@ -266,15 +263,16 @@ class PriorBNNmodel(nn.Module):
             dh = torch.empty(N, D, device=dev, dtype=torch.float32)
             gA = []
             for (lo, hi), a in zip(slices, A):
-                dh[:, lo:hi] = torch.mm(dw[:, lo:hi], a.detach().t())
+                torch.mm(dw[:, lo:hi], a.detach().t(), out=dh[:, lo:hi])
                 if training_mappings:
                     gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
             # ---- fused posterior update -------------------------------------------------------------------
             dh3 = dh.view(N, 1, D)
+            kl_acc = kl_buf[i]            # KL of the pre-update parameters, accumulated by the fused kernel
             for lv, (pl, ps), e, stt in zip(net, net_priors, eps, net_state):
-                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt)
+                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt, kl_accum=kl_acc)
             ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), d_lpe,
-                              e_lpe, 1, adam=cfg, state=lpe_state)
+                              e_lpe, 1, adam=cfg, state=lpe_state, kl_accum=kl_acc)
             if training_mappings:
                 grads = gA + [g.contiguous() for g in g_in[1:]]
                 if world > 1:
@@ -289,7 +287,7 @@ class PriorBNNmodel(nn.Module):
                     ops.adam_flat(p.data, g.contiguous(), m, v, cfg)
         kl_final = self._kl_value(priors)
         mse_h = mse_buf.cpu()
-        elbo_h = elbo_buf.cpu().tolist()
+        elbo_h = (-(mse_buf + kl_buf.sum(1) * float(kl_beta))).cpu().tolist()
         return float(mse_h[-1]) / N, float(kl_final.item()) / N, elbo_h
 
 

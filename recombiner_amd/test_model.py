@@ -447,12 +447,12 @@ class TestBNNmodel(nn.Module):
             h_w = sample[..., :D].reshape(N * S, D)
             wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)
             for (lo, hi), a in zip(slices, A):
-                wvec[:, lo:hi] = torch.mm(h_w[:, lo:hi], a)
+                torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
             sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta)
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
             dh = torch.empty(N * S, D, device=dev, dtype=torch.float32)
             for (lo, hi), a in zip(slices, A):
-                dh[:, lo:hi] = torch.mm(dw[:, lo:hi], a.t())
+                torch.mm(dw[:, lo:hi], a.t(), out=dh[:, lo:hi])
             dh3 = dh.view(N, S, D)
             d_full = torch.cat([dh3, d_lpe.reshape(S, N, -1).permute(1, 0, 2)], -1).contiguous()
             adjust = (epoch % self.kl_adjust_gap == 0)
