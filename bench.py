@@ -152,12 +152,31 @@ def main():
         ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
         dims = m.dims
         flops = 6.0 * 1024 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n   # fwd + 2x bwd
-        peak = 2500.0 if m.precision == 1 else 157.3
-        ach = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": "fused SIREN fwd+MSE+bwd (rcb_siren_loss_bwd)", "bound": "mfma", "achieved": round(ach, 3),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                "avg_launch_ms": round(ms, 4), "alg_flops_per_launch": flops,
-                "share_of_step": round(ms / (el / a.steps * 1e3), 4)}
+        # algorithmic HBM bytes per INR: pe read + dpe written (P*16*4 each), target P*C*4, wvec read + dwvec written
+        alg_bytes = (2 * 1024 * 16 * 4 + 1024 * 3 * 4 + 2 * D * 4 + 4) * n
+        t = ms * 1e-3
+        share = round(ms / (el / a.steps * 1e3), 4)
+        if m.precision == 0:
+            # fp32 MFMA path: 0.51 ms of matrix work at peak vs 0.09 ms of HBM traffic -> matrix-bound
+            ach = flops / t / 1e12
+            roof = {"kernel": "fused SIREN fwd+MSE+bwd, fp32 MFMA (rcb_siren_loss_bwd)", "bound": "mfma",
+                    "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+                    "traffic": None, "avg_launch_ms": round(ms, 4), "alg_flops_per_launch": flops,
+                    "alg_bytes_per_launch": alg_bytes, "share_of_step": share}
+        else:
+            # 16-bit operand path: 0.03 ms of matrix work at peak vs 0.09 ms of HBM traffic -> HBM-bound
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_siren_bf16_pmc.json")) as f:
+                    traffic = json.load(f)["hbm_bytes_per_launch"] if n == 4096 else None
+            except (OSError, KeyError, ValueError):
+                traffic = None
+            ach = alg_bytes / t / 1e9
+            roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": traffic, "traffic_source": "profiles/r01_siren_bf16_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                    "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": alg_bytes, "alg_flops_per_launch": flops,
+                    "mfma_tflops": round(flops / t / 1e12, 1), "share_of_step": share}
     cpu = None
     if rank == 0 and ws == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg)
