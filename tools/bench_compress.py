@@ -38,7 +38,9 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("groups %d; test-time training: %.2f ms/step (N=500, S=5) = %.0f INR-steps/s (%.0f INR-sample-steps/s)" % (
     G, dt / steps * 1e3, N * steps / dt, 5 * N * steps / dt))
-m._encode_round(m._l1, True, 0)        # builds tables / gumbel (one-off)
+for glen in np.unique(ge - gs):           # one-off: Sobol/ppf candidate tables for every group length, Gumbel table
+    m._table(m._l1, int(glen), 65536)
+m._encode_round(m._l1, True, 0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 rounds = 10
