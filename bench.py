@@ -85,12 +85,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ws = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        # "nccl" is RCCL over xGMI on ROCm.  RCB_DIST_BACKEND=gloo exists only to rehearse the N>1 code path on a
+        # box with fewer GPUs than ranks (ranks then share a device); it is never used for reported numbers.
+        backend = os.environ.get("RCB_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from recombiner_amd import config, ops, utils
     from recombiner_amd import prior_model as PM

@@ -1,0 +1,112 @@
+"""Size-independent properties at BASELINE.json's full size (CIFAR, 4096 INRs) where the oracle is too slow:
+determinism, batch invariance (an INR's result does not depend on its neighbours), linearity of the
+backward pass in dy, fused-loss == forward + explicit dy, A* job-order invariance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from recombiner_amd import ops, utils  # noqa: E402
+from recombiner_amd.ops import SirenMeta  # noqa: E402
+
+DEV = "cuda"
+N = 4096
+
+
+def _inputs(prec):
+    g = torch.Generator().manual_seed(0)
+    X, Y = utils.synthetic_inputs([32, 32], 16, N, 3, seed=0)
+    meta = SirenMeta(1, 1024, 16, 16, 3, 32, 3, precision=prec)
+    pe = torch.randn(N, 1024, 16, generator=g) * 0.2
+    wv = (torch.rand(N, meta.d_net, generator=g) * 2 - 1) * 0.03
+    return meta, X.to(DEV), Y.to(DEV), pe.to(DEV), wv.to(DEV)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_determinism_and_batch_invariance(prec):
+    meta, X, Y, pe, wv = _inputs(prec)
+    sc = 1.0 / 3072
+    s1, w1, p1 = ops.siren_loss_bwd(X, pe, wv, Y, sc, meta)
+    s2, w2, p2 = ops.siren_loss_bwd(X, pe, wv, Y, sc, meta)
+    assert torch.equal(s1, s2) and torch.equal(w1, w2) and torch.equal(p1, p2)
+    sl = slice(1000, 1007)
+    s3, w3, p3 = ops.siren_loss_bwd(X, pe[sl].contiguous(), wv[sl].contiguous(), Y[sl].contiguous(), sc, meta)
+    assert torch.equal(s3, s1[sl]) and torch.equal(w3, w1[sl]) and torch.equal(p3, p1[sl])
+    assert torch.isfinite(w1).all() and torch.isfinite(p1).all() and float(s1.min()) > 0
+
+
+def test_backward_is_linear_in_dy_and_matches_fused_loss():
+    meta, X, Y, pe, wv = _inputs(0)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    d1 = torch.randn(N, 1024, 3, device=DEV, generator=g)
+    d2 = torch.randn(N, 1024, 3, device=DEV, generator=g)
+    wa, pa = ops.siren_bwd(X, pe, wv, d1, meta)
+    wb, pb = ops.siren_bwd(X, pe, wv, d2, meta)
+    wc, pc = ops.siren_bwd(X, pe, wv, 0.7 * d1 - 1.9 * d2, meta)
+    np.testing.assert_allclose(wc.cpu().numpy(), (0.7 * wa - 1.9 * wb).cpu().numpy(), rtol=2e-4, atol=2e-4 * float(wa.abs().max()))
+    np.testing.assert_allclose(pc.cpu().numpy(), (0.7 * pa - 1.9 * pb).cpu().numpy(), rtol=2e-4, atol=2e-4 * float(pa.abs().max()))
+    # fused loss kernel == forward kernel + explicit dy through the plain backward kernel
+    sc = 1.0 / 3072
+    y = ops.siren_fwd(X, pe, wv, meta)
+    sse, wf, pf = ops.siren_loss_bwd(X, pe, wv, Y, sc, meta)
+    np.testing.assert_allclose(sse.cpu().numpy(), ((y - Y) ** 2).sum((1, 2)).cpu().numpy(), rtol=1e-5)
+    we, pe2 = ops.siren_bwd(X, pe, wv, 2 * sc * (y - Y), meta)
+    np.testing.assert_allclose(wf.cpu().numpy(), we.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(we.abs().max()))
+    np.testing.assert_allclose(pf.cpu().numpy(), pe2.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(pe2.abs().max()))
+
+
+def test_posterior_update_is_row_local():
+    """fused grad + KL + Adam over [4096, 3267] equals the same update applied to a slice on its own."""
+    g = torch.Generator().manual_seed(3)
+    D, S = 3267, 1
+    loc = (0.02 * torch.randn(N, D, generator=g)).to(DEV)
+    ls = (-4 + 0.3 * torch.randn(N, D, generator=g)).to(DEV)
+    eps = torch.randn(N, S, D, generator=g).to(DEV)
+    dout = (1e-3 * torch.randn(N, S, D, generator=g)).to(DEV)
+    pl, ps = torch.zeros(D, device=DEV), torch.full((D,), 0.02, device=DEV)
+
+    def step(l, s, e, d):
+        l, s = l.clone(), s.clone()
+        lv = ops.LevelSpec(l, s, D, l.shape[0])
+        st = {k: torch.zeros_like(l) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+        kl = torch.zeros(1024, device=DEV, dtype=torch.float64)
+        for t in (1, 2):
+            ops.posterior_bwd(lv, pl, ps, False, 1e-4, d, e, S, adam=ops.adam_cfg(2e-4, t), state=st, kl_accum=kl)
+        return l, s, kl.sum()
+    la, sa, kla = step(loc, ls, eps, dout)
+    sl = slice(2048, 2056)
+    lb, sb, _ = step(loc[sl].contiguous(), ls[sl].contiguous(), eps[sl].contiguous(), dout[sl].contiguous())
+    assert torch.equal(la[sl], lb) and torch.equal(sa[sl], sb)
+    rows, _ = ops.gauss_kl(loc, ls, pl, ps)
+    # the kernel accumulated the pre-update KL of step 1 and of step 2: the first equals the standalone KL
+    assert float(kla) > float(rows.sum())
+
+
+def test_rec_job_order_invariance():
+    from golden_util import GOLDEN, O
+    import os
+    g = torch.Generator().manual_seed(4)
+    rows, D = 500, 3779
+    loc = (0.02 * torch.randn(rows, D, generator=g)).to(DEV)
+    scale = (0.002 + 0.004 * torch.rand(rows, D, generator=g)).to(DEV)
+    pl = (0.01 * torch.randn(D, generator=g)).to(DEV)
+    ps = (0.015 + 0.01 * torch.rand(D, generator=g)).to(DEV)
+    gum = torch.from_numpy(np.load(os.path.join(GOLDEN, "tables", "gumbel_seed42_f64.npy"))).to(DEV)
+    tabs = {k: torch.from_numpy(np.load(os.path.join(GOLDEN, "tables", f"sobol_normal_g{k}_seed42_f32.npy")).astype(np.float64)).to(DEV)
+            for k in (3, 5)}
+    rs = np.random.RandomState(1)
+    jr = np.arange(rows)
+    jg = np.array([3, 5])[rs.randint(0, 2, rows)]
+    js = np.array([rs.randint(0, D - 5) for _ in range(rows)])
+    i1, z1, b1, _ = ops.rec_score_argmax(loc, scale, pl, ps, tabs, gum, jr, js, jg)
+    perm = rs.permutation(rows)
+    i2, z2, b2, _ = ops.rec_score_argmax(loc, scale, pl, ps, tabs, gum, jr[perm], js[perm], jg[perm])
+    assert torch.equal(i1[perm], i2) and torch.equal(z1[perm], z2) and torch.equal(b1[perm], b2)
+    assert int(i1.min()) >= 0 and int(i1.max()) < 65536
+    # spot-check three jobs against the fp64 oracle
+    for b in (0, 123, 499):
+        r, s, gl = jr[b], js[b], jg[b]
+        i, zi, _ = O.rec_score(tabs[gl].cpu(), loc[r, s:s + gl].cpu(), scale[r, s:s + gl].cpu(), pl[s:s + gl].cpu(),
+                               ps[s:s + gl].cpu(), gum.cpu())
+        assert int(i1[b]) == i
