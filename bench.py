@@ -32,14 +32,15 @@ STEPS_PER_INR = 200 + 549 * 100   # reference schedule
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed Adam steps (the reference trains 100-200 per train() call)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--inrs", type=int, default=4096, help="INRs per GPU")
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="bf16 = bf16 MFMA operands / fp32 accumulate / fp32 master weights (BASELINE config[1]); "
                          "fp32 = exact-parity mode (fp32 MFMA, MIOpen upsample net)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
+    ap.add_argument("--lowp-gemm", action="store_true", help="bf16-operand A-transform GEMMs (experimental)")
     return ap.parse_args()
 
 
@@ -107,6 +108,7 @@ def main():
                          cfg["pixel_sizes"], cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"],
                          cfg["patch_nums"], cfg["hierarchical_patch_nums"], random_seed=42 + rank, device=dev)
     m.precision = 1 if a.precision == "bf16" else 0
+    m.lowp_gemm = a.lowp_gemm
     torch.manual_seed(123)
     lt = PM.LinearTransform(m.dims).to(dev)
     torch.manual_seed(124)

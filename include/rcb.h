@@ -144,6 +144,8 @@ int rcb_beta_update(const double* kl_group, float* beta, const uint8_t* done, in
 typedef struct {
   float lr, beta1, beta2, eps;
   int32_t step;            /* 1-based step count t                                  */
+  const float* dyn_scalars;/* nullable device pair {lr/(1-beta1^t), sqrt(1-beta2^t)}: when set it overrides the
+                              values derived from `step`, so a captured HIP graph can be replayed for every t   */
 } rcb_adam_cfg;
 
 typedef struct {

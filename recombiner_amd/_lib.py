@@ -34,7 +34,7 @@ class Level(C.Structure):
 
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("step", C.c_int32)]
+                ("step", C.c_int32), ("dyn_scalars", C.c_void_p)]
 
 
 class LevelBwd(C.Structure):

@@ -241,6 +241,7 @@ struct AdamScalars {
   float bc2_sqrt;   // sqrt(1 - beta2^t)
   float eps;
   int enabled;
+  const float* dyn;   // optional device pair {step_size, bc2_sqrt} overriding the by-value ones (graph replay)
 };
 
 static AdamScalars make_adam(const rcb_adam_cfg* c) {
@@ -256,15 +257,18 @@ static AdamScalars make_adam(const rcb_adam_cfg* c) {
   s.bc2_sqrt = (float)sqrt(bc2);
   s.eps = c->eps;
   s.enabled = 1;
+  s.dyn = c->dyn_scalars;
   return s;
 }
 
 // torch.optim.Adam single step (default flags), operation order as in torch/optim/adam.py
 __device__ __forceinline__ void adam_apply(float& p, float g, float& m, float& v, const AdamScalars& s) {
+  const float step_size = s.dyn ? s.dyn[0] : s.step_size;
+  const float bc2_sqrt = s.dyn ? s.dyn[1] : s.bc2_sqrt;
   m = __fadd_rn(m, __fmul_rn(s.w1, __fsub_rn(g, m)));                    // exp_avg.lerp_(grad, 1-beta1)
   v = __fadd_rn(__fmul_rn(v, s.beta2), __fmul_rn(__fmul_rn(s.w2, g), g));  // mul_(beta2).addcmul_(g, g, 1-beta2)
-  float denom = __fadd_rn(__fdiv_rn(sqrtf(v), s.bc2_sqrt), s.eps);
-  p = __fadd_rn(p, __fmul_rn(-s.step_size, __fdiv_rn(m, denom)));        // addcdiv_(exp_avg, denom, -step_size)
+  float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), s.eps);
+  p = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));          // addcdiv_(exp_avg, denom, -step_size)
 }
 
 struct PostBwdArgs {

@@ -332,8 +332,15 @@ def beta_update(kl_group, beta, done_u8, bits=16.0, upper=0.0, lower=0.4, step=0
 # ----------------------------------------------------------------------------------------------
 # Adam, moments, REC, softplus
 # ----------------------------------------------------------------------------------------------
-def adam_cfg(lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
-    return AdamCfg(float(lr), float(beta1), float(beta2), float(eps), int(step))
+def adam_cfg(lr, step, beta1=0.9, beta2=0.999, eps=1e-8, dyn=None):
+    """dyn: optional fp32 GPU tensor [2] = {lr/(1-beta1^t), sqrt(1-beta2^t)} read by the kernels at run time."""
+    return AdamCfg(float(lr), float(beta1), float(beta2), float(eps), int(step), addr(dyn, f32))
+
+
+def adam_table(lr, n_steps, beta1=0.9, beta2=0.999):
+    """[n_steps, 2] host table of the per-step scalars (step t = row t-1), computed in fp64 like torch."""
+    t = np.arange(1, n_steps + 1, dtype=np.float64)
+    return torch.from_numpy(np.stack([lr / (1.0 - beta1 ** t), np.sqrt(1.0 - beta2 ** t)], 1).astype(np.float32))
 
 
 def adam_flat(p, g, m, v, cfg: AdamCfg):

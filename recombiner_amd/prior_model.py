@@ -104,6 +104,8 @@ class PriorBNNmodel(nn.Module):
         self.noise_source = None     # optional callable(shape) -> standard normal GPU tensor (eps injection)
         self.precision = 0           # 0 = fp32 MFMA, 1 = bf16 operands (throughput mode)
         self.dp_group = None         # torch.distributed group for sharded training of the shared mappings
+        self.lowp_gemm = False       # 16-bit mode only: bf16-operand hipBLASLt GEMMs for the A transform
+        self.use_graph = True        # replay the training step as one captured HIP graph when possible
 
     # ---- level descriptions ------------------------------------------------------------------------
     def _levels(self):
@@ -228,17 +230,22 @@ class PriorBNNmodel(nn.Module):
             map_state = [(_zeros_state(p), _zeros_state(p)) for p in A + conv]
         slices = self._layer_slices()
         mse_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
-        kl_buf = torch.zeros(n_epoch, 1024, device=dev, dtype=torch.float64)     # RCB_KL_SLOTS partial sums per step
         D = self._d_net
         world = 1
         if self.dp_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world = torch.distributed.get_world_size(self.dp_group)
-        rng = range(n_epoch)
-        if verbose:
-            from tqdm import tqdm
-            rng = tqdm(rng)
-        for i in rng:
-            cfg = ops.adam_cfg(lr, i + 1)
+        # per-step Adam scalars and the step counter live on the device, so that one captured HIP graph of the
+        # step body can be replayed for every step (the host launch cost of ~60 kernels is ~2 ms per step)
+        tab = ops.adam_table(lr, n_epoch).to(dev)
+        dyn = torch.zeros(2, device=dev, dtype=torch.float32)
+        step_t = torch.zeros(1, device=dev, dtype=torch.long)
+        kl_slots = torch.zeros(1024, device=dev, dtype=torch.float64)
+        kl_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
+        cfg = ops.adam_cfg(lr, 1, dyn=dyn)
+
+        def body():
+            dyn.copy_(tab.index_select(0, step_t).view(2))
+            kl_slots.zero_()
             # ---- sample ---------------------------------------------------------------------------------
             e_lpe = self._noise((N, 1, self._d_lpe))
             lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
@@ -249,30 +256,51 @@ class PriorBNNmodel(nn.Module):
             eps = [self._noise((N, 1, D)) for _ in net]
             h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
             # ---- A transform (dense GEMMs) --------------------------------------------------------------
-            wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
-            for (lo, hi), a in zip(slices, A):
-                torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
+            lowp = self.lowp_gemm and self.precision != 0
+            if lowp:
+                h16 = h_w.to(torch.bfloat16)
+                A16 = [a.detach().to(torch.bfloat16) for a in A]
+                wvec = torch.cat([torch.mm(h16[:, lo:hi], a16) for (lo, hi), a16 in zip(slices, A16)], 1).float()
+            else:
+                wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
+                for (lo, hi), a in zip(slices, A):
+                    torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
-            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
-            mse_buf[i] = sse.sum(dtype=torch.float64) / (P * Cc)
+            if getattr(self, "_exp_fp32_forward", False):
+                # experiment: exact forward / loss, 16-bit kernel only for the gradients
+                import dataclasses
+                m32 = dataclasses.replace(meta, precision=0)
+                yh = ops.siren_fwd(x, pe_c.detach(), wvec, m32)
+                diff = yh - y
+                sse = (diff * diff).sum((1, 2))
+                dw, dpe = ops.siren_bwd(x, pe_c.detach(), wvec, diff * (2.0 / (P * Cc)), meta)
+            else:
+                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
+            mse_buf.index_copy_(0, step_t, (sse.sum(dtype=torch.float64) / (P * Cc)).reshape(1))
             # ---- backward through the shared mappings ------------------------------------------------------
             inputs = [lpe_t] + (conv if training_mappings else [])
             g_in = torch.autograd.grad(pe_c, inputs, dpe)
             d_lpe = g_in[0].reshape(N, 1, self._d_lpe).contiguous()
-            dh = torch.empty(N, D, device=dev, dtype=torch.float32)
             gA = []
-            for (lo, hi), a in zip(slices, A):
-                torch.mm(dw[:, lo:hi], a.detach().t(), out=dh[:, lo:hi])
+            if lowp:
+                dw16 = dw.to(torch.bfloat16)
+                dh = torch.cat([torch.mm(dw16[:, lo:hi], a16.t()) for (lo, hi), a16 in zip(slices, A16)], 1).float()
                 if training_mappings:
-                    gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
-            # ---- fused posterior update -------------------------------------------------------------------
+                    gA = [torch.mm(h16[:, lo:hi].t(), dw16[:, lo:hi]).float() for (lo, hi) in slices]
+            else:
+                dh = torch.empty(N, D, device=dev, dtype=torch.float32)
+                for (lo, hi), a in zip(slices, A):
+                    torch.mm(dw[:, lo:hi], a.detach().t(), out=dh[:, lo:hi])
+                    if training_mappings:
+                        gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
+            # ---- fused posterior update (also accumulates the pre-update KL for the ELBO log) --------------
             dh3 = dh.view(N, 1, D)
-            kl_acc = kl_buf[i]            # KL of the pre-update parameters, accumulated by the fused kernel
             for lv, (pl, ps), e, stt in zip(net, net_priors, eps, net_state):
-                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt, kl_accum=kl_acc)
+                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt, kl_accum=kl_slots)
             ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), d_lpe,
-                              e_lpe, 1, adam=cfg, state=lpe_state, kl_accum=kl_acc)
+                              e_lpe, 1, adam=cfg, state=lpe_state, kl_accum=kl_slots)
+            kl_buf.index_copy_(0, step_t, kl_slots.sum().reshape(1))
             if training_mappings:
                 grads = gA + [g.contiguous() for g in g_in[1:]]
                 if world > 1:
@@ -285,9 +313,39 @@ class PriorBNNmodel(nn.Module):
                     grads = out
                 for p, g, (m, v) in zip(A + conv, grads, map_state):
                     ops.adam_flat(p.data, g.contiguous(), m, v, cfg)
+            step_t.add_(1)
+
+        n_warm = 3
+        graph = None
+        if (self.use_graph and self.noise_source is None and world == 1 and n_epoch >= 2 * n_warm and dev.type == "cuda"
+                and not verbose):
+            for _ in range(n_warm):
+                body()
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body()
+                for _ in range(n_epoch - n_warm - 1):
+                    graph.replay()
+            except Exception as exc:     # capture is an optimisation: fall back to eager stepping
+                import warnings
+                warnings.warn(f"HIP graph capture of the training step failed ({exc}); running eagerly")
+                graph = None
+                torch.cuda.synchronize()
+                done = int(step_t.item())
+                for _ in range(n_epoch - done):
+                    body()
+        else:
+            rng = range(n_epoch)
+            if verbose:
+                from tqdm import tqdm
+                rng = tqdm(rng)
+            for _ in rng:
+                body()
         kl_final = self._kl_value(priors)
         mse_h = mse_buf.cpu()
-        elbo_h = (-(mse_buf + kl_buf.sum(1) * float(kl_beta))).cpu().tolist()
+        elbo_h = (-(mse_buf + kl_buf * float(kl_beta))).cpu().tolist()
         return float(mse_h[-1]) / N, float(kl_final.item()) / N, elbo_h
 
 

@@ -44,12 +44,12 @@ class PhaseStage:
         self.dd = dd
         self.f = [int(v) for v in (factors if isinstance(factors, (tuple, list)) else [factors] * dd)]
         self.plans = [_axis_plan(f, k, pad) for f in self.f]
-        self.k = k
+        self.k, self.pad = k, pad
 
     def eff_weight(self, W):
         """W [Cout, Cin, *k] -> Weff [*taps, Cin, *phases, Cout]."""
         dd = self.dd
-        Rs = [torch.from_numpy(p[4]).to(W.device, W.dtype) for p in self.plans]
+        Rs = [_phase_R(W.device, f, self.k, self.pad).to(W.dtype) for f in self.f]
         letters = "abcdefghijklmnopqrstuvwxyz"
         ph, tp, kk = letters[0:dd], letters[dd:2 * dd], letters[2 * dd:3 * dd]
         o, i = "O", "I"
@@ -133,15 +133,32 @@ class UpsampleFast(torch.nn.Module):
 # ---------------------------------------------------------------------------------------------------
 # HIP path for the CIFAR-shaped net: 2x2 latent grid -> 8x8 -> 16x16 -> 32x32, 128 -> 64 -> 64 -> 16
 # ---------------------------------------------------------------------------------------------------
+_CONST_CACHE = {}
+
+
+def _dev_const(key, dev, make):
+    """small constant tensors are uploaded once per device (an H2D copy is not allowed inside graph capture)."""
+    k = (key, str(dev))
+    if k not in _CONST_CACHE:
+        _CONST_CACHE[k] = make().to(dev)
+    return _CONST_CACHE[k]
+
+
 def _stage1_maps(dev, dtype):
     """My[y, s, k] = 1 iff kernel tap k of output row y (up-sampled 8x8 grid, pad 2) reads source row s."""
-    M = np.zeros([8, 2, 5], dtype=np.float32)
-    for y in range(8):
-        for k in range(5):
-            u = y + k - 2
-            if 0 <= u < 8:
-                M[y, u // 4, k] = 1.0
-    return torch.from_numpy(M).to(dev, dtype)
+    def make():
+        M = np.zeros([8, 2, 5], dtype=np.float32)
+        for y in range(8):
+            for k in range(5):
+                u = y + k - 2
+                if 0 <= u < 8:
+                    M[y, u // 4, k] = 1.0
+        return torch.from_numpy(M)
+    return _dev_const("stage1_M", dev, make).to(dtype)
+
+
+def _phase_R(dev, f, k, pad):
+    return _dev_const(("R", f, k, pad), dev, lambda: torch.from_numpy(_axis_plan(f, k, pad)[4]))
 
 
 def hip_path_supported(net, pixel_sizes, upsample_factors, patch, data_dim):
@@ -190,7 +207,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
         if not need_w:
             return dlpe, None, None, None, None, None, None
         M = _stage1_maps(lpe.device, torch.float32)
-        R = torch.from_numpy(_axis_plan(2, 3, 1)[4]).to(lpe.device)
+        R = _phase_R(lpe.device, 2, 3, 1)
         dWeff3 = ops.upconv_wgrad(h2, dpe, 16, 16)
         dWeff2 = ops.upconv_wgrad(z1, dz2, 8, 64)
         dWeff1 = (lpe.t() @ dz1f).view(2, 2, 128, 8, 8, 64)

@@ -19,13 +19,17 @@ def smooth_targets(n, seed=0):
         out.append((img * 0.5 + 0.5).clamp(0, 1).reshape(3, -1).T)
     return torch.stack(out)
 
-def run(precision, n, steps, lr):
+def run(precision, n, steps, lr, lowp=False, f32fwd=False, up32=False):
     cfg = config.configs["cifar"]
     X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3)
     Y = smooth_targets(n)
     m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
                          cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device="cuda")
     m.precision = precision
+    m.lowp_gemm = lowp
+    m._exp_fp32_forward = f32fwd
+    if up32:
+        m._pe = lambda net, lpe: __import__('recombiner_amd.utils', fromlist=['x']).map_lpe_to_inr_inputs(net, lpe, 128, [32, 32], [16, 16], False, None, 2)
     torch.manual_seed(123); lt = PM.LinearTransform(m.dims).cuda()
     torch.manual_seed(124); up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
     gen = torch.Generator(device="cuda").manual_seed(5)
@@ -39,13 +43,16 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     res = {}
-    for name, prec in (("fp32", 0), ("bf16", 1), ("f16", 2)):
+    variants = (("fp32", dict(precision=0)), ("bf16", dict(precision=1)),
+                ("bf16 grads, fp32 fwd", dict(precision=1, f32fwd=True)),
+                ("bf16 grads, fp32 fwd, fp32 upsample", dict(precision=1, f32fwd=True, up32=True)))
+    for name, kw in variants:
         ps = []
         for rep in range(3):
-            r = run(prec, n, steps, 1e-3)
+            r = run(n=n, steps=steps, lr=1e-3, **kw)
             ps.append(10 * np.log10(1 / r[0]))
         res[name] = ps
         print("%-5s PSNR over 3 runs: %s  mean %.3f" % (name, " ".join("%.3f" % p for p in ps), np.mean(ps)), flush=True)
-    for name in ("bf16", "f16"):
+    for name in [v[0] for v in variants[1:]]:
         print("gap %s - fp32: %.3f dB (fp32 run-to-run spread %.3f dB)" % (name, np.mean(res[name]) - np.mean(res["fp32"]),
                                                                           max(res["fp32"]) - min(res["fp32"])))
