@@ -1,0 +1,194 @@
+"""Host drivers mirroring the reference's two entry points on top of the MI355X models:
+
+  * `train_prior(...)`      <- main_prior_training.py:25-341  (EM loop: train q -> adjust beta -> refit prior ->
+                               every 10 iterations group parameters and write the checkpoint)
+  * `compress(...)`         <- main_compression.py:25-178     (load checkpoint -> reorder priors into group order
+                               -> TestBNNmodel -> optimise -> A* encode -> distortion + index arrays)
+
+Data loading (data/*.py) is out of scope: both take tensors X [N,P,F] / [P,F] and Y [N,P,C].  The checkpoint is
+the reference's own layout -- eight sequential pickles in one file, in the same order with the same tuple
+contents (main_prior_training.py:284-335) -- so priors interchange with the reference in both directions
+(`dropin/prior_model.py` provides the `prior_model.LinearTransform` / `prior_model.Upsample` class paths).
+Under torch.distributed the INRs of `train_prior` are the local shard; the prior refit, the KL that drives
+beta and the grouping statistics are all-reduced (recombiner_amd.dist).
+"""
+import pickle
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import dist, ops
+from .prior_model import LinearTransform, PriorBNNmodel, Upsample, get_grouping_by_kl
+from .test_model import TestBNNmodel
+
+LN2 = np.log(2.)
+
+
+def bit_budgets(config, dataset, max_bitrate):
+    """(budget_max, budget_min) in bits per INR (main_prior_training.py:75-83)."""
+    px = np.prod(config['pixel_sizes'])
+    lo = max(config['lowest_bitrate'], (max_bitrate - config['bitrate_range']))
+    if dataset != 'audio':
+        return max_bitrate * px, lo * px
+    k = px * (3 / 48000) * 1000          # kbps * samples per patch * seconds per sample
+    return max_bitrate * k, lo * k
+
+
+def adjust_beta(kl_beta, kl_bits, budget_max, budget_min):
+    """main_prior_training.py:144-154."""
+    if kl_bits > budget_max:
+        kl_beta *= 1.5
+    if kl_bits < budget_min:
+        kl_beta /= 1.5
+    return min(max(kl_beta, 1e-20), 1)
+
+
+def _grouping(q_loc, q_log_scale, p_loc, p_scale, group=None):
+    """get_grouping over all ranks' INRs: per-parameter KL summed on the device, all-reduced, packed on the host."""
+    colsum = ops.gauss_kl_colsum(q_loc, q_log_scale, p_loc, p_scale, q_is_log=True)
+    return get_grouping_by_kl(dist.grouping_weights(colsum, q_loc.shape[0], group))
+
+
+def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em_iter=550, first_epochs=200,
+                epochs=100, lr=2e-4, kl_beta=1e-8, training_mappings=True, checkpoint_path=None, checkpoint_every=10,
+                precision=0, group=None, log=print):
+    """Coordinate-ascent prior learning.  Returns a dict with the model, mappings, priors, beta and ELBO curve."""
+    train_size = Y.shape[0]
+    patch = config['patch']
+    m = PriorBNNmodel(config['input_dim'], config['hidden_dims'], config['output_dim'], train_size, config['data_dim'],
+                      config['pixel_sizes'], config['upsample_factors'], config['latent_dim'], patch,
+                      config['patch_nums'], config['hierarchical_patch_nums'], random_seed=seed, device=device)
+    m.precision = precision
+    lt = LinearTransform(m.dims).to(device)
+    up = Upsample(config['data_dim'], config['paddings'], config['layerwise_scale_factors']).to(device)
+    budget_max, budget_min = bit_budgets(config, dataset, max_bitrate)
+    assert budget_min <= budget_max
+    s0 = F.softplus(torch.tensor(-2.), beta=1, threshold=20) / 6
+
+    def init_prior(shape):
+        return torch.zeros(shape, device=device), torch.ones(shape, device=device) * s0.to(device)
+    p_loc, p_scale = init_prior(m.loc.shape[1])
+    p_lpe_loc, p_lpe_scale = init_prior(m.lpe_loc.shape[1:])
+    p_h_loc = p_h_scale = p_hh_loc = p_hh_scale = None
+    if patch:
+        p_h_loc, p_h_scale = init_prior(m.h_loc.shape[-1])
+        p_hh_loc, p_hh_scale = init_prior(m.hh_loc.shape[-1])
+    X, Y = X.to(device), Y.to(device)
+    rank, ws = dist.world(group)
+    elbos, n_epoch = [], first_epochs
+    for it in range(n_em_iter):
+        _, _, e = m.train(n_epoch, lr, X, Y, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc,
+                          p_hh_scale, lt, up, kl_beta, training_mappings=training_mappings)
+        elbos += e
+        n_epoch = epochs
+        # average KL in bits per INR over all ranks -> beta rule
+        pack = torch.stack([m._kl_value([p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc, p_hh_scale]),
+                            torch.tensor(float(train_size), dtype=torch.float64, device=m.loc.device)])
+        pack = dist.allreduce_scalar(pack, group)
+        kls = float(pack[0] / LN2 / pack[1])
+        kl_beta = adjust_beta(kl_beta, kls, budget_max, budget_min)
+        # closed-form prior refit (moment matching over every rank's INRs)
+        p_loc, p_scale = dist.refit_prior(m.loc, m.log_scale, group)
+        p_lpe_loc, p_lpe_scale = dist.refit_prior(m.lpe_loc, m.lpe_log_scale, group)
+        if patch:
+            p_h_loc, p_h_scale = dist.refit_prior(m.h_loc, m.h_log_scale, group)
+            p_hh_loc, p_hh_scale = dist.refit_prior(m.hh_loc, m.hh_log_scale, group)
+        if it % checkpoint_every == 0 or it == n_em_iter - 1:
+            log("EM iter %d: KL %.4f bits/INR, beta %.3e" % (it, kls, kl_beta))
+            if checkpoint_path is not None:
+                ck = build_checkpoint(m, lt, up, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc,
+                                      p_hh_scale, kl_beta, group)
+                if rank == 0:
+                    save_checkpoint(checkpoint_path, ck)
+    return dict(model=m, linear_transform=lt, upsample_net=up, kl_beta=kl_beta, elbo=elbos,
+                priors=(p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc, p_hh_scale))
+
+
+def build_checkpoint(m, lt, up, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc, p_hh_scale,
+                     kl_beta, group=None):
+    """The eight objects of the reference checkpoint, in file order (main_prior_training.py:186-335)."""
+    def mean_rows(t):
+        s = t.detach().sum(0, dtype=torch.float64).flatten()
+        pack = torch.cat([s, torch.tensor([float(t.shape[0])], dtype=torch.float64, device=t.device)])
+        pack = dist.allreduce_scalar(pack, group)
+        return (pack[:-1] / pack[-1]).float().cpu()
+    n = m.loc.shape[0]
+    q_loc = torch.cat([m.loc.detach().flatten(1), m.lpe_loc.detach().flatten(1)], -1).contiguous()
+    q_ls = torch.cat([m.log_scale.detach().flatten(1), m.lpe_log_scale.detach().flatten(1)], -1).contiguous()
+    pl = torch.cat([p_loc.flatten(), p_lpe_loc.flatten()])
+    ps = torch.cat([p_scale.flatten(), p_lpe_scale.flatten()])
+    g1 = _grouping(q_loc, q_ls, pl, ps, group)
+    avg_ls = torch.cat([mean_rows(m.log_scale), mean_rows(m.lpe_log_scale)])
+    none8 = (None,) * 8
+    if m.patch:
+        g2 = _grouping(m.h_loc.detach(), m.h_log_scale.detach(), p_h_loc, p_h_scale, group)
+        g3 = _grouping(m.hh_loc.detach(), m.hh_log_scale.detach(), p_hh_loc, p_hh_scale, group)
+        l2 = (p_h_loc.cpu(), p_h_scale.cpu(), kl_beta, mean_rows(m.h_log_scale))
+        l3 = (p_hh_loc.cpu(), p_hh_scale.cpu(), kl_beta, mean_rows(m.hh_log_scale))
+    else:
+        g2 = g3 = none8
+        l2 = l3 = (None, None, kl_beta, None)
+    return [g1, (pl.cpu(), ps.cpu(), kl_beta, avg_ls), g2, l2, g3, l3, lt, up]
+
+
+def save_checkpoint(path, ck):
+    lt, up = ck[6], ck[7]
+    dev = next(lt.parameters()).device
+    with open(path, "wb") as f:
+        for obj in ck[:6]:
+            pickle.dump(obj, f)
+        pickle.dump(lt.cpu(), f)
+        pickle.dump(up.cpu(), f)
+    lt.to(dev)
+    up.to(dev)
+
+
+def load_checkpoint(path):
+    """-> list of the eight objects (main_compression.py:37-45)."""
+    out = []
+    with open(path, "rb") as f:
+        for _ in range(8):
+            out.append(pickle.load(f))
+    return out
+
+
+def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs=30000, lr=2e-4, precision=0,
+             verbose=0, finetune_epochs=None):
+    """main_compression.py:47-178 on an in-memory checkpoint (list from load_checkpoint / build_checkpoint).
+    Returns (distortion, model)."""
+    g1, l1, g2, l2, g3, l3, lt, up = checkpoint
+    group_idx, start, end, group2param, param2group, n_groups, _, _ = g1
+    prior_loc, prior_scale, kl_beta, avg_ls = l1
+
+    def inv_st(s):
+        return torch.log(torch.exp(s * 6) - 1)
+    kw = dict(p_loc=prior_loc.clone()[param2group].to(device), p_log_scale=inv_st(prior_scale).clone()[param2group].to(device),
+              init_log_scale=avg_ls[param2group].cpu().detach(), param_to_group=param2group, group_to_param=group2param,
+              n_groups=n_groups, group_start_index=start, group_end_index=end, group_idx=group_idx)
+    h_n = hh_n = None
+    if config['patch']:
+        for pre, g, l in (("h_", g2, l2), ("hh_", g3, l3)):
+            gi, gs, ge, g2p, p2g, ng, _, _ = g
+            ploc, pscale, _, als = l
+            kw.update({pre + "p_loc": ploc.clone()[p2g].to(device), pre + "p_log_scale": inv_st(pscale).clone()[p2g].to(device),
+                       pre + "init_log_scale": als[p2g].cpu().detach(), pre + "param_to_group": p2g,
+                       pre + "group_to_param": g2p, pre + "n_groups": ng, pre + "group_start_index": gs,
+                       pre + "group_end_index": ge, pre + "group_idx": gi})
+        h_n, hh_n = g2[5], g3[5]
+    x, y = x.to(device), y.to(device)
+    model = TestBNNmodel(config['input_dim'], config['hidden_dims'], config['output_dim'], y.shape[0],
+                         config['upsample_factors'], config['latent_dim'], config['data_dim'], config['pixel_sizes'],
+                         config['patch'], config['patch_nums'], config['hierarchical_patch_nums'], dataset,
+                         linear_transform=lt.to(device), upsample_net=up.to(device), w0=30., c=6., random_seed=seed,
+                         device=device, kl_upper_buffer=0., kl_lower_buffer=0.4, kl_adjust_gap=10, initial_beta=kl_beta,
+                         beta_step_size=0.05, **kw)
+    model.precision = precision
+    model.optimize_posteriors(x, y, n_epochs=n_epochs, lr=lr, verbose=verbose)
+    ft = finetune_epochs
+    distortion = model.compress_posteriors(
+        x, y, n_epochs_finetune=ft if ft is not None else max(30000 // n_groups, 50),
+        h_n_epochs_finetune=None if h_n is None else (ft if ft is not None else max(15000 // h_n, 20)),
+        hh_n_epochs_finetune=None if hh_n is None else (ft if ft is not None else max(15000 // hh_n, 20)),
+        verbose=verbose, lr=lr, fine_tune_gap=1, compress_from_group_with_largest_kl=True)
+    return distortion, model

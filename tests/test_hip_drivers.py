@@ -1,0 +1,64 @@
+"""GPU test of the host drivers (EM loop with beta rule / prior refit / grouping / checkpoint, and the
+compression entry point) against oracle-composed expectations."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import O
+
+pytestmark = pytest.mark.gpu
+
+from recombiner_amd import config, drivers, utils  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_prior_training_checkpoint_and_compression(tmp_path):
+    cfg = config.configs["cifar"]
+    n = 6
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3, seed=1)
+    path = os.path.join(tmp_path, "PRIOR.pkl")
+    logs = []
+    out = drivers.train_prior(cfg, "cifar", X.to(DEV)[None].expand(n, -1, -1), Y, max_bitrate=0.5, device=DEV,
+                              n_em_iter=2, first_epochs=4, epochs=3, lr=2e-3, checkpoint_path=path, checkpoint_every=1,
+                              log=logs.append)
+    m = out["model"]
+    assert len(out["elbo"]) == 4 + 3 and len(logs) == 2
+    # prior refit == oracle moment matching over the model's posteriors
+    mu, sig = O.refit_prior(m.loc.detach().cpu(), m.log_scale.detach().cpu())
+    np.testing.assert_allclose(out["priors"][0].cpu().numpy(), mu.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["priors"][1].cpu().numpy(), sig.numpy(), rtol=1e-5)
+    mu, sig = O.refit_prior(m.lpe_loc.detach().cpu(), m.lpe_log_scale.detach().cpu())
+    np.testing.assert_allclose(out["priors"][3].cpu().numpy(), sig.numpy(), rtol=1e-5)
+    # beta rule: the initial posteriors (sigma = st(-4)) sit ~8000 bits from the initial prior (sigma = st(-2)),
+    # far above the 512-bit budget -> beta grows by 1.5 in each of the two iterations
+    bmax, bmin = drivers.bit_budgets(cfg, "cifar", 0.5)
+    assert bmax == 0.5 * 1024 and bmin == 0.2 * 1024
+    assert out["kl_beta"] == pytest.approx(1e-8 * 1.5 ** 2)
+    assert drivers.adjust_beta(1e-8, 100.0, bmax, bmin) == pytest.approx(1e-8 / 1.5)
+    assert drivers.adjust_beta(0.9, 1e6, bmax, bmin) == 1 and drivers.adjust_beta(1.1e-20, 0.0, bmax, bmin) == 1e-20
+    # checkpoint: the reference's eight pickles in order
+    ck = drivers.load_checkpoint(path)
+    assert len(ck) == 8
+    gi, gs, ge, g2p, p2g, ng, gk, w = ck[0]
+    D = 3267 + 512
+    assert gi.shape == (D,) and len(gs) == ng == len(ge) and sorted(p2g.tolist()) == list(range(D))
+    assert np.array_equal(np.argsort(p2g), g2p) and w.dtype == np.float32
+    pl, ps, beta, avg_ls = ck[1]
+    assert pl.shape == (D,) and ps.shape == (D,) and avg_ls.shape == (D,) and isinstance(beta, float)
+    assert ck[2] == (None,) * 8 and ck[3][0] is None and ck[5][3] is None
+    assert type(ck[6]).__name__ == "LinearTransform" and type(ck[7]).__name__ == "Upsample"
+    # grouping in the checkpoint == oracle grouping of the same posteriors
+    q_loc = torch.cat([m.loc.detach().flatten(1), m.lpe_loc.detach().flatten(1)], -1).cpu()
+    q_sc = torch.cat([O.st(m.log_scale.detach()).flatten(1), O.st(m.lpe_log_scale.detach()).flatten(1)], -1).cpu()
+    ref = O.grouping(q_loc, q_sc, pl, ps)
+    np.testing.assert_allclose(w, ref[7], rtol=2e-4, atol=1e-7)
+    # compression entry point on that checkpoint: every group of every image gets an index
+    dist, model = drivers.compress(cfg, "cifar", ck, X.to(DEV)[None].expand(2, -1, -1), Y[:2], device=DEV, n_epochs=4,
+                                   finetune_epochs=1)
+    assert dist.shape == (2,) and np.isfinite(dist).all()
+    assert model.compressed_mask_groupwise.all()
+    idx = model.compressed_idx_groupwise
+    assert idx.shape == (2, ng) and (idx >= 0).all() and (idx < 65536).all()
