@@ -222,6 +222,7 @@ int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, co
 int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x, int32_t x_is_f32_preact,
                      void* dx, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
 int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
+                     float* dbias /* nullable [cout]: += sum of dy (bias gradient); caller zeroes */,
                      int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
 
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */

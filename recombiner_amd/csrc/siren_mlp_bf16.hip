@@ -263,7 +263,6 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
       xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
     }
-    fetch(t + 4 < ntiles ? t + 4 : t);
     // targets / upstream gradient of this tile, issued early
     float yv[16];
     if (MODE != MODE_FWD) {
@@ -277,6 +276,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         }
       }
     }
+    // next tile's rows are requested after the targets, so the wait at the loss does not cover them
+    fetch(t + 4 < ntiles ? t + 4 : t);
     // ---- forward ----------------------------------------------------------------------------------
     bf16x8 S[NH][2], Cs[NH][2];
     f32x16 acc;
@@ -295,8 +296,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       f32x16 sv, cv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float tt = acc[r] * kk0;
-        tt = tt - rintf(tt);
+        float tt = acc[r] * kk0;      // revolutions; the hardware reduces the range itself for |tt| < 256
         sv[r] = __builtin_amdgcn_sinf(tt);
         cv[r] = __builtin_amdgcn_cosf(tt);
       }

@@ -325,6 +325,7 @@ struct WgradArgs {
   const void* x;
   const void* dy;
   float* dweff;   // accumulated with fp32 atomics (caller zeroes)
+  float* dbias;   // nullable [COUT]: sum of dy over batch and pixels (conv bias gradient), fp32 atomics
   int batch;
 };
 
@@ -353,6 +354,9 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][mt][nt][r] = 0.f;
+  float dbsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
   for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
     __syncthreads();   // previous INR fully consumed (also orders the halo clear)
     // stage x (interior of the halo image) and dy as bf16
@@ -363,11 +367,14 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
       f.v = load8<X_F32 ? 1 : 0>(a.x, ((long long)b * G * G + pix) * CIN + 8 * c8, true);
       *reinterpret_cast<uint4*>(ximg + ((i + 1) * HG + (j + 1)) * CIN + 8 * c8) = f.u;
     }
+    // 512 % (COUT / 8) == 0: a thread always handles the same 8 channels -> private bias-gradient partials
     for (int e = tid; e < OG * OG * (COUT / 8); e += 512) {
       const int pix = e / (COUT / 8), c8 = e - pix * (COUT / 8);
       Frag f;
       f.v = load8<DY_F32 ? 2 : 0>(a.dy, ((long long)b * OG * OG + pix) * COUT + 8 * c8, true);
       *reinterpret_cast<uint4*>(dimg + pix * COUT + 8 * c8) = f.u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
     }
     __syncthreads();
 #pragma unroll
@@ -397,6 +404,17 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
         }
       }
     }
+  }
+  if (a.dbias) {   // reduce the per-thread channel partials through LDS, one atomic per channel per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);
+    for (int e = tid; e < COUT; e += 512) red[e] = 0.f;
+    __syncthreads();
+    const int c8 = tid % (COUT / 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&red[8 * c8 + j], dbsum[j]);
+    __syncthreads();
+    for (int e = tid; e < COUT; e += 512) atomicAdd(a.dbias + e, red[e]);
   }
   // D[m = ci, n = co]: rows in registers, column on the lane
 #pragma unroll
@@ -479,10 +497,10 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
 }
 
 extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
-                                int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream) {
+                                float* dbias, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream) {
   RCB_REQUIRE(x && dy && dweff, RCB_ERR_ARG, "upconv_wgrad: null pointer");
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_wgrad: empty batch");
-  WgradArgs a{x, dy, dweff, batch};
+  WgradArgs a{x, dy, dweff, dbias, batch};
   hipStream_t st = (hipStream_t)stream;
   int g = batch < 256 ? batch : 256;
   if (grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32) {

@@ -438,9 +438,11 @@ def upconv_dgrad(dy, weff, x, grid, cout):
 
 
 def upconv_wgrad(x, dy, grid, cout):
+    """-> (dWeff [2,2,64,2,2,cout], dbias [cout]) in one pass over x and dy."""
     lib = _lib.load()
     B = x.shape[0]
-    dw = torch.zeros(2, 2, 64, 2, 2, cout, device=x.device, dtype=f32)
-    check(lib.rcb_upconv_wgrad(ptr(x), int(x.dtype == f32), ptr(dy), int(dy.dtype == f32), ptr(dw), B, grid, cout,
-                               stream_ptr()), "rcb_upconv_wgrad")
-    return dw
+    buf = torch.zeros(2 * 2 * 64 * 2 * 2 * cout + cout, device=x.device, dtype=f32)
+    dw, db = buf[:-cout].view(2, 2, 64, 2, 2, cout), buf[-cout:]
+    check(lib.rcb_upconv_wgrad(ptr(x), int(x.dtype == f32), ptr(dy), int(dy.dtype == f32), ptr(dw), ptr(db), B, grid,
+                               cout, stream_ptr()), "rcb_upconv_wgrad")
+    return dw, db

@@ -258,9 +258,14 @@ class PriorBNNmodel(nn.Module):
             # ---- A transform (dense GEMMs) --------------------------------------------------------------
             lowp = self.lowp_gemm and self.precision != 0
             if lowp:
+                # forward: f16 operands (11-bit mantissa; A pre-scaled by 2^10 so that the ~1e-4 products of
+                # h_w @ A stay in f16's normal range) -- finer than the bf16 rounding the MLP kernel applies to
+                # its weights anyway; backward GEMMs: bf16 operands (range-safe, gradients only)
+                hf = h_w.to(torch.float16)
+                wvec = torch.cat([torch.mm(hf[:, lo:hi], (a.detach() * 1024.0).to(torch.float16))
+                                  for (lo, hi), a in zip(slices, A)], 1).float() * (1.0 / 1024.0)
                 h16 = h_w.to(torch.bfloat16)
                 A16 = [a.detach().to(torch.bfloat16) for a in A]
-                wvec = torch.cat([torch.mm(h16[:, lo:hi], a16) for (lo, hi), a16 in zip(slices, A16)], 1).float()
             else:
                 wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):

@@ -208,15 +208,13 @@ class _UpsampleCifarFn(torch.autograd.Function):
             return dlpe, None, None, None, None, None, None
         M = _stage1_maps(lpe.device, torch.float32)
         R = _phase_R(lpe.device, 2, 3, 1)
-        dWeff3 = ops.upconv_wgrad(h2, dpe, 16, 16)
-        dWeff2 = ops.upconv_wgrad(z1, dz2, 8, 64)
+        dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
+        dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64)
         dWeff1 = (lpe.t() @ dz1f).view(2, 2, 128, 8, 8, 64)
         dW1 = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, dWeff1)
         dW2 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff2)
         dW3 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff3)
         db1 = dz1.sum((0, 1, 2))
-        db2 = dz2.sum((0, 1, 2), dtype=torch.float32)
-        db3 = dpe.sum((0, 1, 2))
         return dlpe, dW1, db1, dW2, db2, dW3, db3
 
 

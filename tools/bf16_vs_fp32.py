@@ -44,15 +44,14 @@ if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     res = {}
     variants = (("fp32", dict(precision=0)), ("bf16", dict(precision=1)),
-                ("bf16 grads, fp32 fwd", dict(precision=1, f32fwd=True)),
-                ("bf16 grads, fp32 fwd, fp32 upsample", dict(precision=1, f32fwd=True, up32=True)))
+                ("bf16 + f16/bf16 A-transform GEMMs", dict(precision=1, lowp=True)))
     for name, kw in variants:
         ps = []
-        for rep in range(3):
+        for rep in range(5):
             r = run(n=n, steps=steps, lr=1e-3, **kw)
             ps.append(10 * np.log10(1 / r[0]))
         res[name] = ps
-        print("%-5s PSNR over 3 runs: %s  mean %.3f" % (name, " ".join("%.3f" % p for p in ps), np.mean(ps)), flush=True)
+        print("%-5s PSNR over 5 runs: %s  mean %.3f" % (name, " ".join("%.3f" % p for p in ps), np.mean(ps)), flush=True)
     for name in [v[0] for v in variants[1:]]:
         print("gap %s - fp32: %.3f dB (fp32 run-to-run spread %.3f dB)" % (name, np.mean(res[name]) - np.mean(res["fp32"]),
                                                                           max(res["fp32"]) - min(res["fp32"])))
