@@ -251,8 +251,9 @@ class PriorBNNmodel(nn.Module):
             lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
             lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
             with torch.enable_grad():
-                pe = self._pe(upsample_net, lpe_t)[:, 0]
-                pe_c = pe.contiguous()
+                pe = self._pe(upsample_net, lpe_t)                       # [N, 1, P, E]
+                pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
+                #                                                               materialises zeros + a copy)
             eps = [self._noise((N, 1, D)) for _ in net]
             h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
             # ---- A transform (dense GEMMs) --------------------------------------------------------------
@@ -272,16 +273,7 @@ class PriorBNNmodel(nn.Module):
                     torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
-            if getattr(self, "_exp_fp32_forward", False):
-                # experiment: exact forward / loss, 16-bit kernel only for the gradients
-                import dataclasses
-                m32 = dataclasses.replace(meta, precision=0)
-                yh = ops.siren_fwd(x, pe_c.detach(), wvec, m32)
-                diff = yh - y
-                sse = (diff * diff).sum((1, 2))
-                dw, dpe = ops.siren_bwd(x, pe_c.detach(), wvec, diff * (2.0 / (P * Cc)), meta)
-            else:
-                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
+            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
             mse_buf.index_copy_(0, step_t, (sse.sum(dtype=torch.float64) / (P * Cc)).reshape(1))
             # ---- backward through the shared mappings ------------------------------------------------------
             inputs = [lpe_t] + (conv if training_mappings else [])
@@ -329,9 +321,9 @@ class PriorBNNmodel(nn.Module):
             try:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph):      # records the step; nothing executes during capture
                     body()
-                for _ in range(n_epoch - n_warm - 1):
+                for _ in range(n_epoch - n_warm):
                     graph.replay()
             except Exception as exc:     # capture is an optimisation: fall back to eager stepping
                 import warnings

@@ -158,3 +158,27 @@ def test_end_to_end_cifar_first_rounds():
     agree = (lv.idx_groupwise[done] == e["idx"][done]).mean()
     print("e2e agreement: groups", same_groups, "indices", agree)
     assert agree >= 0.9, agree
+
+
+def test_end_to_end_patched_first_rounds():
+    """3-level hierarchy (audio-like patched preset): optimise 12 epochs, then the first encode rounds of the
+    top level (one group per level-3 row per round, 2 fine-tune epochs) against the reference run."""
+    d = load("test_patch1d.npz")
+    e = load("e2e_patch1d.npz")
+    cfg, n, m = build(d, "patch1d")
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    Y = t(d, "Y").to(DEV)
+    m.noise_source = lambda kind, shape: torch.randn(shape)       # the reference's CPU stream (seeded per epoch)
+    m.optimize_posteriors(X, Y, n_epochs=12, lr=2e-4, verbose=False)
+    check(e, "opt_loc", m.loc, rtol=1e-4, atol=3e-5)
+    lv = m._l3
+    rounds = 4
+    for r in range(rounds):
+        m._encode_round(lv, True, r)
+        m.train(X, Y, 2, torch.optim.Adam(m.parameters(), lr=2e-4), False)
+    done = lv.mask_groupwise
+    assert done.sum() == rounds * lv.rows
+    agree = (lv.idx_groupwise[done] == e["hh_idx"][done]).mean()
+    same_groups = (done & (e["hh_idx"] != 0)).sum() / done.sum()
+    print("patched e2e: level-3 groups", same_groups, "indices", agree)
+    assert agree >= 0.85, agree

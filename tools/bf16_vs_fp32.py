@@ -19,7 +19,7 @@ def smooth_targets(n, seed=0):
         out.append((img * 0.5 + 0.5).clamp(0, 1).reshape(3, -1).T)
     return torch.stack(out)
 
-def run(precision, n, steps, lr, lowp=False, f32fwd=False, up32=False):
+def run(precision, n, steps, lr, lowp=False):
     cfg = config.configs["cifar"]
     X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3)
     Y = smooth_targets(n)
@@ -27,9 +27,6 @@ def run(precision, n, steps, lr, lowp=False, f32fwd=False, up32=False):
                          cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device="cuda")
     m.precision = precision
     m.lowp_gemm = lowp
-    m._exp_fp32_forward = f32fwd
-    if up32:
-        m._pe = lambda net, lpe: __import__('recombiner_amd.utils', fromlist=['x']).map_lpe_to_inr_inputs(net, lpe, 128, [32, 32], [16, 16], False, None, 2)
     torch.manual_seed(123); lt = PM.LinearTransform(m.dims).cuda()
     torch.manual_seed(124); up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
     gen = torch.Generator(device="cuda").manual_seed(5)
