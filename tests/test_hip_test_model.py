@@ -182,3 +182,27 @@ def test_end_to_end_patched_first_rounds():
     same_groups = (done & (e["hh_idx"] != 0)).sum() / done.sum()
     print("patched e2e: level-3 groups", same_groups, "indices", agree)
     assert agree >= 0.85, agree
+
+
+def test_graph_replayed_training_tracks_eager_training():
+    """captured-graph stepping (one noise stream per call) vs eager stepping (reseeded per epoch): different
+    noise, same optimisation -- parameters move the same way and the per-group beta agree."""
+    d = load("test_cifar.npz")
+    out = []
+    for use_graph in (True, False):
+        cfg, n, m = build(d, "cifar")
+        set_post(d, cfg, m)
+        m.use_graph = use_graph
+        X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+        Y = t(d, "Y").to(DEV)
+        l0 = m.loc.detach().clone()
+        m.train(X, Y, 40, torch.optim.Adam(m.parameters(), lr=2e-4), False)
+        m.train(X, Y, 12, torch.optim.Adam(m.parameters(), lr=2e-4), False)      # second call re-uses the graphs
+        out.append(((m.loc.detach() - l0).cpu().numpy(), m.kl_beta.cpu().numpy().copy()))
+        if use_graph:
+            assert m._ws is not None and set(m._ws["graphs"].keys()) == {True, False}
+    (da, ba), (db, bb) = out
+    cos = float((da * db).sum() / np.sqrt((da * da).sum() * (db * db).sum()))
+    assert cos > 0.9, cos                       # same direction of travel
+    assert abs(np.abs(da).mean() / np.abs(db).mean() - 1) < 0.1
+    assert (ba != bb).mean() < 0.05
