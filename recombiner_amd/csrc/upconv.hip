@@ -319,6 +319,177 @@ __global__ void __launch_bounds__(512) upconv_dgrad_kernel(DgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage-3 variants (G = 16: one INR = 8 tiles = one 8-wave workgroup pass): the INR's source image is
+// staged once in LDS (zero halo, padded rows: conflict-free 16-byte gathers), so every gather is an LDS
+// read instead of an L2 round trip; the next INR's image is prefetched into registers during compute.
+// ------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
+  constexpr int G = 16, HG = 18, RS = 72;   // image row stride in elements (64 channels + 8 pad = 144 B)
+  constexpr int NF = 4 * 4 * 4;             // MT = 1 (COUT <= 32)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  for (int e = tid; e < NF * 64; e += 512) {
+    const int ln = e & 63, slot = e >> 6;
+    const int kb = slot & 3, t = (slot >> 2) & 3, p = slot >> 4;
+    const int fq = ln & 31, fh = ln >> 5;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float w = 0.f;
+      if (fq < COUT) w = a.weff[weff_index(t >> 1, t & 1, 16 * kb + 8 * fh + j, p >> 1, p & 1, fq, COUT)];
+      f.v[j] = (__bf16)w;
+    }
+    frags[e] = f.u;
+  }
+  for (int e = tid; e < HG * HG * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  // each thread stages 4 x 16 B of the 32 KB image: element e -> pixel e / 8, chunk e % 8
+  uint4 pre0, pre1, pre2, pre3;
+  pre0 = pre1 = pre2 = pre3 = make_uint4(0, 0, 0, 0);
+#define RCB_FETCH3(bb)                                                                                          \
+  {                                                                                                            \
+    const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + (long long)(bb) * G * G * CIN); \
+    pre0 = src_[tid]; pre1 = src_[tid + 512]; pre2 = src_[tid + 1024]; pre3 = src_[tid + 1536];               \
+  }
+#define RCB_COMMIT3(kk, val)                                                                                    \
+  {                                                                                                            \
+    const int e_ = tid + 512 * (kk), pix_ = e_ >> 3, c8_ = e_ & 7;                                             \
+    *reinterpret_cast<uint4*>(img + (((pix_ >> 4) + 1) * HG + ((pix_ & 15) + 1)) * RS + 8 * c8_) = (val);      \
+  }
+  int b = blockIdx.x;
+  if (b < a.batch) RCB_FETCH3(b)
+  const int i = (wave * 32 + q) >> 4, j = (wave * 32 + q) & 15;
+  for (; b < a.batch; b += gridDim.x) {
+    __syncthreads();          // everyone is done with the previous image (and with the frag / halo setup)
+    RCB_COMMIT3(0, pre0) RCB_COMMIT3(1, pre1) RCB_COMMIT3(2, pre2) RCB_COMMIT3(3, pre3)
+    __syncthreads();
+    if (b + (int)gridDim.x < a.batch) RCB_FETCH3(b + gridDim.x)
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 9; ++nb) {
+      const int dy = nb / 3 - 1, dx = nb % 3 - 1;
+      const __bf16* px = img + ((i + dy + 1) * HG + (j + dx + 1)) * RS + 8 * h;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        Frag bf;
+        bf.u = *reinterpret_cast<const uint4*>(px + 16 * kb);
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+          const int ty = dy + 1 - pa;
+          if (ty < 0 || ty > 1) continue;
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int tx = dx + 1 - pb;
+            if (tx < 0 || tx > 1) continue;
+            const int p = pa * 2 + pb, t = ty * 2 + tx;
+            Frag fa;
+            fa.u = frags[((p * 4 + t) * 4 + kb) * 64 + lane];
+            acc[p] = mfma16(fa.v, bf.v, acc[p]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long long opix = ((long long)b * (2 * G) + 2 * i + (p >> 1)) * (2 * G) + 2 * j + (p & 1);
+#pragma unroll
+      for (int g4 = 0; g4 < COUT / 8; ++g4) {
+        const int co = 8 * g4 + 4 * h;
+        float4 o = make_float4(acc[p][4 * g4] + a.bias[co], acc[p][4 * g4 + 1] + a.bias[co + 1],
+                               acc[p][4 * g4 + 2] + a.bias[co + 2], acc[p][4 * g4 + 3] + a.bias[co + 3]);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + co) = o;
+      }
+    }
+  }
+#undef RCB_FETCH3
+#undef RCB_COMMIT3
+}
+
+template <int COUT>
+__global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
+  constexpr int G = 16, OG = 32, HO = 34, RS = 24;   // dy image: [34][34] pixels x 16 channels (+8 pad = 48 B rows)
+  constexpr int NF = 16 * 2;                          // KB = 1, [combo][mt]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  for (int e = tid; e < NF * 64; e += 512) {
+    const int ln = e & 63, slot = e >> 6;
+    const int mt = slot & 1, combo = slot >> 1;
+    const int ry = (combo >> 2) - 1, rx = (combo & 3) - 1;
+    const int pa = (ry & 1), ty = (ry <= 0) ? 1 : 0;
+    const int pb = (rx & 1), tx = (rx <= 0) ? 1 : 0;
+    const int fq = ln & 31, fh = ln >> 5, ci = 32 * mt + fq;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, ci, pa, pb, 8 * fh + j, COUT)];
+    frags[e] = f.u;
+  }
+  for (int e = tid; e < HO * HO * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  // dy image of one INR: 32*32 pixels x 16 fp32 = 64 KB = 4096 float4 -> 8 per thread, converted to bf16 on commit
+  float4 pre[8];
+  auto fetch = [&](int b) {
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dy) + (long long)b * OG * OG * COUT);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre[k] = src[tid + 512 * k];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = tid + 512 * k, pix = e >> 2, c4 = e & 3;
+      const int oy = pix >> 5, ox = pix & 31;
+      bf16x4 v = {(__bf16)pre[k].x, (__bf16)pre[k].y, (__bf16)pre[k].z, (__bf16)pre[k].w};
+      *reinterpret_cast<bf16x4*>(img + ((oy + 1) * HO + (ox + 1)) * RS + 4 * c4) = v;
+    }
+  };
+  int b = blockIdx.x;
+  if (b < a.batch) fetch(b);
+  const int u = (wave * 32 + q) >> 4, v = (wave * 32 + q) & 15;
+  for (; b < a.batch; b += gridDim.x) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (b + (int)gridDim.x < a.batch) fetch(b + gridDim.x);
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
+      Frag bf;
+      bf.u = *reinterpret_cast<const uint4*>(img + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        Frag fa;
+        fa.u = frags[(n * 2 + mt) * 64 + lane];
+        acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
+      }
+    }
+    const long long xpix = ((long long)b * G * G + wave * 32 + q) * CIN;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int ci = 32 * mt + 8 * g4 + 4 * h;
+        bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + ci);
+        bf16x4 ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)t[k] > 0.f ? 1.0f : SLOPE));
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -472,7 +643,7 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear) {
     static bool done = false;
-    return launch(upconv_fwd_kernel<16, 16, 0, 1>, a, grid_for(batch * 8, 4 * 4 * 4 * 1 * 1024), 4 * 4 * 4 * 1 * 1024, st, done);
+    return launch(upconv_fwd3_lds_kernel<16>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_fwd: grid=%d cout=%d in_f32=%d out_f32=%d not instantiated", grid, cout,
               x_is_f32_preact, y_is_f32_linear);
@@ -487,7 +658,7 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (grid == 16 && cout == 16 && dy_is_f32 && !x_is_f32_preact) {
     static bool done = false;
-    return launch(upconv_dgrad_kernel<16, 16, 1, 0>, a, grid_for(batch * 8, 16 * 1 * 2 * 1024), 16 * 1 * 2 * 1024, st, done);
+    return launch(upconv_dgrad3_lds_kernel<16>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact) {
     static bool done = false;
