@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
     ap.add_argument("--lowp-gemm", action="store_true", help="bf16-operand A-transform GEMMs (experimental)")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="do not load the committed TunableOp GEMM selections")
     return ap.parse_args()
 
 
@@ -99,7 +100,8 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
 
-    from recombiner_amd import config, ops, utils
+    from recombiner_amd import config, ops, tuning, utils
+    tuned = False if a.no_tuned_gemms else tuning.enable_tuned_gemms()
     from recombiner_amd import prior_model as PM
     cfg = config.configs["cifar"]
     n = a.inrs
@@ -197,7 +199,7 @@ def main():
                "inr_steps_per_sec": inr_steps, "steps_per_inr_reference_schedule": STEPS_PER_INR,
                "config": {"workload": f"CIFAR-10 32x32, {n} INRs/GPU, 3x32 SIREN (in 32 = 16 Fourier + 16 upsampled pe), "
                                       f"S=1, training_mappings={tm}, Adam lr 2e-4", "inrs_per_gpu": n,
-                          "parallelism": f"datapoint-sharded x{ws}"},
+                          "parallelism": f"datapoint-sharded x{ws}", "tuned_library_gemms": bool(tuned)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if ws > 1:

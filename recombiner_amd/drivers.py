@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import dist, ops
+from . import dist, ops, tuning
 from .prior_model import LinearTransform, PriorBNNmodel, Upsample, get_grouping_by_kl
 from .test_model import TestBNNmodel
 
@@ -54,6 +54,7 @@ def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em
                 epochs=100, lr=2e-4, kl_beta=1e-8, training_mappings=True, checkpoint_path=None, checkpoint_every=10,
                 precision=0, group=None, log=print):
     """Coordinate-ascent prior learning.  Returns a dict with the model, mappings, priors, beta and ELBO curve."""
+    tuning.enable_tuned_gemms()
     train_size = Y.shape[0]
     patch = config['patch']
     m = PriorBNNmodel(config['input_dim'], config['hidden_dims'], config['output_dim'], train_size, config['data_dim'],
@@ -157,6 +158,7 @@ def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs
              verbose=0, finetune_epochs=None):
     """main_compression.py:47-178 on an in-memory checkpoint (list from load_checkpoint / build_checkpoint).
     Returns (distortion, model)."""
+    tuning.enable_tuned_gemms()
     g1, l1, g2, l2, g3, l3, lt, up = checkpoint
     group_idx, start, end, group2param, param2group, n_groups, _, _ = g1
     prior_loc, prior_scale, kl_beta, avg_ls = l1
