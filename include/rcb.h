@@ -210,7 +210,8 @@ int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, con
  * up2/conv2/act2, up3/conv3) in sub-pixel (phase) form, bf16 MFMA / fp32 accumulate, channel-last images,
  * Cin = 64.  weff = kernel taps pre-summed per (phase, 2x2 window tap), fp32 [ty][tx][ci][a][b][co].
  *   fwd  : y[b, 2i+a, 2j+b', co] = bias[co] + sum weff[ty,tx,ci,a,b',co] * x[b, i+a+ty-1, j+b'+tx-1, ci]
- *          x: bf16 activations, or fp32 pre-activations (LeakyReLU(0.01) applied on load);
+ *          x: bf16 activations (x_is_f32_preact = 0), fp32 pre-activations (1) or bf16 pre-activations (2);
+ *             LeakyReLU(0.01) is applied on load to pre-activations;
  *          y: bf16 with LeakyReLU applied, or fp32 linear output.
  *   dgrad: dx = (conv^T dy) * LeakyReLU'(x)   (sign taken from the stored activation / pre-activation)
  *   wgrad: dweff += sum_b,i,j x (x) dy   (fp32 atomics; the caller zeroes dweff)

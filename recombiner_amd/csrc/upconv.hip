@@ -43,13 +43,17 @@ union Frag {
 };
 
 // 8 consecutive channels of one pixel as a bf16 fragment; `ok` false -> zeros (halo)
-template <int MODE>  // 0: bf16 image, 1: fp32 pre-activation (LeakyReLU applied), 2: fp32 plain
+template <int MODE>  // 0: bf16 image, 1: fp32 pre-activation (LeakyReLU applied), 2: fp32 plain, 3: bf16 pre-activation
 __device__ __forceinline__ bf16x8 load8(const void* base, long long elem_off, bool ok) {
   Frag f;
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 3) {
     const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + elem_off);
     f.u = *p;
     if (!ok) f.u = make_uint4(0, 0, 0, 0);
+    if (MODE == 3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)lrelu((float)f.v[j]);
+    }
   } else {
     const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
     float4 v0 = p[0], v1 = p[1];
@@ -71,11 +75,12 @@ template <int MODE> struct Raw8;
 template <> struct Raw8<0> { uint4 u; };
 template <> struct Raw8<1> { float4 a, b; };
 template <> struct Raw8<2> { float4 a, b; };
+template <> struct Raw8<3> { uint4 u; };
 
 template <int MODE>
 __device__ __forceinline__ Raw8<MODE> raw_load(const void* base, long long elem_off) {
   Raw8<MODE> r;
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || MODE == 3) {
     r.u = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + elem_off);
   } else {
     const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
@@ -88,8 +93,12 @@ __device__ __forceinline__ Raw8<MODE> raw_load(const void* base, long long elem_
 template <int MODE>
 __device__ __forceinline__ bf16x8 raw_frag(const Raw8<MODE>& r, bool ok) {
   Frag f;
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || MODE == 3) {
     f.u = ok ? r.u : make_uint4(0, 0, 0, 0);
+    if constexpr (MODE == 3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)lrelu((float)f.v[j]);
+    }
   } else {
     float t[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
 #pragma unroll
@@ -505,7 +514,7 @@ __device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-template <int COUT, int G, int X_F32, int DY_F32>
+template <int COUT, int G, int X_MODE, int DY_F32>
 __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = (COUT + 31) / 32;
   constexpr int HG = G + 2;             // halo grid
@@ -535,7 +544,7 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
       const int pix = e / (CIN / 8), c8 = e - pix * (CIN / 8);
       const int i = pix / G, j = pix - i * G;
       Frag f;
-      f.v = load8<X_F32 ? 1 : 0>(a.x, ((long long)b * G * G + pix) * CIN + 8 * c8, true);
+      f.v = load8<X_MODE>(a.x, ((long long)b * G * G + pix) * CIN + 8 * c8, true);
       *reinterpret_cast<uint4*>(ximg + ((i + 1) * HG + (j + 1)) * CIN + 8 * c8) = f.u;
     }
     // 512 % (COUT / 8) == 0: a thread always handles the same 8 channels -> private bias-gradient partials
@@ -637,7 +646,7 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_fwd: empty batch");
   FwdArgs a{x, weff, bias, y, batch};
   hipStream_t st = (hipStream_t)stream;
-  if (grid == 8 && cout == 64 && x_is_f32_preact && !y_is_f32_linear) {
+  if (grid == 8 && cout == 64 && x_is_f32_preact == 1 && !y_is_f32_linear) {
     static bool done = false;
     return launch(upconv_fwd_kernel<64, 8, 1, 0>, a, grid_for(batch * 2, 4 * 4 * 4 * 2 * 1024), 4 * 4 * 4 * 2 * 1024, st, done);
   }
@@ -645,7 +654,11 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
     static bool done = false;
     return launch(upconv_fwd3_lds_kernel<16>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
   }
-  return fail(RCB_ERR_UNSUPPORTED, "upconv_fwd: grid=%d cout=%d in_f32=%d out_f32=%d not instantiated", grid, cout,
+  if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input
+    static bool done = false;
+    return launch(upconv_fwd_kernel<64, 8, 3, 0>, a, grid_for(batch * 2, 4 * 4 * 4 * 2 * 1024), 4 * 4 * 4 * 2 * 1024, st, done);
+  }
+  return fail(RCB_ERR_UNSUPPORTED, "upconv_fwd: grid=%d cout=%d in_mode=%d out_f32=%d not instantiated", grid, cout,
               x_is_f32_preact, y_is_f32_linear);
 }
 
@@ -660,9 +673,13 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
     static bool done = false;
     return launch(upconv_dgrad3_lds_kernel<16>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
   }
-  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact) {
+  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 1) {
     static bool done = false;
     return launch(upconv_dgrad_kernel<64, 8, 0, 1>, a, grid_for(batch * 2, 16 * 4 * 2 * 1024), 16 * 4 * 2 * 1024, st, done);
+  }
+  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 2) {   // bf16 pre-activation: sign source, bf16 dx
+    static bool done = false;
+    return launch(upconv_dgrad_kernel<64, 8, 0, 0>, a, grid_for(batch * 2, 16 * 4 * 2 * 1024), 16 * 4 * 2 * 1024, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_dgrad: grid=%d cout=%d not instantiated", grid, cout);
 }
@@ -678,9 +695,13 @@ extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const vo
     static bool done = false;
     return launch(upconv_wgrad_kernel<16, 16, 0, 1>, a, g, (18 * 18 * 64 + 32 * 32 * 16) * 2, st, done);
   }
-  if (grid == 8 && cout == 64 && x_is_f32_preact && !dy_is_f32) {
+  if (grid == 8 && cout == 64 && x_is_f32_preact == 1 && !dy_is_f32) {
     static bool done = false;
     return launch(upconv_wgrad_kernel<64, 8, 1, 0>, a, g, (10 * 10 * 64 + 16 * 16 * 64) * 2, st, done);
+  }
+  if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !dy_is_f32) {
+    static bool done = false;
+    return launch(upconv_wgrad_kernel<64, 8, 3, 0>, a, g, (10 * 10 * 64 + 16 * 16 * 64) * 2, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
 }

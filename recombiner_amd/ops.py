@@ -418,31 +418,38 @@ def rec_score_argmax(loc, scale, p_loc, p_scale, tables: dict, gumbel, job_row, 
 bf16 = torch.bfloat16
 
 
-def upconv_fwd(x, weff, bias, grid, cout, out_f32):
+def _xmode(x, preact):
+    """0: bf16 activation, 1: fp32 pre-activation, 2: bf16 pre-activation"""
+    if x.dtype == f32:
+        return 1
+    return 2 if preact else 0
+
+
+def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False):
     """x [B, g, g, 64] (fp32 pre-activation or bf16 activation) -> y [B, 2g, 2g, cout]."""
     lib = _lib.load()
     B = x.shape[0]
     y = torch.empty(B, 2 * grid, 2 * grid, cout, device=x.device, dtype=f32 if out_f32 else bf16)
-    check(lib.rcb_upconv_fwd(ptr(x), int(x.dtype == f32), ptr(weff, f32), ptr(bias, f32), ptr(y), int(out_f32), B, grid,
+    check(lib.rcb_upconv_fwd(ptr(x), _xmode(x, preact), ptr(weff, f32), ptr(bias, f32), ptr(y), int(out_f32), B, grid,
                              cout, stream_ptr()), "rcb_upconv_fwd")
     return y
 
 
-def upconv_dgrad(dy, weff, x, grid, cout):
+def upconv_dgrad(dy, weff, x, grid, cout, preact=False):
     lib = _lib.load()
     B = x.shape[0]
     dx = torch.empty_like(x)
-    check(lib.rcb_upconv_dgrad(ptr(dy), int(dy.dtype == f32), ptr(weff, f32), ptr(x), int(x.dtype == f32), ptr(dx), B,
+    check(lib.rcb_upconv_dgrad(ptr(dy), int(dy.dtype == f32), ptr(weff, f32), ptr(x), _xmode(x, preact), ptr(dx), B,
                                grid, cout, stream_ptr()), "rcb_upconv_dgrad")
     return dx
 
 
-def upconv_wgrad(x, dy, grid, cout):
+def upconv_wgrad(x, dy, grid, cout, preact=False):
     """-> (dWeff [2,2,64,2,2,cout], dbias [cout]) in one pass over x and dy."""
     lib = _lib.load()
     B = x.shape[0]
     buf = torch.zeros(2 * 2 * 64 * 2 * 2 * cout + cout, device=x.device, dtype=f32)
     dw, db = buf[:-cout].view(2, 2, 64, 2, 2, cout), buf[-cout:]
-    check(lib.rcb_upconv_wgrad(ptr(x), int(x.dtype == f32), ptr(dy), int(dy.dtype == f32), ptr(dw), ptr(db), B, grid,
+    check(lib.rcb_upconv_wgrad(ptr(x), _xmode(x, preact), ptr(dy), int(dy.dtype == f32), ptr(dw), ptr(db), B, grid,
                                cout, stream_ptr()), "rcb_upconv_wgrad")
     return dw, db

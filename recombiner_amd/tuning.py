@@ -7,13 +7,18 @@ import os
 import torch
 
 TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_mi355x.csv")
+_tuning_to = None      # set while tools/tune_gemms.py is recording: later lookup requests must not switch it off
 
 
 def enable_tuned_gemms(path=TUNED_FILE, tune=False):
     if not torch.cuda.is_available():
         return False
     import torch.cuda.tunable as tun
+    global _tuning_to
+    if _tuning_to is not None:
+        return True
     if tune:
+        _tuning_to = path
         tun.enable(True)
         tun.tuning_enable(True)
         tun.set_max_tuning_duration(300)

@@ -179,15 +179,20 @@ class _UpsampleCifarFn(torch.autograd.Function):
     pre-summed 512 x 4096 weight (hipBLASLt); stages 2 and 3 are the rcb_upconv_* kernels."""
 
     @staticmethod
-    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3):
+    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3, stage1_bf16):
         from . import ops
         B = lpe.shape[0]
         M = _stage1_maps(lpe.device, torch.float32)
         Weff1 = torch.einsum("ysk,xtl,oikl->stiyxo", M, M, W1).reshape(512, 4096)
-        z1 = torch.addmm(b1.repeat(64), lpe, Weff1).view(B, 8, 8, 64)
+        if stage1_bf16:      # bf16 operands and a bf16 z1: stage 2 rounds z1 to bf16 for its MFMA operand anyway
+            Weff1 = Weff1.to(torch.bfloat16)
+            lpe = lpe.to(torch.bfloat16)
+            z1 = torch.addmm(b1.repeat(64).to(torch.bfloat16), lpe, Weff1).view(B, 8, 8, 64)
+        else:
+            z1 = torch.addmm(b1.repeat(64), lpe, Weff1).view(B, 8, 8, 64)
         st = PhaseStage(2, 3, 1, 2)
         Weff2 = st.eff_weight(W2).contiguous()
-        h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False)
+        h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True)
         Weff3 = st.eff_weight(W3).contiguous()
         pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=True)
         ctx.save_for_backward(lpe, Weff1, z1, Weff2, h2, Weff3)
@@ -201,26 +206,27 @@ class _UpsampleCifarFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[1:])
         dpe = dpe.contiguous().view(B, 32, 32, 16)
         dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16)                     # bf16 [B,16,16,64]
-        dz1 = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64)                      # fp32 [B,8,8,64]
+        dz1 = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True)         # [B,8,8,64] in the dtype of z1
         dz1f = dz1.view(B, 4096)
-        dlpe = dz1f @ Weff1.t() if ctx.needs_input_grad[0] else None
+        dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
         if not need_w:
-            return dlpe, None, None, None, None, None, None
+            return dlpe, None, None, None, None, None, None, None
         M = _stage1_maps(lpe.device, torch.float32)
         R = _phase_R(lpe.device, 2, 3, 1)
         dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
-        dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64)
-        dWeff1 = (lpe.t() @ dz1f).view(2, 2, 128, 8, 8, 64)
+        dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64, preact=True)
+        dWeff1 = (lpe.t() @ dz1f).float().view(2, 2, 128, 8, 8, 64)
         dW1 = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, dWeff1)
         dW2 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff2)
         dW3 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff3)
-        db1 = dz1.sum((0, 1, 2))
-        return dlpe, dW1, db1, dW2, db2, dW3, db3
+        db1 = dz1.sum((0, 1, 2), dtype=torch.float32)
+        return dlpe, dW1, db1, dW2, db2, dW3, db3, None
 
 
-def upsample_cifar_hip(net, lpe):
-    """lpe [S, N, 2, 2, 128] -> pe [N, S, 1024, 16] through the HIP phase-conv kernels."""
+def upsample_cifar_hip(net, lpe, stage1_bf16=True):
+    """lpe [S, N, 2, 2, 128] -> pe [N, S, 1024, 16] through the HIP phase-conv kernels.  `stage1_bf16` runs the
+    stage-1 library GEMMs (fwd, dgrad, wgrad) with bf16 operands / fp32 accumulation and keeps z1 in bf16."""
     S, N = lpe.shape[:2]
     pe = _UpsampleCifarFn.apply(lpe.reshape(S * N, 512), net.conv1.weight, net.conv1.bias, net.conv2.weight,
-                                net.conv2.bias, net.conv3.weight, net.conv3.bias)
+                                net.conv2.bias, net.conv3.weight, net.conv3.bias, bool(stage1_bf16))
     return pe.view(S, N, 1024, 16).permute(1, 0, 2, 3)

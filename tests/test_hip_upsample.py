@@ -17,8 +17,8 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("S,N", [(1, 6), (5, 3)])
-def test_upsample_hip_forward_backward(S, N):
+@pytest.mark.parametrize("S,N,stage1_bf16", [(1, 6, False), (5, 3, False), (2, 5, True)])
+def test_upsample_hip_forward_backward(S, N, stage1_bf16):
     torch.manual_seed(0)
     net = PM.Upsample(2, [2, 1, 1], [4, 2, 2]).to(DEV)
     assert hip_path_supported(net, [32, 32], [16, 16], False, 2)
@@ -32,15 +32,15 @@ def test_upsample_hip_forward_backward(S, N):
     lpe64 = lpe.detach().double().requires_grad_(True)
     ref = map_lpe_to_inr_inputs(net64, lpe64, 128, [32, 32], [16, 16], False, None, 2)
     gr = torch.autograd.grad(ref, [lpe64] + list(net64.parameters()), g.double())
-    out = upsample_cifar_hip(net, lpe)
+    out = upsample_cifar_hip(net, lpe, stage1_bf16)
     go = torch.autograd.grad(out, [lpe] + params, g)
     e_fwd = rel(out, ref)
     errs = [rel(a, b) for a, b in zip(go, gr)]
     print("upsample hip: fwd %.2e  dlpe %.2e  dW1 %.2e db1 %.2e dW2 %.2e db2 %.2e dW3 %.2e db3 %.2e" % (e_fwd, *errs))
     # bf16 operands (8-bit mantissa), fp32 accumulation
     # bf16 operands and bf16 intermediate images (h2, dz2): max-norm errors of a few 1e-2 on gradients
-    assert e_fwd < 1e-2
-    assert max(errs) < 6e-2
+    assert e_fwd < (2e-2 if stage1_bf16 else 1e-2)
+    assert max(errs) < (8e-2 if stage1_bf16 else 6e-2)
 
 
 def test_phase_form_is_exact_on_gpu():

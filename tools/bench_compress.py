@@ -5,7 +5,9 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recombiner_amd import config, utils
-from recombiner_amd import prior_model as PM, test_model as TM
+from recombiner_amd import prior_model as PM, test_model as TM, tuning
+
+tuning.enable_tuned_gemms()
 
 prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else 0
 cfg = config.configs["cifar"]

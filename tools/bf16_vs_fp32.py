@@ -19,7 +19,7 @@ def smooth_targets(n, seed=0):
         out.append((img * 0.5 + 0.5).clamp(0, 1).reshape(3, -1).T)
     return torch.stack(out)
 
-def run(precision, n, steps, lr, lowp=False):
+def run(precision, n, steps, lr, lowp=False, stage1=False):
     cfg = config.configs["cifar"]
     X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3)
     Y = smooth_targets(n)
@@ -27,6 +27,7 @@ def run(precision, n, steps, lr, lowp=False):
                          cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device="cuda")
     m.precision = precision
     m.lowp_gemm = lowp
+    m.stage1_bf16 = stage1
     torch.manual_seed(123); lt = PM.LinearTransform(m.dims).cuda()
     torch.manual_seed(124); up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
     gen = torch.Generator(device="cuda").manual_seed(5)
@@ -39,16 +40,19 @@ def run(precision, n, steps, lr, lowp=False):
 if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    res = {}
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     variants = (("fp32", dict(precision=0)), ("bf16", dict(precision=1)),
+                ("bf16 + bf16 stage-1 GEMMs", dict(precision=1, stage1=True)),
                 ("bf16 + f16/bf16 A-transform GEMMs", dict(precision=1, lowp=True)))
+    if len(sys.argv) > 4:
+        keep = sys.argv[4].split(",")
+        variants = tuple(v for i, v in enumerate(variants) if str(i) in keep)
+    res = {}
     for name, kw in variants:
-        ps = []
-        for rep in range(5):
-            r = run(n=n, steps=steps, lr=1e-3, **kw)
-            ps.append(10 * np.log10(1 / r[0]))
+        ps = [10 * np.log10(1 / run(n=n, steps=steps, lr=1e-3, **kw)[0]) for _ in range(reps)]
         res[name] = ps
-        print("%-5s PSNR over 5 runs: %s  mean %.3f" % (name, " ".join("%.3f" % p for p in ps), np.mean(ps)), flush=True)
+        print("%-34s PSNR mean %.3f  std %.3f  (%s)" % (name, np.mean(ps), np.std(ps), " ".join("%.2f" % p for p in ps)), flush=True)
     for name in [v[0] for v in variants[1:]]:
-        print("gap %s - fp32: %.3f dB (fp32 run-to-run spread %.3f dB)" % (name, np.mean(res[name]) - np.mean(res["fp32"]),
-                                                                          max(res["fp32"]) - min(res["fp32"])))
+        d = np.mean(res[name]) - np.mean(res["fp32"])
+        se = np.sqrt(np.var(res[name]) / reps + np.var(res["fp32"]) / reps)
+        print("gap %s - fp32: %.3f +- %.3f dB" % (name, d, se))
