@@ -61,24 +61,27 @@ typedef struct {
   int64_t xf_inr_stride; /* floats between INRs in xf; 0 = shared grid              */
   int64_t w_row_stride;  /* floats between rows of wvec and of dwvec                */
   float   w0;            /* sine frequency (30)                                     */
-  int32_t precision;     /* 0 fp32, 1 bf16                                          */
+  int32_t precision;     /* 0 fp32, 1 bf16, 2 f16 operands                           */
+  int32_t pe_bf16;       /* 1: pe and dpe are bf16 arrays (precision >= 1, pe_dim % 8 == 0): the 16-bit
+                          * kernels round pe / dpe to bf16 for their MFMA operands anyway, so storing
+                          * them as bf16 gives bit-identical results with half the traffic        */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */
-int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
+int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
                   float* y_out, rcb_stream_t stream);
 
 /* Given dy[G, P, C]: dwvec[G, :] (same layout/stride as wvec) and, if dpe != NULL, dpe[G, P, E].
  * The forward pass is recomputed in registers; no activations are read from memory.            */
-int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
-                  const float* dy, float* dwvec, float* dpe, rcb_stream_t stream);
+int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
+                  const float* dy, float* dwvec, void* dpe, rcb_stream_t stream);
 
 /* Fused training pass: sse[g] = sum_{p,c} (y - target[g/S])^2 and the gradients of
  * dy_scale * sse[g] with respect to wvec row g and pe row g (dpe may be NULL).  With
  * dy_scale = 1/(S*P*C) this is the reference's `mean((y_hat - y)**2) * N` term.              */
-int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, const float* pe,
+int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, const void* pe,
                        const float* wvec, const float* target, float dy_scale, float* sse,
-                       float* dwvec, float* dpe, rcb_stream_t stream);
+                       float* dwvec, void* dpe, rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K1 + K10: reparameterised sampling of the latent vector of every (INR, sample) from a 1- or
@@ -212,11 +215,11 @@ int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, con
  *   fwd  : y[b, 2i+a, 2j+b', co] = bias[co] + sum weff[ty,tx,ci,a,b',co] * x[b, i+a+ty-1, j+b'+tx-1, ci]
  *          x: bf16 activations (x_is_f32_preact = 0), fp32 pre-activations (1) or bf16 pre-activations (2);
  *             LeakyReLU(0.01) is applied on load to pre-activations;
- *          y: bf16 with LeakyReLU applied, or fp32 linear output.
+ *          y: bf16 with LeakyReLU applied (y_is_f32_linear = 0), fp32 linear output (1) or bf16 linear output (2).
  *   dgrad: dx = (conv^T dy) * LeakyReLU'(x)   (sign taken from the stored activation / pre-activation)
  *   wgrad: dweff += sum_b,i,j x (x) dy   (fp32 atomics; the caller zeroes dweff)
- * Instantiated for (grid, cout) = (8, 64) [stage 2: fp32 pre-activation in, bf16 out] and (16, 16)
- * [stage 3: bf16 in, fp32 out]; batch = number of images (INR x sample).
+ * Instantiated for (grid, cout) = (8, 64) [stage 2: fp32 or bf16 pre-activation in, bf16 out] and (16, 16)
+ * [stage 3: bf16 in, fp32 or bf16 linear out; dy fp32 or bf16]; batch = number of images (INR x sample).
  * ------------------------------------------------------------------------------------------- */
 int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, const float* bias, void* y,
                    int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);

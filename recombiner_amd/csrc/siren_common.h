@@ -26,6 +26,7 @@ struct SirenArgs {
   int dnet, wt_total, tile_base, smem_floats;
   float k_hi, k_lo;   // w0 / (2 pi) split in two floats
   float w0, dy_scale;
+  int pe_bf16;        // pe / dpe hold bf16 elements (16-bit kernels only)
 };
 
 // row of accumulator register r for lane half h (32x32 MFMA C/D layout)

@@ -377,7 +377,11 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d->n_rows > 0 && d->samples > 0 && d->n_pix > 0 && d->n_rows % d->samples == 0, RCB_ERR_SHAPE,
               "siren: rows=%d samples=%d pix=%d", d->n_rows, d->samples, d->n_pix);
   RCB_REQUIRE(d->precision >= 0 && d->precision <= 2, RCB_ERR_UNSUPPORTED, "siren: precision %d not built", d->precision);
+  RCB_REQUIRE(d->pe_bf16 == 0 || (d->pe_bf16 == 1 && d->precision >= 1 && d->pe_dim % 8 == 0), RCB_ERR_UNSUPPORTED,
+              "siren: bf16 pe storage needs a 16-bit precision mode and pe_dim %% 8 == 0 (precision=%d, E=%d)", d->precision,
+              d->pe_dim);
   memset(&a, 0, sizeof(a));
+  a.pe_bf16 = d->pe_bf16;
   a.G = d->n_rows;
   a.S = d->samples;
   a.P = d->n_pix;
@@ -395,50 +399,50 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
 
 }  // namespace
 
-extern "C" int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
+extern "C" int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
                              float* y_out, rcb_stream_t stream) {
   SirenArgs a;
   int rc = fill_args(d, a);
   if (rc) return rc;
   RCB_REQUIRE(xf && wvec && y_out && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_fwd: null pointer");
   a.xf = xf;
-  a.pe = pe;
+  a.pe = static_cast<const float*>(pe);
   a.wvec = wvec;
   a.yout = y_out;
   if (d->precision >= 1) return siren_bf16_dispatch(MODE_FWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_FWD>(d, a, (hipStream_t)stream);
 }
 
-extern "C" int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
-                             const float* dy, float* dwvec, float* dpe, rcb_stream_t stream) {
+extern "C" int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
+                             const float* dy, float* dwvec, void* dpe, rcb_stream_t stream) {
   SirenArgs a;
   int rc = fill_args(d, a);
   if (rc) return rc;
   RCB_REQUIRE(xf && wvec && dy && dwvec && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_bwd: null pointer");
   a.xf = xf;
-  a.pe = pe;
+  a.pe = static_cast<const float*>(pe);
   a.wvec = wvec;
   a.yin = dy;
   a.dwvec = dwvec;
-  a.dpe = dpe;
+  a.dpe = static_cast<float*>(dpe);
   if (d->precision >= 1) return siren_bf16_dispatch(MODE_BWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_BWD>(d, a, (hipStream_t)stream);
 }
 
-extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, const float* pe, const float* wvec,
-                                  const float* target, float dy_scale, float* sse, float* dwvec, float* dpe,
+extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
+                                  const float* target, float dy_scale, float* sse, float* dwvec, void* dpe,
                                   rcb_stream_t stream) {
   SirenArgs a;
   int rc = fill_args(d, a);
   if (rc) return rc;
   RCB_REQUIRE(xf && wvec && target && sse && dwvec && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_loss_bwd: null pointer");
   a.xf = xf;
-  a.pe = pe;
+  a.pe = static_cast<const float*>(pe);
   a.wvec = wvec;
   a.yin = target;
   a.sse = sse;
   a.dwvec = dwvec;
-  a.dpe = dpe;
+  a.dpe = static_cast<float*>(dpe);
   a.dy_scale = dy_scale;
   if (d->precision >= 1) return siren_bf16_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
   return dispatch<MODE_LOSS>(d, a, (hipStream_t)stream);

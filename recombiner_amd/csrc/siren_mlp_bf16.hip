@@ -226,6 +226,19 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     const float* src = (h == 0) ? (a.xf + (long long)n * a.xf_stride + (long long)pcl * F)
                                 : (a.pe + ((long long)g * P + pcl) * E);
     const int kh = (h == 0) ? KH0 : KH1;
+    if (VEC4 && a.pe_bf16 && h == 1) {   // bf16-stored pe: 16 B per 8 features, widened exactly
+      const uint4* s16 = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.pe) + ((long long)g * P + pcl) * E);
+#pragma unroll
+      for (int s = 0; s < K0S; ++s) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (8 * s + 8 <= KH1) u = s16[s];
+        raw[2 * s] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        raw[2 * s + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                     __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < K0S; ++s) {
       if (VEC4) {
@@ -426,7 +439,15 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         for (int s = 0; s < 2; ++s) dx = Op16<T>::mfma(FA(base + s), dzb[s], dx);
         if (valid) {
           float* dst = a.dpe + ((long long)g * P + p) * E;
-          if (E % 8 == 0) {
+          if (E % 8 == 0 && a.pe_bf16) {
+            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
+#pragma unroll
+            for (int g4 = 0; g4 < E / 8; ++g4) {
+              typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
+                                              (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
+              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
+            }
+          } else if (E % 8 == 0) {
 #pragma unroll
             for (int g4 = 0; g4 < E / 8; ++g4)
               *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),

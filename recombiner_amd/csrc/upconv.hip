@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad_kernel(DgradArgs a) {
 // staged once in LDS (zero halo, padded rows: conflict-free 16-byte gathers), so every gather is an LDS
 // read instead of an L2 round trip; the next INR's image is prefetched into registers during compute.
 // ------------------------------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, int OUT_BF16>
 __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
   constexpr int G = 16, HG = 18, RS = 72;   // image row stride in elements (64 channels + 8 pad = 144 B)
   constexpr int NF = 4 * 4 * 4;             // MT = 1 (COUT <= 32)
@@ -412,7 +412,12 @@ __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
         const int co = 8 * g4 + 4 * h;
         float4 o = make_float4(acc[p][4 * g4] + a.bias[co], acc[p][4 * g4 + 1] + a.bias[co + 1],
                                acc[p][4 * g4 + 2] + a.bias[co + 2], acc[p][4 * g4 + 3] + a.bias[co + 3]);
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + co) = o;
+        if (OUT_BF16) {
+          bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + co) = ob;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + co) = o;
+        }
       }
     }
   }
@@ -420,7 +425,7 @@ __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
 #undef RCB_COMMIT3
 }
 
-template <int COUT>
+template <int COUT, int DY_BF16>
 __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
   constexpr int G = 16, OG = 32, HO = 34, RS = 24;   // dy image: [34][34] pixels x 16 channels (+8 pad = 48 B rows)
   constexpr int NF = 16 * 2;                          // KB = 1, [combo][mt]
@@ -442,19 +447,29 @@ __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
   }
   for (int e = tid; e < HO * HO * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
   // dy image of one INR: 32*32 pixels x 16 fp32 = 64 KB = 4096 float4 -> 8 per thread, converted to bf16 on commit
-  float4 pre[8];
+  // (bf16 dy: 32 KB = 2048 x 16 B -> 4 per thread, committed as they are)
+  constexpr int NPRE = DY_BF16 ? 4 : 8;
+  float4 pre[NPRE];
   auto fetch = [&](int b) {
-    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dy) + (long long)b * OG * OG * COUT);
+    const float4* src = DY_BF16
+        ? reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)b * OG * OG * COUT)
+        : reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dy) + (long long)b * OG * OG * COUT);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pre[k] = src[tid + 512 * k];
+    for (int k = 0; k < NPRE; ++k) pre[k] = src[tid + 512 * k];
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = tid + 512 * k, pix = e >> 2, c4 = e & 3;
-      const int oy = pix >> 5, ox = pix & 31;
-      bf16x4 v = {(__bf16)pre[k].x, (__bf16)pre[k].y, (__bf16)pre[k].z, (__bf16)pre[k].w};
-      *reinterpret_cast<bf16x4*>(img + ((oy + 1) * HO + (ox + 1)) * RS + 4 * c4) = v;
+    for (int k = 0; k < NPRE; ++k) {
+      if (DY_BF16) {
+        const int e = tid + 512 * k, pix = e >> 1, c8 = e & 1;
+        const int oy = pix >> 5, ox = pix & 31;
+        *reinterpret_cast<float4*>(img + ((oy + 1) * HO + (ox + 1)) * RS + 8 * c8) = pre[k];
+      } else {
+        const int e = tid + 512 * k, pix = e >> 2, c4 = e & 3;
+        const int oy = pix >> 5, ox = pix & 31;
+        bf16x4 v = {(__bf16)pre[k].x, (__bf16)pre[k].y, (__bf16)pre[k].z, (__bf16)pre[k].w};
+        *reinterpret_cast<bf16x4*>(img + ((oy + 1) * HO + (ox + 1)) * RS + 4 * c4) = v;
+      }
     }
   };
   int b = blockIdx.x;
@@ -650,9 +665,13 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
     static bool done = false;
     return launch(upconv_fwd_kernel<64, 8, 1, 0>, a, grid_for(batch * 2, 4 * 4 * 4 * 2 * 1024), 4 * 4 * 4 * 2 * 1024, st, done);
   }
-  if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear) {
+  if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 1) {
     static bool done = false;
-    return launch(upconv_fwd3_lds_kernel<16>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
+    return launch(upconv_fwd3_lds_kernel<16, 0>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
+  }
+  if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 2) {   // bf16 output, no activation
+    static bool done = false;
+    return launch(upconv_fwd3_lds_kernel<16, 1>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input
     static bool done = false;
@@ -671,7 +690,11 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (grid == 16 && cout == 16 && dy_is_f32 && !x_is_f32_preact) {
     static bool done = false;
-    return launch(upconv_dgrad3_lds_kernel<16>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
+    return launch(upconv_dgrad3_lds_kernel<16, 0>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
+  }
+  if (grid == 16 && cout == 16 && !dy_is_f32 && !x_is_f32_preact) {
+    static bool done = false;
+    return launch(upconv_dgrad3_lds_kernel<16, 1>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 1) {
     static bool done = false;
@@ -694,6 +717,10 @@ extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const vo
   if (grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32) {
     static bool done = false;
     return launch(upconv_wgrad_kernel<16, 16, 0, 1>, a, g, (18 * 18 * 64 + 32 * 32 * 16) * 2, st, done);
+  }
+  if (grid == 16 && cout == 16 && !x_is_f32_preact && !dy_is_f32) {
+    static bool done = false;
+    return launch(upconv_wgrad_kernel<16, 16, 0, 0>, a, g, (18 * 18 * 64 + 32 * 32 * 16) * 2, st, done);
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 1 && !dy_is_f32) {
     static bool done = false;

@@ -57,7 +57,7 @@ def _xf_stride(xf, meta, n_inr):
     return int(xf.stride(0))
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf):
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -67,7 +67,7 @@ def _siren_desc(meta: SirenMeta, wvec, xf):
         raise RcbError("rows of wvec must be a multiple of samples")
     d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
-                  meta.precision)
+                  meta.precision, int(pe is not None and pe.dtype == bf16))
     return d, G
 
 
@@ -82,28 +82,30 @@ def _check_pe(pe, G, meta):
         return
     if pe is None or tuple(pe.shape) != (G, meta.n_pix, meta.pe_dim):
         raise RcbError(f"pe must be [{G},{meta.n_pix},{meta.pe_dim}]")
+    if pe.dtype not in (f32, bf16) or (pe.dtype == bf16 and meta.precision == 0):
+        raise RcbError("pe must be fp32 (any precision mode) or bf16 (16-bit modes only)")
 
 
 def siren_fwd(xf, pe, wvec, meta: SirenMeta):
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf)
+    d, G = _siren_desc(meta, wvec, xf, pe)
     _check_pe(pe, G, meta)
     y = torch.empty(G, meta.n_pix, meta.out_dim, device=wvec.device, dtype=f32)
-    check(lib.rcb_siren_fwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, f32, True), _dev_ptr_strided(wvec),
+    check(lib.rcb_siren_fwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
                             ptr(y), stream_ptr()), "rcb_siren_fwd")
     return y
 
 
 def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True):
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf)
+    d, G = _siren_desc(meta, wvec, xf, pe)
     _check_pe(pe, G, meta)
     if tuple(dy.shape) != (G, meta.n_pix, meta.out_dim):
         raise RcbError("dy shape mismatch")
     dw = torch.empty(G, wvec.stride(0), device=wvec.device, dtype=f32)[:, :meta.d_net]
     dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
-    check(lib.rcb_siren_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, f32, True), _dev_ptr_strided(wvec),
-                            ptr(dy.contiguous(), f32), _dev_ptr_strided(dw), ptr(dpe, f32, True), stream_ptr()),
+    check(lib.rcb_siren_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
+                            ptr(dy.contiguous(), f32), _dev_ptr_strided(dw), ptr(dpe, None, True), stream_ptr()),
           "rcb_siren_bwd")
     return dw, dpe
 
@@ -111,7 +113,7 @@ def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True):
 def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True):
     """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None)."""
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf)
+    d, G = _siren_desc(meta, wvec, xf, pe)
     _check_pe(pe, G, meta)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
@@ -119,9 +121,9 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
     sse = torch.empty(G, device=wvec.device, dtype=f32)
     dw = torch.empty(G, wvec.stride(0), device=wvec.device, dtype=f32)[:, :meta.d_net]
     dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
-    check(lib.rcb_siren_loss_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, f32, True), _dev_ptr_strided(wvec),
+    check(lib.rcb_siren_loss_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
                                  ptr(target, f32), C.c_float(dy_scale), ptr(sse), _dev_ptr_strided(dw),
-                                 ptr(dpe, f32, True), stream_ptr()), "rcb_siren_loss_bwd")
+                                 ptr(dpe, None, True), stream_ptr()), "rcb_siren_loss_bwd")
     return sse, dw, dpe
 
 
@@ -425,12 +427,14 @@ def _xmode(x, preact):
     return 2 if preact else 0
 
 
-def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False):
-    """x [B, g, g, 64] (fp32 pre-activation or bf16 activation) -> y [B, 2g, 2g, cout]."""
+def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False, linear_bf16=False):
+    """x [B, g, g, 64] (fp32/bf16 pre-activation or bf16 activation) -> y [B, 2g, 2g, cout]: bf16 with LeakyReLU,
+    fp32 linear (out_f32) or bf16 linear (linear_bf16)."""
     lib = _lib.load()
     B = x.shape[0]
     y = torch.empty(B, 2 * grid, 2 * grid, cout, device=x.device, dtype=f32 if out_f32 else bf16)
-    check(lib.rcb_upconv_fwd(ptr(x), _xmode(x, preact), ptr(weff, f32), ptr(bias, f32), ptr(y), int(out_f32), B, grid,
+    omode = 1 if out_f32 else (2 if linear_bf16 else 0)
+    check(lib.rcb_upconv_fwd(ptr(x), _xmode(x, preact), ptr(weff, f32), ptr(bias, f32), ptr(y), omode, B, grid,
                              cout, stream_ptr()), "rcb_upconv_fwd")
     return y
 

@@ -106,6 +106,7 @@ class PriorBNNmodel(nn.Module):
         self.dp_group = None         # torch.distributed group for sharded training of the shared mappings
         self.lowp_gemm = False       # 16-bit mode only: bf16-operand hipBLASLt GEMMs for the A transform
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
+        self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.use_graph = True        # replay the training step as one captured HIP graph when possible
 
     # ---- level descriptions ------------------------------------------------------------------------
@@ -129,7 +130,7 @@ class PriorBNNmodel(nn.Module):
         where the geometry is instantiated, the nn.Module (MIOpen) otherwise."""
         if self.precision != 0 and hip_path_supported(upsample_net, self.pixel_sizes, self.upsample_factors, self.patch,
                                                       self.data_dim):
-            return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16)
+            return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
         return map_lpe_to_inr_inputs(upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
                                      self.patch, self.patch_nums, self.data_dim)
 

@@ -166,6 +166,7 @@ class TestBNNmodel(nn.Module):
         self.noise_source = None     # optional callable(kind, shape) for eps injection in parity tests
         self.precision = 0
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
+        self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.use_graph = True        # replay the fused training step as captured HIP graphs when possible
         self._specs = None
         self._ws = None
@@ -227,7 +228,7 @@ class TestBNNmodel(nn.Module):
     def _pe(self, lpe):
         if self.precision != 0 and hip_path_supported(self.upsample_net, self.pixel_sizes, self.upsample_factors,
                                                       self.patch, self.data_dim):
-            return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16)
+            return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
         return map_lpe_to_inr_inputs(self.upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
                                      self.patch, self.patch_nums, self.data_dim)
 

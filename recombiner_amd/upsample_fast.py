@@ -179,7 +179,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
     pre-summed 512 x 4096 weight (hipBLASLt); stages 2 and 3 are the rcb_upconv_* kernels."""
 
     @staticmethod
-    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3, stage1_bf16):
+    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3, stage1_bf16, pe_bf16):
         from . import ops
         B = lpe.shape[0]
         M = _stage1_maps(lpe.device, torch.float32)
@@ -194,7 +194,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
         Weff2 = st.eff_weight(W2).contiguous()
         h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True)
         Weff3 = st.eff_weight(W3).contiguous()
-        pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=True)
+        pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=not pe_bf16, linear_bf16=pe_bf16)
         ctx.save_for_backward(lpe, Weff1, z1, Weff2, h2, Weff3)
         return pe.view(B, 1024, 16)
 
@@ -210,7 +210,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
         dz1f = dz1.view(B, 4096)
         dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
         if not need_w:
-            return dlpe, None, None, None, None, None, None, None
+            return dlpe, None, None, None, None, None, None, None, None
         M = _stage1_maps(lpe.device, torch.float32)
         R = _phase_R(lpe.device, 2, 3, 1)
         dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
@@ -220,13 +220,17 @@ class _UpsampleCifarFn(torch.autograd.Function):
         dW2 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff2)
         dW3 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff3)
         db1 = dz1.sum((0, 1, 2), dtype=torch.float32)
-        return dlpe, dW1, db1, dW2, db2, dW3, db3, None
+        return dlpe, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
-def upsample_cifar_hip(net, lpe, stage1_bf16=True):
-    """lpe [S, N, 2, 2, 128] -> pe [N, S, 1024, 16] through the HIP phase-conv kernels.  `stage1_bf16` runs the
-    stage-1 library GEMMs (fwd, dgrad, wgrad) with bf16 operands / fp32 accumulation and keeps z1 in bf16."""
+def upsample_cifar_hip(net, lpe, stage1_bf16=True, pe_bf16=True):
+    """lpe [S, N, 2, 2, 128] -> pe [N, S, 1024, 16] (contiguous) through the HIP phase-conv kernels.
+    `stage1_bf16` runs the stage-1 library GEMMs (fwd, dgrad, wgrad) with bf16 operands / fp32 accumulation and keeps
+    z1 in bf16.  `pe_bf16` stores pe (and hence its gradient) as bf16: the 16-bit SIREN kernels and the stage-3
+    gradient kernels round both to bf16 for their MFMA operands anyway, so the results are bit-identical to fp32
+    storage at half the traffic.  The (small) lpe is reordered to INR-major so that pe needs no transpose."""
     S, N = lpe.shape[:2]
-    pe = _UpsampleCifarFn.apply(lpe.reshape(S * N, 512), net.conv1.weight, net.conv1.bias, net.conv2.weight,
-                                net.conv2.bias, net.conv3.weight, net.conv3.bias, bool(stage1_bf16))
-    return pe.view(S, N, 1024, 16).permute(1, 0, 2, 3)
+    pe = _UpsampleCifarFn.apply(lpe.permute(1, 0, 2, 3, 4).reshape(N * S, 512), net.conv1.weight, net.conv1.bias,
+                                net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias, bool(stage1_bf16),
+                                bool(pe_bf16))
+    return pe.view(N, S, 1024, 16)

@@ -133,6 +133,32 @@ def test_siren_16bit_operands(case, prec):
     assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
 
 
+@pytest.mark.parametrize("prec", [1, 2])
+def test_siren_bf16_pe_storage_is_bit_identical(prec):
+    """pe / dpe held as bf16 arrays: the 16-bit kernels round pe to the operand type on load and the consumers of
+    dpe round it to bf16 on load, so bf16 storage must reproduce fp32 storage exactly (dpe: after that rounding)."""
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=1000, N=3, S=2)       # ragged last tile
+    dims, D, xf, pe, wv, y = _siren_case(seed=11, **case)
+    meta = SirenMeta(2, 1000, 16, 16, 3, 32, 3, precision=prec)
+    pe16 = g(pe).bfloat16()
+    pe32 = pe16.float()
+    scale = 1.0 / (2 * 1000 * 3)
+    y32 = ops.siren_fwd(g(xf), pe32, g(wv), meta)
+    y16 = ops.siren_fwd(g(xf), pe16, g(wv), meta)
+    assert torch.equal(y32, y16)
+    s32, w32, d32 = ops.siren_loss_bwd(g(xf), pe32, g(wv), g(y), scale, meta)
+    s16, w16, d16 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta)
+    assert d16.dtype == torch.bfloat16
+    assert torch.equal(s32, s16) and torch.equal(w32, w16) and torch.equal(d32.bfloat16(), d16)
+    dy = 1e-3 * torch.randn(6, 1000, 3, device=DEV)       # gradient-sized: unit-scale dy overflows the f16 operands
+    wb32, db32 = ops.siren_bwd(g(xf), pe32, g(wv), dy, meta)
+    wb16, db16 = ops.siren_bwd(g(xf), pe16, g(wv), dy, meta)
+    assert torch.isfinite(wb32).all() and torch.isfinite(db32).all()
+    assert torch.equal(wb32, wb16) and torch.equal(db32.bfloat16(), db16)
+    with pytest.raises(ops.RcbError):                                  # the fp32 kernel has no bf16-storage variant
+        ops.siren_fwd(g(xf), pe16, g(wv), SirenMeta(2, 1000, 16, 16, 3, 32, 3, precision=0))
+
+
 @pytest.mark.parametrize("prec", [0, 2])
 def test_siren_model_scale_weights(prec):
     """the regime of the real model: effective weights (h_w @ A) ~1e-4, biases ~1e-2.  f16 operands

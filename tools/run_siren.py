@@ -1,4 +1,4 @@
-"""Launches the fused SIREN kernel alone (for rocprofv3): python tools/run_siren.py [bf16|fp32] [N] [reps]"""
+"""Launches the fused SIREN kernel alone (for rocprofv3): python tools/run_siren.py [bf16|fp32] [N] [reps] [pe16]"""
 import os
 import sys
 
@@ -17,13 +17,26 @@ meta = SirenMeta(1, 1024, 16, 16, 3, 32, 3, precision=prec)
 Xd, Yd = X.to(dev), Y.to(dev)
 pe = torch.randn(n, 1024, 16, device=dev) * 0.1
 wv = (torch.rand(n, meta.d_net, device=dev) * 2 - 1) * 0.02
-for _ in range(reps):
-    sse, dw, dpe = ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
-    ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta)
-e1.record()
-torch.cuda.synchronize()
-print("avg ms", e0.elapsed_time(e1) / reps, "sse", float(sse.sum()))
+if len(sys.argv) > 4 and sys.argv[4] == "pe16":
+    pe = pe.bfloat16()
+
+
+def timed(fn):
+    for _ in range(3):
+        out = fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, out
+
+
+t, out = timed(lambda: ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta))
+print("loss_bwd (pe %s): avg ms %.4f  sse %.6f" % (pe.dtype, t, float(out[0].sum())))
+t, _ = timed(lambda: ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta, want_dpe=False))
+print("loss_bwd without dpe: avg ms %.4f" % t)
+t, _ = timed(lambda: ops.siren_fwd(Xd, pe, wv, meta))
+print("fwd: avg ms %.4f" % t)
