@@ -217,7 +217,7 @@ int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, con
  *             LeakyReLU(0.01) is applied on load to pre-activations;
  *          y: bf16 with LeakyReLU applied (y_is_f32_linear = 0), fp32 linear output (1) or bf16 linear output (2).
  *   dgrad: dx = (conv^T dy) * LeakyReLU'(x)   (sign taken from the stored activation / pre-activation)
- *   wgrad: dweff += sum_b,i,j x (x) dy   (fp32 atomics; the caller zeroes dweff)
+ *   wgrad: dweff = sum_b,i,j x (x) dy    (per-workgroup partial sums + fixed-order reduction)
  * Instantiated for (grid, cout) = (8, 64) [stage 2: fp32 or bf16 pre-activation in, bf16 out] and (16, 16)
  * [stage 3: bf16 in, fp32 or bf16 linear out; dy fp32 or bf16]; batch = number of images (INR x sample).
  * ------------------------------------------------------------------------------------------- */
@@ -225,9 +225,13 @@ int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, co
                    int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
 int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x, int32_t x_is_f32_preact,
                      void* dx, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+/* wgrad writes (does not accumulate) dweff [2][2][64][2][2][cout] and, if non-NULL, dbias [cout] = sum of dy.
+ * Each workgroup sums its INRs into its own slab of `workspace` and a second kernel adds the slabs in a fixed
+ * order: no atomics, bitwise reproducible.  workspace: >= rcb_upconv_wgrad_workspace(batch, cout) floats.   */
+int64_t rcb_upconv_wgrad_workspace(int32_t batch, int32_t cout);
 int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
-                     float* dbias /* nullable [cout]: += sum of dy (bias gradient); caller zeroes */,
-                     int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+                     float* dbias, int32_t batch, int32_t grid, int32_t cout, float* workspace,
+                     int64_t workspace_floats, rcb_stream_t stream);
 
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);

@@ -6,12 +6,13 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librcb_hip.so")
+# RCB_LIB: alternative build of the same ABI (same-box A/B timing of kernel changes); never a different backend
+LIB_PATH = os.environ.get("RCB_LIB") or os.path.join(_HERE, "lib", "librcb_hip.so")
 
 EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
-           "rcb_upconv_dgrad", "rcb_upconv_wgrad"]
+           "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace"]
 
 
 class RcbError(RuntimeError):
@@ -59,6 +60,7 @@ def load():
             raise RcbError(f"{LIB_PATH} not found: run `python -m recombiner_amd.build` (no CPU fallback exists)")
         lib = C.CDLL(LIB_PATH)
         lib.rcb_last_error_string.restype = C.c_char_p
+        lib.rcb_upconv_wgrad_workspace.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RcbError(f"{LIB_PATH} does not export {name}")

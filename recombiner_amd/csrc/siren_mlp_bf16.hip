@@ -156,9 +156,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
     }
     __syncthreads();
-    for (int e = tid; e < (NFA + NFB) * 64; e += 256) {
-      const int slot = e >> 6, ln = e & 63;
-      const int fq = ln & 31, fh = ln >> 5;
+    // one fragment slot per wave and pass; `slot` is a compile-time constant inside the unrolled loop, so the layer
+    // offsets and shapes below fold away and only the lane-dependent part of the gather address remains
+#pragma unroll
+    for (int slot = 0; slot < NFA + NFB; ++slot) {
+      if ((slot & 3) != wave) continue;
+      const int fq = lane & 31, fh = lane >> 5;
       union { bf16x8 v; uint4 u; } fr;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         }
         fr.v[j] = (T)(w * WS);
       }
-      frags[e] = fr.u;
+      frags[slot * 64 + lane] = fr.u;
     }
     __syncthreads();
   }
@@ -491,23 +494,21 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   __syncthreads();
   {
     float* dst = a.dwvec + (long long)g * a.w_stride;
-    for (int idx = tid; idx < DNET; idx += 256) {
-      int l = 0;
+    // layer by layer with compile-time shapes (constant divisors, no layer search per element)
 #pragma unroll
-      for (int k = 1; k < NL; ++k) l += (idx >= G::off(k)) ? 1 : 0;
-      int ol = 0, no = 0, ro = 0, rs = 0;
-#pragma unroll
-      for (int k = 0; k < NL; ++k)
-        if (k == l) { ol = G::off(k); no = G::lout(k); ro = G::roff(k); rs = 32 * ((k == 0) ? NB0 : 1) + 1; }
-      const int e = idx - ol;
-      int src;
-      if (e < no) {
-        src = ro + no * rs + e;                 // bias
-      } else {
-        const int i = (e - no) / no, o = (e - no) - i * no;
-        src = ro + o * rs + i;
+    for (int l = 0; l < NL; ++l) {
+      const int ol = G::off(l), no = G::lout(l), ro = G::roff(l), rs = 32 * ((l == 0) ? NB0 : 1) + 1;
+      const int size = no * (G::lin(l) + 1);
+      for (int e = tid; e < size; e += 256) {
+        int src;
+        if (e < no) {
+          src = ro + no * rs + e;                 // bias
+        } else {
+          const int i = (e - no) / no, o = (e - no) - i * no;
+          src = ro + o * rs + i;
+        }
+        dst[ol + e] = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
       }
-      dst[idx] = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
     }
   }
   if (MODE == MODE_LOSS) {

@@ -332,97 +332,169 @@ __global__ void __launch_bounds__(512) upconv_dgrad_kernel(DgradArgs a) {
 // staged once in LDS (zero halo, padded rows: conflict-free 16-byte gathers), so every gather is an LDS
 // read instead of an L2 round trip; the next INR's image is prefetched into registers during compute.
 // ------------------------------------------------------------------------------------------------
+// Forward: wave w owns output-row phase pa = w & 1 and the source tiles 2 * (w >> 1), + 1 (32 positions each), both
+// column phases.  Its 32 weight fragments ([pb][ty][tx][kb]) stay in registers for the whole kernel, so LDS only
+// serves the image: 24 fragment reads feed 32 MFMAs per tile.  In the epilogue the two lane halves swap
+// (v_permlane32_swap) so that each lane owns all 16 channels of one output pixel and stores them contiguously.
 template <int COUT, int OUT_BF16>
-__global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
-  constexpr int G = 16, HG = 18, RS = 72;   // image row stride in elements (64 channels + 8 pad = 144 B)
-  constexpr int NF = 4 * 4 * 4;             // MT = 1 (COUT <= 32)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
-  __bf16* img = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
-  for (int e = tid; e < NF * 64; e += 512) {
-    const int ln = e & 63, slot = e >> 6;
-    const int kb = slot & 3, t = (slot >> 2) & 3, p = slot >> 4;
-    const int fq = ln & 31, fh = ln >> 5;
-    Frag f;
+__device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2][2][2][4], const FwdArgs& a, int b,
+                                          int pa, int tp, int q, int h, const float (&bia)[8]) {
+  constexpr int G = 16, HG = 18, RS = 72;
+#pragma unroll 1
+  for (int tt = 0; tt < 2; ++tt) {     // tiles one after the other: two accumulator chains live, no spills
+    const int pos = (2 * tp + tt) * 32 + q, i = pos >> 4, j = pos & 15;
+    f32x16 acc[2];   // [pb]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float w = 0.f;
-      if (fq < COUT) w = a.weff[weff_index(t >> 1, t & 1, 16 * kb + 8 * fh + j, p >> 1, p & 1, fq, COUT)];
-      f.v[j] = (__bf16)w;
-    }
-    frags[e] = f.u;
-  }
-  for (int e = tid; e < HG * HG * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
-  // each thread stages 4 x 16 B of the 32 KB image: element e -> pixel e / 8, chunk e % 8
-  uint4 pre0, pre1, pre2, pre3;
-  pre0 = pre1 = pre2 = pre3 = make_uint4(0, 0, 0, 0);
-#define RCB_FETCH3(bb)                                                                                          \
-  {                                                                                                            \
-    const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + (long long)(bb) * G * G * CIN); \
-    pre0 = src_[tid]; pre1 = src_[tid + 512]; pre2 = src_[tid + 1024]; pre3 = src_[tid + 1536];               \
-  }
-#define RCB_COMMIT3(kk, val)                                                                                    \
-  {                                                                                                            \
-    const int e_ = tid + 512 * (kk), pix_ = e_ >> 3, c8_ = e_ & 7;                                             \
-    *reinterpret_cast<uint4*>(img + (((pix_ >> 4) + 1) * HG + ((pix_ & 15) + 1)) * RS + 8 * c8_) = (val);      \
-  }
-  int b = blockIdx.x;
-  if (b < a.batch) RCB_FETCH3(b)
-  const int i = (wave * 32 + q) >> 4, j = (wave * 32 + q) & 15;
-  for (; b < a.batch; b += gridDim.x) {
-    __syncthreads();          // everyone is done with the previous image (and with the frag / halo setup)
-    RCB_COMMIT3(0, pre0) RCB_COMMIT3(1, pre1) RCB_COMMIT3(2, pre2) RCB_COMMIT3(3, pre3)
-    __syncthreads();
-    if (b + (int)gridDim.x < a.batch) RCB_FETCH3(b + gridDim.x)
-    f32x16 acc[4];
+    for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+      for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
+    const __bf16* base = img + ((i + pa) * HG + j) * RS + 8 * h;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    for (int ty = 0; ty < 2; ++ty) {
 #pragma unroll
-    for (int nb = 0; nb < 9; ++nb) {
-      const int dy = nb / 3 - 1, dx = nb % 3 - 1;
-      const __bf16* px = img + ((i + dy + 1) * HG + (j + dx + 1)) * RS + 8 * h;
+      for (int dxi = 0; dxi < 3; ++dxi) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        Frag bf;
-        bf.u = *reinterpret_cast<const uint4*>(px + 16 * kb);
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa) {
-          const int ty = dy + 1 - pa;
-          if (ty < 0 || ty > 1) continue;
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            const int tx = dx + 1 - pb;
-            if (tx < 0 || tx > 1) continue;
-            const int p = pa * 2 + pb, t = ty * 2 + tx;
-            Frag fa;
-            fa.u = frags[((p * 4 + t) * 4 + kb) * 64 + lane];
-            acc[p] = mfma16(fa.v, bf.v, acc[p]);
+        for (int kb = 0; kb < 4; ++kb) {
+          Frag bf;
+          bf.u = *reinterpret_cast<const uint4*>(base + (ty * HG + dxi) * RS + 16 * kb);
+          Frag fa;
+          if (dxi <= 1) {
+            fa.u = fr[0][ty][dxi][kb];
+            acc[0] = mfma16(fa.v, bf.v, acc[0]);
+          }
+          if (dxi >= 1) {
+            fa.u = fr[1][ty][dxi - 1][kb];
+            acc[1] = mfma16(fa.v, bf.v, acc[1]);
           }
         }
       }
     }
+    // before: lane (q, h) holds channels {0..3, 8..11} + 4h of pixels (2j) [acc 0] and (2j+1) [acc 1]
+    float va[8], vb[8];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const long long opix = ((long long)b * (2 * G) + 2 * i + (p >> 1)) * (2 * G) + 2 * j + (p & 1);
+    for (int r = 0; r < 8; ++r) {
+      const float x0 = acc[0][r] + bia[r], x1 = acc[1][r] + bia[r];
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+      va[r] = __uint_as_float(sw[0]);   // channels {0..3, 8..11} of this lane's pixel (2j + h)
+      vb[r] = __uint_as_float(sw[1]);   // channels {4..7, 12..15}
+    }
+    const long long opix = ((long long)b * (2 * G) + 2 * i + pa) * (2 * G) + 2 * j + h;
+    if (OUT_BF16) {
+      Frag o0, o1;
 #pragma unroll
-      for (int g4 = 0; g4 < COUT / 8; ++g4) {
-        const int co = 8 * g4 + 4 * h;
-        float4 o = make_float4(acc[p][4 * g4] + a.bias[co], acc[p][4 * g4 + 1] + a.bias[co + 1],
-                               acc[p][4 * g4 + 2] + a.bias[co + 2], acc[p][4 * g4 + 3] + a.bias[co + 3]);
-        if (OUT_BF16) {
-          bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + co) = ob;
-        } else {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + co) = o;
-        }
+      for (int k = 0; k < 4; ++k) {
+        o0.v[k] = (__bf16)va[k];     o0.v[4 + k] = (__bf16)vb[k];
+        o1.v[k] = (__bf16)va[4 + k]; o1.v[4 + k] = (__bf16)vb[4 + k];
       }
+      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT);
+      dst[0] = o0.u;
+      dst[1] = o1.u;
+    } else {
+      float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT);
+      dst[0] = make_float4(va[0], va[1], va[2], va[3]);
+      dst[1] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+      dst[2] = make_float4(va[4], va[5], va[6], va[7]);
+      dst[3] = make_float4(vb[4], vb[5], vb[6], vb[7]);
     }
   }
+}
+
+template <int COUT, int OUT_BF16>
+__global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
+  static_assert(COUT == 16, "epilogue lane swap is written for 16 output channels");
+  constexpr int G = 16, HG = 18, RS = 72;   // image row stride in elements (64 channels + 8 pad = 144 B)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  const int pa = wave & 1, tp = wave >> 1;
+  const float wmask = q < COUT ? 1.f : 0.f;
+  uint4 fr[2][2][2][4];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          Frag f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)      // rows >= COUT of the 32-row A tile are zero (clamped load, masked)
+            f.v[j] = (__bf16)(a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, q < COUT ? q : COUT - 1, COUT)] * wmask);
+          fr[pb][ty][tx][kb] = f.u;
+        }
+  float bia[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) bia[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+  for (int e = tid; e < HG * HG * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  // each thread stages 4 x 16 B of the 32 KB image (element e -> pixel e / 8, chunk e % 8); the next INR's image is
+  // in flight while the current one is consumed
+  uint4 pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pre[k] = make_uint4(0, 0, 0, 0);
+#define RCB_FETCH3(bb)                                                                                          \
+  {                                                                                                            \
+    const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + (long long)(bb) * G * G * CIN); \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) pre[k] = src_[tid + 512 * k];                                \
+  }
+  const int gs = gridDim.x;
+  int b = blockIdx.x;
+  if (b < a.batch) RCB_FETCH3(b)
+  for (; b < a.batch; b += gs) {
+    __syncthreads();          // everyone is done with the previous image (and with the halo setup)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e_ = tid + 512 * k, pix_ = e_ >> 3, c8_ = e_ & 7;
+      *reinterpret_cast<uint4*>(img + (((pix_ >> 4) + 1) * HG + ((pix_ & 15) + 1)) * RS + 8 * c8_) = pre[k];
+    }
+    __syncthreads();
+    if (b + gs < a.batch) RCB_FETCH3(b + gs)
+    fwd3_body<COUT, OUT_BF16>(img, fr, a, b, pa, tp, q, h, bia);
+  }
 #undef RCB_FETCH3
-#undef RCB_COMMIT3
+}
+
+// one INR's 16x16x64 input gradient from the LDS dy image; the sign source is requested before the MFMA loop
+template <int COUT>
+__device__ __forceinline__ void dgrad3_body(const __bf16* img, const uint4* frags, const DgradArgs& a, int b, int u, int v,
+                                            int h, int lane, int wave, int q) {
+  constexpr int G = 16, HO = 34, RS = 24;
+  const long long xpix = ((long long)b * G * G + wave * 32 + q) * CIN;
+  bf16x4 xs[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      xs[mt][g4] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + 32 * mt + 8 * g4 + 4 * h);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
+    Frag bf;
+    bf.u = *reinterpret_cast<const uint4*>(img + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      Frag fa;
+      fa.u = frags[(n * 2 + mt) * 64 + lane];
+      acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int ci = 32 * mt + 8 * g4 + 4 * h;
+      bf16x4 ob;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)xs[mt][g4][k] > 0.f ? 1.0f : SLOPE));
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
+    }
+  }
 }
 
 template <int COUT, int DY_BF16>
@@ -446,71 +518,51 @@ __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
     frags[e] = f.u;
   }
   for (int e = tid; e < HO * HO * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
-  // dy image of one INR: 32*32 pixels x 16 fp32 = 64 KB = 4096 float4 -> 8 per thread, converted to bf16 on commit
-  // (bf16 dy: 32 KB = 2048 x 16 B -> 4 per thread, committed as they are)
+  // dy image of one INR: 32*32 pixels x 16 channels: fp32 = 4096 float4 (8 per thread, converted to bf16 on
+  // commit), bf16 = 2048 x 16 B (4 per thread, committed as they are).  Two register sets: two INRs in flight.
   constexpr int NPRE = DY_BF16 ? 4 : 8;
-  float4 pre[NPRE];
-  auto fetch = [&](int b) {
-    const float4* src = DY_BF16
-        ? reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)b * OG * OG * COUT)
-        : reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dy) + (long long)b * OG * OG * COUT);
+  float4 preA[NPRE], preB[NPRE];
 #pragma unroll
-    for (int k = 0; k < NPRE; ++k) pre[k] = src[tid + 512 * k];
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      if (DY_BF16) {
-        const int e = tid + 512 * k, pix = e >> 1, c8 = e & 1;
-        const int oy = pix >> 5, ox = pix & 31;
-        *reinterpret_cast<float4*>(img + ((oy + 1) * HO + (ox + 1)) * RS + 8 * c8) = pre[k];
-      } else {
-        const int e = tid + 512 * k, pix = e >> 2, c4 = e & 3;
-        const int oy = pix >> 5, ox = pix & 31;
-        bf16x4 v = {(__bf16)pre[k].x, (__bf16)pre[k].y, (__bf16)pre[k].z, (__bf16)pre[k].w};
-        *reinterpret_cast<bf16x4*>(img + ((oy + 1) * HO + (ox + 1)) * RS + 4 * c4) = v;
-      }
-    }
-  };
+  for (int k = 0; k < NPRE; ++k) preA[k] = preB[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define RCB_FETCHD(set, bb)                                                                                          \
+  {                                                                                                                 \
+    const float4* src_ = DY_BF16                                                                                    \
+        ? reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)(bb) * OG * OG * COUT) \
+        : reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dy) + (long long)(bb) * OG * OG * COUT); \
+    _Pragma("unroll") for (int k = 0; k < NPRE; ++k) set[k] = src_[tid + 512 * k];                                  \
+  }
+#define RCB_COMMITD(set)                                                                                             \
+  _Pragma("unroll") for (int k = 0; k < NPRE; ++k) {                                                                \
+    if (DY_BF16) {                                                                                                  \
+      const int e_ = tid + 512 * k, pix_ = e_ >> 1, c8_ = e_ & 1;                                                   \
+      *reinterpret_cast<float4*>(img + (((pix_ >> 5) + 1) * HO + ((pix_ & 31) + 1)) * RS + 8 * c8_) = set[k];       \
+    } else {                                                                                                        \
+      const int e_ = tid + 512 * k, pix_ = e_ >> 2, c4_ = e_ & 3;                                                   \
+      bf16x4 v_ = {(__bf16)set[k].x, (__bf16)set[k].y, (__bf16)set[k].z, (__bf16)set[k].w};                         \
+      *reinterpret_cast<bf16x4*>(img + (((pix_ >> 5) + 1) * HO + ((pix_ & 31) + 1)) * RS + 4 * c4_) = v_;           \
+    }                                                                                                               \
+  }
+  const int gs = gridDim.x;
   int b = blockIdx.x;
-  if (b < a.batch) fetch(b);
+  if (b < a.batch) RCB_FETCHD(preA, b)
+  if (b + gs < a.batch) RCB_FETCHD(preB, b + gs)
   const int u = (wave * 32 + q) >> 4, v = (wave * 32 + q) & 15;
-  for (; b < a.batch; b += gridDim.x) {
+  for (; b < a.batch; b += 2 * gs) {
     __syncthreads();
-    commit();
+    RCB_COMMITD(preA)
     __syncthreads();
-    if (b + (int)gridDim.x < a.batch) fetch(b + gridDim.x);
-    f32x16 acc[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-#pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
-      Frag bf;
-      bf.u = *reinterpret_cast<const uint4*>(img + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        Frag fa;
-        fa.u = frags[(n * 2 + mt) * 64 + lane];
-        acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
-      }
-    }
-    const long long xpix = ((long long)b * G * G + wave * 32 + q) * CIN;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int ci = 32 * mt + 8 * g4 + 4 * h;
-        bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + ci);
-        bf16x4 ob;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)t[k] > 0.f ? 1.0f : SLOPE));
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
-      }
+    if (b + 2 * gs < a.batch) RCB_FETCHD(preA, b + 2 * gs)
+    dgrad3_body<COUT>(img, frags, a, b, u, v, h, lane, wave, q);
+    if (b + gs < a.batch) {
+      __syncthreads();
+      RCB_COMMITD(preB)
+      __syncthreads();
+      if (b + 3 * gs < a.batch) RCB_FETCHD(preB, b + 3 * gs)
+      dgrad3_body<COUT>(img, frags, a, b + gs, u, v, h, lane, wave, q);
     }
   }
+#undef RCB_FETCHD
+#undef RCB_COMMITD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -519,8 +571,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
 struct WgradArgs {
   const void* x;
   const void* dy;
-  float* dweff;   // accumulated with fp32 atomics (caller zeroes)
-  float* dbias;   // nullable [COUT]: sum of dy over batch and pixels (conv bias gradient), fp32 atomics
+  float* partial;   // [gridDim.x][1024 * COUT + COUT]: every workgroup's own sums (weights, then bias)
   int batch;
 };
 
@@ -529,11 +580,19 @@ __device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
+// One persistent workgroup per CU walks its INRs: the x / dy images of the NEXT INR are fetched into registers
+// while the matrix cores consume the current ones from LDS (a CU needs tens of KB in flight to keep its share of
+// HBM busy), and the workgroup's sums go to its own slab: no atomics, bitwise reproducible after the fixed-order
+// reduction below.
 template <int COUT, int G, int X_MODE, int DY_F32>
 __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = (COUT + 31) / 32;
   constexpr int HG = G + 2;             // halo grid
   constexpr int OG = 2 * G;             // output grid
+  constexpr int DM = DY_F32 ? 2 : 0;
+  constexpr int NX = G * G * (CIN / 8) / 512, ND = OG * OG * (COUT / 8) / 512;
+  static_assert(NX * 512 == G * G * (CIN / 8) && ND * 512 == OG * OG * (COUT / 8) && 512 % (COUT / 8) == 0, "tiling");
+  constexpr int WSZ = 1024 * COUT, ROW = WSZ + COUT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* ximg = reinterpret_cast<__bf16*>(smem_raw);               // [HG*HG][64]
   __bf16* dimg = ximg + HG * HG * CIN;                              // [OG*OG][COUT]
@@ -552,26 +611,38 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   float dbsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
-  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+  Raw8<X_MODE> px[NX];
+  Raw8<DM> pd[ND];
+#define RCB_WG_FETCH(bb)                                                                                   \
+  {                                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < NX; ++k)                                                         \
+        px[k] = raw_load<X_MODE>(a.x, (long long)(bb) * G * G * CIN + 8 * (tid + 512 * k));                \
+    _Pragma("unroll") for (int k = 0; k < ND; ++k)                                                         \
+        pd[k] = raw_load<DM>(a.dy, (long long)(bb) * OG * OG * COUT + 8 * (tid + 512 * k));                \
+  }
+  int b = blockIdx.x;
+  if (b < a.batch) RCB_WG_FETCH(b)
+  for (; b < a.batch; b += gridDim.x) {
     __syncthreads();   // previous INR fully consumed (also orders the halo clear)
-    // stage x (interior of the halo image) and dy as bf16
-    for (int e = tid; e < G * G * (CIN / 8); e += 512) {
-      const int pix = e / (CIN / 8), c8 = e - pix * (CIN / 8);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = tid + 512 * k, pix = e >> 3, c8 = e & 7;
       const int i = pix / G, j = pix - i * G;
       Frag f;
-      f.v = load8<X_MODE>(a.x, ((long long)b * G * G + pix) * CIN + 8 * c8, true);
+      f.v = raw_frag<X_MODE>(px[k], true);
       *reinterpret_cast<uint4*>(ximg + ((i + 1) * HG + (j + 1)) * CIN + 8 * c8) = f.u;
     }
     // 512 % (COUT / 8) == 0: a thread always handles the same 8 channels -> private bias-gradient partials
-    for (int e = tid; e < OG * OG * (COUT / 8); e += 512) {
-      const int pix = e / (COUT / 8), c8 = e - pix * (COUT / 8);
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
       Frag f;
-      f.v = load8<DY_F32 ? 2 : 0>(a.dy, ((long long)b * OG * OG + pix) * COUT + 8 * c8, true);
-      *reinterpret_cast<uint4*>(dimg + pix * COUT + 8 * c8) = f.u;
+      f.v = raw_frag<DM>(pd[k], true);
+      reinterpret_cast<uint4*>(dimg)[tid + 512 * k] = f.u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
     }
     __syncthreads();
+    if (b + (int)gridDim.x < a.batch) RCB_WG_FETCH(b + gridDim.x)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int combo = 2 * wave + c;                 // 16 combos over 8 waves
@@ -600,16 +671,21 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
       }
     }
   }
-  if (a.dbias) {   // reduce the per-thread channel partials through LDS, one atomic per channel per workgroup
+#undef RCB_WG_FETCH
+  float* slab = a.partial + (long long)blockIdx.x * ROW;
+  {   // bias gradient: per-thread channel partials through LDS (fixed order: deterministic)
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem_raw);
-    for (int e = tid; e < COUT; e += 512) red[e] = 0.f;
-    __syncthreads();
-    const int c8 = tid % (COUT / 8);
+    float* red = reinterpret_cast<float*>(smem_raw);      // [512][8]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&red[8 * c8 + j], dbsum[j]);
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dbsum[j];
     __syncthreads();
-    for (int e = tid; e < COUT; e += 512) atomicAdd(a.dbias + e, red[e]);
+    if (tid < COUT) {
+      constexpr int C8 = COUT / 8;                        // thread t holds channels 8 * (t % C8) .. + 7
+      const int c8 = tid >> 3, j = tid & 7;
+      float sacc = 0.f;
+      for (int t = c8; t < 512; t += C8) sacc += red[t * 8 + j];
+      slab[WSZ + tid] = sacc;
+    }
   }
   // D[m = ci, n = co]: rows in registers, column on the lane
 #pragma unroll
@@ -625,11 +701,32 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ci = 32 * mt + rho(r, h);
-            atomicAdd(a.dweff + weff_index(t >> 1, t & 1, ci, p >> 1, p & 1, co, COUT), acc[c][mt][nt][r]);
+            slab[weff_index(t >> 1, t & 1, ci, p >> 1, p & 1, co, COUT)] = acc[c][mt][nt][r];
           }
         }
       }
   }
+}
+
+// fixed-order sum of the workgroup slabs: out[j] = sum_w partial[w][j]
+__global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int row,
+                                                                  int wsz, float* __restrict__ dweff,
+                                                                  float* __restrict__ dbias) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= row) return;
+  const float* p = partial + j;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  int w = 0;
+  for (; w + 8 <= nblk; w += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += p[(long long)(w + u) * row];
+  }
+  for (; w < nblk; ++w) s[0] += p[(long long)w * row];
+  const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  if (j < wsz) dweff[j] = tot;
+  else if (dbias) dbias[j - wsz] = tot;
 }
 
 template <typename K, typename A>
@@ -667,11 +764,11 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 1) {
     static bool done = false;
-    return launch(upconv_fwd3_lds_kernel<16, 0>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
+    return launch(upconv_fwd3_lds_kernel<16, 0>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 2) {   // bf16 output, no activation
     static bool done = false;
-    return launch(upconv_fwd3_lds_kernel<16, 1>, a, batch < 256 ? batch : 256, 64 * 1024 + 18 * 18 * 72 * 2, st, done);
+    return launch(upconv_fwd3_lds_kernel<16, 1>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input
     static bool done = false;
@@ -707,28 +804,41 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
   return fail(RCB_ERR_UNSUPPORTED, "upconv_dgrad: grid=%d cout=%d not instantiated", grid, cout);
 }
 
+static inline int wgrad_blocks(int batch) { return batch < 256 ? batch : 256; }
+
+extern "C" int64_t rcb_upconv_wgrad_workspace(int32_t batch, int32_t cout) {
+  if (batch <= 0 || cout <= 0) return 0;
+  return (int64_t)wgrad_blocks(batch) * (1024LL * cout + cout);
+}
+
 extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
-                                float* dbias, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream) {
-  RCB_REQUIRE(x && dy && dweff, RCB_ERR_ARG, "upconv_wgrad: null pointer");
+                                float* dbias, int32_t batch, int32_t grid, int32_t cout, float* workspace,
+                                int64_t workspace_floats, rcb_stream_t stream) {
+  RCB_REQUIRE(x && dy && dweff && workspace, RCB_ERR_ARG, "upconv_wgrad: null pointer");
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_wgrad: empty batch");
-  WgradArgs a{x, dy, dweff, dbias, batch};
+  RCB_REQUIRE(workspace_floats >= rcb_upconv_wgrad_workspace(batch, cout), RCB_ERR_SHAPE,
+              "upconv_wgrad: workspace of %lld floats, %lld needed", (long long)workspace_floats,
+              (long long)rcb_upconv_wgrad_workspace(batch, cout));
+  WgradArgs a{x, dy, workspace, batch};
   hipStream_t st = (hipStream_t)stream;
-  int g = batch < 256 ? batch : 256;
-  if (grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32) {
-    static bool done = false;
-    return launch(upconv_wgrad_kernel<16, 16, 0, 1>, a, g, (18 * 18 * 64 + 32 * 32 * 16) * 2, st, done);
+  const int g = wgrad_blocks(batch);
+  int rc = RCB_ERR_UNSUPPORTED;
+  bool hit = false;
+#define RCB_WGRAD_CASE(cond, COUTv, Gv, XM, DF, SMEM)                                        \
+  if (!hit && (cond)) {                                                                      \
+    static bool done = false;                                                                \
+    hit = true;                                                                              \
+    rc = launch(upconv_wgrad_kernel<COUTv, Gv, XM, DF>, a, g, SMEM, st, done);               \
   }
-  if (grid == 16 && cout == 16 && !x_is_f32_preact && !dy_is_f32) {
-    static bool done = false;
-    return launch(upconv_wgrad_kernel<16, 16, 0, 0>, a, g, (18 * 18 * 64 + 32 * 32 * 16) * 2, st, done);
-  }
-  if (grid == 8 && cout == 64 && x_is_f32_preact == 1 && !dy_is_f32) {
-    static bool done = false;
-    return launch(upconv_wgrad_kernel<64, 8, 1, 0>, a, g, (10 * 10 * 64 + 16 * 16 * 64) * 2, st, done);
-  }
-  if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !dy_is_f32) {
-    static bool done = false;
-    return launch(upconv_wgrad_kernel<64, 8, 3, 0>, a, g, (10 * 10 * 64 + 16 * 16 * 64) * 2, st, done);
-  }
-  return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
+  RCB_WGRAD_CASE(grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32, 16, 16, 0, 1, (18 * 18 * 64 + 32 * 32 * 16) * 2)
+  RCB_WGRAD_CASE(grid == 16 && cout == 16 && !x_is_f32_preact && !dy_is_f32, 16, 16, 0, 0, (18 * 18 * 64 + 32 * 32 * 16) * 2)
+  RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 1 && !dy_is_f32, 64, 8, 1, 0, (10 * 10 * 64 + 16 * 16 * 64) * 2)
+  RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 2 && !dy_is_f32, 64, 8, 3, 0, (10 * 10 * 64 + 16 * 16 * 64) * 2)
+#undef RCB_WGRAD_CASE
+  if (!hit) return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
+  if (rc) return rc;
+  const int row = 1024 * cout + cout;
+  upconv_wgrad_reduce_kernel<<<(row + 255) / 256, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
 }

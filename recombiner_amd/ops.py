@@ -449,11 +449,13 @@ def upconv_dgrad(dy, weff, x, grid, cout, preact=False):
 
 
 def upconv_wgrad(x, dy, grid, cout, preact=False):
-    """-> (dWeff [2,2,64,2,2,cout], dbias [cout]) in one pass over x and dy."""
+    """-> (dWeff [2,2,64,2,2,cout], dbias [cout]) in one pass over x and dy (deterministic: no atomics)."""
     lib = _lib.load()
     B = x.shape[0]
-    buf = torch.zeros(2 * 2 * 64 * 2 * 2 * cout + cout, device=x.device, dtype=f32)
+    buf = torch.empty(2 * 2 * 64 * 2 * 2 * cout + cout, device=x.device, dtype=f32)
     dw, db = buf[:-cout].view(2, 2, 64, 2, 2, cout), buf[-cout:]
+    n_ws = int(lib.rcb_upconv_wgrad_workspace(B, cout))
+    ws = torch.empty(n_ws, device=x.device, dtype=f32)
     check(lib.rcb_upconv_wgrad(ptr(x), _xmode(x, preact), ptr(dy), int(dy.dtype == f32), ptr(dw), ptr(db), B, grid,
-                               cout, stream_ptr()), "rcb_upconv_wgrad")
+                               cout, ptr(ws), C.c_int64(n_ws), stream_ptr()), "rcb_upconv_wgrad")
     return dw, db
