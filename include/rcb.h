@@ -182,6 +182,29 @@ int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_str
 int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const rcb_adam_cfg* cfg,
                   rcb_stream_t stream);
 
+/* The same update for a list of tensors in ONE launch (the optimiser step over the shared mappings,
+ * main_prior_training.py / prior_model.py train(): torch.optim.Adam over linear_transform + upsample_net). */
+#define RCB_ADAM_MAX_TENSORS 16
+typedef struct {
+  float* p;            /* parameters, updated in place */
+  const float* g;      /* gradient                     */
+  float* m;            /* exp_avg                      */
+  float* v;            /* exp_avg_sq                   */
+  int64_t n;           /* elements                     */
+} rcb_adam_tensor;
+int rcb_adam_multi(const rcb_adam_tensor* tensors, int32_t count, const rcb_adam_cfg* cfg, rcb_stream_t stream);
+
+/* Bookkeeping of one optimisation step whose counter lives on the device, so that the whole step can be captured
+ * once as a HIP graph and replayed (prior_model.py train() / test_model.py train() loop bodies):
+ *   begin: dyn[0..1] = adam_table[step] ({lr / (1 - beta1^t), sqrt(1 - beta2^t)}, row clamped to the table);
+ *          kl_slots[RCB_KL_SLOTS] = 0 (nullable)
+ *   end  : mse_log[step] = mse_scale * sum(sse[0..n_sse)),  kl_log[step] = sum(kl_slots)  (each nullable, written
+ *          only while step < n_log; fixed-order fp64 sums);  step += 1                                              */
+int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, double* kl_slots,
+                   rcb_stream_t stream);
+int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const double* kl_slots, double* mse_log,
+                 double* kl_log, int64_t n_log, int64_t* step, rcb_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172).
  * For x = loc[rows, cols]: sum[j], m2[j] = sum_r (x - mean_j)^2, and sig2[j] = sum_r sigma(r,j)^2
@@ -232,6 +255,16 @@ int64_t rcb_upconv_wgrad_workspace(int32_t batch, int32_t cout);
 int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
                      float* dbias, int32_t batch, int32_t grid, int32_t cout, float* workspace,
                      int64_t workspace_floats, rcb_stream_t stream);
+
+/* The phase-form ("effective") weights of the CIFAR-geometry upsampling net from its conv weights, and the
+ * transposed map for their gradients (one launch each; prior_model.py:39-57 defines the convolutions):
+ *   weff1 [512][4096] (rows (s,t,i) of the 2x2x128 latent grid, columns (y,x,o) of the 8x8x64 stage-1 output) and
+ *   b1rep [4096] in bf16 (bf16_out = 1) or fp32; weff2 [2][2][64][2][2][64], weff3 [2][2][64][2][2][16] fp32.
+ *   grad: dW1 [64][128][5][5], dW2 [64][64][3][3], dW3 [16][64][3][3] written (not accumulated).               */
+int rcb_upconv_weff_build(const float* W1, const float* b1, const float* W2, const float* W3, void* weff1, void* b1rep,
+                          int32_t bf16_out, float* weff2, float* weff3, rcb_stream_t stream);
+int rcb_upconv_weff_grad(const void* dweff1, int32_t bf16_in, const float* dweff2, const float* dweff3, float* dW1,
+                         float* dW2, float* dW3, rcb_stream_t stream);
 
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);

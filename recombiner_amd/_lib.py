@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("RCB_LIB") or os.path.join(_HERE, "lib", "librcb_hip.s
 EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
-           "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace"]
+           "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
+           "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad"]
 
 
 class RcbError(RuntimeError):
@@ -31,6 +32,10 @@ class Level(C.Structure):
                 ("enc_mask", C.c_void_p), ("row_map", C.c_void_p), ("row_perm", C.c_void_p),
                 ("col_map", C.c_void_p), ("eps", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("cols_out", C.c_int32)]
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
 class AdamCfg(C.Structure):

@@ -102,6 +102,30 @@ __global__ void reparam_fwd_kernel(ReparamArgs a) {
   }
 }
 
+// fast path: one level, one sample, no maps / masks -> purely elementwise over the flat [n_inr * cols] arrays
+// (rows of 3267 floats are not 16-byte aligned, the flat arrays are): 16-byte accesses, same arithmetic
+__global__ void __launch_bounds__(256) reparam_flat_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
+                                                           const float* __restrict__ eps, float* __restrict__ out,
+                                                           long long n) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 m = reinterpret_cast<const float4*>(loc)[i];
+    const float4 l = reinterpret_cast<const float4*>(ls)[i];
+    const float4 e = reinterpret_cast<const float4*>(eps)[i];
+    float4 o;
+    o.x = __fadd_rn(m.x, __fmul_rn(st_f32(l.x), e.x));
+    o.y = __fadd_rn(m.y, __fmul_rn(st_f32(l.y), e.y));
+    o.z = __fadd_rn(m.z, __fmul_rn(st_f32(l.z), e.z));
+    o.w = __fadd_rn(m.w, __fmul_rn(st_f32(l.w), e.w));
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    out[i] = __fadd_rn(loc[i], __fmul_rn(st_f32(ls[i]), eps[i]));
+  }
+}
+
 extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t samples,
                                int32_t out_cols, float* out, rcb_stream_t stream) {
   RCB_REQUIRE(levels && out, RCB_ERR_ARG, "reparam_fwd: null pointer");
@@ -122,6 +146,20 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
   a.samples = samples;
   a.out_cols = out_cols;
   a.out = out;
+  {
+    const rcb_level& L = a.lv[0];
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (n_levels == 1 && samples == 1 && !L.enc_mask && !L.row_map && !L.row_perm && !L.col_map && L.cols == out_cols &&
+        L.rows == n_inr && al16(L.loc) && al16(L.log_scale) && al16(L.eps) && al16(out)) {
+      const long long n = (long long)n_inr * out_cols;
+      int blocks = cdiv(n >> 2, 256);
+      if (blocks > 16384) blocks = 16384;
+      if (blocks < 1) blocks = 1;
+      reparam_flat_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(L.loc, L.log_scale, L.eps, out, n);
+      RCB_LAUNCH_CHECK();
+      return RCB_OK;
+    }
+  }
   dim3 grid(n_inr, cdiv(out_cols, 256));
   RCB_REQUIRE(grid.y <= 65535, RCB_ERR_SHAPE, "reparam_fwd: too many columns");
   reparam_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
@@ -371,6 +409,130 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, l
     m[i] = mi;
     v[i] = vi;
   }
+}
+
+// ---- per-step bookkeeping of a captured training step (device-resident step counter) -------------------------
+__global__ void __launch_bounds__(1024) step_begin_kernel(const float* __restrict__ table, long long n_steps,
+                                                          const long long* __restrict__ step, float* __restrict__ dyn,
+                                                          double* __restrict__ kl_slots) {
+  const int t = threadIdx.x;
+  if (t < 2) {
+    long long s = *step;
+    if (s < 0) s = 0;
+    if (s >= n_steps) s = n_steps - 1;      // replayed past the table: keep the last row rather than read outside
+    dyn[t] = table[2 * s + t];
+  }
+  if (kl_slots) kl_slots[t] = 0.0;
+}
+
+// fixed-order fp64 sums (thread-strided partials, then a tree over LDS): the same value eagerly and under replay
+__global__ void __launch_bounds__(1024) step_end_kernel(const float* __restrict__ sse, int n_sse, double mse_scale,
+                                                        const double* __restrict__ kl_slots, double* __restrict__ mse_log,
+                                                        double* __restrict__ kl_log, long long n_log,
+                                                        long long* __restrict__ step) {
+  __shared__ double red[2][1024];
+  const int t = threadIdx.x;
+  double a = 0.0;
+  if (sse)
+    for (int i = t; i < n_sse; i += 1024) a += (double)sse[i];
+  red[0][t] = a;
+  red[1][t] = kl_slots ? kl_slots[t] : 0.0;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (t < off) {
+      red[0][t] += red[0][t + off];
+      red[1][t] += red[1][t + off];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const long long s = *step;
+    if (s >= 0 && s < n_log) {
+      if (mse_log && sse) mse_log[s] = red[0][0] * mse_scale;
+      if (kl_log && kl_slots) kl_log[s] = red[1][0];
+    }
+    *step = s + 1;
+  }
+}
+
+extern "C" int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, double* kl_slots,
+                              rcb_stream_t stream) {
+  RCB_REQUIRE(adam_table && step && dyn && n_steps >= 1, RCB_ERR_ARG, "step_begin: null pointer / empty table");
+  static_assert(RCB_KL_SLOTS == 1024, "one slot per thread");
+  step_begin_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(adam_table, (long long)n_steps, (const long long*)step, dyn, kl_slots);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+extern "C" int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const double* kl_slots, double* mse_log,
+                            double* kl_log, int64_t n_log, int64_t* step, rcb_stream_t stream) {
+  RCB_REQUIRE(step, RCB_ERR_ARG, "step_end: null step counter");
+  RCB_REQUIRE(n_sse >= 0 && n_log >= 0, RCB_ERR_SHAPE, "step_end: negative size");
+  step_end_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(sse, n_sse, mse_scale, kl_slots, mse_log, kl_log, (long long)n_log,
+                                                     (long long*)step);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+struct AdamMultiArgs {
+  float* p[RCB_ADAM_MAX_TENSORS];
+  const float* g[RCB_ADAM_MAX_TENSORS];
+  float* m[RCB_ADAM_MAX_TENSORS];
+  float* v[RCB_ADAM_MAX_TENSORS];
+  long long n[RCB_ADAM_MAX_TENSORS];
+  int blk_start[RCB_ADAM_MAX_TENSORS + 1];   // first block of each tensor (1024 elements per block)
+  int count;
+  AdamScalars s;
+};
+
+// one launch for a list of tensors (the shared mappings: 4 A matrices + 6 conv tensors)
+__global__ void __launch_bounds__(256) adam_multi_kernel(AdamMultiArgs a) {
+  int t = 0;
+#pragma unroll 1
+  while (t + 1 < a.count && (int)blockIdx.x >= a.blk_start[t + 1]) ++t;
+  const long long base = (long long)((int)blockIdx.x - a.blk_start[t]) * 1024;
+  float* p = a.p[t];
+  const float* g = a.g[t];
+  float* m = a.m[t];
+  float* v = a.v[t];
+  const long long n = a.n[t];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      float pi = p[i], mi = m[i], vi = v[i];
+      adam_apply(pi, g[i], mi, vi, a.s);
+      p[i] = pi;
+      m[i] = mi;
+      v[i] = vi;
+    }
+  }
+}
+
+extern "C" int rcb_adam_multi(const rcb_adam_tensor* tensors, int32_t count, const rcb_adam_cfg* cfg,
+                              rcb_stream_t stream) {
+  RCB_REQUIRE(tensors && cfg, RCB_ERR_ARG, "adam_multi: null pointer");
+  RCB_REQUIRE(count >= 1 && count <= RCB_ADAM_MAX_TENSORS, RCB_ERR_ARG, "adam_multi: %d tensors (1..%d)", count,
+              RCB_ADAM_MAX_TENSORS);
+  RCB_REQUIRE(cfg->step >= 1, RCB_ERR_ARG, "adam_multi: step must be >= 1");
+  AdamMultiArgs a;
+  memset(&a, 0, sizeof(a));
+  long long blocks = 0;
+  for (int t = 0; t < count; ++t) {
+    const rcb_adam_tensor& x = tensors[t];
+    RCB_REQUIRE(x.n >= 0 && (x.n == 0 || (x.p && x.g && x.m && x.v)), RCB_ERR_ARG, "adam_multi: tensor %d has a null pointer", t);
+    a.p[t] = x.p; a.g[t] = x.g; a.m[t] = x.m; a.v[t] = x.v; a.n[t] = x.n;
+    a.blk_start[t] = (int)blocks;
+    blocks += (x.n + 1023) / 1024;
+    RCB_REQUIRE(blocks < (1LL << 30), RCB_ERR_SHAPE, "adam_multi: too many elements");
+  }
+  a.blk_start[count] = (int)blocks;
+  a.count = count;
+  a.s = make_adam(cfg);
+  if (blocks == 0) return RCB_OK;
+  adam_multi_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
 }
 
 extern "C" int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const rcb_adam_cfg* cfg,

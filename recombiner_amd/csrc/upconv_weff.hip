@@ -1,0 +1,156 @@
+// N1 (host-side algebra of the phase form, moved onto the device): effective weights of the three upsampling stages
+// from the conv weights, and the transposed map for their gradients.  Replaces the einsum chains of
+// upsample_fast._UpsampleCifarFn (about twenty tiny launches per training step) by one launch each way.
+//
+//   stage 1 (nearest x4 of the 2x2 latent grid -> conv 5x5 pad 2 -> 8x8): every output pixel only sees the 2x2
+//     source pixels, so the stage is one dense map  z1[b, (y,x,o)] = b1[o] + sum_{(s,t,i)} lpe[b, (s,t,i)] Weff1[(s,t,i), (y,x,o)]
+//       Weff1[s,t,i,y,x,o] = sum_{k,l : (y+k-2) in rows of s, (x+l-2) in cols of t} W1[o,i,k,l]
+//   stages 2, 3 (nearest x2 -> conv 3x3 pad 1): Weff[ty,tx,ci,a,b,co] = sum_{k in K(a,ty), l in K(b,tx)} W[co,ci,k,l]
+//       with K(0,0) = {0}, K(0,1) = {1,2}, K(1,0) = {0,1}, K(1,1) = {2}      (layout of upconv.hip's weff_index)
+#include "rcb_common.h"
+
+using namespace rcb;
+
+namespace {
+
+__device__ __forceinline__ int tap_of(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0); }
+
+struct WeffArgs {
+  const float* W1;   // [64][128][5][5]
+  const float* b1;   // [64]
+  const float* W2;   // [64][64][3][3]
+  const float* W3;   // [16][64][3][3]
+  void* weff1;       // [512][4096] bf16 or fp32
+  void* b1rep;       // [4096] same type: b1 tiled over the 64 output pixels
+  float* weff2;      // [2][2][64][2][2][64]
+  float* weff3;      // [2][2][64][2][2][16]
+  int bf16_out;
+};
+
+template <int COUT>
+__device__ __forceinline__ void build_stage(const float* __restrict__ W, float* __restrict__ out, int ci, float* w, int tid) {
+  for (int e = tid; e < COUT * 9; e += 256) w[e] = W[((e / 9) * 64 + ci) * 9 + e % 9];
+  __syncthreads();
+  for (int e = tid; e < 16 * COUT; e += 256) {
+    const int co = e % COUT, ab = (e / COUT) & 3, tt = e / (4 * COUT);
+    const int a = ab >> 1, b = ab & 1, ty = tt >> 1, tx = tt & 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+        if (tap_of(a, k) == ty && tap_of(b, l) == tx) acc += w[co * 9 + k * 3 + l];
+    out[((tt * 64 + ci) * 4 + ab) * COUT + co] = acc;
+  }
+}
+
+// blocks [0, 512): stage 1, one (input channel i, source pixel st) each; [512, 576): stage 2 per ci;
+// [576, 640): stage 3 per ci; 640: the tiled bias
+__global__ void __launch_bounds__(256) weff_build_kernel(WeffArgs a) {
+  __shared__ float w[64 * 25];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk < 512) {
+    const int i = blk >> 2, st = blk & 3, s = st >> 1, t = st & 1;
+    for (int e = tid; e < 64 * 25; e += 256) w[e] = a.W1[((e / 25) * 128 + i) * 25 + e % 25];
+    __syncthreads();
+    for (int rem = tid; rem < 4096; rem += 256) {
+      const int y = rem >> 9, x = (rem >> 6) & 7, o = rem & 63;
+      // taps whose source row y + k - 2 lies in rows [4s, 4s + 3] of the up-sampled grid (and likewise for columns)
+      const int k0 = max(0, 4 * s + 2 - y), k1 = min(4, 4 * s + 5 - y);
+      const int l0 = max(0, 4 * t + 2 - x), l1 = min(4, 4 * t + 5 - x);
+      float acc = 0.f;
+      for (int k = k0; k <= k1; ++k)
+        for (int l = l0; l <= l1; ++l) acc += w[o * 25 + k * 5 + l];
+      const long long idx = ((long long)st * 128 + i) * 4096 + rem;
+      if (a.bf16_out) reinterpret_cast<__bf16*>(a.weff1)[idx] = (__bf16)acc;
+      else reinterpret_cast<float*>(a.weff1)[idx] = acc;
+    }
+  } else if (blk < 576) {
+    build_stage<64>(a.W2, a.weff2, blk - 512, w, tid);
+  } else if (blk < 640) {
+    build_stage<16>(a.W3, a.weff3, blk - 576, w, tid);
+  } else {
+    for (int e = tid; e < 4096; e += 256) {
+      const float v = a.b1[e & 63];
+      if (a.bf16_out) reinterpret_cast<__bf16*>(a.b1rep)[e] = (__bf16)v;
+      else reinterpret_cast<float*>(a.b1rep)[e] = v;
+    }
+  }
+}
+
+struct WeffGradArgs {
+  const void* dweff1;   // [512][4096] bf16 or fp32
+  const float* dweff2;
+  const float* dweff3;
+  float* dW1;
+  float* dW2;
+  float* dW3;
+  int bf16_in;
+};
+
+template <int COUT>
+__device__ __forceinline__ void grad_stage(const float* __restrict__ dweff, float* __restrict__ dW, int ci, int tid) {
+  for (int e = tid; e < COUT * 9; e += 256) {
+    const int co = e % COUT, kl = e / COUT, k = kl / 3, l = kl % 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      const int tt = tap_of(ab >> 1, k) * 2 + tap_of(ab & 1, l);
+      acc += dweff[((tt * 64 + ci) * 4 + ab) * COUT + co];
+    }
+    dW[(co * 64 + ci) * 9 + kl] = acc;
+  }
+}
+
+// blocks [0, 800): stage 1, one thread per dW1[o, i, k, l] (o fastest: the 64 lanes of a wave read 64 consecutive
+// channels of dWeff1); [800, 864): stage 2 per ci; [864, 928): stage 3 per ci
+__global__ void __launch_bounds__(256) weff_grad_kernel(WeffGradArgs a) {
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk < 800) {
+    const int e = blk * 256 + tid;                  // < 128 * 25 * 64
+    const int o = e & 63, kl = (e >> 6) % 25, i = (e >> 6) / 25, k = kl / 5, l = kl % 5;
+    // fixed-trip, branch-free: all (up to 64) loads of a thread are in flight together
+    float acc = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const int u = y + k - 2;
+      const bool oky = u >= 0 && u < 8;
+      const int s = oky ? (u >> 2) : 0;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int v = x + l - 2;
+        const bool ok = oky && v >= 0 && v < 8;
+        const int t = ok ? (v >> 2) : 0;
+        const long long idx = ((long long)(s * 2 + t) * 128 + i) * 4096 + y * 512 + x * 64 + o;
+        const float val = a.bf16_in ? (float)reinterpret_cast<const __bf16*>(a.dweff1)[idx]
+                                    : reinterpret_cast<const float*>(a.dweff1)[idx];
+        acc += ok ? val : 0.f;
+      }
+    }
+    a.dW1[(o * 128 + i) * 25 + kl] = acc;
+  } else if (blk < 864) {
+    grad_stage<64>(a.dweff2, a.dW2, blk - 800, tid);
+  } else {
+    grad_stage<16>(a.dweff3, a.dW3, blk - 864, tid);
+  }
+}
+
+}  // namespace
+
+extern "C" int rcb_upconv_weff_build(const float* W1, const float* b1, const float* W2, const float* W3, void* weff1,
+                                     void* b1rep, int32_t bf16_out, float* weff2, float* weff3, rcb_stream_t stream) {
+  RCB_REQUIRE(W1 && b1 && W2 && W3 && weff1 && b1rep && weff2 && weff3, RCB_ERR_ARG, "upconv_weff_build: null pointer");
+  WeffArgs a{W1, b1, W2, W3, weff1, b1rep, weff2, weff3, bf16_out ? 1 : 0};
+  weff_build_kernel<<<641, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+extern "C" int rcb_upconv_weff_grad(const void* dweff1, int32_t bf16_in, const float* dweff2, const float* dweff3,
+                                    float* dW1, float* dW2, float* dW3, rcb_stream_t stream) {
+  RCB_REQUIRE(dweff1 && dweff2 && dweff3 && dW1 && dW2 && dW3, RCB_ERR_ARG, "upconv_weff_grad: null pointer");
+  WeffGradArgs a{dweff1, dweff2, dweff3, dW1, dW2, dW3, bf16_in ? 1 : 0};
+  weff_grad_kernel<<<928, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamCfg, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
+from ._lib import AdamCfg, AdamTensor, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
 
 f32 = torch.float32
 f64 = torch.float64
@@ -353,6 +353,42 @@ def adam_flat(p, g, m, v, cfg: AdamCfg):
                             C.byref(cfg), stream_ptr()), "rcb_adam_flat")
 
 
+def step_begin(table, step, dyn, kl_slots=None):
+    """dyn <- table[step] (per-step Adam scalars), kl_slots <- 0 (rcb_step_begin); everything stays on the device."""
+    lib = _lib.load()
+    if table.dim() != 2 or table.shape[1] != 2 or (kl_slots is not None and kl_slots.numel() != 1024):
+        raise RcbError("step_begin: table must be [n_steps, 2], kl_slots [1024]")
+    check(lib.rcb_step_begin(ptr(table, f32), C.c_int64(table.shape[0]), ptr(step, torch.int64), ptr(dyn, f32),
+                             ptr(kl_slots, f64, True), stream_ptr()), "rcb_step_begin")
+
+
+def step_end(step, sse=None, mse_scale=1.0, kl_slots=None, mse_log=None, kl_log=None):
+    """mse_log[step] = mse_scale * sum(sse), kl_log[step] = sum(kl_slots), step += 1 (rcb_step_end)."""
+    lib = _lib.load()
+    n_log = min(t.numel() for t in (mse_log, kl_log) if t is not None) if (mse_log is not None or kl_log is not None) else 0
+    check(lib.rcb_step_end(ptr(sse, f32, True), 0 if sse is None else sse.numel(), C.c_double(mse_scale),
+                           ptr(kl_slots, f64, True), ptr(mse_log, f64, True), ptr(kl_log, f64, True), C.c_int64(n_log),
+                           ptr(step, torch.int64), stream_ptr()), "rcb_step_end")
+
+
+ADAM_MAX_TENSORS = 16
+
+
+def adam_multi(params, grads, ms, vs, cfg: AdamCfg):
+    """Adam step over a list of fp32 tensors in one launch (rcb_adam_multi); lists longer than 16 are chunked."""
+    lib = _lib.load()
+    items = list(zip(params, grads, ms, vs))
+    for k in range(0, len(items), ADAM_MAX_TENSORS):
+        chunk = items[k:k + ADAM_MAX_TENSORS]
+        arr = (AdamTensor * len(chunk))()
+        for i, (p, g, m, v) in enumerate(chunk):
+            if not (p.is_contiguous() and g.is_contiguous()) or g.numel() != p.numel():
+                raise RcbError("adam_multi needs contiguous tensors of matching size")
+            arr[i] = AdamTensor(ptr(p.detach(), f32).value, ptr(g, f32).value, ptr(m, f32).value, ptr(v, f32).value,
+                                p.numel())
+        check(lib.rcb_adam_multi(arr, len(chunk), C.byref(cfg), stream_ptr()), "rcb_adam_multi")
+
+
 def col_moments(loc, log_scale):
     """-> (sum, m2, sum sigma^2) fp64 [cols] over the rows of loc (rcb_col_moments)."""
     lib = _lib.load()
@@ -459,3 +495,34 @@ def upconv_wgrad(x, dy, grid, cout, preact=False):
     check(lib.rcb_upconv_wgrad(ptr(x), _xmode(x, preact), ptr(dy), int(dy.dtype == f32), ptr(dw), ptr(db), B, grid,
                                cout, ptr(ws), C.c_int64(n_ws), stream_ptr()), "rcb_upconv_wgrad")
     return dw, db
+
+
+def upconv_weff_build(W1, b1, W2, W3, bf16_out):
+    """conv weights of the CIFAR-geometry upsampling net -> (Weff1 [512,4096], b1rep [4096], Weff2, Weff3)."""
+    lib = _lib.load()
+    dev = W1.device
+    if (tuple(W1.shape), tuple(W2.shape), tuple(W3.shape)) != ((64, 128, 5, 5), (64, 64, 3, 3), (16, 64, 3, 3)):
+        raise RcbError("upconv_weff_build: conv weight shapes of the CIFAR upsampling net expected")
+    dt = bf16 if bf16_out else f32
+    weff1 = torch.empty(512, 4096, device=dev, dtype=dt)
+    b1rep = torch.empty(4096, device=dev, dtype=dt)
+    weff2 = torch.empty(2, 2, 64, 2, 2, 64, device=dev, dtype=f32)
+    weff3 = torch.empty(2, 2, 64, 2, 2, 16, device=dev, dtype=f32)
+    check(lib.rcb_upconv_weff_build(ptr(W1.detach(), f32), ptr(b1.detach(), f32), ptr(W2.detach(), f32),
+                                    ptr(W3.detach(), f32), ptr(weff1), ptr(b1rep), int(bool(bf16_out)), ptr(weff2),
+                                    ptr(weff3), stream_ptr()), "rcb_upconv_weff_build")
+    return weff1, b1rep, weff2, weff3
+
+
+def upconv_weff_grad(dweff1, dweff2, dweff3):
+    """gradients of the effective weights -> (dW1 [64,128,5,5], dW2 [64,64,3,3], dW3 [16,64,3,3])."""
+    lib = _lib.load()
+    dev = dweff1.device
+    if dweff1.numel() != 512 * 4096 or dweff2.numel() != 65536 or dweff3.numel() != 16384:
+        raise RcbError("upconv_weff_grad: shape mismatch")
+    dW1 = torch.empty(64, 128, 5, 5, device=dev, dtype=f32)
+    dW2 = torch.empty(64, 64, 3, 3, device=dev, dtype=f32)
+    dW3 = torch.empty(16, 64, 3, 3, device=dev, dtype=f32)
+    check(lib.rcb_upconv_weff_grad(ptr(dweff1), int(dweff1.dtype == bf16), ptr(dweff2, f32), ptr(dweff3, f32), ptr(dW1),
+                                   ptr(dW2), ptr(dW3), stream_ptr()), "rcb_upconv_weff_grad")
+    return dW1, dW2, dW3

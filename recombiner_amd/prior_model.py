@@ -246,8 +246,7 @@ class PriorBNNmodel(nn.Module):
         cfg = ops.adam_cfg(lr, 1, dyn=dyn)
 
         def body():
-            dyn.copy_(tab.index_select(0, step_t).view(2))
-            kl_slots.zero_()
+            ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
             e_lpe = self._noise((N, 1, self._d_lpe))
             lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
@@ -276,7 +275,6 @@ class PriorBNNmodel(nn.Module):
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
             sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
-            mse_buf.index_copy_(0, step_t, (sse.sum(dtype=torch.float64) / (P * Cc)).reshape(1))
             # ---- backward through the shared mappings ------------------------------------------------------
             inputs = [lpe_t] + (conv if training_mappings else [])
             g_in = torch.autograd.grad(pe_c, inputs, dpe)
@@ -299,7 +297,6 @@ class PriorBNNmodel(nn.Module):
                 ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt, kl_accum=kl_slots)
             ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), d_lpe,
                               e_lpe, 1, adam=cfg, state=lpe_state, kl_accum=kl_slots)
-            kl_buf.index_copy_(0, step_t, kl_slots.sum().reshape(1))
             if training_mappings:
                 grads = gA + [g.contiguous() for g in g_in[1:]]
                 if world > 1:
@@ -310,9 +307,9 @@ class PriorBNNmodel(nn.Module):
                         out.append(flat[k:k + g.numel()].view_as(g))
                         k += g.numel()
                     grads = out
-                for p, g, (m, v) in zip(A + conv, grads, map_state):
-                    ops.adam_flat(p.data, g.contiguous(), m, v, cfg)
-            step_t.add_(1)
+                ops.adam_multi([p.data for p in A + conv], [g.contiguous() for g in grads],
+                               [m for m, _ in map_state], [v for _, v in map_state], cfg)
+            ops.step_end(step_t, sse, 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf)
 
         n_warm = 3
         graph = None

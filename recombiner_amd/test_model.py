@@ -457,7 +457,7 @@ class TestBNNmodel(nn.Module):
         cfg = ops.adam_cfg(lr, 1, eps=eps_adam, dyn=dyn)
 
         def body(adjust):
-            dyn.copy_(tab.index_select(0, step_t).view(2))
+            ops.step_begin(tab, step_t, dyn)
             eps = self._draw_all(S)
             sample = ops.reparam_fwd(specs, eps, S)                                   # [N,S,Dtot]
             lpe_t = self._pe_from_sample(sample, S).contiguous().requires_grad_(True)
@@ -483,7 +483,7 @@ class TestBNNmodel(nn.Module):
                 for lv, gk in zip(self._levels, grp):
                     ops.beta_update(gk, lv.kl_beta, lv.d_done, float(self.bit_per_group), float(self.kl_upper_buffer),
                                     float(self.kl_lower_buffer), float(self.beta_step_size))
-            step_t.add_(1)
+            ops.step_end(step_t)
 
         use_graph = self.use_graph and self.noise_source is None and not verbose and n_epochs >= 8 and dev.type == "cuda"
         if use_graph:

@@ -182,18 +182,13 @@ class _UpsampleCifarFn(torch.autograd.Function):
     def forward(ctx, lpe, W1, b1, W2, b2, W3, b3, stage1_bf16, pe_bf16):
         from . import ops
         B = lpe.shape[0]
-        M = _stage1_maps(lpe.device, torch.float32)
-        Weff1 = torch.einsum("ysk,xtl,oikl->stiyxo", M, M, W1).reshape(512, 4096)
-        if stage1_bf16:      # bf16 operands and a bf16 z1: stage 2 rounds z1 to bf16 for its MFMA operand anyway
-            Weff1 = Weff1.to(torch.bfloat16)
+        # effective (phase-form) weights of all three stages in one launch; bf16 stage 1 = bf16 operands and a bf16 z1
+        # (stage 2 rounds z1 to bf16 for its MFMA operand anyway)
+        Weff1, b1rep, Weff2, Weff3 = ops.upconv_weff_build(W1, b1, W2, W3, stage1_bf16)
+        if stage1_bf16:
             lpe = lpe.to(torch.bfloat16)
-            z1 = torch.addmm(b1.repeat(64).to(torch.bfloat16), lpe, Weff1).view(B, 8, 8, 64)
-        else:
-            z1 = torch.addmm(b1.repeat(64), lpe, Weff1).view(B, 8, 8, 64)
-        st = PhaseStage(2, 3, 1, 2)
-        Weff2 = st.eff_weight(W2).contiguous()
+        z1 = torch.addmm(b1rep, lpe, Weff1).view(B, 8, 8, 64)
         h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True)
-        Weff3 = st.eff_weight(W3).contiguous()
         pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=not pe_bf16, linear_bf16=pe_bf16)
         ctx.save_for_backward(lpe, Weff1, z1, Weff2, h2, Weff3)
         return pe.view(B, 1024, 16)
@@ -203,7 +198,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
         from . import ops
         lpe, Weff1, z1, Weff2, h2, Weff3 = ctx.saved_tensors
         B = lpe.shape[0]
-        need_w = any(ctx.needs_input_grad[1:])
+        need_w = any(ctx.needs_input_grad[1:7])
         dpe = dpe.contiguous().view(B, 32, 32, 16)
         dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16)                     # bf16 [B,16,16,64]
         dz1 = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True)         # [B,8,8,64] in the dtype of z1
@@ -211,14 +206,10 @@ class _UpsampleCifarFn(torch.autograd.Function):
         dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
         if not need_w:
             return dlpe, None, None, None, None, None, None, None, None
-        M = _stage1_maps(lpe.device, torch.float32)
-        R = _phase_R(lpe.device, 2, 3, 1)
         dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
         dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64, preact=True)
-        dWeff1 = (lpe.t() @ dz1f).float().view(2, 2, 128, 8, 8, 64)
-        dW1 = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, dWeff1)
-        dW2 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff2)
-        dW3 = torch.einsum("atk,bul,tuiabo->oikl", R, R, dWeff3)
+        dWeff1 = lpe.t() @ dz1f                                            # [512, 4096], dtype of the stage-1 operands
+        dW1, dW2, dW3 = ops.upconv_weff_grad(dWeff1, dWeff2, dWeff3)
         db1 = dz1.sum((0, 1, 2), dtype=torch.float32)
         return dlpe, dW1, db1, dW2, db2, dW3, db3, None, None
 

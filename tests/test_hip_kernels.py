@@ -247,6 +247,21 @@ def test_reparam_fwd_and_posterior_grads(name):
         assert rel_err(gs, pr[b].grad) < 2e-5
 
 
+@pytest.mark.parametrize("N,D", [(3, 3267), (5, 512), (1, 7)])
+def test_reparam_flat_fast_path_equals_generic(N, D):
+    """one level / one sample / no maps takes the 16-byte flat kernel: same bits as the generic kernel (forced here
+    by an identity column map), including the tail when N * D is not a multiple of 4."""
+    gen = torch.Generator().manual_seed(12)
+    loc = g(torch.randn(N, D, generator=gen))
+    ls = g(torch.randn(N, D, generator=gen) * 3 - 2)
+    eps = g(torch.randn(N, 1, D, generator=gen))
+    fast = ops.reparam_fwd([LevelSpec(loc, ls, D, N)], [eps], 1)
+    slow = ops.reparam_fwd([LevelSpec(loc, ls, D, N, col_map=np.arange(D))], [eps], 1)
+    assert torch.equal(fast, slow)
+    ref = loc.double() + torch.nn.functional.softplus(ls.double()) / 6 * eps[:, 0].double()
+    assert rel_err(fast[:, 0], ref) < 1e-6
+
+
 def test_adam_matches_torch():
     gen = torch.Generator().manual_seed(4)
     p0 = torch.randn(1000, generator=gen)
@@ -260,6 +275,34 @@ def test_adam_matches_torch():
         opt.step()
         ops.adam_flat(p, g(gr), m, v, ops.adam_cfg(2e-4, step))
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_adam_multi_equals_adam_flat():
+    """one launch over a ragged list of tensors == one adam_flat launch per tensor, bit for bit"""
+    gen = torch.Generator().manual_seed(9)
+    sizes = [1056 * 1056, 99 * 99, 73728, 64, 1, 1023, 1024, 1025, 0, 36864, 16]
+    ps = [g(torch.randn(n, generator=gen)) for n in sizes]
+    gs = [g(torch.randn(n, generator=gen) * 1e-3) for n in sizes]
+    ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    ps2, ms2, vs2 = [p.clone() for p in ps], [m.clone() for m in ms], [v.clone() for v in vs]
+    for step in (1, 2, 3):
+        cfg = ops.adam_cfg(2e-4, step)
+        ops.adam_multi(ps, gs, ms, vs, cfg)
+        for p, gr, m, v in zip(ps2, gs, ms2, vs2):
+            if p.numel():
+                ops.adam_flat(p, gr, m, v, cfg)
+    for a, b in zip(ps + ms + vs, ps2 + ms2 + vs2):
+        assert torch.equal(a, b)
+    # more tensors than one launch holds: chunked
+    many = [g(torch.randn(37, generator=gen)) for _ in range(20)]
+    many2 = [p.clone() for p in many]
+    gm = [g(torch.randn(37, generator=gen)) for _ in range(20)]
+    z = lambda: [torch.zeros(37, device=DEV) for _ in range(20)]  # noqa: E731
+    m1, v1, m2, v2 = z(), z(), z(), z()
+    ops.adam_multi(many, gm, m1, v1, ops.adam_cfg(1e-3, 1))
+    for p, gr, m, v in zip(many2, gm, m2, v2):
+        ops.adam_flat(p, gr, m, v, ops.adam_cfg(1e-3, 1))
+    assert all(torch.equal(a, b) for a, b in zip(many, many2))
 
 
 def test_posterior_adam_step_matches_autograd_adam():

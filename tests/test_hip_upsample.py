@@ -69,3 +69,36 @@ def test_bf16_pe_storage_is_bit_identical():
     assert torch.equal(g32[0], g16r[0])                      # data gradient: deterministic kernels, same operands
     for a, b in zip(g32[1:], g16r[1:]):                      # weight gradients: fp32 atomics, order-dependent sums
         assert rel(a, b) < 1e-5
+
+
+def test_effective_weight_kernels_match_einsum():
+    """rcb_upconv_weff_build / _grad against the einsum definition of the phase form (fp64)."""
+    from recombiner_amd import ops
+    from recombiner_amd.upsample_fast import PhaseStage, _phase_R, _stage1_maps
+    torch.manual_seed(5)
+    W1 = torch.randn(64, 128, 5, 5, device=DEV)
+    b1 = torch.randn(64, device=DEV)
+    W2 = torch.randn(64, 64, 3, 3, device=DEV)
+    W3 = torch.randn(16, 64, 3, 3, device=DEV)
+    M = _stage1_maps(DEV, torch.float64)
+    st = PhaseStage(2, 3, 1, 2)
+    ref1 = torch.einsum("ysk,xtl,oikl->stiyxo", M, M, W1.double()).reshape(512, 4096)
+    ref2, ref3 = st.eff_weight(W2.double()), st.eff_weight(W3.double())
+    for bf in (False, True):
+        e1, b1rep, e2, e3 = ops.upconv_weff_build(W1, b1, W2, W3, bf)
+        assert e1.dtype == (torch.bfloat16 if bf else torch.float32)
+        assert rel(e1, ref1) < (5e-3 if bf else 1e-6) and rel(e2, ref2) < 1e-6 and rel(e3, ref3) < 1e-6
+        assert torch.equal(b1rep.float().view(64, 64), b1.to(b1rep.dtype).float().expand(64, 64))
+    # gradient map = transpose of the build map
+    g1 = torch.randn(512, 4096, device=DEV)
+    g2 = torch.randn(2, 2, 64, 2, 2, 64, device=DEV)
+    g3 = torch.randn(2, 2, 64, 2, 2, 16, device=DEV)
+    R = _phase_R(DEV, 2, 3, 1).double()
+    r1 = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, g1.double().view(2, 2, 128, 8, 8, 64))
+    r2 = torch.einsum("atk,bul,tuiabo->oikl", R, R, g2.double())
+    r3 = torch.einsum("atk,bul,tuiabo->oikl", R, R, g3.double())
+    d1, d2, d3 = ops.upconv_weff_grad(g1, g2, g3)
+    assert rel(d1, r1) < 1e-6 and rel(d2, r2) < 1e-6 and rel(d3, r3) < 1e-6
+    d1b, _, _ = ops.upconv_weff_grad(g1.bfloat16(), g2, g3)
+    r1b = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, g1.bfloat16().double().view(2, 2, 128, 8, 8, 64))
+    assert rel(d1b, r1b) < 1e-6
