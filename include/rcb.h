@@ -246,8 +246,11 @@ int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, con
  * ------------------------------------------------------------------------------------------- */
 int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, const float* bias, void* y,
                    int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+/* dgrad, stage-2 geometry only: if dbias_partial != NULL it receives [rcb_upconv_dgrad_partial_rows(batch)][64]
+ * per-workgroup channel sums of dx (= the bias gradient of the stage that produced x); elsewhere it must be NULL. */
+int32_t rcb_upconv_dgrad_partial_rows(int32_t batch);
 int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x, int32_t x_is_f32_preact,
-                     void* dx, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+                     void* dx, float* dbias_partial, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
 /* wgrad writes (does not accumulate) dweff [2][2][64][2][2][cout] and, if non-NULL, dbias [cout] = sum of dy.
  * Each workgroup sums its INRs into its own slab of `workspace` and a second kernel adds the slabs in a fixed
  * order: no atomics, bitwise reproducible.  workspace: >= rcb_upconv_wgrad_workspace(batch, cout) floats.   */
@@ -264,7 +267,9 @@ int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int
 int rcb_upconv_weff_build(const float* W1, const float* b1, const float* W2, const float* W3, void* weff1, void* b1rep,
                           int32_t bf16_out, float* weff2, float* weff3, rcb_stream_t stream);
 int rcb_upconv_weff_grad(const void* dweff1, int32_t bf16_in, const float* dweff2, const float* dweff3, float* dW1,
-                         float* dW2, float* dW3, rcb_stream_t stream);
+                         float* dW2, float* dW3, const float* db1_partial /* nullable [n_partial][64] */,
+                         int32_t n_partial, float* db1 /* nullable [64] = column sums of db1_partial */,
+                         rcb_stream_t stream);
 
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);

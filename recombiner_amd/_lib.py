@@ -13,7 +13,8 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
-           "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad"]
+           "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad",
+           "rcb_upconv_dgrad_partial_rows"]
 
 
 class RcbError(RuntimeError):

@@ -42,6 +42,10 @@ union Frag {
   uint4 u;
 };
 
+// the value must exist in registers here: stops the compiler from sinking a prologue's conversions into the main loop
+// (where their operands would stay live, and spill, across it)
+__device__ __forceinline__ void pin(uint4& u) { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
+
 // 8 consecutive channels of one pixel as a bf16 fragment; `ok` false -> zeros (halo)
 template <int MODE>  // 0: bf16 image, 1: fp32 pre-activation (LeakyReLU applied), 2: fp32 plain, 3: bf16 pre-activation
 __device__ __forceinline__ bf16x8 load8(const void* base, long long elem_off, bool ok) {
@@ -422,6 +426,7 @@ __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
           for (int j = 0; j < 8; ++j)      // rows >= COUT of the 32-row A tile are zero (clamped load, masked)
             f.v[j] = (__bf16)(a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, q < COUT ? q : COUT - 1, COUT)] * wmask);
           fr[pb][ty][tx][kb] = f.u;
+          pin(fr[pb][ty][tx][kb]);
         }
   float bia[8];
 #pragma unroll
@@ -563,6 +568,278 @@ __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
   }
 #undef RCB_FETCHD
 #undef RCB_COMMITD
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-2 variants (G = 8, 64 -> 64 channels) with register-resident weight fragments.
+//
+// forward: wave w = (INR of the pair w >> 2, output phase w & 3); it owns both 32-position tiles of its INR and both
+// halves of the 64 output channels: 32 fragments in registers, 16 image reads feed 32 MFMAs per tile.  Two INRs per
+// pass halve the barriers per INR; LeakyReLU of the pre-activation input is applied once, when the image is staged.
+// ------------------------------------------------------------------------------------------------
+template <int IN_MODE>   // 1: fp32 pre-activation, 3: bf16 pre-activation
+__global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
+  constexpr int G = 8, HG = 10, RS = 72, COUT = 64, IMG = HG * HG * RS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                  // [2][IMG]
+  float* bs = reinterpret_cast<float*>(smem_raw + 2 * IMG * 2);      // [64]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  const int ph = wave & 3, pa = ph >> 1, pb = ph & 1, inr = wave >> 2;
+  uint4 fr[2][2][2][4];   // [mt][ty][tx][kb]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          Frag f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, 32 * mt + q, COUT)];
+          fr[mt][ty][tx][kb] = f.u;
+          pin(fr[mt][ty][tx][kb]);
+        }
+  for (int e = tid; e < 2 * IMG / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  if (tid < COUT) bs[tid] = a.bias[tid];
+  // a pair of INRs = 2 x 64 pixels x 8 chunks of 8 channels = 1024 chunks, 2 per thread
+  Raw8<IN_MODE> pre[2];
+  const int npair = (a.batch + 1) >> 1;
+#define RCB_FETCH2(pp)                                                                      \
+  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                          \
+    const int e_ = tid + 512 * k;                                                          \
+    int b_ = 2 * (pp) + (e_ >> 9);                                                         \
+    if (b_ >= a.batch) b_ = a.batch - 1;                                                   \
+    pre[k] = raw_load<IN_MODE>(a.x, (long long)b_ * G * G * CIN + 8 * (e_ & 511));         \
+  }
+  const int gs = gridDim.x;
+  int p = blockIdx.x;
+  if (p < npair) RCB_FETCH2(p)
+  for (; p < npair; p += gs) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e_ = tid + 512 * k, pix = (e_ >> 3) & 63, c8 = e_ & 7;
+      Frag f;
+      f.v = raw_frag<IN_MODE>(pre[k], true);
+      *reinterpret_cast<uint4*>(img + (e_ >> 9) * IMG + (((pix >> 3) + 1) * HG + ((pix & 7) + 1)) * RS + 8 * c8) = f.u;
+    }
+    __syncthreads();
+    if (p + gs < npair) RCB_FETCH2(p + gs)
+    const int b = 2 * p + inr;
+    if (b < a.batch) {
+      const __bf16* im = img + inr * IMG;
+#pragma unroll 1
+      for (int tt = 0; tt < 2; ++tt) {
+        const int pos = tt * 32 + q, i = pos >> 3, j = pos & 7;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        const __bf16* base = im + ((i + pa) * HG + (j + pb)) * RS + 8 * h;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+              Frag bf, fa;
+              bf.u = *reinterpret_cast<const uint4*>(base + (ty * HG + tx) * RS + 16 * kb);
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                fa.u = fr[mt][ty][tx][kb];
+                acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
+              }
+            }
+        // bias + LeakyReLU on the original channels, then the lane halves swap so that lane (q, h) owns the 16
+        // consecutive channels 32 mt + 16 h .. + 15 of its pixel
+        const long long opix = ((long long)b * (2 * G) + 2 * i + pa) * (2 * G) + 2 * j + pb;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float v[16];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bb = *reinterpret_cast<const float4*>(bs + 32 * mt + 8 * g4 + 4 * h);
+            v[4 * g4 + 0] = lrelu(acc[mt][4 * g4 + 0] + bb.x);
+            v[4 * g4 + 1] = lrelu(acc[mt][4 * g4 + 1] + bb.y);
+            v[4 * g4 + 2] = lrelu(acc[mt][4 * g4 + 2] + bb.z);
+            v[4 * g4 + 3] = lrelu(acc[mt][4 * g4 + 3] + bb.w);
+          }
+          float xa[8], ya[8];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[m]), __float_as_uint(v[8 + m]), false, false);
+            xa[m] = __uint_as_float(sw[0]);   // channel 32 mt + 16 h + (m & 3) + 8 (m >> 2)
+            ya[m] = __uint_as_float(sw[1]);   //   ... + 4
+          }
+          Frag o0, o1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            o0.v[k] = (__bf16)xa[k];     o0.v[4 + k] = (__bf16)ya[k];
+            o1.v[k] = (__bf16)xa[4 + k]; o1.v[4 + k] = (__bf16)ya[4 + k];
+          }
+          uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + 32 * mt + 16 * h);
+          dst[0] = o0.u;
+          dst[1] = o1.u;
+        }
+      }
+    }
+  }
+#undef RCB_FETCH2
+}
+
+// data gradient of stage 2: D[ci, pos] = sum over the 16 window combos and 64 output channels.  The 128 fragments do
+// not fit one wave, so wave w = (ci half w & 1, tile (w >> 1) & 1, combo half w >> 2) keeps 32 of them and the two
+// combo halves are added through LDS.  The epilogue (combo-half 0 waves) multiplies by LeakyReLU'(x), swaps lane halves
+// for 32-byte stores and accumulates the per-channel sums of dx (the bias gradient of the stage before) per workgroup.
+template <int X_F32>   // sign source / dx type: 1 fp32, 0 bf16
+__global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, float* __restrict__ dbias_partial) {
+  constexpr int G = 8, OG = 16, HO = 18, RS = 72, COUT = 64, IMG = HO * HO * RS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                               // [IMG]
+  float* red = reinterpret_cast<float*>(smem_raw + ((IMG * 2 + 15) / 16) * 16);   // [4 waves][16][64]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  const int mt = wave & 1, tile = (wave >> 1) & 1, kh = wave >> 2;
+  uint4 fr[8][4];   // [combo of this half][kb]
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int n = 8 * kh + c, ry = (n >> 2) - 1, rx = (n & 3) - 1;
+    const int pa = ry & 1, ty = (ry <= 0) ? 1 : 0, pb = rx & 1, tx = (rx <= 0) ? 1 : 0;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {     // the 8 elements are consecutive output channels: two 16-byte loads
+      const float4* wp = reinterpret_cast<const float4*>(a.weff + weff_index(ty, tx, 32 * mt + q, pa, pb, 16 * kb + 8 * h, COUT));
+      const float4 w0 = wp[0], w1 = wp[1];
+      Frag f;
+      f.v[0] = (__bf16)w0.x; f.v[1] = (__bf16)w0.y; f.v[2] = (__bf16)w0.z; f.v[3] = (__bf16)w0.w;
+      f.v[4] = (__bf16)w1.x; f.v[5] = (__bf16)w1.y; f.v[6] = (__bf16)w1.z; f.v[7] = (__bf16)w1.w;
+      fr[c][kb] = f.u;
+      pin(fr[c][kb]);
+    }
+  }
+  for (int e = tid; e < IMG / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  float dbsum[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dbsum[k] = 0.f;
+  // dy image of one INR: 16 x 16 pixels x 64 channels bf16 = 2048 x 16 B -> 4 per thread
+  uint4 pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pre[k] = make_uint4(0, 0, 0, 0);
+#define RCB_FETCHD2(bb)                                                                                           \
+  {                                                                                                               \
+    const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)(bb) * OG * OG * COUT); \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) pre[k] = src_[tid + 512 * k];                                   \
+  }
+  const int gs = gridDim.x;
+  int b = blockIdx.x;
+  __syncthreads();   // also a scheduling boundary: the prefetch registers must not overlap the prologue's register peak
+  if (b < a.batch) RCB_FETCHD2(b)
+  const int pos = tile * 32 + q, u = pos >> 3, v = pos & 7;
+  for (; b < a.batch; b += gs) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e_ = tid + 512 * k, pix = e_ >> 3, c8 = e_ & 7;
+      *reinterpret_cast<uint4*>(img + (((pix >> 4) + 1) * HO + ((pix & 15) + 1)) * RS + 8 * c8) = pre[k];
+    }
+    __syncthreads();
+    if (b + gs < a.batch) RCB_FETCHD2(b + gs)
+    // sign source of this lane's 16 output channels, requested before the MFMA loop
+    const long long xoff = ((long long)b * G * G + pos) * CIN + 32 * mt + 16 * h;
+    float xf[16];     // fp32 sign source
+    Frag xb[2];       // bf16 sign source
+    if (kh == 0) {
+      if (X_F32) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 t = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.x) + xoff)[k];
+          xf[4 * k] = t.x; xf[4 * k + 1] = t.y; xf[4 * k + 2] = t.z; xf[4 * k + 3] = t.w;
+        }
+      } else {
+        xb[0].u = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + xoff)[0];
+        xb[1].u = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + xoff)[1];
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // combos one at a time: the scheduler would otherwise hoist all 32 fragment reads and push the prefetch
+    // registers into scratch
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int n = 8 * kh + c, ry = (n >> 2) - 1, rx = (n & 3) - 1;
+      const __bf16* px = img + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h;
+      uint4 cur[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) cur[kb] = *reinterpret_cast<const uint4*>(px + 16 * kb);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        Frag bf, fa;
+        bf.u = cur[kb];
+        fa.u = fr[c][kb];
+        acc = mfma16(fa.v, bf.v, acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one combo at a time (the other wave of the SIMD covers the LDS latency)
+    }
+    // add the two combo halves (register-major layout: conflict-free)
+    float* rw = red + (wave & 3) * 16 * 64;
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rw[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += rw[r * 64 + lane];
+      // lane halves swap so that lane (q, h) owns channels 32 mt + 16 h + {0..15}; two halves of 8 channels keep the
+      // live temporaries small (the prefetch registers must not spill)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[4 * hf + k]), __float_as_uint(acc[8 + 4 * hf + k]),
+                                                     false, false);
+          o[k] = __uint_as_float(sw[0]);
+          o[4 + k] = __uint_as_float(sw[1]);
+        }
+        if (X_F32) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            o[k] *= (xf[8 * hf + k] > 0.f ? 1.0f : SLOPE);
+            dbsum[8 * hf + k] += o[k];
+          }
+          float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dx) + xoff + 8 * hf);
+          dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+          dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+          Frag oo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            oo.v[k] = (__bf16)(o[k] * ((float)xb[hf].v[k] > 0.f ? 1.0f : SLOPE));
+            dbsum[8 * hf + k] += (float)oo.v[k];     // sums of the values as stored
+          }
+          reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.dx) + xoff)[hf] = oo.u;
+        }
+      }
+    }
+  }
+#undef RCB_FETCHD2
+  if (dbias_partial) {   // fixed-order reduction over the 32 pixels of a lane half, then over the two tiles
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) dbsum[k] += __shfl_xor(dbsum[k], off, 64);
+    }
+    float* r2 = red;   // [tile][64]
+    if (kh == 0 && q == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) r2[tile * 64 + 32 * mt + 16 * h + k] = dbsum[k];
+    }
+    __syncthreads();
+    if (tid < 64) dbias_partial[(long long)blockIdx.x * 64 + tid] = r2[tid] + r2[64 + tid];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -758,9 +1035,11 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_fwd: empty batch");
   FwdArgs a{x, weff, bias, y, batch};
   hipStream_t st = (hipStream_t)stream;
+  constexpr int kFwd2Smem = 2 * 10 * 10 * 72 * 2 + 64 * 4;
+  const int npair = (batch + 1) / 2;
   if (grid == 8 && cout == 64 && x_is_f32_preact == 1 && !y_is_f32_linear) {
     static bool done = false;
-    return launch(upconv_fwd_kernel<64, 8, 1, 0>, a, grid_for(batch * 2, 4 * 4 * 4 * 2 * 1024), 4 * 4 * 4 * 2 * 1024, st, done);
+    return launch(upconv_fwd2_reg_kernel<1>, a, npair < 256 ? npair : 256, kFwd2Smem, st, done);
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 1) {
     static bool done = false;
@@ -772,19 +1051,41 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input
     static bool done = false;
-    return launch(upconv_fwd_kernel<64, 8, 3, 0>, a, grid_for(batch * 2, 4 * 4 * 4 * 2 * 1024), 4 * 4 * 4 * 2 * 1024, st, done);
+    return launch(upconv_fwd2_reg_kernel<3>, a, npair < 256 ? npair : 256, kFwd2Smem, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_fwd: grid=%d cout=%d in_mode=%d out_f32=%d not instantiated", grid, cout,
               x_is_f32_preact, y_is_f32_linear);
 }
 
+static inline int dgrad_blocks(int batch) { return batch < 256 ? batch : 256; }
+
+extern "C" int32_t rcb_upconv_dgrad_partial_rows(int32_t batch) { return batch > 0 ? dgrad_blocks(batch) : 0; }
+
+template <int X_F32>
+static int launch_dgrad2(const DgradArgs& a, float* dbias_partial, hipStream_t st) {
+  constexpr int kSmem = ((18 * 18 * 72 * 2 + 15) / 16) * 16 + 4 * 16 * 64 * 4;
+  static bool done = false;
+  auto kfn = upconv_dgrad2_reg_kernel<X_F32>;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    done = true;
+  }
+  kfn<<<dgrad_blocks(a.batch), 512, kSmem, st>>>(a, dbias_partial);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
 extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x,
-                                int32_t x_is_f32_preact, void* dx, int32_t batch, int32_t grid, int32_t cout,
-                                rcb_stream_t stream) {
+                                int32_t x_is_f32_preact, void* dx, float* dbias_partial, int32_t batch, int32_t grid,
+                                int32_t cout, rcb_stream_t stream) {
   RCB_REQUIRE(dy && weff && x && dx, RCB_ERR_ARG, "upconv_dgrad: null pointer");
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_dgrad: empty batch");
   DgradArgs a{dy, weff, x, dx, batch};
   hipStream_t st = (hipStream_t)stream;
+  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 1) return launch_dgrad2<1>(a, dbias_partial, st);
+  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 2) return launch_dgrad2<0>(a, dbias_partial, st);
+  RCB_REQUIRE(dbias_partial == nullptr, RCB_ERR_UNSUPPORTED, "upconv_dgrad: channel sums of dx only for the stage-2 kernels");
   if (grid == 16 && cout == 16 && dy_is_f32 && !x_is_f32_preact) {
     static bool done = false;
     return launch(upconv_dgrad3_lds_kernel<16, 0>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
@@ -792,14 +1093,6 @@ extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* 
   if (grid == 16 && cout == 16 && !dy_is_f32 && !x_is_f32_preact) {
     static bool done = false;
     return launch(upconv_dgrad3_lds_kernel<16, 1>, a, batch < 256 ? batch : 256, 32 * 1024 + 34 * 34 * 24 * 2, st, done);
-  }
-  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 1) {
-    static bool done = false;
-    return launch(upconv_dgrad_kernel<64, 8, 0, 1>, a, grid_for(batch * 2, 16 * 4 * 2 * 1024), 16 * 4 * 2 * 1024, st, done);
-  }
-  if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 2) {   // bf16 pre-activation: sign source, bf16 dx
-    static bool done = false;
-    return launch(upconv_dgrad_kernel<64, 8, 0, 0>, a, grid_for(batch * 2, 16 * 4 * 2 * 1024), 16 * 4 * 2 * 1024, st, done);
   }
   return fail(RCB_ERR_UNSUPPORTED, "upconv_dgrad: grid=%d cout=%d not instantiated", grid, cout);
 }

@@ -86,6 +86,9 @@ struct WeffGradArgs {
   float* dW2;
   float* dW3;
   int bf16_in;
+  const float* db1_partial;   // nullable [n_partial][64]: per-workgroup channel sums of dz1 (rcb_upconv_dgrad)
+  int n_partial;
+  float* db1;                 // [64]
 };
 
 template <int COUT>
@@ -130,8 +133,21 @@ __global__ void __launch_bounds__(256) weff_grad_kernel(WeffGradArgs a) {
     a.dW1[(o * 128 + i) * 25 + kl] = acc;
   } else if (blk < 864) {
     grad_stage<64>(a.dweff2, a.dW2, blk - 800, tid);
-  } else {
+  } else if (blk < 928) {
     grad_stage<16>(a.dweff3, a.dW3, blk - 864, tid);
+  } else {   // stage-1 bias gradient: fixed-order sum of the per-workgroup partials (4 row groups x 4 accumulators)
+    __shared__ float red[4][64];
+    const int ch = tid & 63, part = tid >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int w = part;
+    for (; w + 12 < a.n_partial; w += 16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += a.db1_partial[(w + 4 * k) * 64 + ch];
+    }
+    for (; w < a.n_partial; w += 4) acc[0] += a.db1_partial[w * 64 + ch];
+    red[part][ch] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (tid < 64) a.db1[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 
@@ -147,10 +163,13 @@ extern "C" int rcb_upconv_weff_build(const float* W1, const float* b1, const flo
 }
 
 extern "C" int rcb_upconv_weff_grad(const void* dweff1, int32_t bf16_in, const float* dweff2, const float* dweff3,
-                                    float* dW1, float* dW2, float* dW3, rcb_stream_t stream) {
+                                    float* dW1, float* dW2, float* dW3, const float* db1_partial, int32_t n_partial,
+                                    float* db1, rcb_stream_t stream) {
   RCB_REQUIRE(dweff1 && dweff2 && dweff3 && dW1 && dW2 && dW3, RCB_ERR_ARG, "upconv_weff_grad: null pointer");
-  WeffGradArgs a{dweff1, dweff2, dweff3, dW1, dW2, dW3, bf16_in ? 1 : 0};
-  weff_grad_kernel<<<928, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_REQUIRE((db1_partial == nullptr) == (db1 == nullptr) && n_partial >= 0, RCB_ERR_ARG,
+              "upconv_weff_grad: db1 and its partials go together");
+  WeffGradArgs a{dweff1, dweff2, dweff3, dW1, dW2, dW3, bf16_in ? 1 : 0, db1_partial, n_partial, db1};
+  weff_grad_kernel<<<db1 ? 929 : 928, 256, 0, (hipStream_t)stream>>>(a);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

@@ -475,13 +475,17 @@ def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False, linear_bf16=Fal
     return y
 
 
-def upconv_dgrad(dy, weff, x, grid, cout, preact=False):
+def upconv_dgrad(dy, weff, x, grid, cout, preact=False, want_dbias=False):
+    """-> dx (dtype of x); with want_dbias (stage-2 geometry) also the [workgroups, 64] partial channel sums of dx."""
     lib = _lib.load()
     B = x.shape[0]
     dx = torch.empty_like(x)
-    check(lib.rcb_upconv_dgrad(ptr(dy), int(dy.dtype == f32), ptr(weff, f32), ptr(x), _xmode(x, preact), ptr(dx), B,
-                               grid, cout, stream_ptr()), "rcb_upconv_dgrad")
-    return dx
+    part = None
+    if want_dbias:
+        part = torch.empty(int(lib.rcb_upconv_dgrad_partial_rows(B)), 64, device=x.device, dtype=f32)
+    check(lib.rcb_upconv_dgrad(ptr(dy), int(dy.dtype == f32), ptr(weff, f32), ptr(x), _xmode(x, preact), ptr(dx),
+                               ptr(part, f32, True), B, grid, cout, stream_ptr()), "rcb_upconv_dgrad")
+    return (dx, part) if want_dbias else dx
 
 
 def upconv_wgrad(x, dy, grid, cout, preact=False):
@@ -514,8 +518,9 @@ def upconv_weff_build(W1, b1, W2, W3, bf16_out):
     return weff1, b1rep, weff2, weff3
 
 
-def upconv_weff_grad(dweff1, dweff2, dweff3):
-    """gradients of the effective weights -> (dW1 [64,128,5,5], dW2 [64,64,3,3], dW3 [16,64,3,3])."""
+def upconv_weff_grad(dweff1, dweff2, dweff3, db1_partial=None):
+    """gradients of the effective weights -> (dW1 [64,128,5,5], dW2 [64,64,3,3], dW3 [16,64,3,3]) and, given the
+    per-workgroup partials of upconv_dgrad(want_dbias=True), the stage-1 bias gradient db1 [64]."""
     lib = _lib.load()
     dev = dweff1.device
     if dweff1.numel() != 512 * 4096 or dweff2.numel() != 65536 or dweff3.numel() != 16384:
@@ -523,6 +528,9 @@ def upconv_weff_grad(dweff1, dweff2, dweff3):
     dW1 = torch.empty(64, 128, 5, 5, device=dev, dtype=f32)
     dW2 = torch.empty(64, 64, 3, 3, device=dev, dtype=f32)
     dW3 = torch.empty(16, 64, 3, 3, device=dev, dtype=f32)
+    db1 = torch.empty(64, device=dev, dtype=f32) if db1_partial is not None else None
     check(lib.rcb_upconv_weff_grad(ptr(dweff1), int(dweff1.dtype == bf16), ptr(dweff2, f32), ptr(dweff3, f32), ptr(dW1),
-                                   ptr(dW2), ptr(dW3), stream_ptr()), "rcb_upconv_weff_grad")
-    return dW1, dW2, dW3
+                                   ptr(dW2), ptr(dW3), ptr(db1_partial, f32, True),
+                                   0 if db1_partial is None else db1_partial.shape[0], ptr(db1, f32, True), stream_ptr()),
+          "rcb_upconv_weff_grad")
+    return (dW1, dW2, dW3) if db1_partial is None else (dW1, dW2, dW3, db1)

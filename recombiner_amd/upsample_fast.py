@@ -201,7 +201,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[1:7])
         dpe = dpe.contiguous().view(B, 32, 32, 16)
         dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16)                     # bf16 [B,16,16,64]
-        dz1 = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True)         # [B,8,8,64] in the dtype of z1
+        dz1, db1_part = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, want_dbias=True)   # [B,8,8,64], dtype of z1
         dz1f = dz1.view(B, 4096)
         dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
         if not need_w:
@@ -209,8 +209,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
         dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
         dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64, preact=True)
         dWeff1 = lpe.t() @ dz1f                                            # [512, 4096], dtype of the stage-1 operands
-        dW1, dW2, dW3 = ops.upconv_weff_grad(dWeff1, dWeff2, dWeff3)
-        db1 = dz1.sum((0, 1, 2), dtype=torch.float32)
+        dW1, dW2, dW3, db1 = ops.upconv_weff_grad(dWeff1, dWeff2, dWeff3, db1_part)
         return dlpe, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
