@@ -26,6 +26,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# PMC traffic of the SIREN training kernel per launch (4096 INRs), by pe/dpe storage type (True: bf16)
+PMC_FILE = {True: "r01_siren_bf16pe_pmc.json", False: "r01_siren_bf16_pmc.json"}
 STEPS_PER_INR = 200 + 549 * 100   # reference schedule
 
 
@@ -153,6 +155,9 @@ def main():
     if rank == 0:
         meta = m._meta(Xd, 16)
         pe = torch.randn(n, 1024, 16, device=dev) * 0.1
+        pe16 = m.precision != 0 and m.pe_bf16          # the storage type the training step uses for pe / dpe
+        if pe16:
+            pe = pe.bfloat16()
         wv = (torch.rand(n, D, device=dev) * 2 - 1) * 0.02
         for _ in range(2):
             ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta)
@@ -166,8 +171,9 @@ def main():
         ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
         dims = m.dims
         flops = 6.0 * 1024 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n   # fwd + 2x bwd
-        # algorithmic HBM bytes per INR: pe read + dpe written (P*16*4 each), target P*C*4, wvec read + dwvec written
-        alg_bytes = (2 * 1024 * 16 * 4 + 1024 * 3 * 4 + 2 * D * 4 + 4) * n
+        # algorithmic HBM bytes per INR: pe read + dpe written (P*16 elements each, 2 B in bf16 storage, else 4 B),
+        # target P*C*4, wvec read + dwvec written, sse
+        alg_bytes = (2 * 1024 * 16 * (2 if pe16 else 4) + 1024 * 3 * 4 + 2 * D * 4 + 4) * n
         t = ms * 1e-3
         share = round(ms / (el / a.steps * 1e3), 4)
         if m.precision == 0:
@@ -181,14 +187,14 @@ def main():
             # 16-bit operand path: 0.03 ms of matrix work at peak vs 0.09 ms of HBM traffic -> HBM-bound
             traffic = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_siren_bf16_pmc.json")) as f:
+                with open(os.path.join(ROOT, "profiles", PMC_FILE[pe16])) as f:
                     traffic = json.load(f)["hbm_bytes_per_launch"] if n == 4096 else None
             except (OSError, KeyError, ValueError):
                 traffic = None
             ach = alg_bytes / t / 1e9
             roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": traffic, "traffic_source": "profiles/r01_siren_bf16_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                    "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" % PMC_FILE[pe16],
                     "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": alg_bytes, "alg_flops_per_launch": flops,
                     "mfma_tflops": round(flops / t / 1e12, 1), "share_of_step": share}
     cpu = None

@@ -7,9 +7,10 @@
 // with Weff the kernel taps pre-summed per (phase, window tap) (host: upsample_fast.PhaseStage.eff_weight,
 // layout [ty][tx][ci][a][b][co] fp32).  All images are channel-last; Cin = 64.
 //
-// Three kernels, all with the *position on the MFMA lane* (the B / D column), channels on rows:
-//   forward : D[co, pos] += A[co, (tap,ci)] * B[(tap,ci), pos]    A = weight fragments (LDS), B gathered from x
-//   dgrad   : D[ci, pos] += A[ci, (combo,co)] * B[(combo,co), pos] A = transposed weight fragments, B gathered from dy
+// Three kernel families, all persistent (one workgroup per CU walking its INRs, the next INR's images prefetched into
+// registers), with the *position on the MFMA lane* (the B / D column) and channels on rows:
+//   forward : D[co, pos] += A[co, (tap,ci)] * B[(tap,ci), pos]    A = weight fragments resident in registers, B from the LDS image of x
+//   dgrad   : D[ci, pos] += A[ci, (combo,co)] * B[(combo,co), pos] A = transposed weight fragments, B from the LDS image of dy
 //   wgrad   : D[ci, co]  += A[ci, pos] * B[pos, co]                per-INR images staged in LDS, transposed reads
 // LeakyReLU(0.01) is fused: forward applies it on load (fp32 pre-activation input) or in the epilogue;
 // dgrad multiplies by its derivative taken from the sign of the stored activation.
@@ -46,35 +47,8 @@ union Frag {
 // (where their operands would stay live, and spill, across it)
 __device__ __forceinline__ void pin(uint4& u) { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
 
-// 8 consecutive channels of one pixel as a bf16 fragment; `ok` false -> zeros (halo)
-template <int MODE>  // 0: bf16 image, 1: fp32 pre-activation (LeakyReLU applied), 2: fp32 plain, 3: bf16 pre-activation
-__device__ __forceinline__ bf16x8 load8(const void* base, long long elem_off, bool ok) {
-  Frag f;
-  if (MODE == 0 || MODE == 3) {
-    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + elem_off);
-    f.u = *p;
-    if (!ok) f.u = make_uint4(0, 0, 0, 0);
-    if (MODE == 3) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)lrelu((float)f.v[j]);
-    }
-  } else {
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
-    float4 v0 = p[0], v1 = p[1];
-    float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float x = ok ? t[j] : 0.f;
-      if (MODE == 1) x = lrelu(x);
-      f.v[j] = (__bf16)x;
-    }
-  }
-  return f.v;
-}
-
-// raw (unconverted) 8-channel loads, so that the next gather can be in flight while the current
-// one feeds the matrix cores (explicit two-stage pipeline; hipcc otherwise hoists every gather of a
-// tile and spills)
+// raw (unconverted) 8-channel loads: the next INR's image is requested into registers while the current one is
+// consumed, and converted (mode 1/3: with LeakyReLU) only when it is committed to LDS
 template <int MODE> struct Raw8;
 template <> struct Raw8<0> { uint4 u; };
 template <> struct Raw8<1> { float4 a, b; };
@@ -126,109 +100,6 @@ struct FwdArgs {
   int batch;
 };
 
-template <int COUT, int G, int IN_MODE, int OUT_F32>
-__global__ void __launch_bounds__(512) upconv_fwd_kernel(FwdArgs a) {
-  constexpr int MT = (COUT + 31) / 32;
-  constexpr int NF = 4 * 4 * 4 * MT;   // [phase][tap][kb][mt]
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
-  for (int e = tid; e < NF * 64; e += 512) {
-    const int ln = e & 63, slot = e >> 6;
-    const int mt = slot % MT, kb = (slot / MT) & 3, t = (slot / (MT * 4)) & 3, p = slot / (MT * 16);
-    const int fq = ln & 31, fh = ln >> 5, co = 32 * mt + fq;
-    Frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float w = 0.f;
-      if (co < COUT) w = a.weff[weff_index(t >> 1, t & 1, 16 * kb + 8 * fh + j, p >> 1, p & 1, co, COUT)];
-      f.v[j] = (__bf16)w;
-    }
-    frags[e] = f.u;
-  }
-  __syncthreads();
-  const int ntiles = a.batch * (G * G / 32);
-  for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
-    const int pos = tile * 32 + q;
-    const int b = pos / (G * G), rem = pos - b * (G * G), i = rem / G, j = rem - i * G;
-    f32x16 acc[4][MT];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
-    // 9 source neighbours, 4 channel blocks each; neighbour n+1 is fetched while n is consumed
-    Raw8<IN_MODE> cur[4], nxt[4];
-    bool ok_cur = false, ok_nxt = false;
-    auto issue = [&](int nb, Raw8<IN_MODE>(&dst)[4], bool& ok) {
-      const int dy = nb / 3 - 1, dx = nb % 3 - 1;
-      const int si = i + dy, sj = j + dx;
-      ok = si >= 0 && si < G && sj >= 0 && sj < G;
-      const long long pix = ((long long)b * G + (ok ? si : i)) * G + (ok ? sj : j);
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) dst[kb] = raw_load<IN_MODE>(a.x, pix * CIN + 16 * kb + 8 * h);
-    };
-    issue(0, cur, ok_cur);
-#pragma unroll
-    for (int nb = 0; nb < 9; ++nb) {
-      if (nb + 1 < 9) issue(nb + 1, nxt, ok_nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      const int dy = nb / 3 - 1, dx = nb % 3 - 1;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 bf = raw_frag<IN_MODE>(cur[kb], ok_cur);
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa) {
-          const int ty = dy + 1 - pa;
-          if (ty < 0 || ty > 1) continue;
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            const int tx = dx + 1 - pb;
-            if (tx < 0 || tx > 1) continue;
-            const int p = pa * 2 + pb, t = ty * 2 + tx;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              Frag fa;
-              fa.u = frags[(((p * 4 + t) * 4 + kb) * MT + mt) * 64 + lane];
-              acc[p][mt] = mfma16(fa.v, bf, acc[p][mt]);
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) cur[kb] = nxt[kb];
-      ok_cur = ok_nxt;
-    }
-    // epilogue: bias (+ LeakyReLU), scatter the four phases
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const long long opix = ((long long)b * (2 * G) + 2 * i + (p >> 1)) * (2 * G) + 2 * j + (p & 1);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int co = 32 * mt + 8 * g4 + 4 * h;
-          if (32 * mt + 8 * g4 >= COUT) continue;
-          float v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k] = acc[p][mt][4 * g4 + k] + a.bias[co + k];
-            if (!OUT_F32) v[k] = lrelu(v[k]);
-          }
-          if (OUT_F32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + co) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + co) = o;
-          }
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // data gradient
 // ------------------------------------------------------------------------------------------------
@@ -239,97 +110,6 @@ struct DgradArgs {
   void* dx;
   int batch;
 };
-
-template <int COUT, int G, int DY_F32, int X_F32>
-__global__ void __launch_bounds__(512) upconv_dgrad_kernel(DgradArgs a) {
-  constexpr int KB = COUT / 16;
-  constexpr int NF = 16 * KB * 2;      // [combo(ry,rx)][kb][mt]
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* frags = reinterpret_cast<uint4*>(smem_raw);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
-  for (int e = tid; e < NF * 64; e += 512) {
-    const int ln = e & 63, slot = e >> 6;
-    const int mt = slot & 1, kb = (slot >> 1) % KB, combo = slot / (2 * KB);
-    const int ry = (combo >> 2) - 1, rx = (combo & 3) - 1;
-    // output row offset ry -> (phase a, window tap ty):  -1:(1,1)  0:(0,1)  1:(1,0)  2:(0,0)
-    const int pa = (ry & 1), ty = (ry <= 0) ? 1 : 0;
-    const int pb = (rx & 1), tx = (rx <= 0) ? 1 : 0;
-    const int fq = ln & 31, fh = ln >> 5, ci = 32 * mt + fq;
-    Frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, ci, pa, pb, 16 * kb + 8 * fh + j, COUT)];
-    frags[e] = f.u;
-  }
-  __syncthreads();
-  const int ntiles = a.batch * (G * G / 32);
-  for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
-    const int pos = tile * 32 + q;
-    const int b = pos / (G * G), rem = pos - b * (G * G), u = rem / G, v = rem - u * G;
-    f32x16 acc[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-    // 16 output-pixel offsets (ry, rx) in [-1, 2]^2; offset n+1 is fetched while n is consumed
-    constexpr int DM = DY_F32 ? 2 : 0;
-    Raw8<DM> cur[KB], nxt[KB];
-    bool ok_cur = false, ok_nxt = false;
-    auto issue = [&](int n, Raw8<DM>(&dst)[KB], bool& ok) {
-      const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
-      const int oy = 2 * u + ry, ox = 2 * v + rx;
-      ok = oy >= 0 && oy < 2 * G && ox >= 0 && ox < 2 * G;
-      const long long pix = ((long long)b * (2 * G) + (ok ? oy : 2 * u)) * (2 * G) + (ok ? ox : 2 * v);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) dst[kb] = raw_load<DM>(a.dy, pix * COUT + 16 * kb + 8 * h);
-    };
-    issue(0, cur, ok_cur);
-#pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      if (n + 1 < 16) issue(n + 1, nxt, ok_nxt);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const bf16x8 bf = raw_frag<DM>(cur[kb], ok_cur);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          Frag fa;
-          fa.u = frags[((n * KB + kb) * 2 + mt) * 64 + lane];
-          acc[mt] = mfma16(fa.v, bf, acc[mt]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) cur[kb] = nxt[kb];
-      ok_cur = ok_nxt;
-    }
-    // epilogue: multiply by LeakyReLU'(x) and store
-    const long long xpix = (long long)pos * CIN;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int ci = 32 * mt + 8 * g4 + 4 * h;
-        float xs[4];
-        if (X_F32) {
-          float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.x) + xpix + ci);
-          xs[0] = t.x; xs[1] = t.y; xs[2] = t.z; xs[3] = t.w;
-        } else {
-          bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + ci);
-          xs[0] = (float)t[0]; xs[1] = (float)t[1]; xs[2] = (float)t[2]; xs[3] = (float)t[3];
-        }
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = acc[mt][4 * g4 + k] * (xs[k] > 0.f ? 1.0f : SLOPE);
-        if (X_F32) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dx) + xpix + ci) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
-          bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
-        }
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // stage-3 variants (G = 16: one INR = 8 tiles = one 8-wave workgroup pass): the INR's source image is
@@ -1018,14 +798,6 @@ int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& at
   return RCB_OK;
 }
 
-// persistent grid: as many 512-thread workgroups per CU as the fragment LDS allows (max 2 by waves)
-int grid_for(int ntiles, size_t smem) {
-  int per_cu = (int)((160 * 1024) / (smem + 1024));
-  if (per_cu > 1) per_cu = 1;   // measured: a second resident workgroup per CU is slower (L2 / LDS contention)
-  if (per_cu < 1) per_cu = 1;
-  int g = (ntiles + 7) / 8;
-  return g < 256 * per_cu ? g : 256 * per_cu;
-}
 
 }  // namespace
 
