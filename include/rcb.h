@@ -194,6 +194,19 @@ typedef struct {
 } rcb_adam_tensor;
 int rcb_adam_multi(const rcb_adam_tensor* tensors, int32_t count, const rcb_adam_cfg* cfg, rcb_stream_t stream);
 
+/* Split-bf16 GEMM operands (K2: the dense A transform `h_w @ A[l]`, prior_model.py:101-127, and its data gradient, on
+ * the bf16 matrix cores at fp32 accuracy): x = hi + lo, hi = bf16(x), lo = bf16(x - hi).  For every item (all of one
+ * shape) writes  out[r * out_row_stride + blk * out_block_stride + c] = (lo_mask >> blk) & 1 ? lo[r, c] : hi[r, c]
+ * for blk = 0, 1, 2, so that [hi | lo | hi] @ [hi ; hi ; lo] (one bf16 GEMM, fp32 accumulation, K tripled) equals the
+ * fp32 product to ~2^-17 relative.  cols must be even.                                                          */
+#define RCB_SPLIT_MAX_ITEMS 8
+typedef struct {
+  const float* x;   /* [rows, cols] with row stride ld_x */
+  void* out;        /* bf16 */
+} rcb_split_item;
+int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, int64_t cols, int64_t ld_x,
+                   int64_t out_row_stride, int64_t out_block_stride, int32_t lo_mask, rcb_stream_t stream);
+
 /* Bookkeeping of one optimisation step whose counter lives on the device, so that the whole step can be captured
  * once as a HIP graph and replayed (prior_model.py train() / test_model.py train() loop bodies):
  *   begin: dyn[0..1] = adam_table[step] ({lr / (1 - beta1^t), sqrt(1 - beta2^t)}, row clamped to the table);

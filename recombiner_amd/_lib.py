@@ -14,7 +14,7 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
            "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad",
-           "rcb_upconv_dgrad_partial_rows"]
+           "rcb_upconv_dgrad_partial_rows", "rcb_split_bf16"]
 
 
 class RcbError(RuntimeError):
@@ -33,6 +33,10 @@ class Level(C.Structure):
                 ("enc_mask", C.c_void_p), ("row_map", C.c_void_p), ("row_perm", C.c_void_p),
                 ("col_map", C.c_void_p), ("eps", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("cols_out", C.c_int32)]
+
+
+class SplitItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p)]
 
 
 class AdamTensor(C.Structure):

@@ -411,6 +411,62 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, l
   }
 }
 
+// ---- split-bf16 operands for fp32-grade GEMMs on the bf16 matrix cores --------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): hi*hi' + lo*hi' + hi*lo' reproduces the fp32 product to ~2^-17
+// relative.  The three products become ONE bf16 GEMM with fp32 accumulation by concatenating along K: the left
+// operand [hi | lo | hi], the right operand [hi ; hi ; lo].  This kernel writes the three blocks of an operand:
+//   out[item][r * out_row_stride + blk * out_block_stride + c] = (lo_mask >> blk) & 1 ? lo : hi,   blk = 0, 1, 2
+struct SplitArgs {
+  const float* x[RCB_SPLIT_MAX_ITEMS];
+  __bf16* out[RCB_SPLIT_MAX_ITEMS];
+  long long rows, cols, ld_x, out_row_stride, out_block_stride;
+  int lo_mask;
+};
+
+__global__ void __launch_bounds__(256) split_bf16_kernel(SplitArgs a) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const float* __restrict__ x = a.x[blockIdx.z];
+  __bf16* __restrict__ out = a.out[blockIdx.z];
+  const long long half = a.cols >> 1;                       // pairs of columns (cols is even)
+  const long long total = a.rows * half;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / half, c = (i - r * half) * 2;
+    const float v0 = x[r * a.ld_x + c], v1 = x[r * a.ld_x + c + 1];
+    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+    const bf2 hi = {h0, h1};
+    const bf2 lo = {(__bf16)(v0 - (float)h0), (__bf16)(v1 - (float)h1)};
+    __bf16* o = out + r * a.out_row_stride + c;
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk)
+      *reinterpret_cast<bf2*>(o + blk * a.out_block_stride) = ((a.lo_mask >> blk) & 1) ? lo : hi;
+  }
+}
+
+extern "C" int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, int64_t cols, int64_t ld_x,
+                              int64_t out_row_stride, int64_t out_block_stride, int32_t lo_mask, rcb_stream_t stream) {
+  RCB_REQUIRE(items && n_items >= 1 && n_items <= RCB_SPLIT_MAX_ITEMS, RCB_ERR_ARG, "split_bf16: %d items (1..%d)", n_items,
+              RCB_SPLIT_MAX_ITEMS);
+  RCB_REQUIRE(rows > 0 && cols > 0 && (cols & 1) == 0 && ld_x >= cols, RCB_ERR_SHAPE, "split_bf16: rows=%lld cols=%lld ld=%lld",
+              (long long)rows, (long long)cols, (long long)ld_x);
+  RCB_REQUIRE((out_row_stride & 1) == 0 && (out_block_stride & 1) == 0, RCB_ERR_SHAPE, "split_bf16: odd output strides");
+  SplitArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < n_items; ++i) {
+    RCB_REQUIRE(items[i].x && items[i].out && (reinterpret_cast<uintptr_t>(items[i].out) & 3) == 0, RCB_ERR_ARG,
+                "split_bf16: item %d null / misaligned", i);
+    a.x[i] = items[i].x;
+    a.out[i] = reinterpret_cast<__bf16*>(items[i].out);
+  }
+  a.rows = rows; a.cols = cols; a.ld_x = ld_x;
+  a.out_row_stride = out_row_stride; a.out_block_stride = out_block_stride; a.lo_mask = lo_mask;
+  long long blocks = (rows * (cols >> 1) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  split_bf16_kernel<<<dim3((unsigned)blocks, 1, (unsigned)n_items), 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
 // ---- per-step bookkeeping of a captured training step (device-resident step counter) -------------------------
 __global__ void __launch_bounds__(1024) step_begin_kernel(const float* __restrict__ table, long long n_steps,
                                                           const long long* __restrict__ step, float* __restrict__ dyn,

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamCfg, AdamTensor, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
+from ._lib import AdamCfg, AdamTensor, SplitItem, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
 
 f32 = torch.float32
 f64 = torch.float64
@@ -534,3 +534,66 @@ def upconv_weff_grad(dweff1, dweff2, dweff3, db1_partial=None):
                                    0 if db1_partial is None else db1_partial.shape[0], ptr(db1, f32, True), stream_ptr()),
           "rcb_upconv_weff_grad")
     return (dW1, dW2, dW3) if db1_partial is None else (dW1, dW2, dW3, db1)
+
+
+def split_bf16(xs, layout, lo_mask):
+    """Split-bf16 GEMM operands (rcb_split_bf16).  xs: fp32 2-D views of one shape and row stride (unit column stride).
+    layout "cols": each result is [rows, 3 * cols] (blocks side by side: a left operand, or a right operand to be used
+    transposed); "rows": [3 * rows, cols] (blocks stacked: a right operand).  lo_mask: bit b set -> block b holds the
+    low part.  Left operands use 0b010 ([hi | lo | hi]), right operands 0b100 ([hi ; hi ; lo])."""
+    lib = _lib.load()
+    rows, cols = xs[0].shape
+    ld = xs[0].stride(0)
+    outs = []
+    arr = (SplitItem * len(xs))()
+    for i, x in enumerate(xs):
+        if x.dtype != f32 or not x.is_cuda or tuple(x.shape) != (rows, cols) or x.stride(1) != 1 or x.stride(0) != ld:
+            raise RcbError("split_bf16: fp32 GPU views of one shape and row stride expected")
+        o = torch.empty((rows, 3 * cols) if layout == "cols" else (3 * rows, cols), device=x.device, dtype=bf16)
+        outs.append(o)
+        arr[i] = SplitItem(x.data_ptr(), o.data_ptr())
+    if layout == "cols":
+        row_stride, blk_stride = 3 * cols, cols
+    else:
+        row_stride, blk_stride = cols, rows * cols
+    check(lib.rcb_split_bf16(arr, len(xs), C.c_int64(rows), C.c_int64(cols), C.c_int64(ld), C.c_int64(row_stride),
+                             C.c_int64(blk_stride), int(lo_mask), stream_ptr()), "rcb_split_bf16")
+    return outs
+
+
+class SplitATransform:
+    """The A transform `wvec[:, lo:hi] = h_w[:, lo:hi] @ A[l]` (prior_model.py:101-127) and its data gradient
+    `dh[:, lo:hi] = dw[:, lo:hi] @ A[l]^T` with split-bf16 operands for the layers of one common even width (the three
+    1056-wide layers of the 3x32 SIREN); other layers (the 99-wide output layer) stay plain fp32 GEMMs.
+    prepare(A) splits the mappings once (per step when they are trained, per train() call when they are fixed)."""
+
+    def __init__(self, slices):
+        self.slices = list(slices)
+        widths = [hi - lo for lo, hi in self.slices]
+        big = max(widths)
+        self.fast = [i for i, w in enumerate(widths) if w == big and w % 2 == 0 and w >= 256]
+        self.rest = [i for i in range(len(widths)) if i not in self.fast]
+        self.a_rows = self.a_cols = None
+
+    def prepare(self, A):
+        mats = [A[i].detach() for i in self.fast]
+        self.a_rows = split_bf16(mats, "rows", 0b100)      # [hi ; hi ; lo]          right operand of the forward
+        self.a_cols = split_bf16(mats, "cols", 0b100)      # [hi | hi | lo] (^T)     right operand of the data gradient
+        self.A = A
+
+    def _apply(self, x, out, right, transpose):
+        lefts = split_bf16([x[:, lo:hi] for lo, hi in (self.slices[i] for i in self.fast)], "cols", 0b010)
+        for k, i in enumerate(self.fast):
+            lo, hi = self.slices[i]
+            torch.mm(lefts[k], right[k].t() if transpose else right[k], out_dtype=f32, out=out[:, lo:hi])
+        for i in self.rest:
+            lo, hi = self.slices[i]
+            a = self.A[i].detach()
+            torch.mm(x[:, lo:hi], a.t() if transpose else a, out=out[:, lo:hi])
+        return out
+
+    def forward(self, h_w, out):
+        return self._apply(h_w, out, self.a_rows, False)
+
+    def dgrad(self, dw, out):
+        return self._apply(dw, out, self.a_cols, True)

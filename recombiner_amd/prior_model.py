@@ -107,6 +107,7 @@ class PriorBNNmodel(nn.Module):
         self.lowp_gemm = False       # 16-bit mode only: bf16-operand hipBLASLt GEMMs for the A transform
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
+        self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
         self.use_graph = True        # replay the training step as one captured HIP graph when possible
 
     # ---- level descriptions ------------------------------------------------------------------------
@@ -244,6 +245,9 @@ class PriorBNNmodel(nn.Module):
         kl_slots = torch.zeros(1024, device=dev, dtype=torch.float64)
         kl_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
         cfg = ops.adam_cfg(lr, 1, dyn=dyn)
+        split = ops.SplitATransform(slices) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
+        if split is not None and not split.fast:
+            split = None
 
         def body():
             ops.step_begin(tab, step_t, dyn, kl_slots)
@@ -268,6 +272,9 @@ class PriorBNNmodel(nn.Module):
                                   for (lo, hi), a in zip(slices, A)], 1).float() * (1.0 / 1024.0)
                 h16 = h_w.to(torch.bfloat16)
                 A16 = [a.detach().to(torch.bfloat16) for a in A]
+            elif split is not None:
+                split.prepare(A)                      # the mappings change every step when they are trained
+                wvec = split.forward(h_w, torch.empty(N, D, device=dev, dtype=torch.float32))
             else:
                 wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):
@@ -285,6 +292,10 @@ class PriorBNNmodel(nn.Module):
                 dh = torch.cat([torch.mm(dw16[:, lo:hi], a16.t()) for (lo, hi), a16 in zip(slices, A16)], 1).float()
                 if training_mappings:
                     gA = [torch.mm(h16[:, lo:hi].t(), dw16[:, lo:hi]).float() for (lo, hi) in slices]
+            elif split is not None:
+                dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
+                if training_mappings:             # K = 4096 INRs: the split form is not faster here, plain fp32
+                    gA = [torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]) for (lo, hi) in slices]
             else:
                 dh = torch.empty(N, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):

@@ -167,6 +167,7 @@ class TestBNNmodel(nn.Module):
         self.precision = 0
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
+        self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
         self.use_graph = True        # replay the fused training step as captured HIP graphs when possible
         self._specs = None
         self._ws = None
@@ -440,7 +441,7 @@ class TestBNNmodel(nn.Module):
         # workspace that survives across calls (Adam state is re-zeroed = a fresh optimiser, the step counter
         # restarts): its stable addresses let the two captured step graphs be reused by every fine-tune call
         key = (x.data_ptr(), y.data_ptr(), tuple(x.shape), S, float(lr), float(eps_adam), self.precision,
-               self.loc.data_ptr(), self.log_scale.data_ptr())
+               self.loc.data_ptr(), self.log_scale.data_ptr(), bool(self.split_gemm))
         ws = self._ws
         if ws is None or ws["key"] != key or ws["tab"].shape[0] < n_epochs:
             ws = dict(key=key, tab=ops.adam_table(lr, max(n_epochs, 2048)).to(dev),
@@ -455,6 +456,17 @@ class TestBNNmodel(nn.Module):
         ws["step_t"].zero_()
         tab, dyn, step_t, states = ws["tab"], ws["dyn"], ws["step_t"], ws["states"]
         cfg = ops.adam_cfg(lr, 1, eps=eps_adam, dyn=dyn)
+        split = None
+        if self.split_gemm and self.precision != 0:
+            split = ws.get("split")
+            if split is None:                       # the mappings are fixed at test time: split them once per workspace
+                split = ops.SplitATransform(slices)
+                if split.fast:
+                    split.prepare(A)
+                else:
+                    split = False
+                ws["split"] = split
+            split = split or None
 
         def body(adjust):
             ops.step_begin(tab, step_t, dyn)
@@ -466,13 +478,19 @@ class TestBNNmodel(nn.Module):
                 pe_c = pe.reshape(N * S, P, pe.shape[-1]).contiguous()
             h_w = sample[..., :D].reshape(N * S, D)
             wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)
-            for (lo, hi), a in zip(slices, A):
-                torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
+            if split is not None:
+                split.forward(h_w, wvec)
+            else:
+                for (lo, hi), a in zip(slices, A):
+                    torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
             sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta)
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
             dh = torch.empty(N * S, D, device=dev, dtype=torch.float32)
-            for (lo, hi), a in zip(slices, A):
-                torch.mm(dw[:, lo:hi], a.t(), out=dh[:, lo:hi])
+            if split is not None:
+                split.dgrad(dw, dh)
+            else:
+                for (lo, hi), a in zip(slices, A):
+                    torch.mm(dw[:, lo:hi], a.t(), out=dh[:, lo:hi])
             dh3 = dh.view(N, S, D)
             d_full = torch.cat([dh3, d_lpe.reshape(S, N, -1).permute(1, 0, 2)], -1).contiguous()
             grp = [self._group_kls(lv) for lv in self._levels] if adjust else None

@@ -262,6 +262,39 @@ def test_reparam_flat_fast_path_equals_generic(N, D):
     assert rel_err(fast[:, 0], ref) < 1e-6
 
 
+def test_split_bf16_operands_and_a_transform():
+    """rcb_split_bf16: exact hi / lo parts in both layouts; the split-bf16 A transform and its data gradient agree with
+    the fp32 product at fp32-rounding level (not at bf16 level)."""
+    gen = torch.Generator().manual_seed(21)
+    N, D = 37, 3267
+    slices = [(0, 1056), (1056, 2112), (2112, 3168), (3168, 3267)]
+    x = g(torch.randn(N, D, generator=gen) * 0.03)
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    left = ops.split_bf16([x[:, a:b] for a, b in slices[:3]], "cols", 0b010)
+    for (a, b), o in zip(slices[:3], left):
+        assert o.shape == (N, 3 * 1056)
+        assert torch.equal(o[:, :1056], hi[:, a:b]) and torch.equal(o[:, 1056:2112], lo[:, a:b]) and torch.equal(o[:, 2112:], hi[:, a:b])
+    A = [g(torch.randn(b - a, b - a, generator=gen) / (b - a) ** 0.5) for a, b in slices]
+    ah = [m.bfloat16() for m in A]
+    al = [(m - h.float()).bfloat16() for m, h in zip(A, ah)]
+    rows = ops.split_bf16(A[:3], "rows", 0b100)
+    cols = ops.split_bf16(A[:3], "cols", 0b100)
+    for k in range(3):
+        assert torch.equal(rows[k], torch.cat([ah[k], ah[k], al[k]], 0))
+        assert torch.equal(cols[k], torch.cat([ah[k], ah[k], al[k]], 1))
+    tr = ops.SplitATransform(slices)
+    assert tr.fast == [0, 1, 2] and tr.rest == [3]
+    tr.prepare(A)
+    w = tr.forward(x, torch.empty(N, D, device=DEV))
+    dh = tr.dgrad(x, torch.empty(N, D, device=DEV))
+    for (a, b), m in zip(slices, A):
+        ref = x[:, a:b].double() @ m.double()
+        refT = x[:, a:b].double() @ m.double().t()
+        assert rel_err(w[:, a:b], ref) < 2e-5 and rel_err(dh[:, a:b], refT) < 2e-5
+        assert rel_err(x[:, a:b].bfloat16().float() @ m.bfloat16().float(), ref) > 5e-4      # what plain bf16 would give
+
+
 def test_adam_matches_torch():
     gen = torch.Generator().manual_seed(4)
     p0 = torch.randn(1000, generator=gen)

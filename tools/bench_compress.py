@@ -27,6 +27,8 @@ m = TM.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], N, 
                     group_to_param=g2p, n_groups=G, group_start_index=gs, group_end_index=ge, group_idx=gi, device=dev,
                     initial_beta=1e-8)
 m.precision = prec
+if len(sys.argv) > 2 and sys.argv[2] == "nosplit":
+    m.split_gemm = False
 with torch.no_grad():
     m.loc.add_(0.02 * torch.randn_like(m.loc))
 Xd, Yd = X.to(dev)[None].expand(N, -1, -1), Y.to(dev)

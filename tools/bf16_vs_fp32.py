@@ -19,7 +19,7 @@ def smooth_targets(n, seed=0):
         out.append((img * 0.5 + 0.5).clamp(0, 1).reshape(3, -1).T)
     return torch.stack(out)
 
-def run(precision, n, steps, lr, lowp=False, stage1=False):
+def run(precision, n, steps, lr, lowp=False, stage1=False, split=False, seed=5):
     cfg = config.configs["cifar"]
     X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3)
     Y = smooth_targets(n)
@@ -28,9 +28,10 @@ def run(precision, n, steps, lr, lowp=False, stage1=False):
     m.precision = precision
     m.lowp_gemm = lowp
     m.stage1_bf16 = stage1
+    m.split_gemm = split
     torch.manual_seed(123); lt = PM.LinearTransform(m.dims).cuda()
     torch.manual_seed(124); up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
-    gen = torch.Generator(device="cuda").manual_seed(5)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
     m.noise_source = lambda shape: torch.randn(shape, device="cuda", generator=gen)
     D = m._d_net; s0 = 0.0211547
     pri = [torch.zeros(D).cuda(), torch.full((D,), s0).cuda(), torch.zeros(2, 2, 128).cuda(), torch.full((2, 2, 128), s0).cuda()] + [None] * 4
@@ -43,16 +44,17 @@ if __name__ == "__main__":
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     variants = (("fp32", dict(precision=0)), ("bf16", dict(precision=1)),
                 ("bf16 + bf16 stage-1 GEMMs", dict(precision=1, stage1=True)),
+                ("bf16 + stage-1 + split-bf16 A transform", dict(precision=1, stage1=True, split=True)),
                 ("bf16 + f16/bf16 A-transform GEMMs", dict(precision=1, lowp=True)))
     if len(sys.argv) > 4:
         keep = sys.argv[4].split(",")
         variants = tuple(v for i, v in enumerate(variants) if str(i) in keep)
     res = {}
-    for name, kw in variants:
-        ps = [10 * np.log10(1 / run(n=n, steps=steps, lr=1e-3, **kw)[0]) for _ in range(reps)]
-        res[name] = ps
-        print("%-34s PSNR mean %.3f  std %.3f  (%s)" % (name, np.mean(ps), np.std(ps), " ".join("%.2f" % p for p in ps)), flush=True)
+    for name, kw in variants:      # repetition r of every variant sees the same noise stream (seed 5 + r): paired gaps
+        ps = [10 * np.log10(1 / run(n=n, steps=steps, lr=1e-3, seed=5 + r, **kw)[0]) for r in range(reps)]
+        res[name] = np.array(ps)
+        print("%-40s PSNR mean %.3f  std %.3f  (%s)" % (name, np.mean(ps), np.std(ps), " ".join("%.2f" % p for p in ps)), flush=True)
+    base = variants[0][0]
     for name in [v[0] for v in variants[1:]]:
-        d = np.mean(res[name]) - np.mean(res["fp32"])
-        se = np.sqrt(np.var(res[name]) / reps + np.var(res["fp32"]) / reps)
-        print("gap %s - fp32: %.3f +- %.3f dB" % (name, d, se))
+        d = res[name] - res[base]
+        print("paired gap %s - %s: %.3f +- %.3f dB" % (name, base, d.mean(), d.std(ddof=1) / np.sqrt(reps)))
