@@ -154,11 +154,9 @@ def load_checkpoint(path):
     return out
 
 
-def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs=30000, lr=2e-4, precision=0,
-             verbose=0, finetune_epochs=None):
-    """main_compression.py:47-178 on an in-memory checkpoint (list from load_checkpoint / build_checkpoint).
-    Returns (distortion, model)."""
-    tuning.enable_tuned_gemms()
+def build_test_model(config, dataset, checkpoint, n_datapoints, device="cuda", seed=42):
+    """TestBNNmodel initialised from a prior checkpoint exactly as main_compression.py:47-133 does (priors and average
+    log-scales reordered into group order).  Shared by the encoder (`compress`) and the decoder (`bitstream.decode`)."""
     g1, l1, g2, l2, g3, l3, lt, up = checkpoint
     group_idx, start, end, group2param, param2group, n_groups, _, _ = g1
     prior_loc, prior_scale, kl_beta, avg_ls = l1
@@ -168,7 +166,6 @@ def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs
     kw = dict(p_loc=prior_loc.clone()[param2group].to(device), p_log_scale=inv_st(prior_scale).clone()[param2group].to(device),
               init_log_scale=avg_ls[param2group].cpu().detach(), param_to_group=param2group, group_to_param=group2param,
               n_groups=n_groups, group_start_index=start, group_end_index=end, group_idx=group_idx)
-    h_n = hh_n = None
     if config['patch']:
         for pre, g, l in (("h_", g2, l2), ("hh_", g3, l3)):
             gi, gs, ge, g2p, p2g, ng, _, _ = g
@@ -177,14 +174,26 @@ def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs
                        pre + "init_log_scale": als[p2g].cpu().detach(), pre + "param_to_group": p2g,
                        pre + "group_to_param": g2p, pre + "n_groups": ng, pre + "group_start_index": gs,
                        pre + "group_end_index": ge, pre + "group_idx": gi})
+    return TestBNNmodel(config['input_dim'], config['hidden_dims'], config['output_dim'], n_datapoints,
+                        config['upsample_factors'], config['latent_dim'], config['data_dim'], config['pixel_sizes'],
+                        config['patch'], config['patch_nums'], config['hierarchical_patch_nums'], dataset,
+                        linear_transform=lt.to(device), upsample_net=up.to(device), w0=30., c=6., random_seed=seed,
+                        device=device, kl_upper_buffer=0., kl_lower_buffer=0.4, kl_adjust_gap=10, initial_beta=kl_beta,
+                        beta_step_size=0.05, **kw)
+
+
+def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs=30000, lr=2e-4, precision=0,
+             verbose=0, finetune_epochs=None, bitstream_path=None):
+    """main_compression.py:47-178 on an in-memory checkpoint (list from load_checkpoint / build_checkpoint).
+    Returns (distortion, model); with `bitstream_path` the packed A* indices are written there (bitstream.py)."""
+    tuning.enable_tuned_gemms()
+    g1, _, g2, _, g3, _, _, _ = checkpoint
+    n_groups = g1[5]
+    h_n = hh_n = None
+    if config['patch']:
         h_n, hh_n = g2[5], g3[5]
     x, y = x.to(device), y.to(device)
-    model = TestBNNmodel(config['input_dim'], config['hidden_dims'], config['output_dim'], y.shape[0],
-                         config['upsample_factors'], config['latent_dim'], config['data_dim'], config['pixel_sizes'],
-                         config['patch'], config['patch_nums'], config['hierarchical_patch_nums'], dataset,
-                         linear_transform=lt.to(device), upsample_net=up.to(device), w0=30., c=6., random_seed=seed,
-                         device=device, kl_upper_buffer=0., kl_lower_buffer=0.4, kl_adjust_gap=10, initial_beta=kl_beta,
-                         beta_step_size=0.05, **kw)
+    model = build_test_model(config, dataset, checkpoint, y.shape[0], device, seed)
     model.precision = precision
     model.optimize_posteriors(x, y, n_epochs=n_epochs, lr=lr, verbose=verbose)
     ft = finetune_epochs
@@ -193,4 +202,8 @@ def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs
         h_n_epochs_finetune=None if h_n is None else (ft if ft is not None else max(15000 // h_n, 20)),
         hh_n_epochs_finetune=None if hh_n is None else (ft if ft is not None else max(15000 // hh_n, 20)),
         verbose=verbose, lr=lr, fine_tune_gap=1, compress_from_group_with_largest_kl=True)
+    if bitstream_path is not None:
+        from . import bitstream
+        with open(bitstream_path, "wb") as f:
+            f.write(bitstream.encode(model))
     return distortion, model

@@ -62,3 +62,25 @@ def test_prior_training_checkpoint_and_compression(tmp_path):
     assert model.compressed_mask_groupwise.all()
     idx = model.compressed_idx_groupwise
     assert idx.shape == (2, ng) and (idx >= 0).all() and (idx < 65536).all()
+
+    # N4: bitstream written by the encoder, decoded from checkpoint + bitstream alone
+    from recombiner_amd import bitstream
+    blob = bitstream.encode(model)
+    assert bitstream.payload_bits(blob) == 2 * ng * 16
+    assert bitstream.payload_bits(blob) / (2 * 1024) == pytest.approx(model.bpp if hasattr(model, "bpp") else ng * 16 / 1024)
+    assert np.array_equal(bitstream.unpack_indices(blob)[0], idx.astype(np.int64))
+    Xd = X.to(DEV)[None].expand(2, -1, -1)
+    y_dec = bitstream.decode(cfg, "cifar", ck, blob, Xd, 2, device=DEV)
+    dec_model = drivers.build_test_model(cfg, "cifar", ck, 2, DEV)
+    bitstream.apply_indices(dec_model, bitstream.unpack_indices(blob))
+    assert torch.equal(dec_model._l1.sample, model._l1.sample)            # decoder parameters == encoder's, bit for bit
+    with torch.no_grad():
+        y_enc = model.predict(Xd)
+    assert float((y_dec - y_enc).abs().max()) < 1e-5                      # sigma = 1e-15 on encoded groups: noise-free
+    d_dec = utils.metric(Y[:2].numpy(), y_dec.cpu().numpy(), "cifar")
+    np.testing.assert_allclose(d_dec, dist, rtol=0, atol=1e-3)
+    path_bs = os.path.join(tmp_path, "cifar.rcb")
+    dist2, _ = drivers.compress(cfg, "cifar", ck, Xd, Y[:2], device=DEV, n_epochs=4, finetune_epochs=1, bitstream_path=path_bs)
+    assert os.path.getsize(path_bs) == len(blob)
+    with pytest.raises(ValueError):
+        bitstream.decode(cfg, "cifar", ck, blob, Xd, 3, device=DEV)       # wrong number of datapoints

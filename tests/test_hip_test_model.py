@@ -206,3 +206,34 @@ def test_graph_replayed_training_tracks_eager_training():
     assert cos > 0.9, cos                       # same direction of travel
     assert abs(np.abs(da).mean() / np.abs(db).mean() - 1) < 0.1
     assert (ba != bb).mean() < 0.05
+
+
+@pytest.mark.parametrize("name", ["patch1d", "patch2d"])
+def test_bitstream_round_trip_three_levels(name):
+    """N4 on a patched preset: encode every group of levels 3, 2, 1 (no fine-tuning), pack, and rebuild the encoded
+    samples on a freshly constructed model from the indices alone: bit-identical parameters, same reconstruction."""
+    from recombiner_amd import bitstream
+    d = load(f"test_{name}.npz")
+    cfg, n, m = build(d, name)
+    set_post(d, cfg, m)
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    for lv in (m._l3, m._l2, m._l1):
+        for r in range(lv.n_groups):
+            m._encode_round(lv, True, r)
+    blob = bitstream.encode(m)
+    n_idx = sum(lv.rows * lv.n_groups for lv in (m._l1, m._l2, m._l3))
+    assert bitstream.payload_bits(blob) == 16 * n_idx
+    _, _, m2 = build(d, name)
+    levels = bitstream.unpack_indices(blob)
+    assert [a.shape for a in levels] == [(lv.rows, lv.n_groups) for lv in (m._l1, m._l2, m._l3)]
+    bitstream.apply_indices(m2, levels)
+    for a, b in zip((m._l1, m._l2, m._l3), (m2._l1, m2._l2, m2._l3)):
+        assert torch.equal(a.sample, b.sample) and bool((b.mask == 1).all())
+    with torch.no_grad():
+        y1, y2 = m.predict(X), m2.predict(X)
+    assert float((y1 - y2).abs().max()) < 1e-5
+    m3 = build(d, name)[2]
+    with pytest.raises(ValueError):
+        bitstream.apply_indices(m3, levels[:1])                # a level missing
+    with pytest.raises(ValueError):
+        bitstream.encode(m3)                                   # nothing encoded yet

@@ -96,3 +96,33 @@ def test_level_spec_inverse_maps():
     for dcol, j in enumerate(cm):
         assert ci[j] == dcol
     assert (ci[np.setdiff1d(np.arange(cols), cm)] >= 5).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# N4: bitstream container (pure host logic)
+# ---------------------------------------------------------------------------------------------------
+def test_bitstream_container_round_trip_and_rejects_corruption():
+    from recombiner_amd import bitstream as B
+    rng = np.random.RandomState(0)
+    for shapes in ([(5, 7)], [(6, 11), (3, 4), (1, 9)], [(0, 3)], [(2, 0), (1, 1), (1, 1)]):
+        levels = [rng.randint(0, 65536, size=s) for s in shapes]
+        blob = B.pack_indices(levels)
+        out = B.unpack_indices(blob)
+        assert len(out) == len(levels) and all(np.array_equal(a, b) and b.dtype == np.int64 for a, b in zip(levels, out))
+        n_idx = sum(int(np.prod(s)) for s in shapes)
+        assert B.payload_bits(blob) == 16 * n_idx                      # 16 bits per (row, group): test_model.py:245-250
+        assert len(blob) == 8 + 8 * len(shapes) + 2 * n_idx + 4        # header + indices + CRC, nothing else
+    blob = B.pack_indices([np.array([[0, 65535, 258]])])
+    assert blob[16:22] == bytes([0, 0, 255, 255, 2, 1])               # little-endian uint16
+    bad = bytearray(blob)
+    bad[17] ^= 1
+    for broken in (bytes(bad), blob[:-1], blob + b"\0", b"XXXX" + blob[4:], blob[:4] + b"\x02\x00" + blob[6:]):
+        with pytest.raises(ValueError):
+            B.unpack_indices(broken)
+    for a in (np.array([[65536]]), np.array([[-1]]), np.array([[1.5]]), np.array([1, 2, 3])):
+        with pytest.raises(ValueError):
+            B.pack_indices([a])
+    with pytest.raises(ValueError):
+        B.pack_indices([np.zeros((1, 1))] * 4)                          # at most three levels
+    with pytest.raises(ValueError):
+        B.unpack_indices(B.MAGIC + b"\x01\x00\x04\x10" + b"\0" * 40)   # header claiming four levels
