@@ -249,7 +249,16 @@ class PriorBNNmodel(nn.Module):
         if split is not None and not split.fast:
             split = None
 
-        def body():
+        # The step runs as three segments so that, under data-parallel sharding, the gradient bucket of the shared
+        # mappings is all-reduced asynchronously BETWEEN captured graphs while the per-INR posterior update (which does
+        # not depend on it) proceeds:   seg1: sample .. gradients | all-reduce || seg2: posterior update | seg3: Adam
+        # on the mappings + bookkeeping.
+        st = {}
+        flat = None
+        if training_mappings and world > 1:      # persistent bucket: stable address across graph replays
+            flat = torch.empty(sum(p.numel() for p in A + conv), device=dev, dtype=torch.float32)
+
+        def seg1():
             ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
             e_lpe = self._noise((N, 1, self._d_lpe))
@@ -302,43 +311,74 @@ class PriorBNNmodel(nn.Module):
                     torch.mm(dw[:, lo:hi], a.detach().t(), out=dh[:, lo:hi])
                     if training_mappings:
                         gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
-            # ---- fused posterior update (also accumulates the pre-update KL for the ELBO log) --------------
-            dh3 = dh.view(N, 1, D)
-            for lv, (pl, ps), e, stt in zip(net, net_priors, eps, net_state):
-                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), dh3, e, 1, adam=cfg, state=stt, kl_accum=kl_slots)
-            ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), d_lpe,
-                              e_lpe, 1, adam=cfg, state=lpe_state, kl_accum=kl_slots)
+            st.update(sse=sse, dh3=dh.view(N, 1, D), eps=eps, e_lpe=e_lpe, d_lpe=d_lpe)
             if training_mappings:
                 grads = gA + [g.contiguous() for g in g_in[1:]]
-                if world > 1:
-                    flat = torch.cat([g.reshape(-1) for g in grads])
-                    torch.distributed.all_reduce(flat, group=self.dp_group)
-                    out, k = [], 0
+                if flat is not None:
+                    torch.cat([g.reshape(-1) for g in grads], out=flat)
+                    views, k = [], 0
                     for g in grads:
-                        out.append(flat[k:k + g.numel()].view_as(g))
+                        views.append(flat[k:k + g.numel()].view_as(g))
                         k += g.numel()
-                    grads = out
-                ops.adam_multi([p.data for p in A + conv], [g.contiguous() for g in grads],
+                    grads = views
+                st["grads"] = grads
+
+        def comm():
+            """sum of the mapping gradients over the ranks (the only per-step collective); returns the async handle"""
+            if flat is None:
+                return None
+            return torch.distributed.all_reduce(flat, group=self.dp_group, async_op=True)
+
+        def seg2():
+            # fused posterior update (also accumulates the pre-update KL for the ELBO log)
+            for lv, (pl, ps), e, stt in zip(net, net_priors, st["eps"], net_state):
+                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots)
+            ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), st["d_lpe"],
+                              st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots)
+
+        def seg3():
+            if training_mappings:
+                ops.adam_multi([p.data for p in A + conv], [g.contiguous() for g in st["grads"]],
                                [m for m, _ in map_state], [v for _, v in map_state], cfg)
-            ops.step_end(step_t, sse, 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf)
+            ops.step_end(step_t, st["sse"], 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf)
+
+        def body():
+            seg1()
+            work = comm()
+            seg2()
+            if work is not None:
+                work.wait()
+            seg3()
 
         n_warm = 3
-        graph = None
-        if (self.use_graph and self.noise_source is None and world == 1 and n_epoch >= 2 * n_warm and dev.type == "cuda"
-                and not verbose):
+        if (self.use_graph and self.noise_source is None and n_epoch >= 2 * n_warm and dev.type == "cuda" and not verbose):
             for _ in range(n_warm):
                 body()
             try:
                 torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):      # records the step; nothing executes during capture
-                    body()
-                for _ in range(n_epoch - n_warm):
-                    graph.replay()
+                if flat is None:                   # one rank (or frozen mappings): the whole step is one graph
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):      # records the step; nothing executes during capture
+                        body()
+                    for _ in range(n_epoch - n_warm):
+                        graph.replay()
+                else:                               # sharded: three graphs around the eager, asynchronous all-reduce
+                    pool = torch.cuda.graph_pool_handle()
+                    graphs = []
+                    for seg in (seg1, seg2, seg3):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool):
+                            seg()
+                        graphs.append(g)
+                    for _ in range(n_epoch - n_warm):
+                        graphs[0].replay()
+                        work = comm()
+                        graphs[1].replay()
+                        work.wait()
+                        graphs[2].replay()
             except Exception as exc:     # capture is an optimisation: fall back to eager stepping
                 import warnings
                 warnings.warn(f"HIP graph capture of the training step failed ({exc}); running eagerly")
-                graph = None
                 torch.cuda.synchronize()
                 done = int(step_t.item())
                 for _ in range(n_epoch - done):
