@@ -544,21 +544,29 @@ def split_bf16(xs, layout, lo_mask):
     lib = _lib.load()
     rows, cols = xs[0].shape
     ld = xs[0].stride(0)
-    outs = []
     arr = (SplitItem * len(xs))()
+    shape = (rows, 3 * cols) if layout == "cols" else (3 * rows, cols)
+    stacked = torch.empty((len(xs),) + shape, device=xs[0].device, dtype=bf16)     # one tensor: batched GEMMs can use it
+    outs = list(stacked.unbind(0))
     for i, x in enumerate(xs):
         if x.dtype != f32 or not x.is_cuda or tuple(x.shape) != (rows, cols) or x.stride(1) != 1 or x.stride(0) != ld:
             raise RcbError("split_bf16: fp32 GPU views of one shape and row stride expected")
-        o = torch.empty((rows, 3 * cols) if layout == "cols" else (3 * rows, cols), device=x.device, dtype=bf16)
-        outs.append(o)
-        arr[i] = SplitItem(x.data_ptr(), o.data_ptr())
+        arr[i] = SplitItem(x.data_ptr(), outs[i].data_ptr())
     if layout == "cols":
         row_stride, blk_stride = 3 * cols, cols
     else:
         row_stride, blk_stride = cols, rows * cols
     check(lib.rcb_split_bf16(arr, len(xs), C.c_int64(rows), C.c_int64(cols), C.c_int64(ld), C.c_int64(row_stride),
                              C.c_int64(blk_stride), int(lo_mask), stream_ptr()), "rcb_split_bf16")
-    return outs
+    return _Stacked(outs, stacked)
+
+
+class _Stacked(list):
+    """list of the per-item results that also carries the tensor they are slices of (`.stacked`, [n_items, ...])"""
+
+    def __init__(self, items, stacked):
+        super().__init__(items)
+        self.stacked = stacked
 
 
 class SplitATransform:
@@ -574,6 +582,36 @@ class SplitATransform:
         self.fast = [i for i, w in enumerate(widths) if w == big and w % 2 == 0 and w >= 256]
         self.rest = [i for i in range(len(widths)) if i not in self.fast]
         self.a_rows = self.a_cols = None
+        self._last = {False: None, True: None}      # split left operands of the last forward / dgrad call
+
+    def wgrad(self, h_w, dw, bf16_hi=True):
+        """dA[l] = h_w[:, lo:hi]^T @ dw[:, lo:hi], summed over the rows (INRs x samples).  With bf16_hi the wide layers
+        use the bf16 high parts both split calls already produced (fp32 accumulation and result): the sum over thousands
+        of rows averages the unbiased operand rounding down, unlike the per-row products above."""
+        out = [None] * len(self.slices)
+        hs, ds = self._last[False], self._last[True]
+        if bf16_hi and hs is not None and ds is not None and len(self.fast) > 1:
+            lo, hi = self.slices[self.fast[0]]
+            w = hi - lo
+            # one batched GEMM over the wide layers: a single layer's 1056 x 1056 result has too few tiles for 256 CUs
+            g = torch.bmm(hs.stacked[:, :, :w].transpose(1, 2), ds.stacked[:, :, :w], out_dtype=f32)
+            for k, i in enumerate(self.fast):
+                out[i] = g[k]
+            for i in self.rest:
+                lo, hi = self.slices[i]
+                out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
+            return out
+        for k, i in enumerate(self.fast):
+            lo, hi = self.slices[i]
+            w = hi - lo
+            if bf16_hi and hs is not None and ds is not None:
+                out[i] = torch.mm(hs[k][:, :w].t(), ds[k][:, :w], out_dtype=f32)
+            else:
+                out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
+        for i in self.rest:
+            lo, hi = self.slices[i]
+            out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
+        return out
 
     def prepare(self, A):
         mats = [A[i].detach() for i in self.fast]
@@ -583,6 +621,7 @@ class SplitATransform:
 
     def _apply(self, x, out, right, transpose):
         lefts = split_bf16([x[:, lo:hi] for lo, hi in (self.slices[i] for i in self.fast)], "cols", 0b010)
+        self._last[transpose] = lefts
         for k, i in enumerate(self.fast):
             lo, hi = self.slices[i]
             torch.mm(lefts[k], right[k].t() if transpose else right[k], out_dtype=f32, out=out[:, lo:hi])

@@ -108,6 +108,7 @@ class PriorBNNmodel(nn.Module):
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
+        self.wgrad_bf16 = True       # with split_gemm: bf16 high parts for the A weight-gradient GEMMs (sum over INRs)
         self.use_graph = True        # replay the training step as one captured HIP graph when possible
 
     # ---- level descriptions ------------------------------------------------------------------------
@@ -303,8 +304,8 @@ class PriorBNNmodel(nn.Module):
                     gA = [torch.mm(h16[:, lo:hi].t(), dw16[:, lo:hi]).float() for (lo, hi) in slices]
             elif split is not None:
                 dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
-                if training_mappings:             # K = 4096 INRs: the split form is not faster here, plain fp32
-                    gA = [torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]) for (lo, hi) in slices]
+                if training_mappings:
+                    gA = split.wgrad(h_w, dw, self.wgrad_bf16)
             else:
                 dh = torch.empty(N, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):
