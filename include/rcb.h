@@ -65,6 +65,10 @@ typedef struct {
   int32_t pe_bf16;       /* 1: pe and dpe are bf16 arrays (precision >= 1, pe_dim % 8 == 0): the 16-bit
                           * kernels round pe / dpe to bf16 for their MFMA operands anyway, so storing
                           * them as bf16 gives bit-identical results with half the traffic        */
+  void* dw_split;        /* nullable, 16-bit kernels, rcb_siren_bwd / _loss_bwd only: besides dwvec, the gradient of
+                          * every layer vector of the maximal length W (even) is also written as the split-bf16 LEFT
+                          * operand of rcb_split_bf16: bf16 [n_wide_layers][n_rows][3 * W] = [hi | lo | hi], wide layers
+                          * in layer order -- saves the separate split pass over dwvec                          */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */

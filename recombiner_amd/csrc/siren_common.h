@@ -27,6 +27,7 @@ struct SirenArgs {
   float k_hi, k_lo;   // w0 / (2 pi) split in two floats
   float w0, dy_scale;
   int pe_bf16;        // pe / dpe hold bf16 elements (16-bit kernels only)
+  void* dw_split;     // nullable: split-bf16 copy of the wide layers' weight gradients (see rcb_siren_desc)
 };
 
 // row of accumulator register r for lane half h (32x32 MFMA C/D layout)

@@ -380,8 +380,11 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d->pe_bf16 == 0 || (d->pe_bf16 == 1 && d->precision >= 1 && d->pe_dim % 8 == 0), RCB_ERR_UNSUPPORTED,
               "siren: bf16 pe storage needs a 16-bit precision mode and pe_dim %% 8 == 0 (precision=%d, E=%d)", d->precision,
               d->pe_dim);
+  RCB_REQUIRE(d->dw_split == nullptr || d->precision >= 1, RCB_ERR_UNSUPPORTED,
+              "siren: the split-bf16 gradient output exists in the 16-bit kernels only");
   memset(&a, 0, sizeof(a));
   a.pe_bf16 = d->pe_bf16;
+  a.dw_split = d->dw_split;
   a.G = d->n_rows;
   a.S = d->samples;
   a.P = d->n_pix;

@@ -66,6 +66,18 @@ struct Geo {
     return o;
   }
   static constexpr int DNET = off(NL);
+  __host__ __device__ static constexpr int lsize(int l) { return lout(l) * (lin(l) + 1); }
+  __host__ __device__ static constexpr int wmax() {
+    int w = 0;
+    for (int l = 0; l < NL; ++l) w = lsize(l) > w ? lsize(l) : w;
+    return w;
+  }
+  static constexpr int WMAX = wmax();                        // length of the widest layer vector(s)
+  __host__ __device__ static constexpr int wide_index(int l) {   // rank of layer l among the layers of length WMAX
+    int k = 0;
+    for (int i = 0; i < l; ++i) k += (lsize(i) == WMAX) ? 1 : 0;
+    return k;
+  }
   // LDS map (bytes)
   static constexpr int FR_OFF = ((DNET * 4 + 15) / 16) * 16;
   static constexpr int TILE_OFF = FR_OFF + (NFA + NFB) * 1024;
@@ -507,7 +519,16 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
           const int i = (e - no) / no, o = (e - no) - i * no;
           src = ro + o * rs + i;
         }
-        dst[ol + e] = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
+        const float v = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
+        dst[ol + e] = v;
+        if (size == G::WMAX && (G::WMAX & 1) == 0 && a.dw_split != nullptr) {
+          // split-bf16 left operand [hi | lo | hi] of the data-gradient GEMM (wide layers only, in layer order)
+          const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+          __bf16* o = reinterpret_cast<__bf16*>(a.dw_split) + ((long long)G::wide_index(l) * a.G + g) * (3 * G::WMAX) + e;
+          o[0] = hi;
+          o[G::WMAX] = lo;
+          o[2 * G::WMAX] = hi;
+        }
       }
     }
   }

@@ -57,7 +57,7 @@ def _xf_stride(xf, meta, n_inr):
     return int(xf.stride(0))
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf, pe=None):
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -67,7 +67,7 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None):
         raise RcbError("rows of wvec must be a multiple of samples")
     d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
-                  meta.precision, int(pe is not None and pe.dtype == bf16))
+                  meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split))
     return d, G
 
 
@@ -110,10 +110,26 @@ def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True):
     return dw, dpe
 
 
-def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True):
-    """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None)."""
+def siren_wide_layers(meta: SirenMeta):
+    """(number of layer vectors of maximal length, that length): the layers rcb_siren_desc.dw_split covers"""
+    dims = [meta.fourier_dim + meta.pe_dim] + [meta.hidden] * meta.n_hidden + [meta.out_dim]
+    sizes = [dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1)]
+    return sizes.count(max(sizes)), max(sizes)
+
+
+def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_split=False):
+    """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_split (16-bit modes) also
+    the split-bf16 left operands [n_wide, G, 3 W] of the wide layers' gradients (ops._Stacked, as split_bf16 returns)."""
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf, pe)
+    G = wvec.shape[0]
+    split = None
+    if want_split:
+        n_wide, w = siren_wide_layers(meta)
+        if meta.precision == 0 or w % 2:
+            raise RcbError("the split-bf16 gradient output needs a 16-bit precision mode and an even layer length")
+        stacked = torch.empty(n_wide, G, 3 * w, device=wvec.device, dtype=bf16)
+        split = _Stacked(list(stacked.unbind(0)), stacked)
+    d, G = _siren_desc(meta, wvec, xf, pe, None if split is None else split.stacked)
     _check_pe(pe, G, meta)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
@@ -124,7 +140,7 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
     check(lib.rcb_siren_loss_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
                                  ptr(target, f32), C.c_float(dy_scale), ptr(sse), _dev_ptr_strided(dw),
                                  ptr(dpe, None, True), stream_ptr()), "rcb_siren_loss_bwd")
-    return sse, dw, dpe
+    return (sse, dw, dpe, split) if want_split else (sse, dw, dpe)
 
 
 class SirenFn(torch.autograd.Function):
@@ -619,8 +635,9 @@ class SplitATransform:
         self.a_cols = split_bf16(mats, "cols", 0b100)      # [hi | hi | lo] (^T)     right operand of the data gradient
         self.A = A
 
-    def _apply(self, x, out, right, transpose):
-        lefts = split_bf16([x[:, lo:hi] for lo, hi in (self.slices[i] for i in self.fast)], "cols", 0b010)
+    def _apply(self, x, out, right, transpose, lefts=None):
+        if lefts is None:        # (the producer of x may already have written its split form: siren dw_split, reparam)
+            lefts = split_bf16([x[:, lo:hi] for lo, hi in (self.slices[i] for i in self.fast)], "cols", 0b010)
         self._last[transpose] = lefts
         for k, i in enumerate(self.fast):
             lo, hi = self.slices[i]
@@ -631,8 +648,13 @@ class SplitATransform:
             torch.mm(x[:, lo:hi], a.t() if transpose else a, out=out[:, lo:hi])
         return out
 
-    def forward(self, h_w, out):
-        return self._apply(h_w, out, self.a_rows, False)
+    def forward(self, h_w, out, lefts=None):
+        return self._apply(h_w, out, self.a_rows, False, lefts)
 
-    def dgrad(self, dw, out):
-        return self._apply(dw, out, self.a_cols, True)
+    def dgrad(self, dw, out, lefts=None):
+        return self._apply(dw, out, self.a_cols, True, lefts)
+
+    def matches_siren(self, meta):
+        """True if the wide layers of this transform are exactly those rcb_siren_desc.dw_split covers"""
+        n_wide, w = siren_wide_layers(meta)
+        return len(self.fast) == n_wide and all(self.slices[i][1] - self.slices[i][0] == w for i in self.fast)

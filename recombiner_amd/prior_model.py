@@ -291,7 +291,11 @@ class PriorBNNmodel(nn.Module):
                     torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
-            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
+            dw_split = None
+            if split is not None and split.matches_siren(meta):      # the kernel's epilogue also emits the split form
+                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_split=True)
+            else:
+                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
             # ---- backward through the shared mappings ------------------------------------------------------
             inputs = [lpe_t] + (conv if training_mappings else [])
             g_in = torch.autograd.grad(pe_c, inputs, dpe)
@@ -303,7 +307,7 @@ class PriorBNNmodel(nn.Module):
                 if training_mappings:
                     gA = [torch.mm(h16[:, lo:hi].t(), dw16[:, lo:hi]).float() for (lo, hi) in slices]
             elif split is not None:
-                dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
+                dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32), dw_split)
                 if training_mappings:
                     gA = split.wgrad(h_w, dw, self.wgrad_bf16)
             else:

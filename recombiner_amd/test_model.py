@@ -483,11 +483,15 @@ class TestBNNmodel(nn.Module):
             else:
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
-            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta)
+            dw_split = None
+            if split is not None and split.matches_siren(meta):
+                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, want_split=True)
+            else:
+                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta)
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
             dh = torch.empty(N * S, D, device=dev, dtype=torch.float32)
             if split is not None:
-                split.dgrad(dw, dh)
+                split.dgrad(dw, dh, dw_split)
             else:
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(dw[:, lo:hi], a.t(), out=dh[:, lo:hi])

@@ -262,6 +262,21 @@ def test_reparam_flat_fast_path_equals_generic(N, D):
     assert rel_err(fast[:, 0], ref) < 1e-6
 
 
+def test_siren_split_gradient_output_equals_split_of_dw():
+    """rcb_siren_desc.dw_split: the epilogue's split-bf16 copy of the wide layers' gradients == rcb_split_bf16(dwvec)"""
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=256, N=5, S=1)
+    dims, D, xf, pe, wv, y = _siren_case(seed=13, **case)
+    meta = SirenMeta(1, 256, 16, 16, 3, 32, 3, precision=1)
+    assert ops.siren_wide_layers(meta) == (3, 1056)
+    sse, dw, dpe, sp = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, meta, want_split=True)
+    sse2, dw2, dpe2 = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, meta)
+    assert torch.equal(dw, dw2) and torch.equal(dpe, dpe2) and torch.equal(sse, sse2)
+    ref = ops.split_bf16([dw[:, a:b] for a, b in ((0, 1056), (1056, 2112), (2112, 3168))], "cols", 0b010)
+    assert sp.stacked.shape == (3, 5, 3168) and torch.equal(sp.stacked, ref.stacked)
+    with pytest.raises(ops.RcbError):
+        ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, SirenMeta(1, 256, 16, 16, 3, 32, 3), want_split=True)
+
+
 def test_split_bf16_operands_and_a_transform():
     """rcb_split_bf16: exact hi / lo parts in both layouts; the split-bf16 A transform and its data gradient agree with
     the fp32 product at fp32-rounding level (not at bf16 level)."""
