@@ -9,6 +9,14 @@
 
 #pragma clang fp contract(off)
 
+// Rounded-once arithmetic that must NOT be contracted into FMAs.  These helpers are defined here, under the pragma
+// above, on purpose: HIP's __fadd_rn / __fmul_rn / ... are inline functions from headers compiled with the default
+// -ffp-contract=fast, so after inlining their operations carry the `contract` flag and LLVM may fuse exactly them.
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+
 namespace rcb {
 char* last_error_buf() {
   static thread_local char buf[512] = {0};
@@ -67,8 +75,8 @@ __device__ __forceinline__ void level_mu_sigma(const rcb_level& L, int n, int d,
     float m = L.enc_mask[o];
     float z = L.enc_sample[o];
     // loc*(1-m) + z*m ; st*(1-m) + 1e-15*m   (test_model.py:289-290)
-    loc = __fadd_rn(__fmul_rn(loc, 1.0f - m), __fmul_rn(z, m));
-    s = __fadd_rn(__fmul_rn(s, 1.0f - m), __fmul_rn(1e-15f, m));
+    loc = add_rn(mul_rn(loc, 1.0f - m), mul_rn(z, m));
+    s = add_rn(mul_rn(s, 1.0f - m), mul_rn(1e-15f, m));
   }
   mu = loc;
   sig = s;
@@ -94,8 +102,8 @@ __global__ void reparam_fwd_kernel(ReparamArgs a) {
     for (int l = 0; l < 3; ++l) {
       if (on[l]) {
         float e = a.lv[l].eps[row * a.lv[l].cols_out + d];
-        float v = __fadd_rn(mu[l], __fmul_rn(sg[l], e));
-        acc = (l == 0) ? v : __fadd_rn(acc, v);
+        float v = add_rn(mu[l], mul_rn(sg[l], e));
+        acc = (l == 0) ? v : add_rn(acc, v);
       }
     }
     a.out[row * a.out_cols + d] = acc;
@@ -114,15 +122,15 @@ __global__ void __launch_bounds__(256) reparam_flat_kernel(const float* __restri
     const float4 l = reinterpret_cast<const float4*>(ls)[i];
     const float4 e = reinterpret_cast<const float4*>(eps)[i];
     float4 o;
-    o.x = __fadd_rn(m.x, __fmul_rn(st_f32(l.x), e.x));
-    o.y = __fadd_rn(m.y, __fmul_rn(st_f32(l.y), e.y));
-    o.z = __fadd_rn(m.z, __fmul_rn(st_f32(l.z), e.z));
-    o.w = __fadd_rn(m.w, __fmul_rn(st_f32(l.w), e.w));
+    o.x = add_rn(m.x, mul_rn(st_f32(l.x), e.x));
+    o.y = add_rn(m.y, mul_rn(st_f32(l.y), e.y));
+    o.z = add_rn(m.z, mul_rn(st_f32(l.z), e.z));
+    o.w = add_rn(m.w, mul_rn(st_f32(l.w), e.w));
     reinterpret_cast<float4*>(out)[i] = o;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
-    out[i] = __fadd_rn(loc[i], __fmul_rn(st_f32(ls[i]), eps[i]));
+    out[i] = add_rn(loc[i], mul_rn(st_f32(ls[i]), eps[i]));
   }
 }
 
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(256) kl_rows_kernel(KlArgs a) {
     for (int j = threadIdx.x; j < a.cols; j += 256) {
       float sp = a.p_is_log ? st_f32(a.p_scale[j]) : a.p_scale[j];
       float k = kl_elem_f32(loc[j], st_f32(ls[j]), a.p_loc[j], sp);
-      if (a.beta) k = __fmul_rn(k, a.beta[(long long)r * a.n_groups + a.group_idx[j]]);
+      if (a.beta) k = mul_rn(k, a.beta[(long long)r * a.n_groups + a.group_idx[j]]);
       acc += (double)k;
     }
   } else {
@@ -250,8 +258,8 @@ __global__ void beta_update_kernel(const double* kl, float* beta, const uint8_t*
   if (done && done[i]) return;
   double bits = kl[i] / 0.6931471805599453;  // kls / np.log(2.)
   float b = beta[i];
-  b = __fmul_rn(b, bits > hi ? factor : 1.0f);
-  b = __fdiv_rn(b, bits <= lo ? factor : 1.0f);
+  b = mul_rn(b, bits > hi ? factor : 1.0f);
+  b = div_rn(b, bits <= lo ? factor : 1.0f);
   b = fminf(fmaxf(b, 0.0f), 10000.0f);
   beta[i] = b;
 }
@@ -303,16 +311,24 @@ static AdamScalars make_adam(const rcb_adam_cfg* c) {
 __device__ __forceinline__ void adam_apply(float& p, float g, float& m, float& v, const AdamScalars& s) {
   const float step_size = s.dyn ? s.dyn[0] : s.step_size;
   const float bc2_sqrt = s.dyn ? s.dyn[1] : s.bc2_sqrt;
-  m = __fadd_rn(m, __fmul_rn(s.w1, __fsub_rn(g, m)));                    // exp_avg.lerp_(grad, 1-beta1)
-  v = __fadd_rn(__fmul_rn(v, s.beta2), __fmul_rn(__fmul_rn(s.w2, g), g));  // mul_(beta2).addcmul_(g, g, 1-beta2)
-  float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), s.eps);
-  p = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));          // addcdiv_(exp_avg, denom, -step_size)
+  m = add_rn(m, mul_rn(s.w1, sub_rn(g, m)));                    // exp_avg.lerp_(grad, 1-beta1)
+  v = add_rn(mul_rn(v, s.beta2), mul_rn(mul_rn(s.w2, g), g));  // mul_(beta2).addcmul_(g, g, 1-beta2)
+  float denom = add_rn(div_rn(sqrtf(v), bc2_sqrt), s.eps);
+  p = add_rn(p, mul_rn(-step_size, div_rn(m, denom)));          // addcdiv_(exp_avg, denom, -step_size)
 }
 
 struct PostBwdArgs {
   rcb_level_bwd L;
   AdamScalars adam;
 };
+
+// KL part of the gradient and the chain rule through softplus, with explicitly unfused roundings: the generic and the
+// flat kernel must produce the same bits, and the reference computes these with separate torch ops anyway
+__device__ __forceinline__ void kl_grad_add(float loc, float sig, float pl, float sp, float w, float& g_mu, float& g_sig) {
+  const float inv_var_p = 1.0f / mul_rn(sp, sp);
+  g_mu = add_rn(g_mu, mul_rn(w, mul_rn(sub_rn(loc, pl), inv_var_p)));
+  g_sig = add_rn(g_sig, mul_rn(w, sub_rn(mul_rn(sig, inv_var_p), 1.0f / sig)));
+}
 
 __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   const rcb_level_bwd& L = a.L;
@@ -335,18 +351,18 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
       for (int s = 0; s < L.samples; ++s) {
         long long e = ((long long)n * L.samples + s) * L.cols_out + d;
         float go = L.d_out[e];
-        g_mu += go;
-        g_sig += go * L.eps[e];
+        g_mu = add_rn(g_mu, go);
+        g_sig = add_rn(g_sig, mul_rn(go, L.eps[e]));
       }
     }
     if (L.enc_mask) {
       float keep = 1.0f - L.enc_mask[o];
-      g_mu *= keep;
-      g_sig *= keep;
+      g_mu = mul_rn(g_mu, keep);
+      g_sig = mul_rn(g_sig, keep);
     }
   }
   float w = L.kl_scalar;
-  if (L.beta) w *= L.beta[(long long)r * L.n_groups + L.group_idx[j]];
+  if (L.beta) w = mul_rn(w, L.beta[(long long)r * L.n_groups + L.group_idx[j]]);
   if (L.kl_accum) {   // unweighted KL of the parameters *before* this update (ELBO logging)
     __shared__ double s_kl[4];
     float spk = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
@@ -359,11 +375,9 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   }
   if (w != 0.0f) {
     float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
-    float inv_var_p = 1.0f / (sp * sp);
-    g_mu += w * ((loc - L.p_loc[j]) * inv_var_p);
-    g_sig += w * (sig * inv_var_p - 1.0f / sig);
+    kl_grad_add(loc, sig, L.p_loc[j], sp, w, g_mu, g_sig);
   }
-  float g_ls = g_sig * dst_f32(ls);
+  float g_ls = mul_rn(g_sig, dst_f32(ls));
   if (!act) return;
   if (a.adam.enabled) {
     float m1 = L.m_loc[o], v1 = L.v_loc[o], m2 = L.m_ls[o], v2 = L.v_ls[o];
@@ -380,6 +394,62 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   if (L.g_log_scale) L.g_log_scale[o] = g_ls;
 }
 
+// Fast path of the kernel above for the plain case (prior training of un-patched presets): one sample, no hierarchy /
+// permutation / column maps, no encode mask, no per-group beta, Adam enabled, every column produced.  Purely
+// elementwise over the flat [rows * cols] arrays with 16-byte accesses (rows of 3267 floats are not 16-byte aligned,
+// the flat arrays are); same per-element arithmetic, so the updated parameters are bit-identical.
+__global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long long n_total) {
+  const rcb_level_bwd& L = a.L;
+  const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // group of 4 consecutive elements
+  const long long base = i4 * 4;
+  const bool act = base < n_total;                                             // n_total % 4 == 0 on this path
+  const long long b = act ? base : 0;
+  float4 loc4 = reinterpret_cast<const float4*>(L.loc + b)[0];
+  float4 ls4 = reinterpret_cast<const float4*>(L.log_scale + b)[0];
+  const float4 go4 = reinterpret_cast<const float4*>(L.d_out + b)[0];
+  const float4 ep4 = reinterpret_cast<const float4*>(L.eps + b)[0];
+  float4 m14 = reinterpret_cast<const float4*>(L.m_loc + b)[0], v14 = reinterpret_cast<const float4*>(L.v_loc + b)[0];
+  float4 m24 = reinterpret_cast<const float4*>(L.m_ls + b)[0], v24 = reinterpret_cast<const float4*>(L.v_ls + b)[0];
+  float* locv = &loc4.x; float* lsv = &ls4.x;
+  const float* gov = &go4.x; const float* epv = &ep4.x;
+  float* m1v = &m14.x; float* v1v = &v14.x; float* m2v = &m24.x; float* v2v = &v24.x;
+  int j = (int)(b % L.cols);
+  double kl = 0.0;
+  const float w = L.kl_scalar;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float loc = locv[k], ls = lsv[k];
+    const float sig = st_f32(ls);
+    float g_mu = gov[k];
+    float g_sig = mul_rn(gov[k], epv[k]);
+    const float pl = L.p_loc[j];
+    const float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
+    if (L.kl_accum) kl += (double)kl_elem_f32(loc, sig, pl, sp);
+    if (w != 0.0f) kl_grad_add(loc, sig, pl, sp, w, g_mu, g_sig);
+    const float g_ls = mul_rn(g_sig, dst_f32(ls));
+    adam_apply(loc, g_mu, m1v[k], v1v[k], a.adam);
+    adam_apply(ls, g_ls, m2v[k], v2v[k], a.adam);
+    locv[k] = loc;
+    lsv[k] = ls;
+    if (++j == L.cols) j = 0;
+  }
+  if (L.kl_accum) {
+    __shared__ double s_kl[4];
+    const double kv = wave_sum(act ? kl : 0.0);
+    if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicAdd(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
+  }
+  if (!act) return;
+  reinterpret_cast<float4*>(L.loc + b)[0] = loc4;
+  reinterpret_cast<float4*>(L.log_scale + b)[0] = ls4;
+  reinterpret_cast<float4*>(L.m_loc + b)[0] = m14;
+  reinterpret_cast<float4*>(L.v_loc + b)[0] = v14;
+  reinterpret_cast<float4*>(L.m_ls + b)[0] = m24;
+  reinterpret_cast<float4*>(L.v_ls + b)[0] = v24;
+}
+
 extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream) {
   RCB_REQUIRE(lv, RCB_ERR_ARG, "posterior_bwd: null level");
   RCB_REQUIRE(lv->loc && lv->log_scale && lv->p_loc && lv->p_scale, RCB_ERR_ARG, "posterior_bwd: null tensor");
@@ -393,6 +463,18 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
   PostBwdArgs a;
   a.L = *lv;
   a.adam = make_adam(adam);
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const long long n_total = (long long)lv->rows * lv->cols;
+    if (adam && lv->d_out && lv->samples == 1 && lv->cols_out == lv->cols && !lv->enc_mask && !lv->beta && !lv->member_ptr &&
+        !lv->row_perm_inv && !lv->col_inv && !lv->g_loc && !lv->g_log_scale && (n_total & 3) == 0 && al16(lv->loc) &&
+        al16(lv->log_scale) && al16(lv->d_out) && al16(lv->eps) && al16(lv->m_loc) && al16(lv->v_loc) && al16(lv->m_ls) &&
+        al16(lv->v_ls)) {
+      posterior_flat_kernel<<<cdiv(n_total >> 2, 256), 256, 0, (hipStream_t)stream>>>(a, n_total);
+      RCB_LAUNCH_CHECK();
+      return RCB_OK;
+    }
+  }
   dim3 grid(lv->rows, cdiv(lv->cols, 256));
   posterior_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   RCB_LAUNCH_CHECK();
@@ -621,7 +703,7 @@ __global__ void __launch_bounds__(256) col_moments_kernel(const float* __restric
     a1 += x;
     a2 += x * x;
     float s = st_f32(ls[(long long)r * cols + j]);
-    a3 += (double)__fmul_rn(s, s);
+    a3 += (double)mul_rn(s, s);
   }
   atomicAdd(&s1[j], a1);
   atomicAdd(&s2[j], a2);

@@ -9,6 +9,11 @@
 
 #pragma clang fp contract(off)
 
+// un-contracted fp64 mul / add (HIP's __dmul_rn / __dadd_rn come from headers compiled with -ffp-contract=fast: after
+// inlining LLVM may fuse them; these are defined under the pragma above)
+__device__ __forceinline__ double dadd_rn(double a, double b) { return a + b; }
+__device__ __forceinline__ double dmul_rn(double a, double b) { return a * b; }
+
 using namespace rcb;
 
 constexpr int kMaxGlen = 32;
@@ -89,7 +94,7 @@ __global__ void __launch_bounds__(256) rec_score_kernel(RecArgs a) {
     const double* x = xi + (long long)k * g;
     double lq = 0.0, lp = 0.0;
     for (int j = 0; j < g; ++j) {
-      double z = __dadd_rn(s_mp[j], __dmul_rn(s_sp[j], x[j]));
+      double z = dadd_rn(s_mp[j], dmul_rn(s_sp[j], x[j]));
       double dq = z - s_mq[j];
       double dp = z - s_mp[j];
       double tq = ((-(dq * dq)) / s_2vq[j] - s_lq[j]) - c;
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(256) rec_score_kernel(RecArgs a) {
   int win = s_top[0].i1;
   if (threadIdx.x < g && a.z_out) {
     int j = threadIdx.x;
-    a.z_out[(long long)b * a.max_glen + j] = __dadd_rn(s_mp[j], __dmul_rn(s_sp[j], xi[(long long)win * g + j]));
+    a.z_out[(long long)b * a.max_glen + j] = dadd_rn(s_mp[j], dmul_rn(s_sp[j], xi[(long long)win * g + j]));
   }
 }
 

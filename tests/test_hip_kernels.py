@@ -379,6 +379,33 @@ def test_posterior_adam_step_matches_autograd_adam():
     np.testing.assert_allclose(ds.cpu().numpy(), rs.detach().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_posterior_flat_fast_path_equals_generic_kernel():
+    """plain case (one sample, no maps): the 16-byte flat kernel must update loc / log_scale / Adam state bit for bit
+    like the generic kernel (forced here through an identity column map) and accumulate the same KL."""
+    gen = torch.Generator().manual_seed(17)
+    n, D = 8, 3267
+    loc = 0.02 * torch.randn(n, D, generator=gen)
+    ls = -4 + 0.5 * torch.randn(n, D, generator=gen)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    ps = 0.02 + 0.01 * torch.rand(D, generator=gen)
+    eps = g(torch.randn(n, 1, D, generator=gen))
+    Gm = g(torch.randn(n, 1, D, generator=gen) * 1e-3)
+    res = []
+    for col_map in (None, np.arange(D)):
+        dl, ds = g(loc.clone()), g(ls.clone())
+        lv = LevelSpec(dl, ds, D, n, col_map=col_map)
+        state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+        slots = torch.zeros(1024, device=DEV, dtype=torch.float64)
+        for step in (1, 2, 3):
+            ops.posterior_bwd(lv, g(pl), g(ps), False, 1e-3, Gm, eps, 1, adam=ops.adam_cfg(2e-4, step), state=state,
+                              kl_accum=slots)
+        res.append((dl, ds, state, float(slots.sum())))
+    (l0, s0, st0, k0), (l1, s1, st1, k1) = res
+    assert torch.equal(l0, l1) and torch.equal(s0, s1)
+    assert all(torch.equal(st0[k], st1[k]) for k in st0)
+    assert k0 == pytest.approx(k1, rel=1e-12) and k0 > 0
+
+
 # ---------------------------------------------------------------------------------------------------
 # KL family, annealing, moments
 # ---------------------------------------------------------------------------------------------------
