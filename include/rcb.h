@@ -262,12 +262,14 @@ int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, con
  * [stage 3: bf16 in, fp32 or bf16 linear out; dy fp32 or bf16]; batch = number of images (INR x sample).
  * ------------------------------------------------------------------------------------------- */
 int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, const float* bias, void* y,
-                   int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+                   int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, const void* frag_pack,
+                   rcb_stream_t stream);
 /* dgrad, stage-2 geometry only: if dbias_partial != NULL it receives [rcb_upconv_dgrad_partial_rows(batch)][64]
  * per-workgroup channel sums of dx (= the bias gradient of the stage that produced x); elsewhere it must be NULL. */
 int32_t rcb_upconv_dgrad_partial_rows(int32_t batch);
 int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x, int32_t x_is_f32_preact,
-                     void* dx, float* dbias_partial, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream);
+                     void* dx, float* dbias_partial, int32_t batch, int32_t grid, int32_t cout, const void* frag_pack,
+                     rcb_stream_t stream);
 /* wgrad writes (does not accumulate) dweff [2][2][64][2][2][cout] and, if non-NULL, dbias [cout] = sum of dy.
  * Each workgroup sums its INRs into its own slab of `workspace` and a second kernel adds the slabs in a fixed
  * order: no atomics, bitwise reproducible.  workspace: >= rcb_upconv_wgrad_workspace(batch, cout) floats.   */
@@ -281,8 +283,18 @@ int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int
  *   weff1 [512][4096] (rows (s,t,i) of the 2x2x128 latent grid, columns (y,x,o) of the 8x8x64 stage-1 output) and
  *   b1rep [4096] in bf16 (bf16_out = 1) or fp32; weff2 [2][2][64][2][2][64], weff3 [2][2][64][2][2][16] fp32.
  *   grad: dW1 [64][128][5][5], dW2 [64][64][3][3], dW3 [16][64][3][3] written (not accumulated).               */
+/* frag_pack (nullable, RCB_UPCONV_PACK_UINT4 x 16 bytes): the same effective weights as bf16 MFMA A-fragments in the
+ * per-lane order the phase-conv kernels keep in registers, so that their prologue is a few coalesced 16-byte loads
+ * instead of hundreds of strided scalar ones.  16-byte entries (8 bf16), lane = entry & 63, q = lane & 31, h = lane >> 5:
+ *   [    0,  8192) stage-2 forward   [ph][mt][ty][tx][kb][lane]: weff2[ty][tx][16kb+8h+j][ph>>1][ph&1][32mt+q]
+ *   [ 8192, 16384) stage-2 dgrad     [kh][mt][c][kb][lane], window combo n = 8kh+c: weff2[ty][tx][32mt+q][pa][pb][16kb+8h+j]
+ *   [16384, 20480) stage-3 forward   [pa][pb][ty][tx][kb][lane]: weff3[ty][tx][16kb+8h+j][pa][pb][q] (0 for q >= 16)
+ *   [20480, 22528) stage-3 dgrad     [n][mt][lane]: weff3[ty][tx][32mt+q][pa][pb][8h+j]
+ * (ry = (n>>2)-1, rx = (n&3)-1, pa = ry&1, ty = ry<=0, pb = rx&1, tx = rx<=0.)  rcb_upconv_fwd / _dgrad take the pack
+ * through their `frag_pack` argument; with NULL they build the fragments from `weff` themselves.                 */
+#define RCB_UPCONV_PACK_UINT4 22528
 int rcb_upconv_weff_build(const float* W1, const float* b1, const float* W2, const float* W3, void* weff1, void* b1rep,
-                          int32_t bf16_out, float* weff2, float* weff3, rcb_stream_t stream);
+                          int32_t bf16_out, float* weff2, float* weff3, void* frag_pack, rcb_stream_t stream);
 int rcb_upconv_weff_grad(const void* dweff1, int32_t bf16_in, const float* dweff2, const float* dweff3, float* dW1,
                          float* dW2, float* dW3, const float* db1_partial /* nullable [n_partial][64] */,
                          int32_t n_partial, float* db1 /* nullable [64] = column sums of db1_partial */,

@@ -98,6 +98,7 @@ struct FwdArgs {
   const float* bias;
   void* y;
   int batch;
+  const uint4* pack;   // nullable: pre-packed fragments (rcb_upconv_weff_build), else built from weff in the prologue
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -109,6 +110,7 @@ struct DgradArgs {
   const void* x;   // stored activation (bf16 post-LeakyReLU) or fp32 pre-activation: sign source
   void* dx;
   int batch;
+  const uint4* pack;   // nullable, as in FwdArgs
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -202,9 +204,13 @@ __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           Frag f;
+          if (a.pack) {                     // one coalesced 16-byte load per fragment
+            f.u = a.pack[16384 + ((((pa * 2 + pb) * 2 + ty) * 2 + tx) * 4 + kb) * 64 + lane];
+          } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j)      // rows >= COUT of the 32-row A tile are zero (clamped load, masked)
-            f.v[j] = (__bf16)(a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, q < COUT ? q : COUT - 1, COUT)] * wmask);
+            for (int j = 0; j < 8; ++j)      // rows >= COUT of the 32-row A tile are zero (clamped load, masked)
+              f.v[j] = (__bf16)(a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, q < COUT ? q : COUT - 1, COUT)] * wmask);
+          }
           fr[pb][ty][tx][kb] = f.u;
           pin(fr[pb][ty][tx][kb]);
         }
@@ -291,6 +297,10 @@ __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
   __bf16* img = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
   for (int e = tid; e < NF * 64; e += 512) {
+    if (a.pack) {                      // [combo][mt][lane] is exactly the layout of the LDS fragment table
+      frags[e] = a.pack[20480 + e];
+      continue;
+    }
     const int ln = e & 63, slot = e >> 6;
     const int mt = slot & 1, combo = slot >> 1;
     const int ry = (combo >> 2) - 1, rx = (combo & 3) - 1;
@@ -361,10 +371,11 @@ template <int IN_MODE>   // 1: fp32 pre-activation, 3: bf16 pre-activation
 __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
   constexpr int G = 8, HG = 10, RS = 72, COUT = 64, IMG = HG * HG * RS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                  // [2][IMG]
-  float* bs = reinterpret_cast<float*>(smem_raw + 2 * IMG * 2);      // [64]
+  constexpr int NI = 4;                                               // INRs per pass
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                  // [NI][IMG]
+  float* bs = reinterpret_cast<float*>(smem_raw + NI * IMG * 2);     // [64]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
-  const int ph = wave & 3, pa = ph >> 1, pb = ph & 1, inr = wave >> 2;
+  const int ph = wave & 3, pa = ph >> 1, pb = ph & 1, half = wave >> 2;   // the wave owns INRs 2 half, 2 half + 1 of a pass
   uint4 fr[2][2][2][4];   // [mt][ty][tx][kb]
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -375,20 +386,24 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           Frag f;
+          if (a.pack) {
+            f.u = a.pack[((((ph * 2 + mt) * 2 + ty) * 2 + tx) * 4 + kb) * 64 + lane];
+          } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, 32 * mt + q, COUT)];
+            for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, 32 * mt + q, COUT)];
+          }
           fr[mt][ty][tx][kb] = f.u;
           pin(fr[mt][ty][tx][kb]);
         }
-  for (int e = tid; e < 2 * IMG / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  for (int e = tid; e < NI * IMG / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
   if (tid < COUT) bs[tid] = a.bias[tid];
-  // a pair of INRs = 2 x 64 pixels x 8 chunks of 8 channels = 1024 chunks, 2 per thread
-  Raw8<IN_MODE> pre[2];
-  const int npair = (a.batch + 1) >> 1;
+  // NI INRs = NI x 64 pixels x 8 chunks of 8 channels = 2048 chunks, 4 per thread: 32 KB (bf16) in flight per CU
+  Raw8<IN_MODE> pre[NI];
+  const int npair = (a.batch + NI - 1) / NI;
 #define RCB_FETCH2(pp)                                                                      \
-  _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                          \
+  _Pragma("unroll") for (int k = 0; k < NI; ++k) {                                         \
     const int e_ = tid + 512 * k;                                                          \
-    int b_ = 2 * (pp) + (e_ >> 9);                                                         \
+    int b_ = NI * (pp) + (e_ >> 9);                                                        \
     if (b_ >= a.batch) b_ = a.batch - 1;                                                   \
     pre[k] = raw_load<IN_MODE>(a.x, (long long)b_ * G * G * CIN + 8 * (e_ & 511));         \
   }
@@ -398,7 +413,7 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
   for (; p < npair; p += gs) {
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NI; ++k) {
       const int e_ = tid + 512 * k, pix = (e_ >> 3) & 63, c8 = e_ & 7;
       Frag f;
       f.v = raw_frag<IN_MODE>(pre[k], true);
@@ -406,11 +421,12 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
     }
     __syncthreads();
     if (p + gs < npair) RCB_FETCH2(p + gs)
-    const int b = 2 * p + inr;
-    if (b < a.batch) {
-      const __bf16* im = img + inr * IMG;
 #pragma unroll 1
-      for (int tt = 0; tt < 2; ++tt) {
+    for (int it = 0; it < 4; ++it) {         // (INR of this wave, tile) pairs, one after the other
+      const int inr = 2 * half + (it >> 1), tt = it & 1;
+      const int b = NI * p + inr;
+      if (b < a.batch) {
+        const __bf16* im = img + inr * IMG;
         const int pos = tt * 32 + q, i = pos >> 3, j = pos & 7;
         f32x16 acc[2];
 #pragma unroll
@@ -487,12 +503,16 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
     const int n = 8 * kh + c, ry = (n >> 2) - 1, rx = (n & 3) - 1;
     const int pa = ry & 1, ty = (ry <= 0) ? 1 : 0, pb = rx & 1, tx = (rx <= 0) ? 1 : 0;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {     // the 8 elements are consecutive output channels: two 16-byte loads
-      const float4* wp = reinterpret_cast<const float4*>(a.weff + weff_index(ty, tx, 32 * mt + q, pa, pb, 16 * kb + 8 * h, COUT));
-      const float4 w0 = wp[0], w1 = wp[1];
+    for (int kb = 0; kb < 4; ++kb) {
       Frag f;
-      f.v[0] = (__bf16)w0.x; f.v[1] = (__bf16)w0.y; f.v[2] = (__bf16)w0.z; f.v[3] = (__bf16)w0.w;
-      f.v[4] = (__bf16)w1.x; f.v[5] = (__bf16)w1.y; f.v[6] = (__bf16)w1.z; f.v[7] = (__bf16)w1.w;
+      if (a.pack) {
+        f.u = a.pack[8192 + (((kh * 2 + mt) * 8 + c) * 4 + kb) * 64 + lane];
+      } else {                             // the 8 elements are consecutive output channels: two 16-byte loads
+        const float4* wp = reinterpret_cast<const float4*>(a.weff + weff_index(ty, tx, 32 * mt + q, pa, pb, 16 * kb + 8 * h, COUT));
+        const float4 w0 = wp[0], w1 = wp[1];
+        f.v[0] = (__bf16)w0.x; f.v[1] = (__bf16)w0.y; f.v[2] = (__bf16)w0.z; f.v[3] = (__bf16)w0.w;
+        f.v[4] = (__bf16)w1.x; f.v[5] = (__bf16)w1.y; f.v[6] = (__bf16)w1.z; f.v[7] = (__bf16)w1.w;
+      }
       fr[c][kb] = f.u;
       pin(fr[c][kb]);
     }
@@ -802,13 +822,15 @@ int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& at
 }  // namespace
 
 extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const float* weff, const float* bias, void* y,
-                              int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, rcb_stream_t stream) {
+                              int32_t y_is_f32_linear, int32_t batch, int32_t grid, int32_t cout, const void* frag_pack,
+                              rcb_stream_t stream) {
   RCB_REQUIRE(x && weff && bias && y, RCB_ERR_ARG, "upconv_fwd: null pointer");
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_fwd: empty batch");
-  FwdArgs a{x, weff, bias, y, batch};
+  RCB_REQUIRE((reinterpret_cast<uintptr_t>(frag_pack) & 15) == 0, RCB_ERR_ARG, "upconv_fwd: frag_pack must be 16-byte aligned");
+  FwdArgs a{x, weff, bias, y, batch, reinterpret_cast<const uint4*>(frag_pack)};
   hipStream_t st = (hipStream_t)stream;
-  constexpr int kFwd2Smem = 2 * 10 * 10 * 72 * 2 + 64 * 4;
-  const int npair = (batch + 1) / 2;
+  constexpr int kFwd2Smem = 4 * 10 * 10 * 72 * 2 + 64 * 4;
+  const int npair = (batch + 3) / 4;
   if (grid == 8 && cout == 64 && x_is_f32_preact == 1 && !y_is_f32_linear) {
     static bool done = false;
     return launch(upconv_fwd2_reg_kernel<1>, a, npair < 256 ? npair : 256, kFwd2Smem, st, done);
@@ -850,10 +872,11 @@ static int launch_dgrad2(const DgradArgs& a, float* dbias_partial, hipStream_t s
 
 extern "C" int rcb_upconv_dgrad(const void* dy, int32_t dy_is_f32, const float* weff, const void* x,
                                 int32_t x_is_f32_preact, void* dx, float* dbias_partial, int32_t batch, int32_t grid,
-                                int32_t cout, rcb_stream_t stream) {
+                                int32_t cout, const void* frag_pack, rcb_stream_t stream) {
   RCB_REQUIRE(dy && weff && x && dx, RCB_ERR_ARG, "upconv_dgrad: null pointer");
   RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_dgrad: empty batch");
-  DgradArgs a{dy, weff, x, dx, batch};
+  RCB_REQUIRE((reinterpret_cast<uintptr_t>(frag_pack) & 15) == 0, RCB_ERR_ARG, "upconv_dgrad: frag_pack must be 16-byte aligned");
+  DgradArgs a{dy, weff, x, dx, batch, reinterpret_cast<const uint4*>(frag_pack)};
   hipStream_t st = (hipStream_t)stream;
   if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 1) return launch_dgrad2<1>(a, dbias_partial, st);
   if (grid == 8 && cout == 64 && !dy_is_f32 && x_is_f32_preact == 2) return launch_dgrad2<0>(a, dbias_partial, st);

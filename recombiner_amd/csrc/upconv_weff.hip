@@ -15,6 +15,18 @@ namespace {
 
 __device__ __forceinline__ int tap_of(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0); }
 
+// one effective weight straight from the 3x3 taps: Weff[ty][tx][ci][a][b][co] = sum_{k in K(a,ty), l in K(b,tx)} W[co][ci][k][l]
+__device__ __forceinline__ float weff_of(const float* __restrict__ W, int ty, int tx, int ci, int a, int b, int co) {
+  const float* w = W + (co * 64 + ci) * 9;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+      if (tap_of(a, k) == ty && tap_of(b, l) == tx) acc += w[k * 3 + l];
+  return acc;
+}
+
 struct WeffArgs {
   const float* W1;   // [64][128][5][5]
   const float* b1;   // [64]
@@ -25,6 +37,7 @@ struct WeffArgs {
   float* weff2;      // [2][2][64][2][2][64]
   float* weff3;      // [2][2][64][2][2][16]
   int bf16_out;
+  uint4* pack;       // nullable: MFMA fragment images for the phase-conv kernels (layout: include/rcb.h)
 };
 
 template <int COUT>
@@ -45,7 +58,7 @@ __device__ __forceinline__ void build_stage(const float* __restrict__ W, float* 
 }
 
 // blocks [0, 512): stage 1, one (input channel i, source pixel st) each; [512, 576): stage 2 per ci;
-// [576, 640): stage 3 per ci; 640: the tiled bias
+// [576, 640): stage 3 per ci; 640: the tiled bias; [641, 641 + 88): the packed MFMA fragments (optional)
 __global__ void __launch_bounds__(256) weff_build_kernel(WeffArgs a) {
   __shared__ float w[64 * 25];
   const int blk = blockIdx.x, tid = threadIdx.x;
@@ -69,12 +82,39 @@ __global__ void __launch_bounds__(256) weff_build_kernel(WeffArgs a) {
     build_stage<64>(a.W2, a.weff2, blk - 512, w, tid);
   } else if (blk < 640) {
     build_stage<16>(a.W3, a.weff3, blk - 576, w, tid);
-  } else {
+  } else if (blk == 640) {
     for (int e = tid; e < 4096; e += 256) {
       const float v = a.b1[e & 63];
       if (a.bf16_out) reinterpret_cast<__bf16*>(a.b1rep)[e] = (__bf16)v;
       else reinterpret_cast<float*>(a.b1rep)[e] = v;
     }
+  } else if (a.pack) {
+    // one 16-byte fragment (8 bf16) per thread, each element summed straight from the conv taps
+    const int e = (blk - 641) * 256 + tid;          // < RCB_UPCONV_PACK_UINT4
+    const int lane = e & 63, q = lane & 31, h = lane >> 5;
+    union { __bf16 v[8]; uint4 u; } f;
+    if (e < 8192) {                                  // F2: stage-2 forward, [ph][mt][ty][tx][kb][lane]
+      const int s5 = e >> 6, kb = s5 & 3, tx = (s5 >> 2) & 1, ty = (s5 >> 3) & 1, mt = (s5 >> 4) & 1, ph = s5 >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)weff_of(a.W2, ty, tx, 16 * kb + 8 * h + j, ph >> 1, ph & 1, 32 * mt + q);
+    } else if (e < 16384) {                          // D2: stage-2 data gradient, [kh][mt][c][kb][lane]
+      const int s5 = (e - 8192) >> 6, kb = s5 & 3, c = (s5 >> 2) & 7, mt = (s5 >> 5) & 1, kh = s5 >> 6;
+      const int n = 8 * kh + c, ry = (n >> 2) - 1, rx = (n & 3) - 1;
+      const int pa = ry & 1, ty = (ry <= 0) ? 1 : 0, pb = rx & 1, tx = (rx <= 0) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)weff_of(a.W2, ty, tx, 32 * mt + q, pa, pb, 16 * kb + 8 * h + j);
+    } else if (e < 20480) {                          // F3: stage-3 forward, [pa][pb][ty][tx][kb][lane]
+      const int s5 = (e - 16384) >> 6, kb = s5 & 3, tx = (s5 >> 2) & 1, ty = (s5 >> 3) & 1, pb = (s5 >> 4) & 1, pa = s5 >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (q < 16) ? (__bf16)weff_of(a.W3, ty, tx, 16 * kb + 8 * h + j, pa, pb, q) : (__bf16)0.f;
+    } else {                                         // D3: stage-3 data gradient, [combo][mt][lane]
+      const int s5 = (e - 20480) >> 6, mt = s5 & 1, n = s5 >> 1;
+      const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
+      const int pa = ry & 1, ty = (ry <= 0) ? 1 : 0, pb = rx & 1, tx = (rx <= 0) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)weff_of(a.W3, ty, tx, 32 * mt + q, pa, pb, 8 * h + j);
+    }
+    a.pack[e] = f.u;
   }
 }
 
@@ -154,10 +194,11 @@ __global__ void __launch_bounds__(256) weff_grad_kernel(WeffGradArgs a) {
 }  // namespace
 
 extern "C" int rcb_upconv_weff_build(const float* W1, const float* b1, const float* W2, const float* W3, void* weff1,
-                                     void* b1rep, int32_t bf16_out, float* weff2, float* weff3, rcb_stream_t stream) {
+                                     void* b1rep, int32_t bf16_out, float* weff2, float* weff3, void* frag_pack,
+                                     rcb_stream_t stream) {
   RCB_REQUIRE(W1 && b1 && W2 && W3 && weff1 && b1rep && weff2 && weff3, RCB_ERR_ARG, "upconv_weff_build: null pointer");
-  WeffArgs a{W1, b1, W2, W3, weff1, b1rep, weff2, weff3, bf16_out ? 1 : 0};
-  weff_build_kernel<<<641, 256, 0, (hipStream_t)stream>>>(a);
+  WeffArgs a{W1, b1, W2, W3, weff1, b1rep, weff2, weff3, bf16_out ? 1 : 0, reinterpret_cast<uint4*>(frag_pack)};
+  weff_build_kernel<<<frag_pack ? 641 + RCB_UPCONV_PACK_UINT4 / 256 : 641, 256, 0, (hipStream_t)stream>>>(a);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

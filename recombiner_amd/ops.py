@@ -479,7 +479,7 @@ def _xmode(x, preact):
     return 2 if preact else 0
 
 
-def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False, linear_bf16=False):
+def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False, linear_bf16=False, pack=None):
     """x [B, g, g, 64] (fp32/bf16 pre-activation or bf16 activation) -> y [B, 2g, 2g, cout]: bf16 with LeakyReLU,
     fp32 linear (out_f32) or bf16 linear (linear_bf16)."""
     lib = _lib.load()
@@ -487,11 +487,11 @@ def upconv_fwd(x, weff, bias, grid, cout, out_f32, preact=False, linear_bf16=Fal
     y = torch.empty(B, 2 * grid, 2 * grid, cout, device=x.device, dtype=f32 if out_f32 else bf16)
     omode = 1 if out_f32 else (2 if linear_bf16 else 0)
     check(lib.rcb_upconv_fwd(ptr(x), _xmode(x, preact), ptr(weff, f32), ptr(bias, f32), ptr(y), omode, B, grid,
-                             cout, stream_ptr()), "rcb_upconv_fwd")
+                             cout, ptr(pack, None, True), stream_ptr()), "rcb_upconv_fwd")
     return y
 
 
-def upconv_dgrad(dy, weff, x, grid, cout, preact=False, want_dbias=False):
+def upconv_dgrad(dy, weff, x, grid, cout, preact=False, want_dbias=False, pack=None):
     """-> dx (dtype of x); with want_dbias (stage-2 geometry) also the [workgroups, 64] partial channel sums of dx."""
     lib = _lib.load()
     B = x.shape[0]
@@ -500,7 +500,7 @@ def upconv_dgrad(dy, weff, x, grid, cout, preact=False, want_dbias=False):
     if want_dbias:
         part = torch.empty(int(lib.rcb_upconv_dgrad_partial_rows(B)), 64, device=x.device, dtype=f32)
     check(lib.rcb_upconv_dgrad(ptr(dy), int(dy.dtype == f32), ptr(weff, f32), ptr(x), _xmode(x, preact), ptr(dx),
-                               ptr(part, f32, True), B, grid, cout, stream_ptr()), "rcb_upconv_dgrad")
+                               ptr(part, f32, True), B, grid, cout, ptr(pack, None, True), stream_ptr()), "rcb_upconv_dgrad")
     return (dx, part) if want_dbias else dx
 
 
@@ -517,8 +517,12 @@ def upconv_wgrad(x, dy, grid, cout, preact=False):
     return dw, db
 
 
+UPCONV_PACK_UINT4 = 22528
+
+
 def upconv_weff_build(W1, b1, W2, W3, bf16_out):
-    """conv weights of the CIFAR-geometry upsampling net -> (Weff1 [512,4096], b1rep [4096], Weff2, Weff3)."""
+    """conv weights of the CIFAR-geometry upsampling net -> (Weff1 [512,4096], b1rep [4096], Weff2, Weff3, pack) where
+    pack holds the stage-2/3 effective weights as pre-ordered bf16 MFMA fragments for upconv_fwd / upconv_dgrad."""
     lib = _lib.load()
     dev = W1.device
     if (tuple(W1.shape), tuple(W2.shape), tuple(W3.shape)) != ((64, 128, 5, 5), (64, 64, 3, 3), (16, 64, 3, 3)):
@@ -528,10 +532,11 @@ def upconv_weff_build(W1, b1, W2, W3, bf16_out):
     b1rep = torch.empty(4096, device=dev, dtype=dt)
     weff2 = torch.empty(2, 2, 64, 2, 2, 64, device=dev, dtype=f32)
     weff3 = torch.empty(2, 2, 64, 2, 2, 16, device=dev, dtype=f32)
+    pack = torch.empty(UPCONV_PACK_UINT4 * 16, device=dev, dtype=torch.uint8)      # bf16 MFMA fragments (include/rcb.h)
     check(lib.rcb_upconv_weff_build(ptr(W1.detach(), f32), ptr(b1.detach(), f32), ptr(W2.detach(), f32),
                                     ptr(W3.detach(), f32), ptr(weff1), ptr(b1rep), int(bool(bf16_out)), ptr(weff2),
-                                    ptr(weff3), stream_ptr()), "rcb_upconv_weff_build")
-    return weff1, b1rep, weff2, weff3
+                                    ptr(weff3), ptr(pack), stream_ptr()), "rcb_upconv_weff_build")
+    return weff1, b1rep, weff2, weff3, pack
 
 
 def upconv_weff_grad(dweff1, dweff2, dweff3, db1_partial=None):

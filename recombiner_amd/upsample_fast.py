@@ -184,24 +184,24 @@ class _UpsampleCifarFn(torch.autograd.Function):
         B = lpe.shape[0]
         # effective (phase-form) weights of all three stages in one launch; bf16 stage 1 = bf16 operands and a bf16 z1
         # (stage 2 rounds z1 to bf16 for its MFMA operand anyway)
-        Weff1, b1rep, Weff2, Weff3 = ops.upconv_weff_build(W1, b1, W2, W3, stage1_bf16)
+        Weff1, b1rep, Weff2, Weff3, pack = ops.upconv_weff_build(W1, b1, W2, W3, stage1_bf16)
         if stage1_bf16:
             lpe = lpe.to(torch.bfloat16)
         z1 = torch.addmm(b1rep, lpe, Weff1).view(B, 8, 8, 64)
-        h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True)
-        pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=not pe_bf16, linear_bf16=pe_bf16)
-        ctx.save_for_backward(lpe, Weff1, z1, Weff2, h2, Weff3)
+        h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True, pack=pack)
+        pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=not pe_bf16, linear_bf16=pe_bf16, pack=pack)
+        ctx.save_for_backward(lpe, Weff1, z1, Weff2, h2, Weff3, pack)
         return pe.view(B, 1024, 16)
 
     @staticmethod
     def backward(ctx, dpe):
         from . import ops
-        lpe, Weff1, z1, Weff2, h2, Weff3 = ctx.saved_tensors
+        lpe, Weff1, z1, Weff2, h2, Weff3, pack = ctx.saved_tensors
         B = lpe.shape[0]
         need_w = any(ctx.needs_input_grad[1:7])
         dpe = dpe.contiguous().view(B, 32, 32, 16)
-        dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16)                     # bf16 [B,16,16,64]
-        dz1, db1_part = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, want_dbias=True)   # [B,8,8,64], dtype of z1
+        dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16, pack=pack)          # bf16 [B,16,16,64]
+        dz1, db1_part = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, want_dbias=True, pack=pack)   # [B,8,8,64]
         dz1f = dz1.view(B, 4096)
         dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
         if not need_w:

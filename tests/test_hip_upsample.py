@@ -85,7 +85,7 @@ def test_effective_weight_kernels_match_einsum():
     ref1 = torch.einsum("ysk,xtl,oikl->stiyxo", M, M, W1.double()).reshape(512, 4096)
     ref2, ref3 = st.eff_weight(W2.double()), st.eff_weight(W3.double())
     for bf in (False, True):
-        e1, b1rep, e2, e3 = ops.upconv_weff_build(W1, b1, W2, W3, bf)
+        e1, b1rep, e2, e3, pack = ops.upconv_weff_build(W1, b1, W2, W3, bf)
         assert e1.dtype == (torch.bfloat16 if bf else torch.float32)
         assert rel(e1, ref1) < (5e-3 if bf else 1e-6) and rel(e2, ref2) < 1e-6 and rel(e3, ref3) < 1e-6
         assert torch.equal(b1rep.float().view(64, 64), b1.to(b1rep.dtype).float().expand(64, 64))
@@ -102,3 +102,28 @@ def test_effective_weight_kernels_match_einsum():
     d1b, _, _ = ops.upconv_weff_grad(g1.bfloat16(), g2, g3)
     r1b = torch.einsum("ysk,xtl,stiyxo->oikl", M, M, g1.bfloat16().double().view(2, 2, 128, 8, 8, 64))
     assert rel(d1b, r1b) < 1e-6
+
+
+def test_packed_fragments_give_the_same_kernels_results():
+    """rcb_upconv_weff_build's fragment pack vs fragments built inside the kernels from the fp32 effective weights:
+    both round the same fp32 values to bf16 (sums of the same taps in a different order: equal to 1 bf16 ulp)"""
+    from recombiner_amd import ops
+    torch.manual_seed(8)
+    W1 = torch.randn(64, 128, 5, 5, device=DEV) * 0.05
+    b1 = torch.randn(64, device=DEV)
+    W2 = torch.randn(64, 64, 3, 3, device=DEV) * 0.05
+    W3 = torch.randn(16, 64, 3, 3, device=DEV) * 0.05
+    _, _, Weff2, Weff3, pack = ops.upconv_weff_build(W1, b1, W2, W3, True)
+    B = 37
+    z1 = torch.randn(B, 8, 8, 64, device=DEV).bfloat16()
+    h2 = torch.randn(B, 16, 16, 64, device=DEV).bfloat16()
+    dz2 = torch.randn(B, 16, 16, 64, device=DEV).bfloat16()
+    dpe = torch.randn(B, 32, 32, 16, device=DEV).bfloat16()
+    b2, b3 = torch.randn(64, device=DEV), torch.randn(16, device=DEV)
+    pairs = [(ops.upconv_fwd(z1, Weff2, b2, 8, 64, out_f32=False, preact=True, pack=pk),
+              ops.upconv_fwd(h2, Weff3, b3, 16, 16, out_f32=False, linear_bf16=True, pack=pk),
+              ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, pack=pk),
+              ops.upconv_dgrad(dpe, Weff3, h2, 16, 16, pack=pk)) for pk in (None, pack)]
+    for a, b in zip(*pairs):
+        assert rel(a, b) < 1e-2
+        assert float((a.float() - b.float()).abs().mean() / b.float().abs().mean()) < 1e-3
