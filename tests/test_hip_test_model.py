@@ -237,3 +237,71 @@ def test_bitstream_round_trip_three_levels(name):
         bitstream.apply_indices(m3, levels[:1])                # a level missing
     with pytest.raises(ValueError):
         bitstream.encode(m3)                                   # nothing encoded yet
+
+
+def test_end_to_end_cifar_full_compression_matches_reference_psnr():
+    """The COMPLETE compression of the reference run (golden e2e_cifar.npz: 12 optimisation epochs, then every one of the
+    1511 groups A*-encoded with 2 fine-tune epochs per round, CPU noise stream): same rate by construction (one 16-bit
+    index per group and image), PSNR per image within 0.1 dB of the reference's, most A* indices identical, and the
+    standalone decoder reproduces the encoder's reconstruction from the bitstream."""
+    from recombiner_amd import bitstream
+    from recombiner_amd.utils import metric
+    d = load("test_cifar.npz")
+    e = load("e2e_cifar.npz")
+    cfg, n, m = build(d, "cifar")
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    Y = t(d, "Y").to(DEV)
+    m.noise_source = lambda kind, shape: torch.randn(shape)        # the reference's CPU stream (reseeded per epoch)
+    m.optimize_posteriors(X, Y, n_epochs=12, lr=2e-4, verbose=False)
+    dist = m.compress_posteriors(X, Y, n_epochs_finetune=2, h_n_epochs_finetune=2, hh_n_epochs_finetune=2, verbose=False,
+                                 lr=2e-4, fine_tune_gap=1)
+    lv = m._l1
+    assert lv.mask_groupwise.all() and lv.idx_groupwise.shape == e["idx"].shape
+    ref = np.asarray(e["distortion"], dtype=np.float64)
+    agree = float((lv.idx_groupwise == e["idx"]).mean())
+    print("full e2e: PSNR ours", np.round(dist, 3), "reference", np.round(ref, 3), "index agreement %.3f" % agree)
+    np.testing.assert_allclose(dist, ref, rtol=0, atol=0.1)          # dB, per image
+    assert abs(float(np.mean(dist)) - float(np.mean(ref))) < 0.05
+    assert agree > 0.5                                               # ties of near-equal candidates flip; most do not
+    # rate: one 16-bit index per (image, group) -- identical to the reference's bpp by construction
+    blob = bitstream.encode(m)
+    assert bitstream.payload_bits(blob) == n * lv.n_groups * 16
+    assert m.bpp == pytest.approx(lv.n_groups * 16 / 1024)
+    # decoder: bitstream -> parameters -> reconstruction; PSNR of the decoded images == the encoder's report
+    _, _, m2 = build(d, "cifar")
+    bitstream.apply_indices(m2, bitstream.unpack_indices(blob))
+    assert torch.equal(m2._l1.sample, lv.sample)
+    with torch.no_grad():
+        y_dec = m2.predict(X)
+    np.testing.assert_allclose(metric(Y.cpu().numpy(), y_dec.cpu().numpy(), "cifar"), dist, rtol=0, atol=1e-3)
+    # the reference's own final reconstruction, scored the same way, gives the reference's distortion (fixture sanity)
+    np.testing.assert_allclose(metric(Y.cpu().numpy(), e["final_pred"], "cifar"), ref, rtol=0, atol=1e-3)
+
+
+def test_end_to_end_patched_full_compression_matches_reference_psnr():
+    """Same for the three-level (audio-like) patched preset: levels 3, 2, 1 encoded in full with 2 fine-tune epochs per
+    round (golden e2e_patch1d.npz); distortion within tolerance of the reference's, decoder round trip exact."""
+    from recombiner_amd import bitstream
+    from recombiner_amd.utils import metric
+    d = load("test_patch1d.npz")
+    e = load("e2e_patch1d.npz")
+    cfg, n, m = build(d, "patch1d")
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    Y = t(d, "Y").to(DEV)
+    m.noise_source = lambda kind, shape: torch.randn(shape)
+    m.optimize_posteriors(X, Y, n_epochs=12, lr=2e-4, verbose=False)
+    dist = np.asarray(m.compress_posteriors(X, Y, n_epochs_finetune=2, h_n_epochs_finetune=2, hh_n_epochs_finetune=2,
+                                            verbose=False, lr=2e-4, fine_tune_gap=1), dtype=np.float64)
+    ref = np.asarray(e["distortion"], dtype=np.float64)
+    agree = [float((lv.idx_groupwise == e[k]).mean()) for lv, k in ((m._l3, "hh_idx"), (m._l2, "h_idx"), (m._l1, "idx"))]
+    print("full patched e2e: distortion ours", np.round(dist, 3), "reference", np.round(ref, 3), "index agreement (L3, L2, L1)",
+          np.round(agree, 3))
+    assert dist.shape == ref.shape
+    np.testing.assert_allclose(dist, ref, rtol=0, atol=0.15)
+    assert abs(float(dist.mean()) - float(ref.mean())) < 0.08
+    assert agree[0] > 0.5
+    blob = bitstream.encode(m)
+    _, _, m2 = build(d, "patch1d")
+    bitstream.apply_indices(m2, bitstream.unpack_indices(blob))
+    for a, b in zip((m._l1, m._l2, m._l3), (m2._l1, m2._l2, m2._l3)):
+        assert torch.equal(a.sample, b.sample)
