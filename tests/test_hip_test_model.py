@@ -239,8 +239,10 @@ def test_bitstream_round_trip_three_levels(name):
         bitstream.encode(m3)                                   # nothing encoded yet
 
 
-def test_end_to_end_cifar_full_compression_matches_reference_psnr():
-    """The COMPLETE compression of the reference run (golden e2e_cifar.npz: 12 optimisation epochs, then every one of the
+@pytest.mark.parametrize("precision", [0, 1])
+def test_end_to_end_cifar_full_compression_matches_reference_psnr(precision):
+    """(precision 0 = fp32 parity mode, 1 = the bf16 throughput mode: same rate, PSNR within 0.25 dB.)
+    The COMPLETE compression of the reference run (golden e2e_cifar.npz: 12 optimisation epochs, then every one of the
     1511 groups A*-encoded with 2 fine-tune epochs per round, CPU noise stream): same rate by construction (one 16-bit
     index per group and image), PSNR per image within 0.1 dB of the reference's, most A* indices identical, and the
     standalone decoder reproduces the encoder's reconstruction from the bitstream."""
@@ -249,6 +251,7 @@ def test_end_to_end_cifar_full_compression_matches_reference_psnr():
     d = load("test_cifar.npz")
     e = load("e2e_cifar.npz")
     cfg, n, m = build(d, "cifar")
+    m.precision = precision
     X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
     Y = t(d, "Y").to(DEV)
     m.noise_source = lambda kind, shape: torch.randn(shape)        # the reference's CPU stream (reseeded per epoch)
@@ -259,16 +262,19 @@ def test_end_to_end_cifar_full_compression_matches_reference_psnr():
     assert lv.mask_groupwise.all() and lv.idx_groupwise.shape == e["idx"].shape
     ref = np.asarray(e["distortion"], dtype=np.float64)
     agree = float((lv.idx_groupwise == e["idx"]).mean())
-    print("full e2e: PSNR ours", np.round(dist, 3), "reference", np.round(ref, 3), "index agreement %.3f" % agree)
-    np.testing.assert_allclose(dist, ref, rtol=0, atol=0.1)          # dB, per image
-    assert abs(float(np.mean(dist)) - float(np.mean(ref))) < 0.05
-    assert agree > 0.5                                               # ties of near-equal candidates flip; most do not
+    print("full e2e (precision %d): PSNR ours" % precision, np.round(dist, 3), "reference", np.round(ref, 3),
+          "index agreement %.3f" % agree)
+    np.testing.assert_allclose(dist, ref, rtol=0, atol=0.1 if precision == 0 else 0.25)          # dB, per image
+    assert abs(float(np.mean(dist)) - float(np.mean(ref))) < (0.05 if precision == 0 else 0.15)
+    if precision == 0:
+        assert agree > 0.5                                           # ties of near-equal candidates flip; most do not
     # rate: one 16-bit index per (image, group) -- identical to the reference's bpp by construction
     blob = bitstream.encode(m)
     assert bitstream.payload_bits(blob) == n * lv.n_groups * 16
     assert m.bpp == pytest.approx(lv.n_groups * 16 / 1024)
     # decoder: bitstream -> parameters -> reconstruction; PSNR of the decoded images == the encoder's report
     _, _, m2 = build(d, "cifar")
+    m2.precision = precision
     bitstream.apply_indices(m2, bitstream.unpack_indices(blob))
     assert torch.equal(m2._l1.sample, lv.sample)
     with torch.no_grad():
