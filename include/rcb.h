@@ -198,6 +198,11 @@ typedef struct {
 } rcb_adam_tensor;
 int rcb_adam_multi(const rcb_adam_tensor* tensors, int32_t count, const rcb_adam_cfg* cfg, rcb_stream_t stream);
 
+/* Test hook: on != 0 forces the generic kernels of rcb_reparam_fwd / rcb_posterior_bwd even where a specialised one
+ * (flat 16-byte path, LDS-staged gather) applies; returns the previous setting.  The specialised kernels perform the
+ * same operations in the same order, so both settings must give identical bits (tests/test_hip_kernels.py).     */
+int rcb_debug_generic_kernels_only(int32_t on);
+
 /* Split-bf16 GEMM operands (K2: the dense A transform `h_w @ A[l]`, prior_model.py:101-127, and its data gradient, on
  * the bf16 matrix cores at fp32 accuracy): x = hi + lo, hi = bf16(x), lo = bf16(x - hi).  For every item (all of one
  * shape) writes  out[r * out_row_stride + blk * out_block_stride + c] = (lo_mask >> blk) & 1 ? lo[r, c] : hi[r, c]

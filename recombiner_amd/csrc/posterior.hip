@@ -55,6 +55,15 @@ extern "C" int rcb_softplus_scale(const float* log_scale, float* scale, int64_t 
   return RCB_OK;
 }
 
+// test hook: 0 (default) = specialised kernels (flat 16-byte paths, LDS-staged gathers) where they apply;
+// 1 = always the generic kernels.  Lets the tests compare both on identical shapes.
+static int g_generic_only = 0;
+extern "C" int rcb_debug_generic_kernels_only(int32_t on) {
+  int old = g_generic_only;
+  g_generic_only = on ? 1 : 0;
+  return old;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1 / K10 reparam forward
 // ------------------------------------------------------------------------------------------
@@ -82,6 +91,8 @@ __device__ __forceinline__ void level_mu_sigma(const rcb_level& L, int n, int d,
   sig = s;
 }
 
+// one thread per (INR, column): mu and sigma -- which may sit behind row / column permutations, i.e. scattered reads --
+// are fetched once and reused for all samples of the INR
 __global__ void reparam_fwd_kernel(ReparamArgs a) {
   int n = blockIdx.x;
   int d = blockIdx.y * blockDim.x + threadIdx.x;
@@ -107,6 +118,39 @@ __global__ void reparam_fwd_kernel(ReparamArgs a) {
       }
     }
     a.out[row * a.out_cols + d] = acc;
+  }
+}
+
+// Test-time layout (parameters stored in group order, read back through a column map): mu / sigma gathers are
+// scattered 4-byte reads, i.e. a 64-byte sector each.  One block per INR stages that INR's parameter rows in LDS with
+// coalesced loads and does the permuted reads there.  One level, no row maps.  Same arithmetic as the generic kernel.
+__global__ void __launch_bounds__(1024) reparam_staged_kernel(ReparamArgs a) {
+  extern __shared__ float sm[];                 // [4][cols]: loc, log_scale, enc_mask, enc_sample
+  const rcb_level& L = a.lv[0];
+  const int n = blockIdx.x, cols = L.cols;
+  const long long base = (long long)n * cols;
+  for (int i = threadIdx.x; i < cols; i += 1024) {
+    sm[i] = L.loc[base + i];
+    sm[cols + i] = L.log_scale[base + i];
+    if (L.enc_mask) {
+      sm[2 * cols + i] = L.enc_mask[base + i];
+      sm[3 * cols + i] = L.enc_sample[base + i];
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < a.out_cols; d += 1024) {
+    const int j = L.col_map ? L.col_map[d] : d;
+    float loc = sm[j];
+    float sg = st_f32(sm[cols + j]);
+    if (L.enc_mask) {
+      const float m = sm[2 * cols + j], z = sm[3 * cols + j];
+      loc = add_rn(mul_rn(loc, 1.0f - m), mul_rn(z, m));
+      sg = add_rn(mul_rn(sg, 1.0f - m), mul_rn(1e-15f, m));
+    }
+    for (int sidx = 0; sidx < a.samples; ++sidx) {
+      const long long row = (long long)n * a.samples + sidx;
+      a.out[row * a.out_cols + d] = add_rn(loc, mul_rn(sg, L.eps[row * L.cols_out + d]));
+    }
   }
 }
 
@@ -157,8 +201,8 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
   {
     const rcb_level& L = a.lv[0];
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (n_levels == 1 && samples == 1 && !L.enc_mask && !L.row_map && !L.row_perm && !L.col_map && L.cols == out_cols &&
-        L.rows == n_inr && al16(L.loc) && al16(L.log_scale) && al16(L.eps) && al16(out)) {
+    if (!g_generic_only && n_levels == 1 && samples == 1 && !L.enc_mask && !L.row_map && !L.row_perm && !L.col_map &&
+        L.cols == out_cols && L.rows == n_inr && al16(L.loc) && al16(L.log_scale) && al16(L.eps) && al16(out)) {
       const long long n = (long long)n_inr * out_cols;
       int blocks = cdiv(n >> 2, 256);
       if (blocks > 16384) blocks = 16384;
@@ -167,6 +211,19 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
       RCB_LAUNCH_CHECK();
       return RCB_OK;
     }
+  }
+  if (!g_generic_only && n_levels == 1 && a.lv[0].col_map && !a.lv[0].row_map && !a.lv[0].row_perm && a.lv[0].rows == n_inr &&
+      a.lv[0].cols_out == out_cols && (size_t)a.lv[0].cols * 16 <= 150 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reparam_staged_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail((int)e, "reparam_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_done = true;
+    }
+    reparam_staged_kernel<<<n_inr, 1024, (size_t)a.lv[0].cols * 16, (hipStream_t)stream>>>(a);
+    RCB_LAUNCH_CHECK();
+    return RCB_OK;
   }
   dim3 grid(n_inr, cdiv(out_cols, 256));
   RCB_REQUIRE(grid.y <= 65535, RCB_ERR_SHAPE, "reparam_fwd: too many columns");
@@ -394,6 +451,83 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   if (L.g_log_scale) L.g_log_scale[o] = g_ls;
 }
 
+// Test-time layout: the gradient / noise slabs [S][cols_out] of one INR are read through the inverse column map, i.e.
+// with scattered 4-byte reads (a 64-byte sector each).  One 1024-thread block per parameter row stages both slabs in
+// LDS with coalesced loads; the permuted reads then hit LDS.  No hierarchy members, no row permutation; everything
+// else (encode mask, per-group beta, KL log, Adam) as in the generic kernel, same operation order: bit-identical.
+__global__ void __launch_bounds__(1024) posterior_staged_kernel(PostBwdArgs a) {
+  extern __shared__ float sm[];                   // [S * cols_out] d_out, [S * cols_out] eps
+  const rcb_level_bwd& L = a.L;
+  const int r = blockIdx.x;
+  const int slab = L.samples * L.cols_out;
+  {
+    const float* sg = L.d_out + (long long)r * slab;
+    const float* se = L.eps + (long long)r * slab;
+    for (int i = threadIdx.x; i < slab; i += 1024) {
+      sm[i] = sg[i];
+      sm[slab + i] = se[i];
+    }
+  }
+  __syncthreads();
+  double kl = 0.0;
+  for (int j = threadIdx.x; j < L.cols; j += 1024) {
+    const long long o = (long long)r * L.cols + j;
+    float loc = L.loc[o];
+    float ls = L.log_scale[o];
+    const float sig = st_f32(ls);
+    float g_mu = 0.f, g_sig = 0.f;
+    const int d = L.col_inv ? L.col_inv[j] : j;
+    if (d < L.cols_out) {
+      for (int s = 0; s < L.samples; ++s) {
+        const float go = sm[s * L.cols_out + d];
+        g_mu = add_rn(g_mu, go);
+        g_sig = add_rn(g_sig, mul_rn(go, sm[slab + s * L.cols_out + d]));
+      }
+      if (L.enc_mask) {
+        const float keep = 1.0f - L.enc_mask[o];
+        g_mu = mul_rn(g_mu, keep);
+        g_sig = mul_rn(g_sig, keep);
+      }
+    }
+    float w = L.kl_scalar;
+    if (L.beta) w = mul_rn(w, L.beta[(long long)r * L.n_groups + L.group_idx[j]]);
+    if (L.kl_accum) {
+      const float spk = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
+      kl += (double)kl_elem_f32(loc, sig, L.p_loc[j], spk);
+    }
+    if (w != 0.0f) {
+      const float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
+      kl_grad_add(loc, sig, L.p_loc[j], sp, w, g_mu, g_sig);
+    }
+    const float g_ls = mul_rn(g_sig, dst_f32(ls));
+    if (a.adam.enabled) {
+      float m1 = L.m_loc[o], v1 = L.v_loc[o], m2 = L.m_ls[o], v2 = L.v_ls[o];
+      adam_apply(loc, g_mu, m1, v1, a.adam);
+      adam_apply(ls, g_ls, m2, v2, a.adam);
+      L.loc[o] = loc;
+      L.log_scale[o] = ls;
+      L.m_loc[o] = m1;
+      L.v_loc[o] = v1;
+      L.m_ls[o] = m2;
+      L.v_ls[o] = v2;
+    }
+    if (L.g_loc) L.g_loc[o] = g_mu;
+    if (L.g_log_scale) L.g_log_scale[o] = g_ls;
+  }
+  if (L.kl_accum) {
+    __shared__ double s_kl[16];
+    const double kv = wave_sum(kl);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int k = 0; k < 16; ++k) t += s_kl[k];
+      atomicAdd(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), t);
+    }
+  }
+}
+
 // Fast path of the kernel above for the plain case (prior training of un-patched presets): one sample, no hierarchy /
 // permutation / column maps, no encode mask, no per-group beta, Adam enabled, every column produced.  Purely
 // elementwise over the flat [rows * cols] arrays with 16-byte accesses (rows of 3267 floats are not 16-byte aligned,
@@ -466,7 +600,20 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const long long n_total = (long long)lv->rows * lv->cols;
-    if (adam && lv->d_out && lv->samples == 1 && lv->cols_out == lv->cols && !lv->enc_mask && !lv->beta && !lv->member_ptr &&
+    if (!g_generic_only && lv->d_out && lv->col_inv && !lv->member_ptr && !lv->row_perm_inv &&
+        (size_t)lv->samples * lv->cols_out * 8 <= 150 * 1024) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(posterior_staged_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   // + 128 B static
+        if (e != hipSuccess) return fail((int)e, "posterior_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+      }
+      posterior_staged_kernel<<<lv->rows, 1024, (size_t)lv->samples * lv->cols_out * 8, (hipStream_t)stream>>>(a);
+      RCB_LAUNCH_CHECK();
+      return RCB_OK;
+    }
+    if (!g_generic_only && adam && lv->d_out && lv->samples == 1 && lv->cols_out == lv->cols && !lv->enc_mask && !lv->beta && !lv->member_ptr &&
         !lv->row_perm_inv && !lv->col_inv && !lv->g_loc && !lv->g_log_scale && (n_total & 3) == 0 && al16(lv->loc) &&
         al16(lv->log_scale) && al16(lv->d_out) && al16(lv->eps) && al16(lv->m_loc) && al16(lv->v_loc) && al16(lv->m_ls) &&
         al16(lv->v_ls)) {

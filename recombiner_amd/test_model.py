@@ -208,9 +208,14 @@ class TestBNNmodel(nn.Module):
     def _draw_all(self, S):
         """noise in the reference's draw order: lpe [S,N,Dlpe], level-1 [N,S,Dnet], level-2, level-3."""
         N, D, Dt = self._n, self._d_net, self._l1.D
-        e_lpe = self._draw("lpe", (S, N, Dt - D))
-        e1 = self._draw("l1", (N, S, D))
-        eps1 = torch.cat([e1, e_lpe.permute(1, 0, 2)], -1).contiguous()
+        if self.noise_source is None:
+            # production: the GPU generator's stream differs from the reference's CPU stream anyway, so the level-1 and
+            # lpe noise is drawn as ONE tensor in the layout the kernels read (no concatenation copy)
+            eps1 = self._draw("l1", (N, S, Dt))
+        else:
+            e_lpe = self._draw("lpe", (S, N, Dt - D))
+            e1 = self._draw("l1", (N, S, D))
+            eps1 = torch.cat([e1, e_lpe.permute(1, 0, 2)], -1).contiguous()
         eps = [eps1]
         if self.patch:
             eps.append(self._draw("l2", (N, S, D)).contiguous())
@@ -489,14 +494,24 @@ class TestBNNmodel(nn.Module):
             else:
                 sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta)
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
-            dh = torch.empty(N * S, D, device=dev, dtype=torch.float32)
+            Dt = self._l1.D
+            if self.patch:        # levels 2 and 3 need the contiguous [N, S, D] gradient as well
+                dh = torch.empty(N * S, D, device=dev, dtype=torch.float32)
+                d_full = None
+            else:                 # the GEMMs write straight into the level-1 gradient buffer [N, S, D + Dlpe]
+                d_full = torch.empty(N, S, Dt, device=dev, dtype=torch.float32)
+                dh = d_full.view(N * S, Dt)[:, :D]
             if split is not None:
                 split.dgrad(dw, dh, dw_split)
             else:
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(dw[:, lo:hi], a.t(), out=dh[:, lo:hi])
-            dh3 = dh.view(N, S, D)
-            d_full = torch.cat([dh3, d_lpe.reshape(S, N, -1).permute(1, 0, 2)], -1).contiguous()
+            if d_full is None:
+                dh3 = dh.view(N, S, D)
+                d_full = torch.cat([dh3, d_lpe.reshape(S, N, -1).permute(1, 0, 2)], -1).contiguous()
+            else:
+                dh3 = None
+                d_full[:, :, D:].copy_(d_lpe.reshape(S, N, -1).permute(1, 0, 2))
             grp = [self._group_kls(lv) for lv in self._levels] if adjust else None
             for li, (lv, sp, e, stt) in enumerate(zip(self._levels, specs, eps, states)):
                 ops.posterior_bwd(sp, lv.p_loc, lv.p_log_scale, True, 1.0, d_full if li == 0 else dh3, e, S,

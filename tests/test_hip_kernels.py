@@ -406,6 +406,46 @@ def test_posterior_flat_fast_path_equals_generic_kernel():
     assert k0 == pytest.approx(k1, rel=1e-12) and k0 > 0
 
 
+def test_lds_staged_gather_kernels_equal_generic_kernels():
+    """test-time layout (column permutation, encode mask, per-group beta, S = 5): the LDS-staged reparam and posterior
+    kernels against the generic ones (rcb_debug_generic_kernels_only) on identical inputs: identical bits."""
+    from recombiner_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(23)
+    n, D, S, G = 6, 3779, 5, 400
+    perm = torch.randperm(D, generator=gen).numpy()
+    loc = 0.02 * torch.randn(n, D, generator=gen)
+    ls = -4 + 0.5 * torch.randn(n, D, generator=gen)
+    mask = (torch.rand(n, D, generator=gen) < 0.3).float()
+    samp = 0.02 * torch.randn(n, D, generator=gen)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    pls = -3 + 0.2 * torch.randn(D, generator=gen)
+    gidx = torch.sort(torch.randint(0, G, (D,), generator=gen)).values.int()
+    beta = torch.rand(n, G, generator=gen) * 1e-3
+    eps = g(torch.randn(n, S, D, generator=gen))
+    Gm = g(torch.randn(n, S, D, generator=gen) * 1e-3)
+    outs = []
+    for generic in (1, 0):
+        lib.rcb_debug_generic_kernels_only(generic)
+        try:
+            dl, ds = g(loc.clone()), g(ls.clone())
+            lv = LevelSpec(dl, ds, D, n, col_map=perm, enc_sample=g(samp), enc_mask=g(mask))
+            h = ops.reparam_fwd([lv], [eps], S)
+            state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+            slots = torch.zeros(1024, device=DEV, dtype=torch.float64)
+            for step in (1, 2):
+                ops.posterior_bwd(lv, g(pl), g(pls), True, 1.0, Gm, eps, S, beta=g(beta), group_idx=g(gidx), n_groups=G,
+                                  adam=ops.adam_cfg(2e-4, step), state=state, kl_accum=slots)
+            outs.append((h, dl, ds, state, float(slots.sum())))
+        finally:
+            lib.rcb_debug_generic_kernels_only(0)
+    (h0, l0, s0, st0, k0), (h1, l1, s1, st1, k1) = outs
+    assert torch.equal(h0, h1)
+    assert torch.equal(l0, l1) and torch.equal(s0, s1) and all(torch.equal(st0[k], st1[k]) for k in st0)
+    assert k0 == pytest.approx(k1, rel=1e-12) and k0 > 0
+    assert float((l0 - g(loc)).abs().max()) > 0          # the update did something
+
+
 # ---------------------------------------------------------------------------------------------------
 # KL family, annealing, moments
 # ---------------------------------------------------------------------------------------------------
