@@ -602,6 +602,9 @@ class SplitATransform:
         big = max(widths)
         self.fast = [i for i, w in enumerate(widths) if w == big and w % 2 == 0 and w >= 256]
         self.rest = [i for i in range(len(widths)) if i not in self.fast]
+        # wide layers adjacent and in order (true for the SIREN layer vectors): their outputs form one [rows, k * W] block
+        self._contiguous_fast = all(self.slices[a][1] == self.slices[b][0] for a, b in zip(self.fast, self.fast[1:])) and \
+            all(b == a + 1 for a, b in zip(self.fast, self.fast[1:]))
         self.a_rows = self.a_cols = None
         self._last = {False: None, True: None}      # split left operands of the last forward / dgrad call
 
@@ -644,9 +647,22 @@ class SplitATransform:
         if lefts is None:        # (the producer of x may already have written its split form: siren dw_split, reparam)
             lefts = split_bf16([x[:, lo:hi] for lo, hi in (self.slices[i] for i in self.fast)], "cols", 0b010)
         self._last[transpose] = lefts
-        for k, i in enumerate(self.fast):
-            lo, hi = self.slices[i]
-            torch.mm(lefts[k], right[k].t() if transpose else right[k], out_dtype=f32, out=out[:, lo:hi])
+        batched = False
+        if self._contiguous_fast and hasattr(lefts, "stacked") and hasattr(right, "stacked") and len(self.fast) > 1:
+            # one batched GEMM over the wide layers, written straight into their column slices of `out`
+            # ([k, rows, W] view with strides (W, ld, 1)): better CU fill than one layer at a time
+            lo0 = self.slices[self.fast[0]][0]
+            k, w = len(self.fast), self.slices[self.fast[0]][1] - lo0
+            try:
+                view = out[:, lo0:lo0 + k * w].view(out.shape[0], k, w).permute(1, 0, 2)
+                torch.bmm(lefts.stacked, right.stacked.transpose(1, 2) if transpose else right.stacked, out_dtype=f32, out=view)
+                batched = True
+            except RuntimeError:
+                batched = False
+        if not batched:
+            for k, i in enumerate(self.fast):
+                lo, hi = self.slices[i]
+                torch.mm(lefts[k], right[k].t() if transpose else right[k], out_dtype=f32, out=out[:, lo:hi])
         for i in self.rest:
             lo, hi = self.slices[i]
             a = self.A[i].detach()
