@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
-from .upsample_fast import hip_path_supported, upsample_cifar_hip
+from .upsample_fast import hip_path_supported, phase_form_preferred, phase_module, upsample_cifar_hip
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs
 
 
@@ -133,7 +133,10 @@ class PriorBNNmodel(nn.Module):
         if self.precision != 0 and hip_path_supported(upsample_net, self.pixel_sizes, self.upsample_factors, self.patch,
                                                       self.data_dim):
             return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
-        return map_lpe_to_inr_inputs(upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
+        net = upsample_net
+        if self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
+            net = phase_module(upsample_net) or upsample_net       # torch-level phase form: same function, fewer flops
+        return map_lpe_to_inr_inputs(net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
                                      self.patch, self.patch_nums, self.data_dim)
 
     def _noise(self, shape):

@@ -20,7 +20,7 @@ from torch.optim import Adam
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
-from .upsample_fast import hip_path_supported, upsample_cifar_hip
+from .upsample_fast import hip_path_supported, phase_form_preferred, phase_module, upsample_cifar_hip
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs, metric
 
 LN2 = np.log(2.)
@@ -235,7 +235,10 @@ class TestBNNmodel(nn.Module):
         if self.precision != 0 and hip_path_supported(self.upsample_net, self.pixel_sizes, self.upsample_factors,
                                                       self.patch, self.data_dim):
             return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
-        return map_lpe_to_inr_inputs(self.upsample_net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
+        net = self.upsample_net
+        if self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
+            net = phase_module(self.upsample_net) or self.upsample_net
+        return map_lpe_to_inr_inputs(net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
                                      self.patch, self.patch_nums, self.data_dim)
 
     def _pe_from_sample(self, sample, S):

@@ -224,3 +224,24 @@ def upsample_cifar_hip(net, lpe, stage1_bf16=True, pe_bf16=True):
                                 net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias, bool(stage1_bf16),
                                 bool(pe_bf16))
     return pe.view(N, S, 1024, 16)
+
+
+def phase_form_preferred(data_dim, patch):
+    """Measured on MI355X (tools/bench_upsample_presets.py, fwd + bwd): against torch.nn -> MIOpen the torch-level phase
+    form is 13x faster on the 3-D video geometry (22 vs 289 ms) and 3.5x faster on many small un-patched signals
+    (protein: 3.5 vs 12 ms); on the large stitched 1-D / 2-D grids of the patched audio / Kodak presets MIOpen is 2-3x
+    faster.  Used only where the hand-written kernels do not apply."""
+    return data_dim == 3 or not patch
+
+
+def phase_module(net):
+    """UpsampleFast wrapper of `net`, built once and cached on the module (shares its parameters); None if the
+    geometry has no phase plan."""
+    fast = getattr(net, "_rcb_phase_form", None)
+    if fast is None:
+        try:
+            fast = UpsampleFast(net)
+        except ValueError:
+            fast = False
+        object.__setattr__(net, "_rcb_phase_form", fast)       # not a registered sub-module: no parameter duplication
+    return fast or None

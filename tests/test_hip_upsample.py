@@ -127,3 +127,26 @@ def test_packed_fragments_give_the_same_kernels_results():
     for a, b in zip(*pairs):
         assert rel(a, b) < 1e-2
         assert float((a.float() - b.float()).abs().mean() / b.float().abs().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["protein", "video"])
+def test_phase_form_routing_for_other_geometries(name):
+    """16-bit mode, geometries without hand-written kernels: the 3-D and the un-patched 1-D presets go through the
+    torch-level phase form, which must reproduce the plain module (forward and gradients) to fp32 rounding."""
+    from recombiner_amd import config
+    from recombiner_amd.upsample_fast import phase_form_preferred, phase_module
+    c = config.configs[name]
+    assert phase_form_preferred(c["data_dim"], c["patch"]) and not phase_form_preferred(2, True)
+    torch.manual_seed(2)
+    net = PM.Upsample(c["data_dim"], c["paddings"], c["layerwise_scale_factors"]).to(DEV)
+    fast = phase_module(net)
+    assert fast is not None and phase_module(net) is fast                   # cached, parameters shared
+    assert len(list(net.parameters())) == 6
+    lat = [c["pixel_sizes"][i] // c["upsample_factors"][i] * (c["patch_nums"][i] if c["patch"] else 1) for i in range(c["data_dim"])]
+    x = torch.randn(3, 128, *lat, device=DEV, requires_grad=True)
+    y0, y1 = net(x), fast(x)
+    assert rel(y1, y0) < 1e-4
+    g = torch.randn_like(y0)
+    g0 = torch.autograd.grad(y0, [x] + list(net.parameters()), g)
+    g1 = torch.autograd.grad(y1, [x] + list(net.parameters()), g)
+    assert max(rel(a, b) for a, b in zip(g1, g0)) < 3e-2                    # MIOpen's own fp32 algorithms differ by ~2e-2
