@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
     ap.add_argument("--lowp-gemm", action="store_true", help="bf16-operand A-transform GEMMs (experimental)")
     ap.add_argument("--no-split-gemm", action="store_true", help="plain fp32 A-transform GEMMs instead of split-bf16 fwd/dgrad")
+    ap.add_argument("--torch-noise", action="store_true", help="torch.randn + reparam instead of in-kernel Philox noise")
     ap.add_argument("--wgrad-fp32", action="store_true", help="fp32 A weight-gradient GEMMs instead of bf16 high parts")
     ap.add_argument("--pe-fp32", action="store_true", help="store pe / dpe as fp32 instead of bf16 (bf16 mode; bit-identical)")
     ap.add_argument("--stage1-fp32", action="store_true", help="keep the stage-1 upsampling GEMMs in fp32 (bf16 mode)")
@@ -121,6 +122,7 @@ def main():
     m.pe_bf16 = not a.pe_fp32
     m.split_gemm = not a.no_split_gemm
     m.wgrad_bf16 = not a.wgrad_fp32
+    m.fused_noise = not a.torch_noise
     torch.manual_seed(123)
     lt = PM.LinearTransform(m.dims).to(dev)
     torch.manual_seed(124)

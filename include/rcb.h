@@ -112,6 +112,17 @@ typedef struct {
 int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t samples,
                     int32_t out_cols, float* out, rcb_stream_t stream);
 
+/* Noise drawn in the kernel (prior_model.py:140-145 draws torch.randn_like and then forms loc + st(log_scale) * eps):
+ * eps[i] ~ N(0,1) from Philox4x32-10 + Box-Muller, a pure function of (seed, rng_stream, step, i), where `step` is read
+ * from device memory so that a replayed HIP graph draws fresh noise.  rcb_reparam_rng_fwd: plain case (one level, one
+ * sample, no maps), flat over n = rows * cols elements; writes eps_out (for rcb_posterior_bwd) and out.
+ * rcb_philox_normal materialises the same stream (step from step_dev if non-NULL, else step_host).              */
+int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev, int64_t step_host,
+                      rcb_stream_t stream);
+int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
+                        const int64_t* step_dev, float* eps_out, float* out, rcb_stream_t stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * K5 + K6 + K7: KL( N(loc, softplus(log_scale)/6) || N(p_loc, p_scale) ) per element
  * (torch.distributions.kl._kl_normal_normal as used at prior_model.py:191-199, test_model.py:357-377,

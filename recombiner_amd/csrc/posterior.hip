@@ -154,6 +154,112 @@ __global__ void __launch_bounds__(1024) reparam_staged_kernel(ReparamArgs a) {
   }
 }
 
+// ---- counter-based noise (Philox4x32-10 + Box-Muller) ----------------------------------------------------------
+// eps of element i depends only on (seed, stream, step, i): no generator state, nothing to capture, and a replayed
+// HIP graph draws fresh noise because `step` is read from device memory.  4 normals per Philox call.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += W0;
+    k.y += W1;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float4 philox_normal4(unsigned long long group, unsigned stream, unsigned long long step,
+                                                 unsigned long long seed) {
+  const uint4 r = philox4x32_10(make_uint4((unsigned)group, (unsigned)(group >> 32), stream ^ (unsigned)(step >> 32) * 0x85EBCA6Bu,
+                                           (unsigned)step),
+                                make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  constexpr float K = 1.0f / 16777216.0f;             // 24-bit uniforms: u1 in (0, 1), u2 in [0, 1)
+  const float u1 = ((float)(r.x >> 8) + 0.5f) * K, u2 = (float)(r.y >> 8) * K;
+  const float u3 = ((float)(r.z >> 8) + 0.5f) * K, u4 = (float)(r.w >> 8) * K;
+  // hardware transcendentals (about 1 ulp: ample for noise): v_log_f32 is log2, v_sin / v_cos take revolutions
+  constexpr float M2LN2 = -1.3862943611198906f;             // -2 ln 2
+  const float ra = __builtin_amdgcn_sqrtf(M2LN2 * __builtin_amdgcn_logf(u1));
+  const float rb = __builtin_amdgcn_sqrtf(M2LN2 * __builtin_amdgcn_logf(u3));
+  return make_float4(ra * __builtin_amdgcn_cosf(u2), ra * __builtin_amdgcn_sinf(u2), rb * __builtin_amdgcn_cosf(u4),
+                     rb * __builtin_amdgcn_sinf(u4));
+}
+
+__global__ void __launch_bounds__(256) philox_normal_kernel(float* __restrict__ out, long long n, unsigned long long seed,
+                                                            unsigned stream, const long long* __restrict__ step_dev,
+                                                            long long step_host) {
+  const unsigned long long step = step_dev ? (unsigned long long)*step_dev : (unsigned long long)step_host;
+  const long long n4 = (n + 3) >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 e = philox_normal4((unsigned long long)i, stream, step, seed);
+    const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * i + k < n) out[4 * i + k] = ev[k];
+  }
+}
+
+// reparameterised sample with the noise drawn in the kernel: out = loc + st(log_scale) * eps, eps written once for the
+// posterior update.  Replaces torch.randn + the flat reparam kernel (the generated values never make a round trip
+// through HBM before their first use); same arithmetic as reparam_flat_kernel on the same eps.
+__global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
+                                                          float* __restrict__ eps_out, float* __restrict__ out, long long n,
+                                                          unsigned long long seed, unsigned stream,
+                                                          const long long* __restrict__ step_dev) {
+  const unsigned long long step = (unsigned long long)*step_dev;
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 m = reinterpret_cast<const float4*>(loc)[i];
+    const float4 l = reinterpret_cast<const float4*>(ls)[i];
+    const float4 e = philox_normal4((unsigned long long)i, stream, step, seed);
+    float4 o;
+    o.x = add_rn(m.x, mul_rn(st_f32(l.x), e.x));
+    o.y = add_rn(m.y, mul_rn(st_f32(l.y), e.y));
+    o.z = add_rn(m.z, mul_rn(st_f32(l.z), e.z));
+    o.w = add_rn(m.w, mul_rn(st_f32(l.w), e.w));
+    reinterpret_cast<float4*>(eps_out)[i] = e;
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 3)) {      // tail group
+    const float4 e = philox_normal4((unsigned long long)n4, stream, step, seed);
+    const float ev[4] = {e.x, e.y, e.z, e.w};
+    for (int k = 0; k < (int)(n & 3); ++k) {
+      const long long i = (n4 << 2) + k;
+      eps_out[i] = ev[k];
+      out[i] = add_rn(loc[i], mul_rn(st_f32(ls[i]), ev[k]));
+    }
+  }
+}
+
+extern "C" int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev,
+                                 int64_t step_host, rcb_stream_t stream) {
+  RCB_REQUIRE(out && n >= 0, RCB_ERR_ARG, "philox_normal: null pointer");
+  if (n == 0) return RCB_OK;
+  int blocks = cdiv((n + 3) >> 2, 256);
+  if (blocks > 16384) blocks = 16384;
+  philox_normal_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(out, (long long)n, seed, rng_stream,
+                                                                (const long long*)step_dev, (long long)step_host);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+extern "C" int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
+                                   const int64_t* step_dev, float* eps_out, float* out, rcb_stream_t stream) {
+  RCB_REQUIRE(loc && log_scale && step_dev && eps_out && out && n > 0, RCB_ERR_ARG, "reparam_rng_fwd: null pointer / empty");
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  RCB_REQUIRE(al16(loc) && al16(log_scale) && al16(eps_out) && al16(out), RCB_ERR_ARG, "reparam_rng_fwd: 16-byte alignment");
+  int blocks = cdiv(n >> 2, 256);
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  reparam_rng_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(loc, log_scale, eps_out, out, (long long)n, seed, rng_stream,
+                                                              (const long long*)step_dev);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
 // fast path: one level, one sample, no maps / masks -> purely elementwise over the flat [n_inr * cols] arrays
 // (rows of 3267 floats are not 16-byte aligned, the flat arrays are): 16-byte accesses, same arithmetic
 __global__ void __launch_bounds__(256) reparam_flat_kernel(const float* __restrict__ loc, const float* __restrict__ ls,

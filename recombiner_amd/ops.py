@@ -224,6 +224,38 @@ def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], sample
     return out
 
 
+def rng_eligible(lv: LevelSpec):
+    """plain level (no maps, no masks, every column produced): the in-kernel noise path applies"""
+    return (lv.row_map is None and lv.row_perm is None and lv.col_map is None and lv.enc_mask is None
+            and lv.cols_out == lv.cols and lv.n_inr == lv.rows and lv.loc.is_contiguous() and lv.log_scale.is_contiguous())
+
+
+def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step):
+    """-> (out [n, 1, cols], eps [n, 1, cols]): reparameterised sample with the noise drawn inside the kernel
+    (rcb_reparam_rng_fwd).  `step` is the device-resident int64 step counter."""
+    lib = _lib.load()
+    if not rng_eligible(lv):
+        raise RcbError("reparam_rng: plain levels only")
+    n, cols = lv.rows, lv.cols
+    out = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
+    eps = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
+    check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
+                                  C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64), ptr(eps),
+                                  ptr(out), stream_ptr()), "rcb_reparam_rng_fwd")
+    return out, eps
+
+
+def philox_normal(n, seed: int, rng_stream: int, step, device="cuda"):
+    """the noise stream of reparam_rng as a tensor (step: python int or device int64 tensor)"""
+    lib = _lib.load()
+    out = torch.empty(n, device=device, dtype=f32)
+    dev_step = step if torch.is_tensor(step) else None
+    check(lib.rcb_philox_normal(ptr(out), C.c_int64(n), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream),
+                                ptr(dev_step, torch.int64, True), C.c_int64(0 if dev_step is not None else int(step)),
+                                stream_ptr()), "rcb_philox_normal")
+    return out
+
+
 def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: float, d_out, eps, samples: int,
                   beta=None, group_idx=None, n_groups=0, adam: Optional[AdamCfg] = None, state=None,
                   want_grads=False, kl_accum=None):

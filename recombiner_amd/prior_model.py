@@ -109,6 +109,8 @@ class PriorBNNmodel(nn.Module):
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
         self.wgrad_bf16 = True       # with split_gemm: bf16 high parts for the A weight-gradient GEMMs (sum over INRs)
+        self.fused_noise = True      # draw eps inside the reparam kernel (Philox) when no noise_source is injected
+        self._train_calls = 0
         self.use_graph = True        # replay the training step as one captured HIP graph when possible
 
     # ---- level descriptions ------------------------------------------------------------------------
@@ -262,18 +264,33 @@ class PriorBNNmodel(nn.Module):
         if training_mappings and world > 1:      # persistent bucket: stable address across graph replays
             flat = torch.empty(sum(p.numel() for p in A + conv), device=dev, dtype=torch.float32)
 
+        # in-kernel noise: a pure function of (seed, stream, step, element), so graph replay and eager stepping draw the
+        # same values; the seed mixes the model seed, torch's current seed and the index of this train() call
+        self._train_calls += 1
+        use_rng = (self.fused_noise and self.noise_source is None and len(net) == 1 and ops.rng_eligible(net[0])
+                   and ops.rng_eligible(lpe_lv))
+        rng_seed = (int(self.random_seed) * 0x9E3779B97F4A7C15 + int(torch.initial_seed()) * 0xBF58476D1CE4E5B9
+                    + self._train_calls * 0x94D049BB133111EB) & (2 ** 64 - 1)
+
         def seg1():
             ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
-            e_lpe = self._noise((N, 1, self._d_lpe))
-            lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
+            if use_rng:
+                lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, step_t)
+            else:
+                e_lpe = self._noise((N, 1, self._d_lpe))
+                lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
             lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
             with torch.enable_grad():
                 pe = self._pe(upsample_net, lpe_t)                       # [N, 1, P, E]
                 pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
                 #                                                               materialises zeros + a copy)
-            eps = [self._noise((N, 1, D)) for _ in net]
-            h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
+            if use_rng:
+                h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, step_t)
+                eps, h_w = [e0], h_w.view(N, D)
+            else:
+                eps = [self._noise((N, 1, D)) for _ in net]
+                h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
             # ---- A transform (dense GEMMs) --------------------------------------------------------------
             lowp = self.lowp_gemm and self.precision != 0
             if lowp:

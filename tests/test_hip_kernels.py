@@ -310,6 +310,35 @@ def test_split_bf16_operands_and_a_transform():
         assert rel_err(x[:, a:b].bfloat16().float() @ m.bfloat16().float(), ref) > 5e-4      # what plain bf16 would give
 
 
+def test_philox_noise_stream_and_fused_reparam():
+    """in-kernel noise: N(0,1) statistics, a pure function of (seed, stream, step, index), and the fused kernel equals
+    the explicit-noise reparam on the materialised stream bit for bit (including a tail that is not a multiple of 4)."""
+    n = 1 << 22
+    e = ops.philox_normal(n, 1234, 0, 7).double()
+    assert abs(float(e.mean())) < 3e-3 and abs(float(e.var()) - 1) < 5e-3
+    assert abs(float((e ** 4).mean()) - 3) < 0.05 and abs(float((e ** 3).mean())) < 0.02
+    assert 4.5 < float(e.abs().max()) < 6.5                              # 24-bit uniforms: tails reach ~5.9 sigma
+    assert abs(float((e[:-1] * e[1:]).mean())) < 3e-3 and abs(float((e[:-4] * e[4:]).mean())) < 3e-3
+    assert torch.equal(ops.philox_normal(1000, 1234, 0, 7), ops.philox_normal(n, 1234, 0, 7)[:1000])   # index-addressed
+    for other in ((1235, 0, 7), (1234, 1, 7), (1234, 0, 8)):            # seed / stream / step all change the values
+        o = ops.philox_normal(4096, *other)
+        assert float((o == e[:4096].float()).float().mean()) < 0.01 and abs(float((o.double() * e[:4096]).mean())) < 0.08
+    step = torch.tensor([7], device=DEV, dtype=torch.int64)
+    assert torch.equal(ops.philox_normal(4096, 1234, 0, step), e[:4096].float())                     # device-side step
+    gen = torch.Generator().manual_seed(31)
+    for N, D in ((5, 3267), (4, 512), (3, 7)):
+        loc = g(torch.randn(N, D, generator=gen))
+        ls = g(torch.randn(N, D, generator=gen) * 2 - 3)
+        lv = LevelSpec(loc, ls, D, N)
+        out, eps = ops.reparam_rng(lv, 99, 3, step)
+        ref_eps = ops.philox_normal(N * D, 99, 3, 7).view(N, 1, D)
+        assert torch.equal(eps, ref_eps)
+        assert torch.equal(out, ops.reparam_fwd([lv], [ref_eps], 1))
+    step += 1
+    out2, eps2 = ops.reparam_rng(lv, 99, 3, step)
+    assert not torch.equal(eps2, eps)                                    # next step: fresh noise
+
+
 def test_adam_matches_torch():
     gen = torch.Generator().manual_seed(4)
     p0 = torch.randn(1000, generator=gen)
