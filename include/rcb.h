@@ -293,6 +293,11 @@ int64_t rcb_upconv_wgrad_workspace(int32_t batch, int32_t cout);
 int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const void* dy, int32_t dy_is_f32, float* dweff,
                      float* dbias, int32_t batch, int32_t grid, int32_t cout, float* workspace,
                      int64_t workspace_floats, rcb_stream_t stream);
+/* Stage-3 geometry (grid 16, cout 16, bf16 tensors): dgrad and wgrad of one stage in ONE pass over dy and x (each is
+ * read once instead of twice).  dx as rcb_upconv_dgrad, dweff / dbias as rcb_upconv_wgrad (same workspace).          */
+int rcb_upconv_bwd_fused(const void* dy, const float* weff, const void* x, void* dx, float* dweff, float* dbias,
+                         int32_t batch, int32_t grid, int32_t cout, float* workspace, int64_t workspace_floats,
+                         const void* frag_pack, rcb_stream_t stream);
 
 /* The phase-form ("effective") weights of the CIFAR-geometry upsampling net from its conv weights, and the
  * transposed map for their gradients (one launch each; prior_model.py:39-57 defines the convolutions):

@@ -785,6 +785,191 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage-3 backward, fused: the data gradient and the weight gradient both need dy (dpe) and x (h2) of every INR; as two
+// kernels each tensor is read twice (268 MB of the 670 MB the pair moves).  Here one staging of the INR's two images
+// in LDS feeds both MFMA loops:
+//   data gradient  : as upconv_dgrad3_lds_kernel (fragments in LDS, dy gathered from the zero-halo image, two channel
+//                    halves per wave); the LeakyReLU' sign now comes from the staged x image instead of a global re-read
+//   weight gradient: as upconv_wgrad_kernel, with the dy operand read (ds_read_b64_tr_b16) from the same halo image
+//                    (row stride 24 elements instead of 16) and the x operand from the staged zero-halo x image
+// bf16 dy / x / dx, COUT = 16.  Sums go to per-workgroup slabs (upconv_wgrad_reduce_kernel finishes them).
+// ------------------------------------------------------------------------------------------------
+struct Bwd3Args {
+  const void* dy;
+  const float* weff;
+  const void* x;
+  void* dx;
+  float* partial;
+  int batch;
+  const uint4* pack;
+};
+
+__global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
+  constexpr int COUT = 16, G = 16, OG = 32, HO = 34, RS = 24, HG = 18, NF = 32;
+  constexpr int WSZ = 1024 * COUT, ROW = WSZ + COUT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* frags = reinterpret_cast<uint4*>(smem_raw);                              // [16 combos][2 mt][64 lanes]
+  __bf16* dyimg = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);                // [34][34][24]
+  __bf16* ximg = dyimg + HO * HO * RS;                                            // [18][18][64]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  const int fb = (lane >> 4) & 1, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+  for (int e = tid; e < NF * 64; e += 512) {
+    if (a.pack) {
+      frags[e] = a.pack[20480 + e];
+      continue;
+    }
+    const int ln = e & 63, slot = e >> 6;
+    const int mt = slot & 1, combo = slot >> 1;
+    const int ry = (combo >> 2) - 1, rx = (combo & 3) - 1;
+    const int pa = (ry & 1), ty = (ry <= 0) ? 1 : 0;
+    const int pb = (rx & 1), tx = (rx <= 0) ? 1 : 0;
+    const int fq = ln & 31, fh = ln >> 5, ci = 32 * mt + fq;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, ci, pa, pb, 8 * fh + j, COUT)];
+    frags[e] = f.u;
+  }
+  for (int e = tid; e < (HO * HO * RS + HG * HG * CIN) / 8; e += 512) reinterpret_cast<uint4*>(dyimg)[e] = make_uint4(0, 0, 0, 0);
+  f32x16 wacc[2][2];   // weight gradient: [combo slot][mt]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wacc[c][mt][r] = 0.f;
+  float dbsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
+  // per INR: dy 32 x 32 x 16 bf16 = 2048 x 16 B, x 16 x 16 x 64 bf16 = 2048 x 16 B: 4 + 4 per thread, 64 KB in flight
+  uint4 pdy[4], px[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pdy[k] = px[k] = make_uint4(0, 0, 0, 0);
+#define RCB_FETCH_B3(bb)                                                                                               \
+  {                                                                                                                   \
+    const uint4* sd_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)(bb) * OG * OG * COUT); \
+    const uint4* sx_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + (long long)(bb) * G * G * CIN);    \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) { pdy[k] = sd_[tid + 512 * k]; px[k] = sx_[tid + 512 * k]; }         \
+  }
+  const int gs = gridDim.x;
+  int b = blockIdx.x;
+  __syncthreads();
+  if (b < a.batch) RCB_FETCH_B3(b)
+  const int u = (wave * 32 + q) >> 4, v = (wave * 32 + q) & 15;      // data gradient: this lane's output position
+  for (; b < a.batch; b += gs) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = tid + 512 * k;
+      {   // dy: pixel e >> 1, chunk of 8 channels e & 1 (the same chunk for every k: private bias partials)
+        const int pix = e >> 1, c8 = e & 1;
+        *reinterpret_cast<uint4*>(dyimg + (((pix >> 5) + 1) * HO + ((pix & 31) + 1)) * RS + 8 * c8) = pdy[k];
+        Frag f;
+        f.u = pdy[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
+      }
+      {   // x: pixel e >> 3, chunk e & 7
+        const int pix = e >> 3, c8 = e & 7;
+        *reinterpret_cast<uint4*>(ximg + (((pix >> 4) + 1) * HG + ((pix & 15) + 1)) * CIN + 8 * c8) = px[k];
+      }
+    }
+    __syncthreads();
+    if (b + gs < a.batch) RCB_FETCH_B3(b + gs)
+    // ---- data gradient --------------------------------------------------------------------------------------
+    {
+      f32x16 acc[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
+        Frag bf;
+        bf.u = *reinterpret_cast<const uint4*>(dyimg + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          Frag fa;
+          fa.u = frags[(n * 2 + mt) * 64 + lane];
+          acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
+        }
+      }
+      const long long xpix = ((long long)b * G * G + wave * 32 + q) * CIN;
+      const __bf16* xs = ximg + ((u + 1) * HG + (v + 1)) * CIN;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ci = 32 * mt + 8 * g4 + 4 * h;
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(xs + ci);
+          bf16x4 ob;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)t[k] > 0.f ? 1.0f : SLOPE));
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
+        }
+      }
+    }
+    // ---- weight gradient --------------------------------------------------------------------------------------
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int combo = 2 * wave + c;                 // 16 combos over 8 waves
+      const int p = combo >> 2, t = combo & 3;
+      const int pa = p >> 1, pb = p & 1, ty = t >> 1, tx = t & 1;
+#pragma unroll 2
+      for (int pt = 0; pt < G * G / 32; ++pt) {       // partly unrolled: the prefetch registers must stay in registers
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          union { s16x4 s[2]; bf16x8 v; } av[2], bv;
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) {
+            const int pos = 32 * pt + 16 * ks + 8 * h + 4 * w2 + q4;
+            const int i = pos >> 4, j = pos & 15;
+            const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb + tx)) * CIN + 16 * fb + 4 * p4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt].s[w2] = tr_read(xr + 32 * mt);
+            bv.s[w2] = tr_read(dyimg + ((2 * i + pa + 1) * HO + (2 * j + pb + 1)) * RS + 4 * p4);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) wacc[c][mt] = mfma16(av[mt].v, bv.v, wacc[c][mt]);
+        }
+      }
+    }
+  }
+#undef RCB_FETCH_B3
+  float* slab = a.partial + (long long)blockIdx.x * ROW;
+  {   // bias gradient: per-thread channel partials through LDS (fixed order: deterministic)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);      // [512][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dbsum[j];
+    __syncthreads();
+    if (tid < COUT) {
+      const int c8 = tid >> 3, j = tid & 7;              // thread t holds channels 8 * (t & 1) .. + 7
+      float sacc = 0.f;
+      for (int t = c8; t < 512; t += 2) sacc += red[t * 8 + j];
+      slab[WSZ + tid] = sacc;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int combo = 2 * wave + c;
+    const int p = combo >> 2, t = combo & 3;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int co = lane & 31;
+      if (co < COUT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = 32 * mt + rho(r, h);
+          slab[weff_index(t >> 1, t & 1, ci, p >> 1, p & 1, co, COUT)] = wacc[c][mt][r];
+        }
+      }
+    }
+  }
+}
+
 // fixed-order sum of the workgroup slabs: out[j] = sum_w partial[w][j]
 __global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int row,
                                                                   int wsz, float* __restrict__ dweff,
@@ -924,6 +1109,29 @@ extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const vo
   RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 2 && !dy_is_f32, 64, 8, 3, 0, (10 * 10 * 64 + 16 * 16 * 64) * 2)
 #undef RCB_WGRAD_CASE
   if (!hit) return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
+  if (rc) return rc;
+  const int row = 1024 * cout + cout;
+  upconv_wgrad_reduce_kernel<<<(row + 255) / 256, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// Stage-3 backward in one pass over dy and x (see upconv_bwd3_fused_kernel).  Same workspace contract as rcb_upconv_wgrad.
+extern "C" int rcb_upconv_bwd_fused(const void* dy, const float* weff, const void* x, void* dx, float* dweff, float* dbias,
+                                    int32_t batch, int32_t grid, int32_t cout, float* workspace, int64_t workspace_floats,
+                                    const void* frag_pack, rcb_stream_t stream) {
+  RCB_REQUIRE(dy && weff && x && dx && dweff && workspace, RCB_ERR_ARG, "upconv_bwd_fused: null pointer");
+  RCB_REQUIRE(batch > 0, RCB_ERR_SHAPE, "upconv_bwd_fused: empty batch");
+  RCB_REQUIRE(grid == 16 && cout == 16, RCB_ERR_UNSUPPORTED, "upconv_bwd_fused: grid=%d cout=%d not instantiated", grid, cout);
+  RCB_REQUIRE(workspace_floats >= rcb_upconv_wgrad_workspace(batch, cout), RCB_ERR_SHAPE,
+              "upconv_bwd_fused: workspace of %lld floats, %lld needed", (long long)workspace_floats,
+              (long long)rcb_upconv_wgrad_workspace(batch, cout));
+  RCB_REQUIRE((reinterpret_cast<uintptr_t>(frag_pack) & 15) == 0, RCB_ERR_ARG, "upconv_bwd_fused: frag_pack must be 16-byte aligned");
+  Bwd3Args a{dy, weff, x, dx, workspace, batch, reinterpret_cast<const uint4*>(frag_pack)};
+  hipStream_t st = (hipStream_t)stream;
+  const int g = wgrad_blocks(batch);
+  static bool done = false;
+  int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * 64) * 2, st, done);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
   upconv_wgrad_reduce_kernel<<<(row + 255) / 256, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);

@@ -549,6 +549,22 @@ def upconv_wgrad(x, dy, grid, cout, preact=False):
     return dw, db
 
 
+def upconv_bwd_fused(dy, weff, x, grid, cout, pack=None):
+    """stage-3 geometry, bf16 tensors: -> (dx, dWeff [2,2,64,2,2,cout], dbias [cout]) in one pass over dy and x"""
+    lib = _lib.load()
+    if dy.dtype != bf16 or x.dtype != bf16:
+        raise RcbError("upconv_bwd_fused: bf16 tensors expected")
+    B = x.shape[0]
+    dx = torch.empty_like(x)
+    buf = torch.empty(2 * 2 * 64 * 2 * 2 * cout + cout, device=x.device, dtype=f32)
+    dw, db = buf[:-cout].view(2, 2, 64, 2, 2, cout), buf[-cout:]
+    n_ws = int(lib.rcb_upconv_wgrad_workspace(B, cout))
+    ws = torch.empty(n_ws, device=x.device, dtype=f32)
+    check(lib.rcb_upconv_bwd_fused(ptr(dy), ptr(weff, f32), ptr(x), ptr(dx), ptr(dw), ptr(db), B, grid, cout, ptr(ws),
+                                   C.c_int64(n_ws), ptr(pack, None, True), stream_ptr()), "rcb_upconv_bwd_fused")
+    return dx, dw, db
+
+
 UPCONV_PACK_UINT4 = 22528
 
 

@@ -200,13 +200,18 @@ class _UpsampleCifarFn(torch.autograd.Function):
         B = lpe.shape[0]
         need_w = any(ctx.needs_input_grad[1:7])
         dpe = dpe.contiguous().view(B, 32, 32, 16)
-        dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16, pack=pack)          # bf16 [B,16,16,64]
+        fused3 = need_w and dpe.dtype == torch.bfloat16
+        if fused3:      # data and weight gradient of stage 3 from one pass over dpe and h2
+            dz2, dWeff3, db3 = ops.upconv_bwd_fused(dpe, Weff3, h2, 16, 16, pack=pack)
+        else:
+            dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16, pack=pack)      # bf16 [B,16,16,64]
         dz1, db1_part = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, want_dbias=True, pack=pack)   # [B,8,8,64]
         dz1f = dz1.view(B, 4096)
         dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
         if not need_w:
             return dlpe, None, None, None, None, None, None, None, None
-        dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
+        if not fused3:
+            dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
         dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64, preact=True)
         dWeff1 = lpe.t() @ dz1f                                            # [512, 4096], dtype of the stage-1 operands
         dW1, dW2, dW3, db1 = ops.upconv_weff_grad(dWeff1, dWeff2, dWeff3, db1_part)
