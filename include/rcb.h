@@ -189,6 +189,8 @@ typedef struct {
   float* m_loc; float* v_loc; float* m_ls; float* v_ls;   /* Adam state            */
   double* kl_accum;        /* nullable [RCB_KL_SLOTS]: partial sums of the unweighted elementwise KL (before the
                               update) are atomically added to the slots; their total is the KL           */
+  const float* kl_scalar_dev; /* nullable device scalar: the KL weight becomes kl_scalar * (*kl_scalar_dev), so a
+                              captured graph can be replayed with a new beta (main_prior_training.py:144-154) */
 } rcb_level_bwd;
 
 int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream);
@@ -232,11 +234,13 @@ int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, i
  *   begin: dyn[0..1] = adam_table[step] ({lr / (1 - beta1^t), sqrt(1 - beta2^t)}, row clamped to the table);
  *          kl_slots[RCB_KL_SLOTS] = 0 (nullable)
  *   end  : mse_log[step] = mse_scale * sum(sse[0..n_sse)),  kl_log[step] = sum(kl_slots)  (each nullable, written
- *          only while step < n_log; fixed-order fp64 sums);  step += 1                                              */
+ *          only while step < n_log; fixed-order fp64 sums);  step += 1;  aux_counter (e.g. a noise counter that is not
+ *          reset between train() calls) += 1                                                                        */
 int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, double* kl_slots,
                    rcb_stream_t stream);
 int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const double* kl_slots, double* mse_log,
-                 double* kl_log, int64_t n_log, int64_t* step, rcb_stream_t stream);
+                 double* kl_log, int64_t n_log, int64_t* step, int64_t* aux_counter /* nullable: += 1 */,
+                 rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172).

@@ -57,7 +57,7 @@ class LevelBwd(C.Structure):
                 ("member_idx", C.c_void_p), ("row_perm_inv", C.c_void_p), ("col_inv", C.c_void_p),
                 ("rows", C.c_int32), ("cols", C.c_int32), ("cols_out", C.c_int32), ("samples", C.c_int32),
                 ("g_loc", C.c_void_p), ("g_log_scale", C.c_void_p), ("m_loc", C.c_void_p), ("v_loc", C.c_void_p),
-                ("m_ls", C.c_void_p), ("v_ls", C.c_void_p), ("kl_accum", C.c_void_p)]
+                ("m_ls", C.c_void_p), ("v_ls", C.c_void_p), ("kl_accum", C.c_void_p), ("kl_scalar_dev", C.c_void_p)]
 
 
 _lib = None

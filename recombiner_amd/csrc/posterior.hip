@@ -525,6 +525,7 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
     }
   }
   float w = L.kl_scalar;
+  if (L.kl_scalar_dev) w = mul_rn(w, *L.kl_scalar_dev);
   if (L.beta) w = mul_rn(w, L.beta[(long long)r * L.n_groups + L.group_idx[j]]);
   if (L.kl_accum) {   // unweighted KL of the parameters *before* this update (ELBO logging)
     __shared__ double s_kl[4];
@@ -596,6 +597,7 @@ __global__ void __launch_bounds__(1024) posterior_staged_kernel(PostBwdArgs a) {
       }
     }
     float w = L.kl_scalar;
+    if (L.kl_scalar_dev) w = mul_rn(w, *L.kl_scalar_dev);
     if (L.beta) w = mul_rn(w, L.beta[(long long)r * L.n_groups + L.group_idx[j]]);
     if (L.kl_accum) {
       const float spk = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
@@ -655,7 +657,7 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   float* m1v = &m14.x; float* v1v = &v14.x; float* m2v = &m24.x; float* v2v = &v24.x;
   int j = (int)(b % L.cols);
   double kl = 0.0;
-  const float w = L.kl_scalar;
+  const float w = L.kl_scalar_dev ? mul_rn(L.kl_scalar, *L.kl_scalar_dev) : L.kl_scalar;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float loc = locv[k], ls = lsv[k];
@@ -820,7 +822,7 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(const float* __restric
 __global__ void __launch_bounds__(1024) step_end_kernel(const float* __restrict__ sse, int n_sse, double mse_scale,
                                                         const double* __restrict__ kl_slots, double* __restrict__ mse_log,
                                                         double* __restrict__ kl_log, long long n_log,
-                                                        long long* __restrict__ step) {
+                                                        long long* __restrict__ step, long long* __restrict__ aux_counter) {
   __shared__ double red[2][1024];
   const int t = threadIdx.x;
   double a = 0.0;
@@ -843,6 +845,7 @@ __global__ void __launch_bounds__(1024) step_end_kernel(const float* __restrict_
       if (kl_log && kl_slots) kl_log[s] = red[1][0];
     }
     *step = s + 1;
+    if (aux_counter) *aux_counter += 1;      // e.g. the noise counter, which is NOT reset between train() calls
   }
 }
 
@@ -856,11 +859,11 @@ extern "C" int rcb_step_begin(const float* adam_table, int64_t n_steps, const in
 }
 
 extern "C" int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const double* kl_slots, double* mse_log,
-                            double* kl_log, int64_t n_log, int64_t* step, rcb_stream_t stream) {
+                            double* kl_log, int64_t n_log, int64_t* step, int64_t* aux_counter, rcb_stream_t stream) {
   RCB_REQUIRE(step, RCB_ERR_ARG, "step_end: null step counter");
   RCB_REQUIRE(n_sse >= 0 && n_log >= 0, RCB_ERR_SHAPE, "step_end: negative size");
   step_end_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(sse, n_sse, mse_scale, kl_slots, mse_log, kl_log, (long long)n_log,
-                                                     (long long*)step);
+                                                     (long long*)step, (long long*)aux_counter);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

@@ -258,7 +258,7 @@ def philox_normal(n, seed: int, rng_stream: int, step, device="cuda"):
 
 def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: float, d_out, eps, samples: int,
                   beta=None, group_idx=None, n_groups=0, adam: Optional[AdamCfg] = None, state=None,
-                  want_grads=False, kl_accum=None):
+                  want_grads=False, kl_accum=None, kl_scalar_dev=None):
     """Fused gradient gather + KL gradient (+ Adam).  Returns (g_loc, g_log_scale) when requested."""
     lib = _lib.load()
     g_loc = g_ls = None
@@ -273,7 +273,8 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  int(n_groups), float(kl_scalar), addr(d_out, f32), addr(eps, f32), addr(lv.member_ptr, i32),
                  addr(lv.member_idx, i32), addr(lv.row_perm_inv, i32), addr(lv.col_inv, i32), lv.rows, lv.cols,
                  lv.cols_out, int(samples), addr(g_loc, f32), addr(g_ls, f32), addr(s.get("m_loc"), f32),
-                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, f64))
+                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, f64),
+                 addr(kl_scalar_dev, f32))
     if d_out is not None and tuple(d_out.shape) != (lv.n_inr, samples, lv.cols_out):
         raise RcbError(f"d_out must be [{lv.n_inr},{samples},{lv.cols_out}], got {tuple(d_out.shape)}")
     check(lib.rcb_posterior_bwd(C.byref(b), C.byref(adam) if adam is not None else None, stream_ptr()),
@@ -410,13 +411,13 @@ def step_begin(table, step, dyn, kl_slots=None):
                              ptr(kl_slots, f64, True), stream_ptr()), "rcb_step_begin")
 
 
-def step_end(step, sse=None, mse_scale=1.0, kl_slots=None, mse_log=None, kl_log=None):
-    """mse_log[step] = mse_scale * sum(sse), kl_log[step] = sum(kl_slots), step += 1 (rcb_step_end)."""
+def step_end(step, sse=None, mse_scale=1.0, kl_slots=None, mse_log=None, kl_log=None, aux_counter=None):
+    """mse_log[step] = mse_scale * sum(sse), kl_log[step] = sum(kl_slots), step += 1, aux_counter += 1 (rcb_step_end)."""
     lib = _lib.load()
     n_log = min(t.numel() for t in (mse_log, kl_log) if t is not None) if (mse_log is not None or kl_log is not None) else 0
     check(lib.rcb_step_end(ptr(sse, f32, True), 0 if sse is None else sse.numel(), C.c_double(mse_scale),
                            ptr(kl_slots, f64, True), ptr(mse_log, f64, True), ptr(kl_log, f64, True), C.c_int64(n_log),
-                           ptr(step, torch.int64), stream_ptr()), "rcb_step_end")
+                           ptr(step, torch.int64), ptr(aux_counter, torch.int64, True), stream_ptr()), "rcb_step_end")
 
 
 ADAM_MAX_TENSORS = 16

@@ -111,6 +111,8 @@ class PriorBNNmodel(nn.Module):
         self.wgrad_bf16 = True       # with split_gemm: bf16 high parts for the A weight-gradient GEMMs (sum over INRs)
         self.fused_noise = True      # draw eps inside the reparam kernel (Philox) when no noise_source is injected
         self._train_calls = 0
+        self._ws = None              # persistent training workspace (captured graphs + everything they reference)
+        self._rng_ctr_init = 0       # first value of the noise counter of a new workspace (tests build exact twins)
         self.use_graph = True        # replay the training step as one captured HIP graph when possible
 
     # ---- level descriptions ------------------------------------------------------------------------
@@ -227,56 +229,89 @@ class PriorBNNmodel(nn.Module):
                   prior_hh_loc, prior_hh_scale]
         priors = [None if p is None else p.detach().to(dev, torch.float32).contiguous() for p in priors]
         net, lpe_lv = self._levels()
-        net_priors = [(priors[0], priors[1])] + ([(priors[4], priors[5]), (priors[6], priors[7])] if self.patch else [])
-
-        def st4(lv):
-            return {k: _zeros_state(lv.loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
-        net_state = [st4(lv) for lv in net]
-        lpe_state = st4(lpe_lv)
         A = [a for a in linear_transform.A]
         conv = [p for p in upsample_net.parameters()]
-        if training_mappings:
-            map_state = [(_zeros_state(p), _zeros_state(p)) for p in A + conv]
         slices = self._layer_slices()
-        mse_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
         D = self._d_net
         world = 1
         if self.dp_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world = torch.distributed.get_world_size(self.dp_group)
+
+        # ---- workspace -----------------------------------------------------------------------------------------
+        # Everything a captured step references lives in a workspace that survives across train() calls: Adam state
+        # (re-zeroed per call = the reference's fresh optimiser), step counter, logs, and device copies of what changes
+        # between calls (priors, beta, the noise counter).  The EM loop calls train() 550 times with 100 steps each;
+        # re-capturing the graph every call costs ~14 ms = 9 % of such a call, replaying a cached one nothing.
+        graphable = bool(self.use_graph and self.noise_source is None and dev.type == "cuda" and not verbose)
+        key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
+               world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm,
+               self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.patch,
+               tuple(None if q is None else tuple(q.shape) for q in priors))
+        ws = self._ws if graphable else None
+        if ws is not None and (ws["key"] != key or ws["rows"] < n_epoch):
+            ws = None
+        if ws is None:
+            def st4(lv):
+                return {k: _zeros_state(lv.loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+            rows = max(n_epoch, 256) if graphable else n_epoch
+            self._train_calls += 1
+            ws = dict(key=key, rows=rows, net_state=[st4(lv) for lv in net], lpe_state=st4(lpe_lv),
+                      map_state=[(_zeros_state(q), _zeros_state(q)) for q in A + conv] if training_mappings else None,
+                      tab=ops.adam_table(lr, rows).to(dev), dyn=torch.zeros(2, device=dev, dtype=torch.float32),
+                      step_t=torch.zeros(1, device=dev, dtype=torch.long),
+                      kl_slots=torch.zeros(1024, device=dev, dtype=torch.float64),
+                      mse_buf=torch.zeros(rows, device=dev, dtype=torch.float64),
+                      kl_buf=torch.zeros(rows, device=dev, dtype=torch.float64),
+                      pri=[None if q is None else torch.empty_like(q) for q in priors],
+                      beta_dev=torch.zeros(1, device=dev, dtype=torch.float32),
+                      rng_ctr=torch.full((1,), int(self._rng_ctr_init), device=dev, dtype=torch.long), graphs=None,
+                      seed=(int(self.random_seed) * 0x9E3779B97F4A7C15 + int(torch.initial_seed()) * 0xBF58476D1CE4E5B9
+                            + self._train_calls * 0x94D049BB133111EB) & (2 ** 64 - 1),
+                      flat=(torch.empty(sum(q.numel() for q in A + conv), device=dev, dtype=torch.float32)
+                            if (training_mappings and world > 1) else None))
+            split = ops.SplitATransform(slices) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
+            ws["split"] = split if (split is not None and split.fast) else None
+            if graphable:
+                self._ws = ws
+        else:
+            for stt in ws["net_state"] + [ws["lpe_state"]]:
+                for t_ in stt.values():
+                    t_.zero_()
+            if ws["map_state"] is not None:
+                for m_, v_ in ws["map_state"]:
+                    m_.zero_()
+                    v_.zero_()
+        net_state, lpe_state, map_state = ws["net_state"], ws["lpe_state"], ws["map_state"]
+        tab, dyn, step_t, kl_slots = ws["tab"], ws["dyn"], ws["step_t"], ws["kl_slots"]
+        mse_buf, kl_buf, beta_dev, rng_ctr, flat, split = (ws["mse_buf"], ws["kl_buf"], ws["beta_dev"], ws["rng_ctr"],
+                                                         ws["flat"], ws["split"])
+        step_t.zero_()
+        beta_dev.fill_(float(kl_beta))
+        for dst, src in zip(ws["pri"], priors):
+            if dst is not None:
+                dst.copy_(src)
+        pri_d = ws["pri"]              # what the kernels read (stable addresses); `priors` = this call's values
+        net_priors = [(pri_d[0], pri_d[1])] + ([(pri_d[4], pri_d[5]), (pri_d[6], pri_d[7])] if self.patch else [])
         # per-step Adam scalars and the step counter live on the device, so that one captured HIP graph of the
         # step body can be replayed for every step (the host launch cost of ~60 kernels is ~2 ms per step)
-        tab = ops.adam_table(lr, n_epoch).to(dev)
-        dyn = torch.zeros(2, device=dev, dtype=torch.float32)
-        step_t = torch.zeros(1, device=dev, dtype=torch.long)
-        kl_slots = torch.zeros(1024, device=dev, dtype=torch.float64)
-        kl_buf = torch.zeros(n_epoch, device=dev, dtype=torch.float64)
         cfg = ops.adam_cfg(lr, 1, dyn=dyn)
-        split = ops.SplitATransform(slices) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
-        if split is not None and not split.fast:
-            split = None
 
         # The step runs as three segments so that, under data-parallel sharding, the gradient bucket of the shared
         # mappings is all-reduced asynchronously BETWEEN captured graphs while the per-INR posterior update (which does
         # not depend on it) proceeds:   seg1: sample .. gradients | all-reduce || seg2: posterior update | seg3: Adam
         # on the mappings + bookkeeping.
         st = {}
-        flat = None
-        if training_mappings and world > 1:      # persistent bucket: stable address across graph replays
-            flat = torch.empty(sum(p.numel() for p in A + conv), device=dev, dtype=torch.float32)
-
-        # in-kernel noise: a pure function of (seed, stream, step, element), so graph replay and eager stepping draw the
-        # same values; the seed mixes the model seed, torch's current seed and the index of this train() call
-        self._train_calls += 1
+        # in-kernel noise: a pure function of (seed, stream, counter, element); the counter lives in the workspace and is
+        # never reset, so every step of every train() call draws fresh noise, replayed or not
         use_rng = (self.fused_noise and self.noise_source is None and len(net) == 1 and ops.rng_eligible(net[0])
                    and ops.rng_eligible(lpe_lv))
-        rng_seed = (int(self.random_seed) * 0x9E3779B97F4A7C15 + int(torch.initial_seed()) * 0xBF58476D1CE4E5B9
-                    + self._train_calls * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        rng_seed = ws["seed"]
 
         def seg1():
             ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
             if use_rng:
-                lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, step_t)
+                lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr)
             else:
                 e_lpe = self._noise((N, 1, self._d_lpe))
                 lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
@@ -286,7 +321,7 @@ class PriorBNNmodel(nn.Module):
                 pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
                 #                                                               materialises zeros + a copy)
             if use_rng:
-                h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, step_t)
+                h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
                 eps, h_w = [e0], h_w.view(N, D)
             else:
                 eps = [self._noise((N, 1, D)) for _ in net]
@@ -357,15 +392,16 @@ class PriorBNNmodel(nn.Module):
         def seg2():
             # fused posterior update (also accumulates the pre-update KL for the ELBO log)
             for lv, (pl, ps), e, stt in zip(net, net_priors, st["eps"], net_state):
-                ops.posterior_bwd(lv, pl, ps, False, float(kl_beta), st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots)
-            ops.posterior_bwd(lpe_lv, priors[2].reshape(-1), priors[3].reshape(-1), False, float(kl_beta), st["d_lpe"],
-                              st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots)
+                ops.posterior_bwd(lv, pl, ps, False, 1.0, st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots,
+                                  kl_scalar_dev=beta_dev)
+            ops.posterior_bwd(lpe_lv, pri_d[2].reshape(-1), pri_d[3].reshape(-1), False, 1.0, st["d_lpe"],
+                              st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots, kl_scalar_dev=beta_dev)
 
         def seg3():
             if training_mappings:
                 ops.adam_multi([p.data for p in A + conv], [g.contiguous() for g in st["grads"]],
                                [m for m, _ in map_state], [v for _, v in map_state], cfg)
-            ops.step_end(step_t, st["sse"], 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf)
+            ops.step_end(step_t, st["sse"], 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf, aux_counter=rng_ctr)
 
         def body():
             seg1()
@@ -376,45 +412,60 @@ class PriorBNNmodel(nn.Module):
             seg3()
 
         n_warm = 3
-        if (self.use_graph and self.noise_source is None and n_epoch >= 2 * n_warm and dev.type == "cuda" and not verbose):
-            for _ in range(n_warm):
-                body()
+
+        def replay(k):
+            kind, gr = ws["graphs"]
+            for _ in range(k):
+                if kind == "one":
+                    gr.replay()
+                else:
+                    gr[0].replay()
+                    work = comm()
+                    gr[1].replay()
+                    work.wait()
+                    gr[2].replay()
+
+        if graphable and (ws["graphs"] is not None or n_epoch > n_warm):
             try:
-                torch.cuda.synchronize()
-                if flat is None:                   # one rank (or frozen mappings): the whole step is one graph
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):      # records the step; nothing executes during capture
+                left = n_epoch
+                if ws["graphs"] is None:               # first call with this workspace: warm up eagerly, then capture
+                    for _ in range(n_warm):
                         body()
-                    for _ in range(n_epoch - n_warm):
-                        graph.replay()
-                else:                               # sharded: three graphs around the eager, asynchronous all-reduce
-                    pool = torch.cuda.graph_pool_handle()
-                    graphs = []
-                    for seg in (seg1, seg2, seg3):
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, pool=pool):
-                            seg()
-                        graphs.append(g)
-                    for _ in range(n_epoch - n_warm):
-                        graphs[0].replay()
-                        work = comm()
-                        graphs[1].replay()
-                        work.wait()
-                        graphs[2].replay()
+                    torch.cuda.synchronize()
+                    if flat is None:                   # one rank (or frozen mappings): the whole step is one graph
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):      # records the step; nothing executes during capture
+                            body()
+                        ws["graphs"] = ("one", graph)
+                    else:                               # sharded: three graphs around the eager, asynchronous all-reduce
+                        pool = torch.cuda.graph_pool_handle()
+                        graphs = []
+                        for seg in (seg1, seg2, seg3):
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, pool=pool):
+                                seg()
+                            graphs.append(g)
+                        ws["graphs"] = ("three", graphs)
+                    left -= n_warm
+                replay(left)
             except Exception as exc:     # capture is an optimisation: fall back to eager stepping
                 import warnings
                 warnings.warn(f"HIP graph capture of the training step failed ({exc}); running eagerly")
+                ws["graphs"] = None
+                self._ws = None
+                self.use_graph = False
                 torch.cuda.synchronize()
                 done = int(step_t.item())
                 for _ in range(n_epoch - done):
                     body()
         else:
-            rng = range(n_epoch)
+            it = range(n_epoch)
             if verbose:
                 from tqdm import tqdm
-                rng = tqdm(rng)
-            for _ in rng:
+                it = tqdm(it)
+            for _ in it:
                 body()
+        mse_buf, kl_buf = mse_buf[:n_epoch], kl_buf[:n_epoch]
         kl_final = self._kl_value(priors)
         mse_h = mse_buf.cpu()
         elbo_h = (-(mse_buf + kl_buf * float(kl_beta))).cpu().tolist()
