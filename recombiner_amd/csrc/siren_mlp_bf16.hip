@@ -168,6 +168,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
     }
     __syncthreads();
+    // the sine layers work in revolutions: w0 / 2 pi is folded into their forward fragments (below) and biases (here),
+    // so the accumulator feeds v_sin / v_cos directly -- no scaling multiply per activation
+    if (tid < HID) {
+#pragma unroll
+      for (int l = 0; l < NH; ++l) wl[G::off(l) + tid] *= a.k_hi;
+    }
     // one fragment slot per wave and pass; `slot` is a compile-time constant inside the unrolled loop, so the layer
     // offsets and shapes below fold away and only the lane-dependent part of the gather address remains
 #pragma unroll
@@ -203,7 +209,10 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
             if (fq < E) w = wl[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
           }
         }
-        fr.v[j] = (T)(w * WS);
+        // forward fragments of the sine layers carry w0 / 2 pi; the output layer and the transposed (data-gradient)
+        // fragments stay in the original units
+        const float sc = (slot < K0S + 2 * (NH - 1)) ? WS * a.k_hi : WS;
+        fr.v[j] = (T)(w * sc);
       }
       frags[slot * 64 + lane] = fr.u;
     }
@@ -226,7 +235,6 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) gb[l] = 0.f;
   }
-  const float kk0 = a.k_hi * (1.0f / WS);
   const float w0 = a.w0 * (1.0f / WS);
   constexpr int KH0 = F, KH1 = E;
 
@@ -324,7 +332,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       f32x16 sv, cv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float tt = acc[r] * kk0;      // revolutions; the hardware reduces the range itself for |tt| < 256
+        const float tt = (WS == 1.0f) ? acc[r] : acc[r] * (1.0f / WS);   // already revolutions; the hardware reduces |tt| < 256 itself
         sv[r] = __builtin_amdgcn_sinf(tt);
         cv[r] = __builtin_amdgcn_cosf(tt);
       }
