@@ -82,10 +82,9 @@ class PhaseStage:
             sel = [[a for a in range(self.f[d]) if self.plans[d][3][a] == combo[d]] for d in range(dd)]
             sl = (slice(None),) + tuple(slice(combo[d], combo[d] + g[d]) for d in range(dd))
             A = col[sl].reshape(B * int(np.prod(g)), K)
-            idx = (Ellipsis,) + tuple(torch.as_tensor(s, device=x.device) for s in [])  # placeholder
             Wsel = Weff
-            for d in range(dd):
-                Wsel = Wsel.index_select(dd + 1 + d, torch.as_tensor(sel[d], device=x.device))
+            for d in range(dd):      # the phases of a shift group are a contiguous range: a view, no index tensor (an
+                Wsel = Wsel.narrow(dd + 1 + d, sel[d][0], len(sel[d]))       # H2D copy would break graph capture)
             nph = [len(s) for s in sel]
             Y = (A @ Wsel.reshape(K, -1)).reshape([B] + g + nph + [Cout]) + b
             # scatter the phases of this shift group into the interleaved output

@@ -180,6 +180,37 @@ def test_cached_graph_is_reused_with_new_priors_and_beta():
     assert abs(e2[0]) > 10 * abs(e1[-1])
 
 
+@pytest.mark.parametrize("name,n_data", [("cifar", 32), ("protein", 32), ("kodak", 1), ("audio", 1), ("video", 1)])
+def test_every_preset_captures_and_replays_in_the_throughput_mode(name, n_data):
+    """production path (no injected noise) of every reference preset in the bf16 mode: the step must capture as a HIP
+    graph (no host-side operation may hide in it), replay on the second call, and produce finite, decreasing losses."""
+    import warnings
+    from recombiner_amd import config, utils
+    cfg = config.configs[name]
+    n = n_data * (int(np.prod(cfg["patch_nums"])) if cfg["patch"] else 1)
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                         cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                         cfg["hierarchical_patch_nums"], random_seed=42, device=DEV)
+    m.precision = 1
+    torch.manual_seed(1)
+    lt = PM.LinearTransform(m.dims).to(DEV)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    D, s0, lat = m._d_net, 0.0211547, list(m.lpe_loc.shape[1:])
+    pri = [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV), torch.zeros(lat, device=DEV), torch.full(lat, s0, device=DEV)]
+    pri += ([torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV)] * 2) if cfg["patch"] else [None] * 4
+    Xd, Yd = X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # a failed capture warns and falls back: not acceptable here
+        _, _, e1 = m.train(6, 1e-3, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)
+        ws = m._ws
+        assert ws is not None and ws["graphs"] is not None
+        _, _, e2 = m.train(6, 1e-3, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)
+    assert m._ws is ws and len(e1) == len(e2) == 6
+    assert np.isfinite(e1).all() and np.isfinite(e2).all()
+    assert np.mean(e2) > np.mean(e1)                          # ELBO = -(loss): the second call continues to improve
+
+
 def test_sharded_training_rehearsal_two_ranks_one_gpu():
     """world_size 2 over gloo with both ranks on this GPU: mappings stay identical across ranks, and the three-graph
     replay (asynchronous all-reduce between captured segments) reproduces eager stepping.  (The RCCL path itself needs
