@@ -311,3 +311,25 @@ def test_end_to_end_patched_full_compression_matches_reference_psnr():
     bitstream.apply_indices(m2, bitstream.unpack_indices(blob))
     for a, b in zip((m._l1, m._l2, m._l3), (m2._l1, m2._l2, m2._l3)):
         assert torch.equal(a.sample, b.sample)
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("precision", [0, 1])
+def test_test_time_training_captures_graphs_for_every_preset(name, precision):
+    """production path of TestBNNmodel.train (no injected noise): both step graphs (with / without the beta update)
+    must capture -- a failed capture warns and falls back to eager stepping -- and the loss must stay finite."""
+    import warnings
+    d = load(f"test_{name}.npz")
+    cfg, n, m = build(d, name)
+    m.precision = precision
+    set_post(d, cfg, m)
+    X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
+    Y = t(d, "Y").to(DEV)
+    loc0 = m.loc.detach().clone()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m.train(X, Y, 40, torch.optim.Adam(m.parameters(), lr=2e-4), False, sample_size=5)
+    assert m._ws is not None and set(m._ws["graphs"].keys()) == {True, False} and m.use_graph
+    assert torch.isfinite(m.loc).all() and float((m.loc - loc0).abs().max()) > 0
+    with torch.no_grad():
+        assert torch.isfinite(m.predict(X)).all()
