@@ -1,5 +1,5 @@
 """A-transform GEMM shapes (4096 x 1056 x 1056): fp32 library GEMM vs bf16 and split-bf16 (hi/lo, 3 products in one
-K-concatenated GEMM).  Reports time and max-norm error against fp64.   python tools/bench_split_gemm.py"""
+K-concatenated GEMM with an fp32 result: torch.mm(..., out_dtype=float32)).  Reports time and max-norm error against fp64.   python tools/bench_split_gemm.py"""
 import os
 import sys
 
@@ -52,12 +52,12 @@ def rel(a, ref):
 
 cases = {
     "fwd   h @ A      ": (lambda: h @ A, lambda: h.bfloat16() @ A.bfloat16(),
-                          lambda: cat3_left(h), lambda: cat3_right(A), lambda l, r: l @ r, h.double() @ A.double()),
+                          lambda: cat3_left(h), lambda: cat3_right(A), lambda l, r: torch.mm(l, r, out_dtype=torch.float32), h.double() @ A.double()),
     "dgrad g @ A^T    ": (lambda: g @ A.t(), lambda: g.bfloat16() @ A.bfloat16().t(),
-                          lambda: cat3_left(g), lambda: cat3_right(A.t().contiguous()), lambda l, r: l @ r,
+                          lambda: cat3_left(g), lambda: cat3_right(A.t().contiguous()), lambda l, r: torch.mm(l, r, out_dtype=torch.float32),
                           g.double() @ A.double().t()),
     "wgrad h^T @ g    ": (lambda: h.t() @ g, lambda: h.bfloat16().t() @ g.bfloat16(),
-                          lambda: cat3_left(h.t().contiguous()), lambda: cat3_right(g), lambda l, r: l @ r,
+                          lambda: cat3_left(h.t().contiguous()), lambda: cat3_right(g), lambda l, r: torch.mm(l, r, out_dtype=torch.float32),
                           h.double().t() @ g.double()),
 }
 for name, (f32, b16, mkl, mkr, mm, ref) in cases.items():
