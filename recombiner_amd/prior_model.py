@@ -233,9 +233,10 @@ class PriorBNNmodel(nn.Module):
         conv = [p for p in upsample_net.parameters()]
         slices = self._layer_slices()
         D = self._d_net
-        world = 1
+        world, rank_id = 1, 0
         if self.dp_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world = torch.distributed.get_world_size(self.dp_group)
+            rank_id = torch.distributed.get_rank(self.dp_group)      # ranks must not draw the same noise
 
         # ---- workspace -----------------------------------------------------------------------------------------
         # Everything a captured step references lives in a workspace that survives across train() calls: Adam state
@@ -266,7 +267,7 @@ class PriorBNNmodel(nn.Module):
                       beta_dev=torch.zeros(1, device=dev, dtype=torch.float32),
                       rng_ctr=torch.full((1,), int(self._rng_ctr_init), device=dev, dtype=torch.long), graphs=None,
                       seed=(int(self.random_seed) * 0x9E3779B97F4A7C15 + int(torch.initial_seed()) * 0xBF58476D1CE4E5B9
-                            + self._train_calls * 0x94D049BB133111EB) & (2 ** 64 - 1),
+                            + self._train_calls * 0x94D049BB133111EB + rank_id * 0xD6E8FEB86659FD93) & (2 ** 64 - 1),
                       flat=(torch.empty(sum(q.numel() for q in A + conv), device=dev, dtype=torch.float32)
                             if (training_mappings and world > 1) else None))
             split = ops.SplitATransform(slices) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
