@@ -282,6 +282,7 @@ class PriorBNNmodel(nn.Module):
                 for m_, v_ in ws["map_state"]:
                     m_.zero_()
                     v_.zero_()
+        n_a = sum(q.numel() for q in A)                     # the A matrices come first in the gradient bucket
         net_state, lpe_state, map_state = ws["net_state"], ws["lpe_state"], ws["map_state"]
         tab, dyn, step_t, kl_slots = ws["tab"], ws["dyn"], ws["step_t"], ws["kl_slots"]
         mse_buf, kl_buf, beta_dev, rng_ctr, flat, split = (ws["mse_buf"], ws["kl_buf"], ws["beta_dev"], ws["rng_ctr"],
@@ -297,10 +298,11 @@ class PriorBNNmodel(nn.Module):
         # step body can be replayed for every step (the host launch cost of ~60 kernels is ~2 ms per step)
         cfg = ops.adam_cfg(lr, 1, dyn=dyn)
 
-        # The step runs as three segments so that, under data-parallel sharding, the gradient bucket of the shared
-        # mappings is all-reduced asynchronously BETWEEN captured graphs while the per-INR posterior update (which does
-        # not depend on it) proceeds:   seg1: sample .. gradients | all-reduce || seg2: posterior update | seg3: Adam
-        # on the mappings + bookkeeping.
+        # The step runs as four segments so that, under data-parallel sharding, the gradient bucket of the shared
+        # mappings is all-reduced asynchronously BETWEEN captured graphs while work that does not depend on it proceeds:
+        #   seg1a: sample .. SIREN .. A-transform backward | all-reduce(A grads, 13.4 MB) ||
+        #   seg1b: upsampling-net backward | all-reduce(conv grads, 1 MB) || seg2: posterior update | wait |
+        #   seg3: Adam on the mappings + bookkeeping.
         st = {}
         # in-kernel noise: a pure function of (seed, stream, counter, element); the counter lives in the workspace and is
         # never reset, so every step of every train() call draws fresh noise, replayed or not
@@ -308,7 +310,7 @@ class PriorBNNmodel(nn.Module):
                    and ops.rng_eligible(lpe_lv))
         rng_seed = ws["seed"]
 
-        def seg1():
+        def seg1a():
             ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
             if use_rng:
@@ -352,10 +354,7 @@ class PriorBNNmodel(nn.Module):
                 sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_split=True)
             else:
                 sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
-            # ---- backward through the shared mappings ------------------------------------------------------
-            inputs = [lpe_t] + (conv if training_mappings else [])
-            g_in = torch.autograd.grad(pe_c, inputs, dpe)
-            d_lpe = g_in[0].reshape(N, 1, self._d_lpe).contiguous()
+            # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
             if lowp:
                 dw16 = dw.to(torch.bfloat16)
@@ -372,23 +371,44 @@ class PriorBNNmodel(nn.Module):
                     torch.mm(dw[:, lo:hi], a.detach().t(), out=dh[:, lo:hi])
                     if training_mappings:
                         gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
-            st.update(sse=sse, dh3=dh.view(N, 1, D), eps=eps, e_lpe=e_lpe, d_lpe=d_lpe)
+            st.update(sse=sse, dh3=dh.view(N, 1, D), eps=eps, e_lpe=e_lpe, pe_c=pe_c, lpe_t=lpe_t, dpe=dpe)
             if training_mappings:
-                grads = gA + [g.contiguous() for g in g_in[1:]]
                 if flat is not None:
-                    torch.cat([g.reshape(-1) for g in grads], out=flat)
+                    torch.cat([g.reshape(-1) for g in gA], out=flat[:n_a])
                     views, k = [], 0
-                    for g in grads:
+                    for g in gA:
                         views.append(flat[k:k + g.numel()].view_as(g))
                         k += g.numel()
-                    grads = views
-                st["grads"] = grads
+                    gA = views
+                st["gA"] = gA
 
-        def comm():
-            """sum of the mapping gradients over the ranks (the only per-step collective); returns the async handle"""
+        def seg1b():
+            # ---- backward through the upsampling net -----------------------------------------------------------
+            inputs = [st["lpe_t"]] + (conv if training_mappings else [])
+            g_in = torch.autograd.grad(st["pe_c"], inputs, st["dpe"])
+            st["d_lpe"] = g_in[0].reshape(N, 1, self._d_lpe).contiguous()
+            if training_mappings:
+                gc = [g.contiguous() for g in g_in[1:]]
+                if flat is not None:
+                    torch.cat([g.reshape(-1) for g in gc], out=flat[n_a:])
+                    views, k = [], n_a
+                    for g in gc:
+                        views.append(flat[k:k + g.numel()].view_as(g))
+                        k += g.numel()
+                    gc = views
+                st["grads"] = st["gA"] + gc
+            # the autograd graph of this step must not outlive it: a graph kept alive from an eager warm-up step (default
+            # stream) into the capture (side stream) makes its AccumulateGrad nodes cross streams and breaks the capture
+            for k_ in ("pe_c", "lpe_t", "dpe"):
+                st.pop(k_, None)
+
+        def comm(part):
+            """sum of the mapping gradients over the ranks (the only per-step collectives): part 0 = the A matrices (13.4 of
+            the 14.4 MB, ready before the upsampling backward starts), part 1 = the conv weights; returns the async handle"""
             if flat is None:
                 return None
-            return torch.distributed.all_reduce(flat, group=self.dp_group, async_op=True)
+            buf = flat[:n_a] if part == 0 else flat[n_a:]
+            return torch.distributed.all_reduce(buf, group=self.dp_group, async_op=True)
 
         def seg2():
             # fused posterior update (also accumulates the pre-update KL for the ELBO log)
@@ -405,11 +425,14 @@ class PriorBNNmodel(nn.Module):
             ops.step_end(step_t, st["sse"], 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf, aux_counter=rng_ctr)
 
         def body():
-            seg1()
-            work = comm()
+            seg1a()
+            w0 = comm(0)
+            seg1b()
+            w1 = comm(1)
             seg2()
-            if work is not None:
-                work.wait()
+            for w_ in (w0, w1):
+                if w_ is not None:
+                    w_.wait()
             seg3()
 
         n_warm = 3
@@ -421,10 +444,13 @@ class PriorBNNmodel(nn.Module):
                     gr.replay()
                 else:
                     gr[0].replay()
-                    work = comm()
+                    w0 = comm(0)
                     gr[1].replay()
-                    work.wait()
+                    w1 = comm(1)
                     gr[2].replay()
+                    w0.wait()
+                    w1.wait()
+                    gr[3].replay()
 
         if graphable and (ws["graphs"] is not None or n_epoch > n_warm):
             try:
@@ -438,15 +464,15 @@ class PriorBNNmodel(nn.Module):
                         with torch.cuda.graph(graph):      # records the step; nothing executes during capture
                             body()
                         ws["graphs"] = ("one", graph)
-                    else:                               # sharded: three graphs around the eager, asynchronous all-reduce
+                    else:                               # sharded: four graphs around the two eager, asynchronous all-reduces
                         pool = torch.cuda.graph_pool_handle()
                         graphs = []
-                        for seg in (seg1, seg2, seg3):
+                        for seg in (seg1a, seg1b, seg2, seg3):
                             g = torch.cuda.CUDAGraph()
                             with torch.cuda.graph(g, pool=pool):
                                 seg()
                             graphs.append(g)
-                        ws["graphs"] = ("three", graphs)
+                        ws["graphs"] = ("segments", graphs)
                     left -= n_warm
                 replay(left)
             except Exception as exc:     # capture is an optimisation: fall back to eager stepping

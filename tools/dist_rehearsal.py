@@ -1,6 +1,6 @@
 """Rehearsal of the sharded training step on fewer GPUs than ranks (gloo; the ranks share device 0):
    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dist_rehearsal.py
-Each rank trains its own INRs; the shared mappings must end up identical on all ranks, and the three-graph replay path
+Each rank trains its own INRs; the shared mappings must end up identical on all ranks, and the segmented-graph replay path
 (async all-reduce between captured segments) must reproduce the eager path.  Prints one line 'REHEARSAL OK ...'."""
 import os
 import sys
@@ -47,7 +47,7 @@ if __name__ == "__main__":
         dist.all_gather(gathered, v)
         for other in gathered[1:]:
             assert torch.equal(gathered[0], other), "%s: mappings differ between ranks" % name
-    # 2. three-graph replay == eager stepping (same seeds; the bf16 mode is deterministic up to the noise stream, which
+    # 2. segmented-graph replay == eager stepping (same seeds; the bf16 mode is deterministic up to the noise stream, which
     #    is drawn identically in both modes)
     rel = float((eager - graph).abs().max() / eager.abs().max())
     rel_loc = float((loc_e - loc_g).abs().max() / loc_e.abs().max())
