@@ -39,5 +39,11 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 
 
 int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);
+int siren_wide_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // hidden width 48 / 64
+
+// the 16-bit kernel family of a descriptor: width 32 or the wide kernel
+inline int siren_16bit_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
+  return d->hidden > HID ? siren_wide_dispatch(mode, d, a, st) : siren_bf16_dispatch(mode, d, a, st);
+}
 
 }  // namespace rcb

@@ -368,7 +368,8 @@ int dispatch(const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
 
 int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d, RCB_ERR_ARG, "siren: null descriptor");
-  RCB_REQUIRE(d->hidden == HID, RCB_ERR_UNSUPPORTED, "siren: hidden width %d (only 32)", d->hidden);
+  RCB_REQUIRE(d->hidden == HID || (d->precision >= 1 && (d->hidden == 48 || d->hidden == 64)), RCB_ERR_UNSUPPORTED,
+              "siren: hidden width %d (32 in every precision mode; 48 and 64 in the 16-bit modes)", d->hidden);
   RCB_REQUIRE(d->n_hidden >= 1 && d->n_hidden <= 4, RCB_ERR_UNSUPPORTED, "siren: n_hidden=%d", d->n_hidden);
   RCB_REQUIRE(d->out_dim >= 1 && d->out_dim <= 32, RCB_ERR_UNSUPPORTED, "siren: out_dim=%d", d->out_dim);
   RCB_REQUIRE(d->fourier_dim >= 1 && d->pe_dim >= 0 && d->fourier_dim + d->pe_dim <= 64, RCB_ERR_UNSUPPORTED,
@@ -412,7 +413,7 @@ extern "C" int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const voi
   a.pe = static_cast<const float*>(pe);
   a.wvec = wvec;
   a.yout = y_out;
-  if (d->precision >= 1) return siren_bf16_dispatch(MODE_FWD, d, a, (hipStream_t)stream);
+  if (d->precision >= 1) return siren_16bit_dispatch(MODE_FWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_FWD>(d, a, (hipStream_t)stream);
 }
 
@@ -428,7 +429,7 @@ extern "C" int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const voi
   a.yin = dy;
   a.dwvec = dwvec;
   a.dpe = static_cast<float*>(dpe);
-  if (d->precision >= 1) return siren_bf16_dispatch(MODE_BWD, d, a, (hipStream_t)stream);
+  if (d->precision >= 1) return siren_16bit_dispatch(MODE_BWD, d, a, (hipStream_t)stream);
   return dispatch<MODE_BWD>(d, a, (hipStream_t)stream);
 }
 
@@ -447,6 +448,6 @@ extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, cons
   a.dwvec = dwvec;
   a.dpe = static_cast<float*>(dpe);
   a.dy_scale = dy_scale;
-  if (d->precision >= 1) return siren_bf16_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
+  if (d->precision >= 1) return siren_16bit_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
   return dispatch<MODE_LOSS>(d, a, (hipStream_t)stream);
 }

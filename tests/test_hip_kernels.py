@@ -27,15 +27,15 @@ def rel_err(a, b):
 # ---------------------------------------------------------------------------------------------------
 # SIREN MLP
 # ---------------------------------------------------------------------------------------------------
-def _siren_case(F, E, n_hidden, C, P, N, S, seed):
+def _siren_case(F, E, n_hidden, C, P, N, S, seed, hidden=32):
     gen = torch.Generator().manual_seed(seed)
     in0 = F + E
-    dims = [in0] + [32] * n_hidden + [C]
+    dims = [in0] + [hidden] * n_hidden + [C]
     D = sum(dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1))
     xf = torch.rand(P, F, generator=gen) * 2 - 1
     pe = torch.randn(N * S, P, E, generator=gen) * 0.5
     # weights with the magnitude the A-transform produces for SIREN-initialised latents
-    wv = (torch.rand(N * S, D, generator=gen) * 2 - 1) * (np.sqrt(6 / 32) / 30) * 3.0
+    wv = (torch.rand(N * S, D, generator=gen) * 2 - 1) * (np.sqrt(6 / hidden) / 30) * 3.0
     y = torch.rand(N, P, C, generator=gen)
     return dims, D, xf, pe, wv, y
 
@@ -184,6 +184,107 @@ def test_siren_model_scale_weights(prec):
     assert e_w < tol and e_p < tol
 
 
+# hidden widths 48 and 64 (BASELINE.json configs "width-48" / "width-64 fp16": siren_mlp_wide.hip, 16-bit modes only)
+WIDE_CASES = [
+    dict(F=16, E=16, n_hidden=3, C=3, P=1000, N=2, S=1, hidden=48),    # kodak geometry, ragged last tile
+    dict(F=16, E=16, n_hidden=3, C=3, P=256, N=2, S=2, hidden=64),
+    dict(F=18, E=16, n_hidden=3, C=3, P=192, N=2, S=1, hidden=64),     # video: input width 34 (two input blocks)
+    dict(F=16, E=16, n_hidden=3, C=1, P=800, N=2, S=1, hidden=64),     # audio
+]
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_siren_wide_16bit_operands(case, prec):
+    """the wide kernel against the fp32 torch restatement of the same MLP: forward, fused loss + backward, plain
+    backward; error bounds of the 16-bit operand types as for width 32; bitwise deterministic."""
+    S, N, P, C, W = case["S"], case["N"], case["P"], case["C"], case["hidden"]
+    dims, D, xf, pe, wv, y = _siren_case(seed=21, **case)
+    meta = SirenMeta(samples=S, n_pix=P, fourier_dim=case["F"], pe_dim=case["E"], n_hidden=case["n_hidden"], hidden=W,
+                     out_dim=C, precision=prec)
+    assert meta.d_net == D
+    pe_r, wv_r = pe.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+    y_ref = _oracle_mlp(dims, xf, pe_r, wv_r, S)
+    tgt = y.repeat_interleave(S, 0)
+    scale = 1.0 / (S * P * C)
+    (((y_ref - tgt) ** 2).sum() * scale).backward()
+    y_hip = ops.siren_fwd(g(xf), g(pe), g(wv), meta)
+    sse, dw, dpe = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    e_y, e_w, e_p = rel_err(y_hip, y_ref.detach()), rel_err(dw, wv_r.grad), rel_err(dpe, pe_r.grad)
+    e_s = rel_err(sse, ((y_ref.detach() - tgt) ** 2).sum((1, 2)))
+    print("width %d prec %d rel err: y %.2e  sse %.2e  dW %.2e  dpe %.2e" % (W, prec, e_y, e_s, e_w, e_p))
+    lim = {1: (0.12, 1e-2, 0.12, 0.15), 2: (0.02, 2e-3, 0.02, 0.03)}[prec]
+    assert e_y < lim[0] and e_s < lim[1] and e_w < lim[2] and e_p < lim[3]
+    # per-layer check of the weight gradient (a mis-indexed small layer would hide behind the global maximum)
+    lo = 0
+    for l in range(len(dims) - 1):
+        n = dims[l + 1] * (dims[l] + 1)
+        assert rel_err(dw[:, lo:lo + n], wv_r.grad[:, lo:lo + n]) < lim[2] * 1.5, l
+        lo += n
+    sse_b, dw_b, dpe_b = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
+    # plain backward with an arbitrary (gradient-sized) dy
+    gen = torch.Generator().manual_seed(3)
+    dy = 1e-3 * torch.randn(N * S, P, C, generator=gen)
+    pe_r.grad = None
+    wv_r.grad = None
+    _oracle_mlp(dims, xf, pe_r, wv_r, S).backward(dy)
+    dw2, dpe2 = ops.siren_bwd(g(xf), g(pe), g(wv), g(dy), meta)
+    assert rel_err(dw2, wv_r.grad) < lim[2] and rel_err(dpe2, pe_r.grad) < lim[3]
+
+
+@pytest.mark.parametrize("W", [48, 64])
+def test_siren_wide_model_scale_weights_f16(W):
+    """the regime of the real model (effective weights ~1e-4, biases ~1e-2) in f16: 5e-3 of the fp32 restatement, which
+    no indexing error in the fragment builders, the image transposes or the layer-wise reduction could meet"""
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=288, N=3, S=1, hidden=W)
+    dims, D, xf, pe, wv, y = _siren_case(seed=7, **case)
+    gen = torch.Generator().manual_seed(8)
+    wv = (torch.rand(3, D, generator=gen) * 2 - 1) * 3e-4
+    lo = 0
+    for l in range(4):
+        n = dims[l + 1] * (dims[l] + 1)
+        wv[:, lo:lo + dims[l + 1]] = (torch.rand(3, dims[l + 1], generator=gen) * 2 - 1) * 0.03
+        lo += n
+    meta = SirenMeta(1, 288, 16, 16, 3, W, 3, precision=2)
+    pe_r, wv_r = pe.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+    y_ref = _oracle_mlp(dims, xf, pe_r, wv_r, 1)
+    scale = 1.0 / (288 * 3)
+    (((y_ref - y) ** 2).sum() * scale).backward()
+    y_hip = ops.siren_fwd(g(xf), g(pe), g(wv), meta)
+    sse, dw, dpe = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    e_y, e_w, e_p = rel_err(y_hip, y_ref.detach()), rel_err(dw, wv_r.grad), rel_err(dpe, pe_r.grad)
+    print("width %d model-scale f16: y %.2e dW %.2e dpe %.2e" % (W, e_y, e_w, e_p))
+    assert e_y < 5e-3 and e_w < 5e-3 and e_p < 5e-3
+    lo = 0
+    for l in range(4):
+        n = dims[l + 1] * (dims[l] + 1)
+        assert rel_err(dw[:, lo:lo + n], wv_r.grad[:, lo:lo + n]) < 5e-3, l
+        lo += n
+
+
+def test_siren_wide_bf16_pe_storage_and_split_output():
+    """width 64: bf16-stored pe / dpe reproduce fp32 storage exactly, and the split-bf16 gradient copy of the two
+    4160-long layer vectors equals split_bf16 of the fp32 gradient (as for width 32)"""
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=200, N=3, S=1, hidden=64)
+    dims, D, xf, pe, wv, y = _siren_case(seed=13, **case)
+    meta = SirenMeta(1, 200, 16, 16, 3, 64, 3, precision=1)
+    pe16 = g(pe).bfloat16()
+    pe32 = pe16.float()
+    scale = 1.0 / (200 * 3)
+    assert torch.equal(ops.siren_fwd(g(xf), pe32, g(wv), meta), ops.siren_fwd(g(xf), pe16, g(wv), meta))
+    s32, w32, d32 = ops.siren_loss_bwd(g(xf), pe32, g(wv), g(y), scale, meta)
+    s16, w16, d16, split = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_split=True)
+    assert d16.dtype == torch.bfloat16
+    assert torch.equal(s32, s16) and torch.equal(w32, w16) and torch.equal(d32.bfloat16(), d16)
+    n_wide, wlen = ops.siren_wide_layers(meta)
+    assert (n_wide, wlen) == (2, 64 * 65)
+    lo0 = 64 * 33
+    want = ops.split_bf16([w32[:, lo0 + k * wlen:lo0 + (k + 1) * wlen] for k in range(n_wide)], "cols", 0b010)
+    for k in range(n_wide):
+        assert torch.equal(split[k], want[k])
+
+
 def test_siren_per_inr_coordinates_and_strided_rows():
     """xf given per INR ([N,P,F]) and wvec rows with a padded stride."""
     case = dict(F=16, E=16, n_hidden=3, C=3, P=64, N=3, S=1)
@@ -206,6 +307,9 @@ def test_siren_rejects_bad_arguments():
     with pytest.raises(ops.RcbError):
         ops.siren_fwd(xf.cpu(), pe, torch.zeros(2, meta.d_net, device=DEV), meta)  # CPU tensor: no fallback
     bad = SirenMeta(1, 64, 16, 16, 3, 48, 3)
+    with pytest.raises(ops.RcbError):
+        ops.siren_fwd(xf, pe, torch.zeros(2, bad.d_net, device=DEV), bad)          # width 48 exists in 16-bit modes only
+    bad = SirenMeta(1, 64, 16, 16, 3, 40, 3, precision=1)
     with pytest.raises(ops.RcbError):
         ops.siren_fwd(xf, pe, torch.zeros(2, bad.d_net, device=DEV), bad)          # unsupported width
 

@@ -1,4 +1,4 @@
-"""Launches the fused SIREN kernel alone (for rocprofv3): python tools/run_siren.py [bf16|fp32] [N] [reps] [pe16]"""
+"""Launches the fused SIREN kernel alone (for rocprofv3): python tools/run_siren.py [bf16|f16|fp32] [N] [reps] [pe16] [width]"""
 import os
 import sys
 
@@ -8,12 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recombiner_amd import ops, utils
 from recombiner_amd.ops import SirenMeta
 
-prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else 0
+prec = {"bf16": 1, "f16": 2}.get(sys.argv[1] if len(sys.argv) > 1 else "fp32", 0)
+width = int(sys.argv[5]) if len(sys.argv) > 5 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = "cuda"
 X, Y = utils.synthetic_inputs([32, 32], 16, n, 3, seed=0)
-meta = SirenMeta(1, 1024, 16, 16, 3, 32, 3, precision=prec)
+meta = SirenMeta(1, 1024, 16, 16, 3, width, 3, precision=prec)
 Xd, Yd = X.to(dev), Y.to(dev)
 pe = torch.randn(n, 1024, 16, device=dev) * 0.1
 wv = (torch.rand(n, meta.d_net, device=dev) * 2 - 1) * 0.02
