@@ -211,8 +211,51 @@ def test_every_preset_captures_and_replays_in_the_throughput_mode(name, n_data):
     assert np.mean(e2) > np.mean(e1)                          # ELBO = -(loss): the second call continues to improve
 
 
+@pytest.mark.parametrize("name,width,prec", [("patch2d", 48, 1), ("patch3d", 64, 2), ("patch1d", 64, 1), ("cifar", 64, 1),
+                                             ("cifar", 48, 2)])
+def test_wide_siren_variants_train_like_the_oracle(name, width, prec):
+    """BASELINE.json's throughput variants (Kodak patches at width 48, 3-D video at width 64 in f16, ...): the golden
+    cases' geometry with wider hidden layers, two training steps incl. the shared mappings on the oracle's own noise;
+    ELBO / MSE / KL within 16-bit operand rounding of the fp32 CPU oracle, parameters within Adam's step size."""
+    d = load(f"prior_{name}.npz")
+    cfg = dict(cfg_of(d))
+    cfg["hidden_dims"] = [width] * 3
+    n = int(d["n"])
+    geo = O.Geometry.from_config(cfg)
+    p = O.init_prior_params(geo, n, seed=42)
+    A = O.make_linear_transform(geo.dims, seed=123)
+    upo = O.UpsampleNet(geo.data_dim, geo.paddings, geo.layerwise_scale_factors, seed=124)
+    X = O.fourier_features(cfg["pixel_sizes"], cfg["fourier_dim"])
+    torch.manual_seed(5)
+    Y = torch.rand(n, X.shape[0], cfg["output_dim"])
+    s0 = 0.0211547
+    pri = [torch.zeros_like(p["loc"][0]), torch.full_like(p["loc"][0], s0),
+           torch.zeros_like(p["lpe_loc"][0]), torch.full_like(p["lpe_loc"][0], s0)]
+    pri += ([torch.zeros_like(p["loc"][0]), torch.full_like(p["loc"][0], s0)] * 2) if cfg["patch"] else [None] * 4
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                         cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                         cfg["hierarchical_patch_nums"], random_seed=42, device=DEV)
+    m.precision = prec
+    torch.manual_seed(123)
+    lt = PM.LinearTransform(m.dims).to(DEV)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    np.testing.assert_array_equal(m.loc.detach().cpu().numpy(), p["loc"].numpy())      # same init draws (A1)
+    torch.manual_seed(77)
+    noise = O.Noise()
+    mse_o, kl_o, elbo_o = O.prior_train(geo, p, X[None].repeat(n, 1, 1), Y, pri, A, upo, 2, 2e-4, 1e-4, True, noise)
+    feed(m, noise.drawn)
+    prg = [None if q is None else q.to(DEV) for q in pri]
+    mse, kl, elbo = m.train(2, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *prg, lt, up, 1e-4,
+                            training_mappings=True)
+    np.testing.assert_allclose([mse, kl], [mse_o, kl_o], rtol=2e-3)
+    np.testing.assert_allclose(elbo, elbo_o, rtol=2e-3)
+    assert_close_mostly(m.loc, p["loc"].detach(), rtol=0, atol=1.5e-4, max_frac=0.02, hard_atol=8.2e-4, what="loc")
+    assert_close_mostly(lt.A[1], A[1].detach(), rtol=0, atol=1.5e-4, max_frac=0.02, hard_atol=8.2e-4, what="A1")
+
+
 def test_sharded_training_rehearsal_two_ranks_one_gpu():
-    """world_size 2 over gloo with both ranks on this GPU: mappings stay identical across ranks, and the three-graph
+    """world_size 2 over gloo with both ranks on this GPU: mappings stay identical across ranks, and the segmented-graph
     replay (asynchronous all-reduce between captured segments) reproduces eager stepping.  (The RCCL path itself needs
     as many GPUs as ranks; the driver runs it.)"""
     import os
