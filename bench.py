@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
     ap.add_argument("--lowp-gemm", action="store_true", help="bf16-operand A-transform GEMMs (experimental)")
     ap.add_argument("--no-split-gemm", action="store_true", help="plain fp32 A-transform GEMMs instead of split-bf16 fwd/dgrad")
+    ap.add_argument("--split-terms", type=int, default=None, choices=[2, 3],
+                    help="A/B switch: 3 = both split-GEMM operands carry a low part, 2 = the mappings enter as bf16")
     ap.add_argument("--torch-noise", action="store_true", help="torch.randn + reparam instead of in-kernel Philox noise")
     ap.add_argument("--wgrad-fp32", action="store_true", help="fp32 A weight-gradient GEMMs instead of bf16 high parts")
     ap.add_argument("--pe-fp32", action="store_true", help="store pe / dpe as fp32 instead of bf16 (bf16 mode; bit-identical)")
@@ -121,6 +123,8 @@ def main():
     m.stage1_bf16 = not a.stage1_fp32
     m.pe_bf16 = not a.pe_fp32
     m.split_gemm = not a.no_split_gemm
+    if a.split_terms is not None:
+        m.split_terms = a.split_terms
     m.wgrad_bf16 = not a.wgrad_fp32
     m.fused_noise = not a.torch_noise
     torch.manual_seed(123)

@@ -645,7 +645,13 @@ class SplitATransform:
     1056-wide layers of the 3x32 SIREN); other layers (the 99-wide output layer) stay plain fp32 GEMMs.
     prepare(A) splits the mappings once (per step when they are trained, per train() call when they are fixed)."""
 
-    def __init__(self, slices):
+    def __init__(self, slices, terms=3):
+        # terms = 3: x hi * A hi + x lo * A hi + x hi * A lo (both operands to ~16 mantissa bits);
+        # terms = 2: the last product is dropped, i.e. the shared mappings enter as bf16 (their fp32 master copy only
+        #            feeds Adam) while the per-INR left operand keeps its low part: K shrinks from 3 W to 2 W
+        if terms not in (2, 3):
+            raise RcbError("SplitATransform: terms must be 2 or 3")
+        self.terms = terms
         self.slices = list(slices)
         widths = [hi - lo for lo, hi in self.slices]
         big = max(widths)
@@ -702,16 +708,19 @@ class SplitATransform:
             # ([k, rows, W] view with strides (W, ld, 1)): better CU fill than one layer at a time
             lo0 = self.slices[self.fast[0]][0]
             k, w = len(self.fast), self.slices[self.fast[0]][1] - lo0
+            kk = self.terms * w                       # leading blocks of [hi | lo | hi] x [hi ; hi ; lo]
             try:
                 view = out[:, lo0:lo0 + k * w].view(out.shape[0], k, w).permute(1, 0, 2)
-                torch.bmm(lefts.stacked, right.stacked.transpose(1, 2) if transpose else right.stacked, out_dtype=f32, out=view)
+                rs = right.stacked[:, :, :kk].transpose(1, 2) if transpose else right.stacked[:, :kk]
+                torch.bmm(lefts.stacked[:, :, :kk], rs, out_dtype=f32, out=view)
                 batched = True
             except RuntimeError:
                 batched = False
         if not batched:
             for k, i in enumerate(self.fast):
                 lo, hi = self.slices[i]
-                torch.mm(lefts[k], right[k].t() if transpose else right[k], out_dtype=f32, out=out[:, lo:hi])
+                kk = self.terms * (hi - lo)
+                torch.mm(lefts[k][:, :kk], right[k][:, :kk].t() if transpose else right[k][:kk], out_dtype=f32, out=out[:, lo:hi])
         for i in self.rest:
             lo, hi = self.slices[i]
             a = self.A[i].detach()

@@ -168,6 +168,7 @@ class TestBNNmodel(nn.Module):
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
+        self.split_terms = 2         # as PriorBNNmodel.split_terms
         self.use_graph = True        # replay the fused training step as captured HIP graphs when possible
         self._specs = None
         self._ws = None
@@ -449,7 +450,7 @@ class TestBNNmodel(nn.Module):
         # workspace that survives across calls (Adam state is re-zeroed = a fresh optimiser, the step counter
         # restarts): its stable addresses let the two captured step graphs be reused by every fine-tune call
         key = (x.data_ptr(), y.data_ptr(), tuple(x.shape), S, float(lr), float(eps_adam), self.precision,
-               self.loc.data_ptr(), self.log_scale.data_ptr(), bool(self.split_gemm))
+               self.loc.data_ptr(), self.log_scale.data_ptr(), bool(self.split_gemm), self.split_terms)
         ws = self._ws
         if ws is None or ws["key"] != key or ws["tab"].shape[0] < n_epochs:
             ws = dict(key=key, tab=ops.adam_table(lr, max(n_epochs, 2048)).to(dev),
@@ -468,7 +469,7 @@ class TestBNNmodel(nn.Module):
         if self.split_gemm and self.precision != 0:
             split = ws.get("split")
             if split is None:                       # the mappings are fixed at test time: split them once per workspace
-                split = ops.SplitATransform(slices)
+                split = ops.SplitATransform(slices, self.split_terms)
                 if split.fast:
                     split.prepare(A)
                 else:

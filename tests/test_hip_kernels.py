@@ -402,7 +402,7 @@ def test_split_bf16_operands_and_a_transform():
     for k in range(3):
         assert torch.equal(rows[k], torch.cat([ah[k], ah[k], al[k]], 0))
         assert torch.equal(cols[k], torch.cat([ah[k], ah[k], al[k]], 1))
-    tr = ops.SplitATransform(slices)
+    tr = ops.SplitATransform(slices, terms=3)
     assert tr.fast == [0, 1, 2] and tr.rest == [3]
     tr.prepare(A)
     w = tr.forward(x, torch.empty(N, D, device=DEV))
@@ -412,6 +412,17 @@ def test_split_bf16_operands_and_a_transform():
         refT = x[:, a:b].double() @ m.double().t()
         assert rel_err(w[:, a:b], ref) < 2e-5 and rel_err(dh[:, a:b], refT) < 2e-5
         assert rel_err(x[:, a:b].bfloat16().float() @ m.bfloat16().float(), ref) > 5e-4      # what plain bf16 would give
+    # terms = 2 (the models' default): the mappings enter as bf16, the per-INR operand keeps hi + lo -> the product with
+    # the ROUNDED mappings at fp32-rounding level
+    tr2 = ops.SplitATransform(slices, terms=2)
+    tr2.prepare(A)
+    w2 = tr2.forward(x, torch.empty(N, D, device=DEV))
+    dh2 = tr2.dgrad(x, torch.empty(N, D, device=DEV))
+    for k, ((a, b), m) in enumerate(zip(slices, A)):
+        mr = m.bfloat16().double() if k < 3 else m.double()
+        assert rel_err(w2[:, a:b], x[:, a:b].double() @ mr) < 2e-5 and rel_err(dh2[:, a:b], x[:, a:b].double() @ mr.t()) < 2e-5
+    with pytest.raises(ops.RcbError):
+        ops.SplitATransform(slices, terms=4)
 
 
 def test_philox_noise_stream_and_fused_reparam():

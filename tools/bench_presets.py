@@ -13,16 +13,24 @@ from recombiner_amd import config, tuning, utils
 from recombiner_amd import prior_model as PM
 
 tuning.enable_tuned_gemms()
-DATA = {"cifar": 4096, "protein": 4096, "kodak": 2, "audio": 8, "video": 4}          # datapoints (images / clips / ...)
-for name, n_data in DATA.items():
-    cfg = config.configs[name]
+# (label, preset, datapoints (images / clips / ...), hidden width, precision mode): the five reference presets, then
+# BASELINE.json's width variants (configs[2]: Kodak patches at width 48; configs[4]: video at width 64 in f16)
+RUNS = [("cifar", "cifar", 4096, 32, 1), ("protein", "protein", 4096, 32, 1), ("kodak", "kodak", 2, 32, 1),
+        ("audio", "audio", 8, 32, 1), ("video", "video", 4, 32, 1),
+        ("kodak-w48", "kodak", 2, 48, 1), ("video-w64-f16", "video", 4, 64, 2), ("cifar-w64", "cifar", 4096, 64, 1)]
+only = sys.argv[1:]
+for label, name, n_data, width, prec in RUNS:
+    if only and label not in only:
+        continue
+    cfg = dict(config.configs[name])
+    cfg["hidden_dims"] = [width] * len(cfg["hidden_dims"])
     per = int(np.prod(cfg["patch_nums"])) if cfg["patch"] else 1
     n = n_data * per
     X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
     m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
                          cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
                          cfg["hierarchical_patch_nums"], random_seed=42, device="cuda")
-    m.precision = 1
+    m.precision = prec
     torch.manual_seed(1)
     lt = PM.LinearTransform(m.dims).cuda()
     up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
@@ -43,6 +51,6 @@ for name, n_data in DATA.items():
         dt = (time.perf_counter() - t0) / steps
     graph = m._ws is not None and m._ws["graphs"] is not None
     px = int(np.prod(cfg["pixel_sizes"]))
-    print("%-8s %5d INRs (%d datapoints) x %5d px: %7.2f ms/step = %9.0f INR-steps/s, %6.1f Mpx-steps/s; graph replay: %s; finite: %s%s"
-          % (name, n, n_data, px, dt * 1e3, n / dt, n * px / dt / 1e6, graph, bool(np.isfinite(elbo).all()),
+    print("%-14s %5d INRs (%d datapoints) x %5d px: %7.2f ms/step = %9.0f INR-steps/s, %6.1f Mpx-steps/s; graph replay: %s; finite: %s%s"
+          % (label, n, n_data, px, dt * 1e3, n / dt, n * px / dt / 1e6, graph, bool(np.isfinite(elbo).all()),
              ("; warnings: " + "; ".join(str(x.message)[:80] for x in w)) if w else ""), flush=True)
