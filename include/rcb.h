@@ -325,6 +325,26 @@ int rcb_upconv_weff_grad(const void* dweff1, int32_t bf16_in, const float* dweff
                          int32_t n_partial, float* db1 /* nullable [64] = column sums of db1_partial */,
                          rcb_stream_t stream);
 
+/* ---- overlapping tiles of a stitched grid (N1 for the patched presets; utils.py:71-116 stitches the patches of a
+ * datapoint into one latent grid before the upsampling net, prior_model.py:52-54) ------------------------------------
+ * The phase-conv kernels above work on small zero-halo images.  A large channel-last bf16 image [n][H][W][C] (C % 8 == 0)
+ * is cut into tiles [n][Ty][Tx][T][T][C]; tile (ty, tx) holds pixels ty*step - off .. + T-1  x  tx*step - off .. + T-1.
+ *   rcb_tile_gather: image -> tiles, zero outside the image and, with ring = 1, on the outermost row / column of each tile.
+ *                    Source tiles of an upconv stage with grid G: T = G, step = G-1, off = 1, ring = 0 (tiles overlap by
+ *                    one source pixel, so all but the outermost of a tile's 2G output rows see their whole window);
+ *                    tiles of the upstream gradient: T = 2G, step = 2G-2, off = 2, ring = 1.
+ *   rcb_tile_crop  : tiles -> image [n][H][W][C] from the inner T-2 rows / columns of every tile (step = T-2):
+ *                    pixel y comes from tile (y+off) / (T-2), row (y+off) % (T-2) + 1.  Stage outputs: T = 2G, off = 1.
+ *   rcb_tile_fold  : tiles -> image, the SUM of all tile elements that map to a pixel (step = T-1; adjoint of the ring-0
+ *                    gather: border pixels belong to two tiles per axis); fp32 sum in a fixed order, rounded once to bf16.
+ * Pure data movement (HBM-bound: bytes = image + tiles).                                                               */
+int rcb_tile_gather(const void* img, void* tiles, int32_t n, int32_t H, int32_t W, int32_t C, int32_t Ty, int32_t Tx,
+                    int32_t T, int32_t step, int32_t off, int32_t ring, rcb_stream_t stream);
+int rcb_tile_crop(const void* tiles, void* img, int32_t n, int32_t H, int32_t W, int32_t C, int32_t Ty, int32_t Tx,
+                  int32_t T, int32_t off, rcb_stream_t stream);
+int rcb_tile_fold(const void* tiles, void* img, int32_t n, int32_t H, int32_t W, int32_t C, int32_t Ty, int32_t Tx,
+                  int32_t T, int32_t off, rcb_stream_t stream);
+
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);
 

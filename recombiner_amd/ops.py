@@ -566,6 +566,51 @@ def upconv_bwd_fused(dy, weff, x, grid, cout, pack=None):
     return dx, dw, db
 
 
+# ---------------------------------------------------------------------------------------------------
+# overlapping tiles of a stitched grid (rcb_tile_*): bf16 channel-last images
+# ---------------------------------------------------------------------------------------------------
+def tile_count(size, grid):
+    """tiles per axis of an upconv stage with kernel grid `grid` over `size` source pixels (tiles overlap by one pixel)"""
+    return -(-(2 * size + 1) // (2 * grid - 2))
+
+
+def _tile_img(img):
+    if img.dtype != bf16 or not img.is_cuda or img.dim() != 4 or not img.is_contiguous() or img.shape[-1] % 8:
+        raise RcbError("tiles: contiguous bf16 GPU image [n, H, W, C] with C % 8 == 0 expected")
+    return img.shape
+
+
+def tile_gather(img, Ty, Tx, T, step, off, ring):
+    """img [n,H,W,C] -> tiles [n*Ty*Tx, T, T, C] (rcb_tile_gather)"""
+    n, H, W, Cc = _tile_img(img)
+    tiles = torch.empty(n * Ty * Tx, T, T, Cc, device=img.device, dtype=bf16)
+    check(_lib.load().rcb_tile_gather(ptr(img), ptr(tiles), n, H, W, Cc, Ty, Tx, T, step, off, ring, stream_ptr()), "rcb_tile_gather")
+    return tiles
+
+
+def _tile_out(tiles, n, H, W, Ty, Tx):
+    if tiles.dtype != bf16 or not tiles.is_cuda or tiles.dim() != 4 or not tiles.is_contiguous() or tiles.shape[0] != n * Ty * Tx \
+            or tiles.shape[1] != tiles.shape[2] or tiles.shape[-1] % 8:
+        raise RcbError("tiles: contiguous bf16 GPU tiles [n*Ty*Tx, T, T, C] expected")
+    return torch.empty(n, H, W, tiles.shape[-1], device=tiles.device, dtype=bf16)
+
+
+def tile_crop(tiles, n, H, W, Ty, Tx, off):
+    """tiles [n*Ty*Tx, T, T, C] -> img [n,H,W,C] from the inner T-2 rows / columns of every tile (rcb_tile_crop)"""
+    img = _tile_out(tiles, n, H, W, Ty, Tx)
+    check(_lib.load().rcb_tile_crop(ptr(tiles), ptr(img), n, H, W, tiles.shape[-1], Ty, Tx, tiles.shape[1], off, stream_ptr()),
+          "rcb_tile_crop")
+    return img
+
+
+def tile_fold(tiles, n, H, W, Ty, Tx, off):
+    """tiles [n*Ty*Tx, T, T, C] -> img [n,H,W,C], overlapping tile borders summed (rcb_tile_fold)"""
+    img = _tile_out(tiles, n, H, W, Ty, Tx)
+    check(_lib.load().rcb_tile_fold(ptr(tiles), ptr(img), n, H, W, tiles.shape[-1], Ty, Tx, tiles.shape[1], off, stream_ptr()),
+          "rcb_tile_fold")
+    return img
+
+
 UPCONV_PACK_UINT4 = 22528
 
 

@@ -20,7 +20,8 @@ from torch.optim import Adam
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
-from .upsample_fast import hip_path_supported, phase_form_preferred, phase_module, upsample_cifar_hip
+from .upsample_fast import (hip_path_supported, hip_stitched_supported, phase_form_preferred, phase_module,
+                            stitched2d_module, upsample_cifar_hip)
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs, metric
 
 LN2 = np.log(2.)
@@ -237,7 +238,9 @@ class TestBNNmodel(nn.Module):
                                                       self.patch, self.data_dim):
             return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
         net = self.upsample_net
-        if self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
+        if self.precision != 0 and hip_stitched_supported(self.upsample_net, self.patch, self.data_dim):
+            net = stitched2d_module(self.upsample_net)
+        elif self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
             net = phase_module(self.upsample_net) or self.upsample_net
         return map_lpe_to_inr_inputs(net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
                                      self.patch, self.patch_nums, self.data_dim)

@@ -249,3 +249,100 @@ def phase_module(net):
             fast = False
         object.__setattr__(net, "_rcb_phase_form", fast)       # not a registered sub-module: no parameter duplication
     return fast or None
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP path for the STITCHED 2-D grids of the patched presets (Kodak: 8 x 12 patches -> one 32 x 48 latent grid per photo
+# -> 128 x 192 -> 256 x 384 -> 512 x 768).  The rcb_upconv_* kernels work on small images with a ZERO halo; a large image is
+# cut into tiles that OVERLAP by one source pixel: tile t holds source rows t (G-1) - 1 .. t (G-1) + G - 2 (row -1 and
+# rows >= H are the conv's zero padding), so of its 2G output rows all but the first and the last see their whole 2 x 2
+# window inside the tile.  Those 2G - 2 valid rows of consecutive tiles abut exactly; the invalid ring is dropped in the
+# forward pass and gets a zero upstream gradient in the backward pass, which makes every sum (data, weight and bias
+# gradients) exact: overlapping source pixels collect their gradient from both tiles (fold), nothing is counted twice.
+# ---------------------------------------------------------------------------------------------------
+class _UpsampleStitched23Fn(torch.autograd.Function):
+    """stages 2 and 3 of the upsampling net on a stitched 2-D grid: z1 [n, H, W, 64] (bf16 pre-activation of stage 1)
+    -> pe [n, 4H, 4W, 16] (bf16, linear) through the rcb_upconv_* kernels on overlapping tiles (8 x 8 source pixels
+    for the 64 -> 64 stage, 16 x 16 for the 64 -> 16 stage); rcb_tile_gather / _crop / _fold move between images and tiles."""
+
+    @staticmethod
+    def forward(ctx, z1, W1, b1, W2, b2, W3, b3):
+        from . import ops
+        n, H, W, _ = z1.shape
+        _, _, Weff2, Weff3, pack = ops.upconv_weff_build(W1, b1, W2, W3, True)      # (the stage-1 part is the CIFAR map: unused)
+        Ty2, Tx2, Ty3, Tx3 = ops.tile_count(H, 8), ops.tile_count(W, 8), ops.tile_count(2 * H, 16), ops.tile_count(2 * W, 16)
+        t1 = ops.tile_gather(z1.contiguous(), Ty2, Tx2, 8, 7, 1, 0)
+        h2 = ops.upconv_fwd(t1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True, pack=pack)
+        h2_img = ops.tile_crop(h2, n, 2 * H, 2 * W, Ty2, Tx2, 1)
+        t2 = ops.tile_gather(h2_img, Ty3, Tx3, 16, 15, 1, 0)
+        pe = ops.upconv_fwd(t2, Weff3, b3.contiguous(), 16, 16, out_f32=False, linear_bf16=True, pack=pack)
+        ctx.save_for_backward(t1, Weff2, t2, Weff3, pack)
+        ctx.geo = (n, H, W, Ty2, Tx2, Ty3, Tx3)
+        return ops.tile_crop(pe, n, 4 * H, 4 * W, Ty3, Tx3, 1)
+
+    @staticmethod
+    def backward(ctx, dpe):
+        from . import ops
+        t1, Weff2, t2, Weff3, pack = ctx.saved_tensors
+        n, H, W, Ty2, Tx2, Ty3, Tx3 = ctx.geo
+        dy3 = ops.tile_gather(dpe.to(torch.bfloat16).contiguous(), Ty3, Tx3, 32, 30, 2, 1)
+        dz2_t, dWeff3, db3 = ops.upconv_bwd_fused(dy3, Weff3, t2, 16, 16, pack=pack)
+        dz2 = ops.tile_fold(dz2_t, n, 2 * H, 2 * W, Ty3, Tx3, 1)
+        dy2 = ops.tile_gather(dz2, Ty2, Tx2, 16, 14, 2, 1)
+        dz1_t = ops.upconv_dgrad(dy2, Weff2, t1, 8, 64, preact=True, pack=pack)
+        dz1 = ops.tile_fold(dz1_t, n, H, W, Ty2, Tx2, 1)
+        dWeff2, db2 = ops.upconv_wgrad(t1, dy2, 8, 64, preact=True)
+        zero1 = _dev_const("dweff1_zero", dpe.device, lambda: torch.zeros(512 * 4096, dtype=torch.bfloat16))
+        _, dW2, dW3 = ops.upconv_weff_grad(zero1, dWeff2, dWeff3)
+        return dz1, None, None, dW2, db2, dW3, db3
+
+
+def _stage1_big_weight(W1, dtype):
+    """conv1 weight [64,128,5,5] -> the (x4, 5x5, pad 2) stage as ONE GEMM on 3 x 3 windows of the latent grid:
+    [3*3*128, 4*4*64] with rows (wy, wx, ci) and columns (a, b, co); phase a of an axis reads the two window taps
+    shift[a] + {0, 1} (differentiable: autograd returns dW1 through the einsum)."""
+    w, pad_l, pad_r, shift, _ = _axis_plan(4, 5, 2)
+    assert (w, pad_l, pad_r, list(shift)) == (2, 1, 1, [0, 0, 1, 1])
+    R = _phase_R(W1.device, 4, 5, 2).to(W1.dtype)                       # [a, t, k]
+    sel = _dev_const("stage1_sel", W1.device, lambda: torch.tensor([[[1., 0.], [0., 1.], [0., 0.]]] * 2 + [[[0., 0.], [1., 0.], [0., 1.]]] * 2))
+    R3 = torch.einsum("awt,atk->awk", sel.to(W1.dtype), R)              # [a, window tap w in 0..2, k]
+    big = torch.einsum("ayk,bxl,oikl->yxiabo", R3, R3, W1)              # [3,3,128,4,4,64]
+    return big.reshape(9 * 128, 16 * 64).to(dtype)
+
+
+def _stage1_stitched(z, W1, b1):
+    """z [n, h, w, 128] (fp32 latent grid) -> z1 [n, 4h, 4w, 64] bf16 pre-activation: 3 x 3 window gather, one bf16 GEMM
+    (fp32 accumulate) against the phase-form weight, pixel shuffle.  Plain tensor ops: autograd supplies the backward."""
+    n, h, w, _ = z.shape
+    zp = torch.nn.functional.pad(z.to(torch.bfloat16), (0, 0, 1, 1, 1, 1))
+    s0, s1, s2, _ = zp.stride()
+    cols = zp.as_strided((n, h, w, 3, 3, 128), (s0, s1, s2, s1, s2, 1)).reshape(n * h * w, 9 * 128)
+    y = torch.addmm(b1.to(torch.bfloat16).repeat(16), cols, _stage1_big_weight(W1, torch.bfloat16))     # [n h w, (a, b, co)]
+    return y.view(n, h, w, 4, 4, 64).permute(0, 1, 3, 2, 4, 5).reshape(n, 4 * h, 4 * w, 64)
+
+
+def hip_stitched_supported(net, patch, data_dim):
+    try:
+        ok = (data_dim == 2 and bool(patch) and isinstance(net.conv1, torch.nn.Conv2d)
+              and tuple(net.conv1.weight.shape) == (64, 128, 5, 5) and tuple(net.conv2.weight.shape) == (64, 64, 3, 3)
+              and tuple(net.conv3.weight.shape) == (16, 64, 3, 3) and tuple(net.conv1.padding) == (2, 2)
+              and tuple(net.conv2.padding) == (1, 1) and tuple(net.conv3.padding) == (1, 1)
+              and [float(net.up1.scale_factor), float(net.up2.scale_factor), float(net.up3.scale_factor)] == [4., 2., 2.])
+    except (AttributeError, TypeError):
+        ok = False
+    return ok
+
+
+def stitched2d_module(net):
+    """channel-first callable (drop-in for `net` inside map_lpe_to_inr_inputs) evaluating the upsampling net on a
+    stitched 2-D latent grid: stage 1 (x4, 5x5, 128 -> 64) in phase form as bf16 GEMMs on the small latent grid, stages 2
+    and 3 through the hand-written phase-conv kernels.  Returns bf16 (the 16-bit SIREN kernels read pe as bf16)."""
+    fast = getattr(net, "_rcb_stitched2d", None)
+    if fast is None:
+        def fast(z_cf):
+            z1 = _stage1_stitched(z_cf.movedim(1, -1), net.conv1.weight, net.conv1.bias)
+            pe = _UpsampleStitched23Fn.apply(z1, net.conv1.weight, net.conv1.bias, net.conv2.weight,
+                                             net.conv2.bias, net.conv3.weight, net.conv3.bias)
+            return pe.movedim(-1, 1)
+        object.__setattr__(net, "_rcb_stitched2d", fast)
+    return fast

@@ -44,7 +44,21 @@ for name, nb in BATCH.items():
         return (time.perf_counter() - t0) / reps * 1e3, r
 
     res = {}
-    for label, fn, ac in (("nn fp32", net, False), ("nn bf16", net, True), ("phase fp32", fast, False), ("phase bf16", fast, True)):
+    only = sys.argv[1:]
+    if only and name not in only:
+        continue
+    xs = {"": x}
+    if dd == 2:
+        xs["cl "] = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    variants = [("nn fp32", net, False), ("nn bf16", net, True), ("phase fp32", fast, False), ("phase bf16", fast, True)]
+    if dd == 2:
+        variants += [("cl nn fp32", net, False), ("cl nn bf16", net, True), ("cl phase bf16", fast, True)]
+    if dd == 2 and c["patch"]:
+        from recombiner_amd.upsample_fast import stitched2d_module
+        variants += [("cl hip tiles", stitched2d_module(net), False)]
+    x_nchw = x
+    for label, fn, ac in variants:
+        x = xs["cl "] if label.startswith("cl ") else x_nchw
         try:
             res[label] = run(fn, ac)
         except Exception as e:      # noqa: BLE001
