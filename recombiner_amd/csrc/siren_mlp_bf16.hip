@@ -139,9 +139,11 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
             if (fq < E) w = wl[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
           }
         }
-        // forward fragments of the sine layers carry w0 / 2 pi; the output layer and the transposed (data-gradient)
-        // fragments stay in the original units
-        const float sc = (slot < K0S + 2 * (NH - 1)) ? WS * a.k_hi : WS;
+        // forward fragments of the sine layers carry w0 / 2 pi; the transposed fragments that produce a hidden layer's
+        // data gradient carry w0 (d sin(w0 z) / dz = w0 cos(w0 z): the multiply by w0 happens inside the MFMA); the output
+        // layer and the fragments of the input (pe) gradient stay in the original units
+        const float sc = (slot < K0S + 2 * (NH - 1)) ? WS * a.k_hi
+                         : (slot >= NFA && slot < NFA + 1 + 2 * (NH - 1)) ? a.w0 : WS;
         fr.v[j] = (T)(w * sc);
       }
       frags[slot * 64 + lane] = fr.u;
@@ -165,7 +167,6 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) gb[l] = 0.f;
   }
-  const float w0 = a.w0 * (1.0f / WS);
   constexpr int KH0 = F, KH1 = E;
 
   const int ntiles = (P + 31) >> 5;
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
           for (int s = 0; s < 2; ++s) dh = Op16<T>::mfma(FA(base + s), dzb[s], dh);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (w0 * (float)Cs[l - 1][r >> 3][r & 7]);
+        for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (float)Cs[l - 1][r >> 3][r & 7];     // w0 is in the fragments
       } else if (a.dpe != nullptr) {
         f32x16 dx;
 #pragma unroll

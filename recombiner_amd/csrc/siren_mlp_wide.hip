@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
     const int fq = lane & 31, fh = lane >> 5;
     auto put = [&](int slot, auto&& elem) {
       union { bf16x8 v; uint4 u; } fr;
-      const float sc = (slot < G::NSINE) ? WS * a.k_hi : WS;
+      // sine-layer forward fragments carry w0 / 2 pi, the fragments producing a hidden layer's data gradient carry w0
+      const float sc = (slot < G::NSINE) ? WS * a.k_hi : (slot >= G::FBO && slot < G::FBX) ? a.w0 : WS;
 #pragma unroll
       for (int j = 0; j < 8; ++j) fr.v[j] = (T)(elem(j) * sc);
       frags[slot * 64 + lane] = fr.u;
@@ -214,7 +215,6 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
 #pragma unroll
       for (int b = 0; b < HB; ++b) gb[l][b] = 0.f;
   }
-  const float w0 = a.w0 * (1.0f / WS);
   constexpr int KH0 = F, KH1 = E;
 
   const int ntiles = (P + 31) >> 5;
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
           // dz of layer l-1, tile ib (written after every use of the old dz tiles: dzb holds their packed copies)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            dz[ib][r] = (2 * ib + (r >> 3) < KSH) ? dh[r] * (w0 * (float)Cs[l - 1][2 * ib + (r >> 3)][r & 7]) : 0.f;
+            dz[ib][r] = (2 * ib + (r >> 3) < KSH) ? dh[r] * (float)Cs[l - 1][2 * ib + (r >> 3)][r & 7] : 0.f;
         }
       } else if (a.dpe != nullptr) {
         f32x16 dx;

@@ -198,3 +198,49 @@ def test_stitched_2d_grid_through_overlapping_tiles(n, grid):
     d = (out.float() - ref.float()).abs()
     seam = d[:, :, 29:33].max() if d.shape[2] > 33 else d.max()      # output rows around the first stage-3 tile border
     assert float(seam) <= float(d.max()) and float(d.max()) < 2.5e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n,H,W,C,G", [(2, 13, 9, 64, 8), (1, 32, 48, 16, 16), (3, 7, 30, 64, 16)])
+def test_tile_kernels_match_their_definitions(n, H, W, C, G):
+    """rcb_tile_gather / _crop / _fold against plain tensor restatements: exact (pure data movement; the fold's sums are
+    exact on small integers), incl. sizes that are no multiple of the tile step and error returns."""
+    from recombiner_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    img = torch.randint(-8, 9, (n, H, W, C), device=DEV, generator=gen).to(torch.bfloat16)
+    Ty, Tx = ops.tile_count(H, G), ops.tile_count(W, G)
+
+    def windows(x, T, step, off):
+        plane = x.new_zeros(n, (Ty - 1) * step + T, (Tx - 1) * step + T, x.shape[-1])
+        hh, ww = min(x.shape[1], plane.shape[1] - off), min(x.shape[2], plane.shape[2] - off)
+        plane[:, off:off + hh, off:off + ww] = x[:, :hh, :ww]
+        s0, s1, s2, _ = plane.stride()
+        return plane.as_strided((n, Ty, Tx, T, T, x.shape[-1]), (s0, step * s1, step * s2, s1, s2, 1)).reshape(n * Ty * Tx, T, T, -1)
+
+    # source tiles: G pixels every G-1, starting at -1
+    t = ops.tile_gather(img, Ty, Tx, G, G - 1, 1, 0)
+    assert torch.equal(t, windows(img, G, G - 1, 1))
+    # upstream-gradient tiles of the 2x output image: 2G pixels every 2G-2 starting at -2, outermost ring zeroed
+    out = torch.randint(-8, 9, (n, 2 * H, 2 * W, C), device=DEV, generator=gen).to(torch.bfloat16)
+    d = ops.tile_gather(out, Ty, Tx, 2 * G, 2 * G - 2, 2, 1)
+    ref = windows(out, 2 * G, 2 * G - 2, 2).clone()
+    ref[:, 0] = 0
+    ref[:, -1] = 0
+    ref[:, :, 0] = 0
+    ref[:, :, -1] = 0
+    assert torch.equal(d, ref)
+    # crop is the inverse of that gather on the valid rows: round trip
+    assert torch.equal(ops.tile_crop(d, n, 2 * H, 2 * W, Ty, Tx, 1), out)
+    # fold = adjoint of the ring-0 gather: every pixel collects all tile elements that map to it
+    tiles = torch.randint(-8, 9, (n * Ty * Tx, G, G, C), device=DEV, generator=gen).to(torch.bfloat16)
+    plane = torch.zeros(n, (Ty - 1) * (G - 1) + G, (Tx - 1) * (G - 1) + G, C, device=DEV)
+    tv = tiles.view(n, Ty, Tx, G, G, C).float()
+    for ty in range(Ty):
+        for tx in range(Tx):
+            plane[:, ty * (G - 1):ty * (G - 1) + G, tx * (G - 1):tx * (G - 1) + G] += tv[:, ty, tx]
+    assert torch.equal(ops.tile_fold(tiles, n, H, W, Ty, Tx, 1), plane[:, 1:H + 1, 1:W + 1].to(torch.bfloat16))
+    with pytest.raises(ops.RcbError):
+        ops.tile_crop(d, n, 2 * H + 64, 2 * W, Ty, Tx, 1)             # image larger than the tiles cover
+    with pytest.raises(ops.RcbError):
+        ops.tile_gather(img.float(), Ty, Tx, G, G - 1, 1, 0)          # bf16 only
+    with pytest.raises(ops.RcbError):
+        ops.tile_fold(tiles, n, (Ty + 1) * G, W, Ty, Tx, 1)
