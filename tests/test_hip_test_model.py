@@ -208,13 +208,16 @@ def test_graph_replayed_training_tracks_eager_training():
     assert (ba != bb).mean() < 0.05
 
 
+@pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("name", ["patch1d", "patch2d"])
-def test_bitstream_round_trip_three_levels(name):
+def test_bitstream_round_trip_three_levels(name, precision):
     """N4 on a patched preset: encode every group of levels 3, 2, 1 (no fine-tuning), pack, and rebuild the encoded
-    samples on a freshly constructed model from the indices alone: bit-identical parameters, same reconstruction."""
+    samples on a freshly constructed model from the indices alone: bit-identical parameters, same reconstruction
+    (precision 1: the decoder runs the bf16 kernels, for patch2d the tiled phase-conv path of the stitched grid)."""
     from recombiner_amd import bitstream
     d = load(f"test_{name}.npz")
     cfg, n, m = build(d, name)
+    m.precision = precision
     set_post(d, cfg, m)
     X = t(d, "X").to(DEV)[None].expand(n, -1, -1)
     for lv in (m._l3, m._l2, m._l1):
@@ -224,6 +227,7 @@ def test_bitstream_round_trip_three_levels(name):
     n_idx = sum(lv.rows * lv.n_groups for lv in (m._l1, m._l2, m._l3))
     assert bitstream.payload_bits(blob) == 16 * n_idx
     _, _, m2 = build(d, name)
+    m2.precision = precision
     levels = bitstream.unpack_indices(blob)
     assert [a.shape for a in levels] == [(lv.rows, lv.n_groups) for lv in (m._l1, m._l2, m._l3)]
     bitstream.apply_indices(m2, levels)
