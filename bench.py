@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-split-gemm", action="store_true", help="plain fp32 A-transform GEMMs instead of split-bf16 fwd/dgrad")
     ap.add_argument("--split-terms", type=int, default=None, choices=[2, 3],
                     help="A/B switch: 3 = both split-GEMM operands carry a low part, 2 = the mappings enter as bf16")
+    ap.add_argument("--split-dgrad-terms", type=int, default=None, choices=[1, 2, 3],
+                    help="A/B switch: terms of the A-transform data-gradient GEMM (default: as --split-terms)")
     ap.add_argument("--torch-noise", action="store_true", help="torch.randn + reparam instead of in-kernel Philox noise")
     ap.add_argument("--wgrad-fp32", action="store_true", help="fp32 A weight-gradient GEMMs instead of bf16 high parts")
     ap.add_argument("--pe-fp32", action="store_true", help="store pe / dpe as fp32 instead of bf16 (bf16 mode; bit-identical)")
@@ -125,6 +127,8 @@ def main():
     m.split_gemm = not a.no_split_gemm
     if a.split_terms is not None:
         m.split_terms = a.split_terms
+    if a.split_dgrad_terms is not None:
+        m.split_dgrad_terms = a.split_dgrad_terms
     m.wgrad_bf16 = not a.wgrad_fp32
     m.fused_noise = not a.torch_noise
     torch.manual_seed(123)

@@ -690,13 +690,18 @@ class SplitATransform:
     1056-wide layers of the 3x32 SIREN); other layers (the 99-wide output layer) stay plain fp32 GEMMs.
     prepare(A) splits the mappings once (per step when they are trained, per train() call when they are fixed)."""
 
-    def __init__(self, slices, terms=3):
+    def __init__(self, slices, terms=3, dgrad_terms=None):
         # terms = 3: x hi * A hi + x lo * A hi + x hi * A lo (both operands to ~16 mantissa bits);
         # terms = 2: the last product is dropped, i.e. the shared mappings enter as bf16 (their fp32 master copy only
         #            feeds Adam) while the per-INR left operand keeps its low part: K shrinks from 3 W to 2 W
         if terms not in (2, 3):
             raise RcbError("SplitATransform: terms must be 2 or 3")
         self.terms = terms
+        # the data gradient dh = dw @ A^T may use fewer terms than the forward product (1 = bf16 high parts only: a
+        # gradient, consumed by Adam's normalisation)
+        self.dgrad_terms = terms if dgrad_terms is None else dgrad_terms
+        if self.dgrad_terms not in (1, 2, 3) or self.dgrad_terms > terms:
+            raise RcbError("SplitATransform: dgrad_terms must be 1 .. terms")
         self.slices = list(slices)
         widths = [hi - lo for lo, hi in self.slices]
         big = max(widths)
@@ -753,7 +758,7 @@ class SplitATransform:
             # ([k, rows, W] view with strides (W, ld, 1)): better CU fill than one layer at a time
             lo0 = self.slices[self.fast[0]][0]
             k, w = len(self.fast), self.slices[self.fast[0]][1] - lo0
-            kk = self.terms * w                       # leading blocks of [hi | lo | hi] x [hi ; hi ; lo]
+            kk = (self.dgrad_terms if transpose else self.terms) * w        # leading blocks of [hi | lo | hi] x [hi ; hi ; lo]
             try:
                 view = out[:, lo0:lo0 + k * w].view(out.shape[0], k, w).permute(1, 0, 2)
                 rs = right.stacked[:, :, :kk].transpose(1, 2) if transpose else right.stacked[:, :kk]
@@ -764,7 +769,7 @@ class SplitATransform:
         if not batched:
             for k, i in enumerate(self.fast):
                 lo, hi = self.slices[i]
-                kk = self.terms * (hi - lo)
+                kk = (self.dgrad_terms if transpose else self.terms) * (hi - lo)
                 torch.mm(lefts[k][:, :kk], right[k][:, :kk].t() if transpose else right[k][:kk], out_dtype=f32, out=out[:, lo:hi])
         for i in self.rest:
             lo, hi = self.slices[i]

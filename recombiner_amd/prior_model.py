@@ -110,6 +110,7 @@ class PriorBNNmodel(nn.Module):
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
         self.split_terms = 2         # with split_gemm: 3 = both operands split; 2 = the mappings enter as bf16 (ops.SplitATransform)
+        self.split_dgrad_terms = None  # with split_gemm: terms of the data-gradient GEMM (None = split_terms)
         self.wgrad_bf16 = True       # with split_gemm: bf16 high parts for the A weight-gradient GEMMs (sum over INRs)
         self.fused_noise = True      # draw eps inside the reparam kernel (Philox) when no noise_source is injected
         self._train_calls = 0
@@ -249,7 +250,7 @@ class PriorBNNmodel(nn.Module):
         # re-capturing the graph every call costs ~14 ms = 9 % of such a call, replaying a cached one nothing.
         graphable = bool(self.use_graph and self.noise_source is None and dev.type == "cuda" and not verbose)
         key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
-               world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms,
+               world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.patch,
                tuple(None if q is None else tuple(q.shape) for q in priors))
         ws = self._ws if graphable else None
@@ -274,7 +275,7 @@ class PriorBNNmodel(nn.Module):
                             + self._train_calls * 0x94D049BB133111EB + rank_id * 0xD6E8FEB86659FD93) & (2 ** 64 - 1),
                       flat=(torch.empty(sum(q.numel() for q in A + conv), device=dev, dtype=torch.float32)
                             if (training_mappings and world > 1) else None))
-            split = ops.SplitATransform(slices, self.split_terms) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
+            split = ops.SplitATransform(slices, self.split_terms, self.split_dgrad_terms) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
             ws["split"] = split if (split is not None and split.fast) else None
             if graphable:
                 self._ws = ws

@@ -19,7 +19,7 @@ def smooth_targets(n, seed=0):
         out.append((img * 0.5 + 0.5).clamp(0, 1).reshape(3, -1).T)
     return torch.stack(out)
 
-def run(precision, n, steps, lr, lowp=False, stage1=False, split=False, wgrad16=False, terms=3, seed=5):
+def run(precision, n, steps, lr, lowp=False, stage1=False, split=False, wgrad16=False, terms=3, dterms=None, seed=5):
     cfg = config.configs["cifar"]
     X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3)
     Y = smooth_targets(n)
@@ -31,6 +31,7 @@ def run(precision, n, steps, lr, lowp=False, stage1=False, split=False, wgrad16=
     m.split_gemm = split
     m.wgrad_bf16 = wgrad16
     m.split_terms = terms
+    m.split_dgrad_terms = dterms
     torch.manual_seed(123); lt = PM.LinearTransform(m.dims).cuda()
     torch.manual_seed(124); up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
     gen = torch.Generator(device="cuda").manual_seed(seed)
@@ -49,7 +50,8 @@ if __name__ == "__main__":
                 ("bf16 + stage-1 + split-bf16 A transform", dict(precision=1, stage1=True, split=True)),
                 ("... + bf16 A weight gradient", dict(precision=1, stage1=True, split=True, wgrad16=True)),
                 ("bf16 + f16/bf16 A-transform GEMMs", dict(precision=1, lowp=True)),
-                ("... + bf16 A weight gradient, 2-term split", dict(precision=1, stage1=True, split=True, wgrad16=True, terms=2)))
+                ("... + bf16 A weight gradient, 2-term split", dict(precision=1, stage1=True, split=True, wgrad16=True, terms=2)),
+                ("... 2-term split, 1-term data gradient", dict(precision=1, stage1=True, split=True, wgrad16=True, terms=2, dterms=1)))
     if len(sys.argv) > 4:
         keep = sys.argv[4].split(",")
         variants = tuple(v for i, v in enumerate(variants) if str(i) in keep)
