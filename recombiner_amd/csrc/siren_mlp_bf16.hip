@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     const float* src = (h == 0) ? (a.xf + (long long)n * a.xf_stride + (long long)pcl * F)
                                 : (a.pe + ((long long)g * P + pcl) * E);
     const int kh = (h == 0) ? KH0 : KH1;
-    if (VEC4 && a.pe_bf16 && h == 1) {   // bf16-stored pe: 16 B per 8 features, widened exactly
+    if (E % 8 == 0 && a.pe_bf16 && h == 1) {   // bf16-stored pe: 16 B per 8 features, widened exactly (whatever F is: the
+                                                // fp32 path below would read the bf16 array as floats, out of bounds)
       const uint4* s16 = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.pe) + ((long long)g * P + pcl) * E);
 #pragma unroll
       for (int s = 0; s < K0S; ++s) {

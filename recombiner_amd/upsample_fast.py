@@ -57,6 +57,41 @@ class PhaseStage:
         out = f"{tp}{i}{ph}{o}"
         return torch.einsum(",".join(terms) + "->" + out, *Rs, W)
 
+    def window3(self):
+        """True if every phase of every axis reads inside the 3-pixel window around its source pixel (all reference nets)"""
+        return all(p[0] + max(p[3]) == 3 and p[1] == 1 and p[2] == 1 for p in self.plans)
+
+    def big_weight(self, W):
+        """W [Cout, Cin, *k] -> [3^d * Cin, prod(f) * Cout]: rows (window offsets lexicographic, ci), columns (phases, co);
+        phase a of an axis uses the window offsets shift[a] + t.  Differentiable (einsums of W with 0/1 tensors)."""
+        dd = self.dd
+        Weff = self.eff_weight(W)                                   # [*taps, Cin, *phases, Cout]
+        letters = "abcdefghijklmnopqrstuvwxyz"
+        tp, wn, ph = letters[0:dd], letters[dd:2 * dd], letters[2 * dd:3 * dd]
+        sels = []
+        for d, (w, _, _, shift, _) in enumerate(self.plans):
+            def make(w=w, shift=shift, f=self.f[d]):
+                m = torch.zeros(f, 3, w)
+                for a in range(f):
+                    for t_ in range(w):
+                        m[a, shift[a] + t_, t_] = 1.0
+                return m
+            sels.append(_dev_const(("win3", self.f[d], self.k, self.pad), W.device, make).to(W.dtype))
+        terms = [f"{ph[d]}{wn[d]}{tp[d]}" for d in range(dd)] + [f"{tp}I{ph}O"]
+        big = torch.einsum(",".join(terms) + f"->{wn}I{ph}O", *sels, Weff)
+        return big.reshape(3 ** dd * W.shape[1], -1)
+
+    def forward_gemm(self, x, W, b, dtype=None):
+        """the stage as ONE GEMM over 3^d-pixel windows (all phases at once) + pixel shuffle: x [B, *g, Cin] -> [B, *(f*g), Cout].
+        `dtype` (bf16 in the 16-bit modes) is the operand / result type; accumulation is fp32 in the library GEMM."""
+        dd, g = self.dd, list(x.shape[1:-1])
+        dt = x.dtype if dtype is None else dtype
+        nph = int(np.prod(self.f))
+        y = _WindowGemmFn.apply(x.to(dt), self.big_weight(W).to(dt), b.to(dt).repeat(nph))
+        y = y.view([x.shape[0]] + g + self.f + [W.shape[0]])
+        perm = [0] + [v for d in range(dd) for v in (1 + d, 1 + dd + d)] + [1 + 2 * dd]
+        return y.permute(perm).reshape([x.shape[0]] + [g[d] * self.f[d] for d in range(dd)] + [W.shape[0]])
+
     def forward(self, x, W, b):
         """x [B, *g, Cin] -> [B, *(f*g), Cout]"""
         dd = self.dd
@@ -101,6 +136,43 @@ class PhaseStage:
         return out
 
 
+class _WindowGemmFn(torch.autograd.Function):
+    """y[rows, Nout] = cols(x) @ Wbig + bias, cols = the 3^d-pixel window around every grid position (zero halo), channel-last.
+    Backward: dW = cols^T dy (fp32), dcols = dy Wbig^T folded back onto the grid by 3^d shifted in-place adds (fp32) --
+    instead of autograd's generic window backward (one zero-filled full-size tensor per tap)."""
+
+    @staticmethod
+    def forward(ctx, x, Wbig, brep):
+        dd = x.dim() - 2
+        g = list(x.shape[1:-1])
+        xp = F.pad(x, [0, 0] + [1, 1] * dd)
+        offs = list(itertools.product(range(3), repeat=dd))
+        cols = torch.cat([xp[(slice(None),) + tuple(slice(o[d], o[d] + g[d]) for d in range(dd))] for o in offs], dim=-1)
+        cols = cols.reshape(-1, cols.shape[-1])
+        ctx.save_for_backward(cols, Wbig)
+        ctx.geo = (tuple(x.shape), offs)
+        return torch.addmm(brep, cols, Wbig)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, Wbig = ctx.saved_tensors
+        shape, offs = ctx.geo
+        dd, g, cin = len(shape) - 2, list(shape[1:-1]), shape[-1]
+        dy = dy.contiguous()
+        lowp = dy.dtype in (torch.bfloat16, torch.float16)
+        dW = torch.mm(cols.t(), dy, out_dtype=torch.float32).to(Wbig.dtype) if lowp else cols.t() @ dy
+        db = dy.sum(0, dtype=torch.float32 if lowp else dy.dtype).to(dy.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcols = (dy @ Wbig.t()).view(shape[0], *g, len(offs), cin)
+            dxp = torch.zeros([shape[0]] + [v + 2 for v in g] + [cin], device=dy.device,
+                              dtype=torch.float32 if lowp else dy.dtype)
+            for k, o in enumerate(offs):
+                dxp[(slice(None),) + tuple(slice(o[d], o[d] + g[d]) for d in range(dd))] += dcols.select(-2, k)
+            dx = dxp[(slice(None),) + tuple(slice(1, 1 + g[d]) for d in range(dd))].to(dy.dtype)
+        return dx, dW, db
+
+
 class UpsampleFast(torch.nn.Module):
     """Drop-in evaluation of an `Upsample` module (same parameters, shared storage) in phase form.
     Input/outputs are channel-FIRST like the reference module so it can replace it anywhere."""
@@ -118,9 +190,16 @@ class UpsampleFast(torch.nn.Module):
             for (w, pl, pr, shift, R), f in zip(st.plans, st.f):
                 if any(shift[a] > shift[a + 1] for a in range(f - 1)):
                     raise ValueError("unsupported upsample/conv geometry")
+        self.window_gemm = True      # one GEMM per stage over 3^d-pixel windows (False: one GEMM per window-shift group)
+        self.gemm_dtype = None       # operand / activation type of the window GEMMs (None: the input's)
 
     def forward_channel_last(self, x):
         n = self.net
+        if self.window_gemm and all(st.window3() for st in self.stages):
+            dt = self.gemm_dtype
+            x = F.leaky_relu(self.stages[0].forward_gemm(x, n.conv1.weight, n.conv1.bias, dt), 0.01)
+            x = F.leaky_relu(self.stages[1].forward_gemm(x, n.conv2.weight, n.conv2.bias, dt), 0.01)
+            return self.stages[2].forward_gemm(x, n.conv3.weight, n.conv3.bias, dt)
         x = F.leaky_relu(self.stages[0].forward(x, n.conv1.weight, n.conv1.bias), 0.01)
         x = F.leaky_relu(self.stages[1].forward(x, n.conv2.weight, n.conv2.bias), 0.01)
         return self.stages[2].forward(x, n.conv3.weight, n.conv3.bias)
@@ -245,6 +324,7 @@ def phase_module(net):
     if fast is None:
         try:
             fast = UpsampleFast(net)
+            fast.gemm_dtype = torch.bfloat16       # only the 16-bit modes route here: bf16 operands, fp32 accumulation
         except ValueError:
             fast = False
         object.__setattr__(net, "_rcb_phase_form", fast)       # not a registered sub-module: no parameter duplication

@@ -133,13 +133,15 @@ def test_siren_16bit_operands(case, prec):
     assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
 
 
+@pytest.mark.parametrize("F", [16, 18])
 @pytest.mark.parametrize("prec", [1, 2])
-def test_siren_bf16_pe_storage_is_bit_identical(prec):
+def test_siren_bf16_pe_storage_is_bit_identical(prec, F):
     """pe / dpe held as bf16 arrays: the 16-bit kernels round pe to the operand type on load and the consumers of
-    dpe round it to bf16 on load, so bf16 storage must reproduce fp32 storage exactly (dpe: after that rounding)."""
-    case = dict(F=16, E=16, n_hidden=3, C=3, P=1000, N=3, S=2)       # ragged last tile
+    dpe round it to bf16 on load, so bf16 storage must reproduce fp32 storage exactly (dpe: after that rounding).
+    F = 18 is the video geometry (34 inputs, the Fourier half not a multiple of 8)."""
+    case = dict(F=F, E=16, n_hidden=3, C=3, P=1000, N=3, S=2)       # ragged last tile
     dims, D, xf, pe, wv, y = _siren_case(seed=11, **case)
-    meta = SirenMeta(2, 1000, 16, 16, 3, 32, 3, precision=prec)
+    meta = SirenMeta(2, 1000, F, 16, 3, 32, 3, precision=prec)
     pe16 = g(pe).bfloat16()
     pe32 = pe16.float()
     scale = 1.0 / (2 * 1000 * 3)
@@ -156,7 +158,7 @@ def test_siren_bf16_pe_storage_is_bit_identical(prec):
     assert torch.isfinite(wb32).all() and torch.isfinite(db32).all()
     assert torch.equal(wb32, wb16) and torch.equal(db32.bfloat16(), db16)
     with pytest.raises(ops.RcbError):                                  # the fp32 kernel has no bf16-storage variant
-        ops.siren_fwd(g(xf), pe16, g(wv), SirenMeta(2, 1000, 16, 16, 3, 32, 3, precision=0))
+        ops.siren_fwd(g(xf), pe16, g(wv), SirenMeta(2, 1000, F, 16, 3, 32, 3, precision=0))
 
 
 @pytest.mark.parametrize("prec", [0, 2])

@@ -13,6 +13,8 @@ from recombiner_amd import config, tuning, utils
 from recombiner_amd import prior_model as PM
 
 tuning.enable_tuned_gemms()
+if os.environ.get("RCB_PHASE_ALL"):        # A/B: torch-level phase form also where MIOpen is the default (audio)
+    PM.phase_form_preferred = lambda *a: True
 # (label, preset, datapoints (images / clips / ...), hidden width, precision mode): the five reference presets, then
 # BASELINE.json's width variants (configs[2]: Kodak patches at width 48; configs[4]: video at width 64 in f16)
 RUNS = [("cifar", "cifar", 4096, 32, 1), ("protein", "protein", 4096, 32, 1), ("kodak", "kodak", 2, 32, 1),
