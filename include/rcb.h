@@ -345,6 +345,17 @@ int rcb_tile_crop(const void* tiles, void* img, int32_t n, int32_t H, int32_t W,
 int rcb_tile_fold(const void* tiles, void* img, int32_t n, int32_t H, int32_t W, int32_t C, int32_t Ty, int32_t Tx,
                   int32_t T, int32_t off, rcb_stream_t stream);
 
+/* 3^d-pixel windows of a channel-last bf16 grid x [B][g0][g1][g2][C] (nd = 1..3 windowed axes, unused trailing axes of size 1,
+ * C % 8 == 0): the operand of the one-GEMM-per-stage phase form of the 1-D / 3-D upsampling nets (prior_model.py:23-59 with
+ * Conv1d / Conv3d; every phase of the reference's stages reads inside the 3-pixel window around its source pixel).
+ *   rcb_window_gather: cols [B*g0*g1*g2][3^nd][C], cols[b,p,k,:] = x[b, p + o(k) - 1, :] (0 outside), o(k) = base-3 digits of k
+ *                      (axis 0 most significant).
+ *   rcb_window_fold  : dx[b,p,:] = sum_k dcols[b, p - o(k) + 1, k, :] (the adjoint), fp32 sum in tap order, rounded to bf16. */
+int rcb_window_gather(const void* x, void* cols, int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t C, int32_t nd,
+                      rcb_stream_t stream);
+int rcb_window_fold(const void* dcols, void* dx, int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t C, int32_t nd,
+                    rcb_stream_t stream);
+
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);
 

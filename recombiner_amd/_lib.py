@@ -15,7 +15,8 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
            "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad",
            "rcb_upconv_dgrad_partial_rows", "rcb_split_bf16", "rcb_debug_generic_kernels_only", "rcb_philox_normal",
-           "rcb_reparam_rng_fwd", "rcb_upconv_bwd_fused", "rcb_tile_gather", "rcb_tile_crop", "rcb_tile_fold"]
+           "rcb_reparam_rng_fwd", "rcb_upconv_bwd_fused", "rcb_tile_gather", "rcb_tile_crop", "rcb_tile_fold",
+           "rcb_window_gather", "rcb_window_fold"]
 
 
 class RcbError(RuntimeError):

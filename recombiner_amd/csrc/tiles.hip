@@ -10,6 +10,7 @@
 // rcb_tile_crop   : tiles -> image from the inner T - 2 ring rows / columns of every tile (the valid outputs)
 // rcb_tile_fold   : tiles -> image, SUM of every tile element that maps to the pixel (the adjoint of the ring-0 gather:
 //                   pixels on a tile border belong to two tiles per axis), fp32 sum rounded once to bf16
+// rcb_window_gather / _fold: the 3^d-pixel window matrix of a channel-last grid and its adjoint (see below).
 // Pure data movement: one 16-byte chunk (8 channels) per thread and iteration, coalesced along the channel / column axis;
 // HBM-bound (bytes = image + tiles).
 #include "rcb_common.h"
@@ -88,6 +89,83 @@ __global__ void __launch_bounds__(256) tile_fold_kernel(const uint4* __restrict_
   }
 }
 
+// ---- 3^d-pixel windows (torch-level phase form of the 1-D / 3-D upsampling nets: one GEMM per stage over these windows) ----
+// cols[b, p, k, :] = x[b, p + o(k) - 1, :] (zero outside the grid), k = window tap, o(k) its base-3 digits (axis 0 most
+// significant), nd = 1..3 windowed axes; fold is the adjoint: dx[b, p, :] = sum_k dcols[b, p - o(k) + 1, k, :].
+struct WinGeo {
+  int B, g[3], nd, C8, taps;
+};
+
+__global__ void __launch_bounds__(256) window_gather_kernel(const uint4* __restrict__ x, uint4* __restrict__ cols, WinGeo w) {
+  const long long npos = (long long)w.B * w.g[0] * w.g[1] * w.g[2];
+  const long long total = npos * w.taps * w.C8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long r = e;
+    const int c = (int)(r % w.C8); r /= w.C8;
+    int k = (int)(r % w.taps); r /= w.taps;
+    int p[3];
+    p[2] = (int)(r % w.g[2]); r /= w.g[2];
+    p[1] = (int)(r % w.g[1]); r /= w.g[1];
+    p[0] = (int)(r % w.g[0]);
+    const long long b = r / w.g[0];
+    bool ok = true;
+#pragma unroll
+    for (int d = 2; d >= 0; --d) {
+      if (d < w.nd) {
+        const int o = k % 3;
+        k /= 3;
+        p[d] += o - 1;
+        ok = ok && p[d] >= 0 && p[d] < w.g[d];
+      }
+    }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) v = x[(((b * w.g[0] + p[0]) * w.g[1] + p[1]) * w.g[2] + p[2]) * w.C8 + c];
+    cols[e] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) window_fold_kernel(const uint4* __restrict__ dcols, uint4* __restrict__ dx, WinGeo w) {
+  const long long total = (long long)w.B * w.g[0] * w.g[1] * w.g[2] * w.C8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long r = e;
+    const int c = (int)(r % w.C8); r /= w.C8;
+    int p[3];
+    p[2] = (int)(r % w.g[2]); r /= w.g[2];
+    p[1] = (int)(r % w.g[1]); r /= w.g[1];
+    p[0] = (int)(r % w.g[0]);
+    const long long b = r / w.g[0];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < w.taps; ++k) {        // fixed order: bitwise reproducible
+      int kk = k, q[3] = {p[0], p[1], p[2]};
+      bool ok = true;
+#pragma unroll
+      for (int d = 2; d >= 0; --d) {
+        if (d < w.nd) {
+          const int o = kk % 3;
+          kk /= 3;
+          q[d] += 1 - o;
+          ok = ok && q[d] >= 0 && q[d] < w.g[d];
+        }
+      }
+      if (ok) add8(acc, dcols[((((b * w.g[0] + q[0]) * w.g[1] + q[1]) * w.g[2] + q[2]) * w.taps + k) * w.C8 + c]);
+    }
+    union { __bf16 h[8]; uint4 u; } o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)acc[j];
+    dx[e] = o.u;
+  }
+}
+
+int check_win(const char* who, const void* a, const void* b, int B, int g0, int g1, int g2, int C, int nd, WinGeo& w) {
+  RCB_REQUIRE(a && b, RCB_ERR_ARG, "%s: null pointer", who);
+  RCB_REQUIRE(B > 0 && g0 > 0 && g1 > 0 && g2 > 0 && C > 0 && C % 8 == 0 && nd >= 1 && nd <= 3 && (nd > 1 || g1 == 1) &&
+                  (nd > 2 || g2 == 1),
+              RCB_ERR_SHAPE, "%s: B=%d grid=%dx%dx%d C=%d nd=%d (unused axes must have size 1)", who, B, g0, g1, g2, C, nd);
+  w.B = B; w.g[0] = g0; w.g[1] = g1; w.g[2] = g2; w.nd = nd; w.C8 = C / 8;
+  w.taps = nd == 1 ? 3 : (nd == 2 ? 9 : 27);
+  return RCB_OK;
+}
+
 int check_geo(const char* who, const void* a, const void* b, int n, int H, int W, int C, int Ty, int Tx, int T, int step,
               int off, int ring, TileGeo& g) {
   RCB_REQUIRE(a && b, RCB_ERR_ARG, "%s: null pointer", who);
@@ -140,6 +218,28 @@ extern "C" int rcb_tile_fold(const void* tiles, void* img, int32_t n, int32_t H,
               "tile_fold: %dx%d tiles of step %d do not cover a %dx%d image at offset %d", Ty, Tx, T - 1, H, W, off);
   const long long total = (long long)n * H * W * g.C8;
   tile_fold_kernel<<<blocks_for(total), 256, 0, (hipStream_t)stream>>>(static_cast<const uint4*>(tiles), static_cast<uint4*>(img), g);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+extern "C" int rcb_window_gather(const void* x, void* cols, int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t C, int32_t nd,
+                                 rcb_stream_t stream) {
+  WinGeo w;
+  int rc = check_win("window_gather", x, cols, B, g0, g1, g2, C, nd, w);
+  if (rc) return rc;
+  const long long total = (long long)B * g0 * g1 * g2 * w.taps * w.C8;
+  window_gather_kernel<<<blocks_for(total), 256, 0, (hipStream_t)stream>>>(static_cast<const uint4*>(x), static_cast<uint4*>(cols), w);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+extern "C" int rcb_window_fold(const void* dcols, void* dx, int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t C, int32_t nd,
+                               rcb_stream_t stream) {
+  WinGeo w;
+  int rc = check_win("window_fold", dcols, dx, B, g0, g1, g2, C, nd, w);
+  if (rc) return rc;
+  const long long total = (long long)B * g0 * g1 * g2 * w.C8;
+  window_fold_kernel<<<blocks_for(total), 256, 0, (hipStream_t)stream>>>(static_cast<const uint4*>(dcols), static_cast<uint4*>(dx), w);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

