@@ -236,7 +236,9 @@ class TestBNNmodel(nn.Module):
     def _pe(self, lpe):
         if self.precision != 0 and hip_path_supported(self.upsample_net, self.pixel_sizes, self.upsample_factors,
                                                       self.patch, self.data_dim):
-            return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
+            if not hasattr(self, "_weff_cache"):
+                self._weff_cache = {}        # the mappings are frozen for this model's lifetime (test_model.py:117-126)
+            return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16, self.pe_bf16, self._weff_cache)
         net = self.upsample_net
         if self.precision != 0 and hip_stitched_supported(self.upsample_net, self.patch, self.data_dim):
             net = stitched2d_module(self.upsample_net)
