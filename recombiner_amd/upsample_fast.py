@@ -406,30 +406,6 @@ class _UpsampleStitched23Fn(torch.autograd.Function):
         return dz1, None, None, dW2, db2, dW3, db3
 
 
-def _stage1_big_weight(W1, dtype):
-    """conv1 weight [64,128,5,5] -> the (x4, 5x5, pad 2) stage as ONE GEMM on 3 x 3 windows of the latent grid:
-    [3*3*128, 4*4*64] with rows (wy, wx, ci) and columns (a, b, co); phase a of an axis reads the two window taps
-    shift[a] + {0, 1} (differentiable: autograd returns dW1 through the einsum)."""
-    w, pad_l, pad_r, shift, _ = _axis_plan(4, 5, 2)
-    assert (w, pad_l, pad_r, list(shift)) == (2, 1, 1, [0, 0, 1, 1])
-    R = _phase_R(W1.device, 4, 5, 2).to(W1.dtype)                       # [a, t, k]
-    sel = _dev_const("stage1_sel", W1.device, lambda: torch.tensor([[[1., 0.], [0., 1.], [0., 0.]]] * 2 + [[[0., 0.], [1., 0.], [0., 1.]]] * 2))
-    R3 = torch.einsum("awt,atk->awk", sel.to(W1.dtype), R)              # [a, window tap w in 0..2, k]
-    big = torch.einsum("ayk,bxl,oikl->yxiabo", R3, R3, W1)              # [3,3,128,4,4,64]
-    return big.reshape(9 * 128, 16 * 64).to(dtype)
-
-
-def _stage1_stitched(z, W1, b1):
-    """z [n, h, w, 128] (fp32 latent grid) -> z1 [n, 4h, 4w, 64] bf16 pre-activation: 3 x 3 window gather, one bf16 GEMM
-    (fp32 accumulate) against the phase-form weight, pixel shuffle.  Plain tensor ops: autograd supplies the backward."""
-    n, h, w, _ = z.shape
-    zp = torch.nn.functional.pad(z.to(torch.bfloat16), (0, 0, 1, 1, 1, 1))
-    s0, s1, s2, _ = zp.stride()
-    cols = zp.as_strided((n, h, w, 3, 3, 128), (s0, s1, s2, s1, s2, 1)).reshape(n * h * w, 9 * 128)
-    y = torch.addmm(b1.to(torch.bfloat16).repeat(16), cols, _stage1_big_weight(W1, torch.bfloat16))     # [n h w, (a, b, co)]
-    return y.view(n, h, w, 4, 4, 64).permute(0, 1, 3, 2, 4, 5).reshape(n, 4 * h, 4 * w, 64)
-
-
 def hip_stitched_supported(net, patch, data_dim):
     try:
         ok = (data_dim == 2 and bool(patch) and isinstance(net.conv1, torch.nn.Conv2d)
@@ -448,8 +424,12 @@ def stitched2d_module(net):
     and 3 through the hand-written phase-conv kernels.  Returns bf16 (the 16-bit SIREN kernels read pe as bf16)."""
     fast = getattr(net, "_rcb_stitched2d", None)
     if fast is None:
+        stage1 = PhaseStage(4, 5, 2, 2)
+
         def fast(z_cf):
-            z1 = _stage1_stitched(z_cf.movedim(1, -1), net.conv1.weight, net.conv1.bias)
+            # stage 1 (x4, 5x5, 128 -> 64) on the small latent grid: ONE bf16 GEMM over 3x3 windows against the phase-form
+            # weight [1152, 1024] (rcb_window_gather / _fold around it), pixel shuffle -> z1 [n, 4h, 4w, 64] pre-activation
+            z1 = stage1.forward_gemm(z_cf.movedim(1, -1), net.conv1.weight, net.conv1.bias, torch.bfloat16)
             pe = _UpsampleStitched23Fn.apply(z1, net.conv1.weight, net.conv1.bias, net.conv2.weight,
                                              net.conv2.bias, net.conv3.weight, net.conv3.bias)
             return pe.movedim(-1, 1)
