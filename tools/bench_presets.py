@@ -20,10 +20,12 @@ if os.environ.get("RCB_PHASE_ALL"):        # A/B: torch-level phase form also wh
 RUNS = [("cifar", "cifar", 4096, 32, 1), ("protein", "protein", 4096, 32, 1), ("kodak", "kodak", 2, 32, 1),
         ("audio", "audio", 8, 32, 1), ("video", "video", 4, 32, 1),
         ("kodak-w48", "kodak", 2, 48, 1), ("video-w64-f16", "video", 4, 64, 2), ("cifar-w64", "cifar", 4096, 64, 1)]
-only = sys.argv[1:]
+only = {a.split(":")[0]: (int(a.split(":")[1]) if ":" in a else None) for a in sys.argv[1:]}     # label[:datapoints]
 for label, name, n_data, width, prec in RUNS:
     if only and label not in only:
         continue
+    if only and only[label]:
+        n_data = only[label]
     cfg = dict(config.configs[name])
     cfg["hidden_dims"] = [width] * len(cfg["hidden_dims"])
     per = int(np.prod(cfg["patch_nums"])) if cfg["patch"] else 1
@@ -55,4 +57,8 @@ for label, name, n_data, width, prec in RUNS:
     px = int(np.prod(cfg["pixel_sizes"]))
     print("%-14s %5d INRs (%d datapoints) x %5d px: %7.2f ms/step = %9.0f INR-steps/s, %6.1f Mpx-steps/s; graph replay: %s; finite: %s%s"
           % (label, n, n_data, px, dt * 1e3, n / dt, n * px / dt / 1e6, graph, bool(np.isfinite(elbo).all()),
-             ("; warnings: " + "; ".join(str(x.message)[:80] for x in w)) if w else ""), flush=True)
+             ("; warnings: " + "; ".join(str(x.message)[:80] for x in w)) if w else "")
+          + "; peak HBM %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
+    del m, lt, up, Xd, Yd, X, Y, pri
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
