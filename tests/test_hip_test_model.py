@@ -337,3 +337,54 @@ def test_test_time_training_captures_graphs_for_every_preset(name, precision):
     assert torch.isfinite(m.loc).all() and float((m.loc - loc0).abs().max()) > 0
     with torch.no_grad():
         assert torch.isfinite(m.predict(X)).all()
+
+
+@pytest.mark.parametrize("width,precision", [(48, 1), (64, 2)])
+def test_wide_variant_test_time_training_and_bit_exact_decode(width, precision):
+    """BASELINE's width variants on the test-time path (S = 5 samples through the wide SIREN kernel, group-ordered
+    parameters, generic posterior kernels where a 64-wide INR no longer fits the LDS-staged ones): the fine-tuning loss
+    falls, every group of a few rounds is encoded, and a decoder built from the indices alone reproduces the encoder's
+    parameters bit for bit and its reconstruction."""
+    from recombiner_amd import bitstream, config, utils
+    cfg = dict(config.configs["cifar"])
+    cfg["hidden_dims"] = [width] * 3
+    N = 6
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], N, 3, seed=0)
+    dims = [cfg["input_dim"]] + cfg["hidden_dims"] + [cfg["output_dim"]]
+    D = sum(dims[i + 1] * (dims[i] + 1) for i in range(4)) + 512
+    bits = np.random.RandomState(0).gamma(0.7, 6.0, size=D).astype(np.float32)
+    gi, gs, ge, g2p, p2g, G, gk, w = PM.get_grouping_by_kl(bits)
+
+    def make():
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(dims).to(DEV)
+        torch.manual_seed(124)
+        up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+        m = TM.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], N, cfg["upsample_factors"],
+                            cfg["latent_dim"], 2, cfg["pixel_sizes"], False, None, None, "cifar", linear_transform=lt,
+                            upsample_net=up, p_loc=torch.zeros(D)[p2g], p_log_scale=torch.full((D,), -2.0)[p2g],
+                            init_log_scale=torch.full((D,), -4.0), param_to_group=p2g, group_to_param=g2p, n_groups=G,
+                            group_start_index=gs, group_end_index=ge, group_idx=gi, device=DEV, initial_beta=1e-8)
+        m.precision = precision
+        return m
+
+    m = make()
+    Xd, Yd = X.to(DEV)[None].expand(N, -1, -1), Y.to(DEV)
+    with torch.no_grad():
+        y0 = m.predict(Xd, random_seed=0, sample_size=1)
+    mse0 = float(((y0 - Yd) ** 2).mean())
+    m.train(Xd, Yd, 30, torch.optim.Adam(m.parameters(), lr=2e-3), False, sample_size=5)
+    with torch.no_grad():
+        y1 = m.predict(Xd, random_seed=0, sample_size=1)
+    mse1 = float(((y1 - Yd) ** 2).mean())
+    assert np.isfinite(mse1) and mse1 < 0.97 * mse0, (mse0, mse1)      # (white-noise targets: slow to fit)
+    for r in range(G):
+        m._encode_round(m._l1, True, r)
+    assert m.compressed_mask_groupwise.all()
+    blob = bitstream.encode(m)
+    m2 = make()
+    bitstream.apply_indices(m2, bitstream.unpack_indices(blob))
+    assert torch.equal(m2._l1.sample, m._l1.sample)
+    with torch.no_grad():
+        ya, yb = m.predict(Xd), m2.predict(Xd)
+    assert float((ya - yb).abs().max()) < 1e-5
