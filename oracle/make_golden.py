@@ -550,13 +550,51 @@ def gen_metrics(out):
     np.savez_compressed(os.path.join(out, "metrics.npz"), **d)
 
 
+# ----------------------------------------------------------------------------------------
+# BASELINE.json's width variants (configs[2]: Kodak patches at width 48; configs[4]: 3-D video at width 64): the
+# reference's own PriorBNNmodel with `hidden_dims` overridden (prior_model.py:65,84-85), 2 Adam steps incl. the mappings
+# ----------------------------------------------------------------------------------------
+def gen_wide_cases(out):
+    P, NI = presets()
+    for name, width in (("patch2d", 48), ("patch3d", 64), ("cifar", 64)):
+        cfg = dict(P[name], hidden_dims=[width] * 3)
+        n = NI[name]
+        d = Bag({"cfg": np.array(jsonable(cfg)), "n": np.array(n)})
+        m = build_prior(cfg, n)
+        d["init_loc"] = tnp(m.loc)
+        lt, up = build_maps(cfg, m.dims)
+        d["A_stats"] = np.stack([stats(a) for a in lt.A])
+        _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
+        torch.manual_seed(5)
+        y = torch.rand(n, x.shape[0], cfg["output_dim"])
+        d["X"] = tnp(x)
+        d["Y"] = tnp(y)
+        pri = priors_for(m, cfg["patch"])
+        for k, v in zip(["pl", "ps", "ll", "ls", "hl", "hs", "hhl", "hhs"], pri):
+            put(d, "prior_" + k, tnp(v))
+        torch.manual_seed(2000)
+        with NoiseTap() as tap:
+            mse, klv, elbo = m.train(2, 2e-4, x[None].repeat(n, 1, 1), y, *pri, lt, up, 1e-4, training_mappings=True)
+        store_noise(d, "tm1_eps", 2000, tap.log, False)
+        d["tm1_ret"] = np.array([mse, klv])
+        d["tm1_elbo"] = np.array(elbo)
+        for k in ["loc", "log_scale", "lpe_loc", "h_loc", "hh_loc"]:
+            if hasattr(m, k):
+                d[f"tm1_{k}"] = tnp(getattr(m, k))
+        d["tm1_A1"] = tnp(lt.A[1])
+        d["tm1_A3"] = tnp(lt.A[-1])
+        d["tm1_conv3_w"] = tnp(up.conv3.weight)
+        np.savez_compressed(os.path.join(out, f"wide_{name}_w{width}.npz"), **d)
+        print("wide", name, width, "ok", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["synthetic", "prior", "grouping", "tables", "test", "metrics"]
+    todo = a.only.split(",") if a.only else ["synthetic", "prior", "grouping", "tables", "test", "metrics", "wide"]
     if "synthetic" in todo:
         gen_synthetic(a.out)
     if "metrics" in todo:
@@ -569,4 +607,6 @@ if __name__ == "__main__":
         gen_prior_cases(a.out)
     if "test" in todo:
         gen_test_cases(a.out)
+    if "wide" in todo:
+        gen_wide_cases(a.out)
     print("done")

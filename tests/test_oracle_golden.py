@@ -89,6 +89,28 @@ def test_prior_train_3_steps(name, tm):
             check(d, "refit_hh_loc", a, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["wide_patch2d_w48", "wide_patch3d_w64", "wide_cifar_w64"])
+def test_prior_train_at_widths_48_and_64(case):
+    """BASELINE.json's width variants: the REFERENCE's PriorBNNmodel run with hidden_dims = [48]*3 / [64]*3
+    (oracle/make_golden.py --only wide), two Adam steps incl. the mappings: pins the oracle's width-generic path to the
+    reference itself, not only to its width-32 presets."""
+    d = load(case + ".npz")
+    cfg, geo, n, p, A, up, X, Y, pri = prior_inputs(d)
+    assert geo.hidden_dims[0] in (48, 64)
+    check(d, "init_loc", p["loc"], rtol=0, atol=0)
+    np.testing.assert_allclose(stats_of(A), d["A_stats"], rtol=1e-6)
+    eps = regen_noise(d, "tm1_eps")
+    mse, kl, elbo = O.prior_train(geo, p, X[None].repeat(n, 1, 1), Y, pri, A, up, 2, 2e-4, 1e-4, True, O.Noise(eps))
+    np.testing.assert_allclose([mse, kl], d["tm1_ret"], rtol=2e-5)
+    np.testing.assert_allclose(elbo, d["tm1_elbo"], rtol=2e-5)
+    for k in ["loc", "log_scale", "lpe_loc", "h_loc", "hh_loc"]:
+        if k in p:
+            check(d, f"tm1_{k}", p[k], rtol=1e-5, atol=2e-6)
+    check(d, "tm1_A1", A[1], rtol=1e-4, atol=2e-6)          # (Adam: elements with a ~0 gradient move by rounding-level amounts)
+    np.testing.assert_allclose(A[-1].detach().numpy(), d["tm1_A3"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(up.weights[4].detach().numpy(), d["tm1_conv3_w"], rtol=1e-4, atol=1e-6)
+
+
 def test_beta_rule():
     assert O.beta_rule(1e-8, 10.0, 5.0, 1.0) == pytest.approx(1.5e-8)
     assert O.beta_rule(1e-8, 0.5, 5.0, 1.0) == pytest.approx(1e-8 / 1.5)
