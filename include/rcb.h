@@ -45,7 +45,7 @@ const char* rcb_last_error_string(void);
  * `wvec` row g holds the layer vectors back to back, each `[bias(out) | W(in,out) row-major]`
  * (prior_model.py:125-126); rows are w_row_stride floats apart.  G = N*S; sample s of INR n is
  * row g = n*S + s; targets / xf are indexed by n = g / S.
- * Hidden width must be 32, 1..4 hidden layers, out_dim <= 32, F + E <= 64.
+ * Hidden width 32 (every precision mode) or 48 / 64 (16-bit modes), 1..4 hidden layers, out_dim <= 32, F + E <= 64.
  * precision: 0 = fp32 MFMA (exact fp32 products); 1 = bf16 operands, 2 = f16 operands (both fp32 accumulate;
  * f16 carries gradients scaled by 2^10 internally).
  * ------------------------------------------------------------------------------------------- */
@@ -56,7 +56,7 @@ typedef struct {
   int32_t fourier_dim;   /* F                                                       */
   int32_t pe_dim;        /* E                                                       */
   int32_t n_hidden;      /* number of hidden layers                                 */
-  int32_t hidden;        /* hidden width (32)                                       */
+  int32_t hidden;        /* hidden width (32; 48 / 64 in the 16-bit modes)           */
   int32_t out_dim;       /* C                                                       */
   int64_t xf_inr_stride; /* floats between INRs in xf; 0 = shared grid              */
   int64_t w_row_stride;  /* floats between rows of wvec and of dwvec                */
@@ -69,6 +69,11 @@ typedef struct {
                           * every layer vector of the maximal length W (even) is also written as the split-bf16 LEFT
                           * operand of rcb_split_bf16: bf16 [n_wide_layers][n_rows][3 * W] = [hi | lo | hi], wide layers
                           * in layer order -- saves the separate split pass over dwvec                          */
+  int32_t pixel_chunks;  /* 0 / 1: one workgroup per row of wvec.  c > 1 (16-bit kernels): the 32-pixel tiles of every row
+                          * are split over c workgroups (launches with few rows -- one Kodak photo is 96 INRs -- would
+                          * otherwise leave most of the 256 CUs idle).  y_out / dpe are unaffected; dwvec and sse then
+                          * receive PARTIAL results: dwvec [c][n_rows][w_row_stride], sse [c][n_rows], to be summed in
+                          * chunk order by rcb_siren_reduce_chunks; dw_split must be NULL (the reduction emits it)  */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */
@@ -79,6 +84,12 @@ int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const void* pe, cons
  * The forward pass is recomputed in registers; no activations are read from memory.            */
 int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
                   const float* dy, float* dwvec, void* dpe, rcb_stream_t stream);
+
+/* Sum of the per-chunk partials of a pixel_chunks = c launch, in chunk order (deterministic): dwvec[g, :] = sum_k
+ * dw_partial[k][g][:], sse[g] = sum_k sse_partial[k][g] (sse_partial / sse may be NULL for rcb_siren_bwd), and, if
+ * d->dw_split != NULL, the split-bf16 copy of the summed wide-layer gradients as rcb_siren_desc.dw_split describes.  */
+int rcb_siren_reduce_chunks(const rcb_siren_desc* d, const float* dw_partial, const float* sse_partial, float* dwvec,
+                            float* sse, rcb_stream_t stream);
 
 /* Fused training pass: sse[g] = sum_{p,c} (y - target[g/S])^2 and the gradients of
  * dy_scale * sse[g] with respect to wvec row g and pe row g (dpe may be NULL).  With

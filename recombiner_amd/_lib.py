@@ -16,7 +16,7 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad",
            "rcb_upconv_dgrad_partial_rows", "rcb_split_bf16", "rcb_debug_generic_kernels_only", "rcb_philox_normal",
            "rcb_reparam_rng_fwd", "rcb_upconv_bwd_fused", "rcb_tile_gather", "rcb_tile_crop", "rcb_tile_fold",
-           "rcb_window_gather", "rcb_window_fold"]
+           "rcb_window_gather", "rcb_window_fold", "rcb_siren_reduce_chunks"]
 
 
 class RcbError(RuntimeError):
@@ -27,7 +27,7 @@ class SirenDesc(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("samples", C.c_int32), ("n_pix", C.c_int32), ("fourier_dim", C.c_int32),
                 ("pe_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
                 ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
-                ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_split", C.c_void_p)]
+                ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_split", C.c_void_p), ("pixel_chunks", C.c_int32)]
 
 
 class Level(C.Structure):

@@ -28,6 +28,7 @@ struct SirenArgs {
   float w0, dy_scale;
   int pe_bf16;        // pe / dpe hold bf16 elements (16-bit kernels only)
   void* dw_split;     // nullable: split-bf16 copy of the wide layers' weight gradients (see rcb_siren_desc)
+  int chunks;         // >= 1: workgroups per row of wvec (pixel tiles split; dwvec / sse hold per-chunk partials)
 };
 
 // row of accumulator register r for lane half h (32x32 MFMA C/D layout)

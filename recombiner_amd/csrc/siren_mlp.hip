@@ -383,7 +383,14 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
               d->pe_dim);
   RCB_REQUIRE(d->dw_split == nullptr || d->precision >= 1, RCB_ERR_UNSUPPORTED,
               "siren: the split-bf16 gradient output exists in the 16-bit kernels only");
+  const int chunks = d->pixel_chunks > 1 ? d->pixel_chunks : 1;
+  RCB_REQUIRE(chunks == 1 || (d->precision >= 1 && chunks <= (d->n_pix + 31) / 32 && d->dw_split == nullptr &&
+                              (long long)d->n_rows * chunks < (1ll << 30)),
+              RCB_ERR_UNSUPPORTED,
+              "siren: pixel_chunks=%d needs a 16-bit precision mode, at most one chunk per 32-pixel tile and dw_split == NULL "
+              "(rcb_siren_reduce_chunks emits it)", d->pixel_chunks);
   memset(&a, 0, sizeof(a));
+  a.chunks = chunks;
   a.pe_bf16 = d->pe_bf16;
   a.dw_split = d->dw_split;
   a.G = d->n_rows;
@@ -399,6 +406,46 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   a.k_hi = (float)k;
   a.k_lo = (float)(k - (double)a.k_hi);
   return RCB_OK;
+}
+
+// ---- sum of the per-chunk partials of a pixel_chunks launch (fixed chunk order: deterministic) ------------------------------
+struct ReduceArgs {
+  const float* part;
+  const float* sse_part;
+  float* dw;
+  float* sse;
+  void* split;
+  long long stride;
+  int G, chunks, dnet, nl, wmax;
+  int off[MAXL + 1], wide[MAXL];     // layer offsets; rank of the layer among the layers of length wmax, or -1
+};
+
+__global__ void __launch_bounds__(256) siren_reduce_chunks_kernel(ReduceArgs r) {
+  const long long total = (long long)r.G * r.dnet;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int g = (int)(e / r.dnet), j = (int)(e - (long long)g * r.dnet);
+    float v = 0.f;
+    for (int k = 0; k < r.chunks; ++k) v += r.part[((long long)k * r.G + g) * r.stride + j];
+    r.dw[(long long)g * r.stride + j] = v;
+    if (r.split) {
+      int l = 0;
+      while (l + 1 < r.nl && j >= r.off[l + 1]) ++l;
+      if (r.wide[l] >= 0) {
+        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+        __bf16* o = reinterpret_cast<__bf16*>(r.split) + ((long long)r.wide[l] * r.G + g) * (3 * r.wmax) + (j - r.off[l]);
+        o[0] = hi;
+        o[r.wmax] = lo;
+        o[2 * r.wmax] = hi;
+      }
+    }
+  }
+  if (r.sse && blockIdx.x == 0) {
+    for (int g = threadIdx.x; g < r.G; g += 256) {
+      float v = 0.f;
+      for (int k = 0; k < r.chunks; ++k) v += r.sse_part[(long long)k * r.G + g];
+      r.sse[g] = v;
+    }
+  }
 }
 
 }  // namespace
@@ -450,4 +497,44 @@ extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, cons
   a.dy_scale = dy_scale;
   if (d->precision >= 1) return siren_16bit_dispatch(MODE_LOSS, d, a, (hipStream_t)stream);
   return dispatch<MODE_LOSS>(d, a, (hipStream_t)stream);
+}
+
+extern "C" int rcb_siren_reduce_chunks(const rcb_siren_desc* d, const float* dw_partial, const float* sse_partial, float* dwvec,
+                                       float* sse, rcb_stream_t stream) {
+  RCB_REQUIRE(d && dw_partial && dwvec && ((sse_partial == nullptr) == (sse == nullptr)), RCB_ERR_ARG,
+              "siren_reduce_chunks: null pointer");
+  RCB_REQUIRE(d->pixel_chunks >= 1 && d->n_rows > 0 && d->n_hidden >= 1 && d->n_hidden <= 4, RCB_ERR_SHAPE,
+              "siren_reduce_chunks: chunks=%d rows=%d", d->pixel_chunks, d->n_rows);
+  ReduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.part = dw_partial;
+  r.sse_part = sse_partial;
+  r.dw = dwvec;
+  r.sse = sse;
+  r.split = d->dw_split;
+  r.stride = d->w_row_stride;
+  r.G = d->n_rows;
+  r.chunks = d->pixel_chunks;
+  r.nl = d->n_hidden + 1;
+  int o = 0, wmax = 0;
+  int size[MAXL];
+  for (int l = 0; l < r.nl; ++l) {
+    const int li = l == 0 ? d->fourier_dim + d->pe_dim : d->hidden, lo = l == r.nl - 1 ? d->out_dim : d->hidden;
+    r.off[l] = o;
+    size[l] = lo * (li + 1);
+    o += size[l];
+    wmax = size[l] > wmax ? size[l] : wmax;
+  }
+  r.off[r.nl] = o;
+  r.dnet = o;
+  r.wmax = wmax;
+  int k = 0;
+  for (int l = 0; l < r.nl; ++l) r.wide[l] = (size[l] == wmax && (wmax & 1) == 0) ? k++ : -1;
+  RCB_REQUIRE(r.stride >= r.dnet, RCB_ERR_SHAPE, "siren_reduce_chunks: row stride %lld < %d", r.stride, r.dnet);
+  const long long total = (long long)r.G * r.dnet;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  siren_reduce_chunks_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
 }

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int q = lane & 31, h = lane >> 5;
-  const int g = blockIdx.x;
+  const int g = blockIdx.x % a.G, chunk = blockIdx.x / a.G;     // chunk-major: partial buffers are [chunk][g]
   const int n = g / a.S;
   const int P = a.P;
 
@@ -263,8 +263,10 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
       }
     }
   };
-  if (wave < ntiles) fetch(wave);
-  for (int t = wave; t < ntiles; t += 4) {
+  // this workgroup's share of the 32-pixel tiles (all of them unless rcb_siren_desc.pixel_chunks > 1)
+  const int t0 = (int)((long long)chunk * ntiles / a.chunks), t1 = (int)((long long)(chunk + 1) * ntiles / a.chunks);
+  if (t0 + wave < t1) fetch(t0 + wave);
+  for (int t = t0 + wave; t < t1; t += 4) {
     const int p = t * 32 + q;
     const bool valid = p < P;
     const int pc = valid ? p : P - 1;
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
         }
       }
     }
-    fetch(t + 4 < ntiles ? t + 4 : t);
+    fetch(t + 4 < t1 ? t + 4 : t);
     // ---- forward ----------------------------------------------------------------------------------------------------
     bf16x8 S[NH][KSH], Cs[NH][KSH];
 #pragma unroll
@@ -492,7 +494,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
 
   // ---- deterministic cross-wave reduction of the weight gradients, one layer at a time -----------------------------------
   float* part = smem + wave * G::RED_WAVE;
-  float* dst = a.dwvec + (long long)g * a.w_stride;
+  float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     const int no = G::lout(l), IBl = G::ib(l), OBl = G::ob(l);
@@ -543,7 +545,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
     __syncthreads();
     if (lane == 0) smem[wave] = v;
     __syncthreads();
-    if (tid == 0) a.sse[g] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
+    if (tid == 0) a.sse[(long long)chunk * a.G + g] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
   }
 }
 
@@ -558,7 +560,7 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
     if (e != hipSuccess) return fail((int)e, "siren(wide): hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
-  kfn<<<a.G, 256, G::LDS_BYTES, st>>>(a);
+  kfn<<<a.G * a.chunks, 256, G::LDS_BYTES, st>>>(a);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

@@ -57,7 +57,24 @@ def _xf_stride(xf, meta, n_inr):
     return int(xf.stride(0))
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None):
+# Opt-in: split the pixel tiles of a row over several workgroups when a launch has few rows (rcb_siren_desc.pixel_chunks).
+# Off by default: the partial sums change the association of the weight-gradient sums with the batch size, i.e. an INR's
+# gradient would no longer be bit-identical whether it is trained alone or in a large batch
+# (test_determinism_and_batch_invariance), for a gain that only matters below ~200 rows (tools/siren_chunks.py on MI355X,
+# 4096 pixels: 96 rows 85 -> 44 us with 4 chunks, 192 rows 90 -> 68 us; nothing at width 48 / 64).
+PIXEL_CHUNKS_AUTO = False
+
+
+def siren_pixel_chunks(G, meta: SirenMeta):
+    """workgroups per row of wvec chosen for a launch of G rows: 1 unless PIXEL_CHUNKS_AUTO is set and the launch is a
+    width-32 16-bit one with fewer than 256 rows; every chunk keeps at least 8 of the 32-pixel tiles (2 per wave)"""
+    ntiles = (meta.n_pix + 31) // 32
+    if not PIXEL_CHUNKS_AUTO or meta.precision == 0 or meta.hidden != 32 or G >= 256 or ntiles < 16:
+        return 1
+    return max(1, min(4 if G <= 128 else 2, ntiles // 8))
+
+
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -67,7 +84,7 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None):
         raise RcbError("rows of wvec must be a multiple of samples")
     d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
-                  meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split))
+                  meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split), int(chunks))
     return d, G
 
 
@@ -86,9 +103,9 @@ def _check_pe(pe, G, meta):
         raise RcbError("pe must be fp32 (any precision mode) or bf16 (16-bit modes only)")
 
 
-def siren_fwd(xf, pe, wvec, meta: SirenMeta):
+def siren_fwd(xf, pe, wvec, meta: SirenMeta, pixel_chunks=None):
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf, pe)
+    d, G = _siren_desc(meta, wvec, xf, pe, None, pixel_chunks or siren_pixel_chunks(wvec.shape[0], meta))
     _check_pe(pe, G, meta)
     y = torch.empty(G, meta.n_pix, meta.out_dim, device=wvec.device, dtype=f32)
     check(lib.rcb_siren_fwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
@@ -96,17 +113,22 @@ def siren_fwd(xf, pe, wvec, meta: SirenMeta):
     return y
 
 
-def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True):
+def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True, pixel_chunks=None):
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf, pe)
+    chunks = pixel_chunks or siren_pixel_chunks(wvec.shape[0], meta)
+    d, G = _siren_desc(meta, wvec, xf, pe, None, chunks)
     _check_pe(pe, G, meta)
     if tuple(dy.shape) != (G, meta.n_pix, meta.out_dim):
         raise RcbError("dy shape mismatch")
     dw = torch.empty(G, wvec.stride(0), device=wvec.device, dtype=f32)[:, :meta.d_net]
+    part = torch.empty(chunks, G, wvec.stride(0), device=wvec.device, dtype=f32) if chunks > 1 else None
     dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
     check(lib.rcb_siren_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
-                            ptr(dy.contiguous(), f32), _dev_ptr_strided(dw), ptr(dpe, None, True), stream_ptr()),
-          "rcb_siren_bwd")
+                            ptr(dy.contiguous(), f32), _dev_ptr_strided(dw if part is None else part), ptr(dpe, None, True),
+                            stream_ptr()), "rcb_siren_bwd")
+    if part is not None:
+        check(lib.rcb_siren_reduce_chunks(C.byref(d), ptr(part), C.c_void_p(0), _dev_ptr_strided(dw), C.c_void_p(0),
+                                          stream_ptr()), "rcb_siren_reduce_chunks")
     return dw, dpe
 
 
@@ -117,7 +139,8 @@ def siren_wide_layers(meta: SirenMeta):
     return sizes.count(max(sizes)), max(sizes)
 
 
-def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_split=False):
+def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_split=False,
+                   pixel_chunks=None):
     """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_split (16-bit modes) also
     the split-bf16 left operands [n_wide, G, 3 W] of the wide layers' gradients (ops._Stacked, as split_bf16 returns)."""
     lib = _lib.load()
@@ -129,7 +152,8 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
             raise RcbError("the split-bf16 gradient output needs a 16-bit precision mode and an even layer length")
         stacked = torch.empty(n_wide, G, 3 * w, device=wvec.device, dtype=bf16)
         split = _Stacked(list(stacked.unbind(0)), stacked)
-    d, G = _siren_desc(meta, wvec, xf, pe, None if split is None else split.stacked)
+    chunks = pixel_chunks or siren_pixel_chunks(G, meta)
+    d, G = _siren_desc(meta, wvec, xf, pe, None if (split is None or chunks > 1) else split.stacked, chunks)
     _check_pe(pe, G, meta)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
@@ -137,9 +161,18 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
     sse = torch.empty(G, device=wvec.device, dtype=f32)
     dw = torch.empty(G, wvec.stride(0), device=wvec.device, dtype=f32)[:, :meta.d_net]
     dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
+    part = sse_part = None
+    if chunks > 1:          # few rows: pixel tiles split over several workgroups per row, partials summed in chunk order
+        part = torch.empty(chunks, G, wvec.stride(0), device=wvec.device, dtype=f32)
+        sse_part = torch.empty(chunks, G, device=wvec.device, dtype=f32)
     check(lib.rcb_siren_loss_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
-                                 ptr(target, f32), C.c_float(dy_scale), ptr(sse), _dev_ptr_strided(dw),
-                                 ptr(dpe, None, True), stream_ptr()), "rcb_siren_loss_bwd")
+                                 ptr(target, f32), C.c_float(dy_scale), ptr(sse if part is None else sse_part),
+                                 _dev_ptr_strided(dw if part is None else part), ptr(dpe, None, True), stream_ptr()),
+          "rcb_siren_loss_bwd")
+    if part is not None:
+        d2, _ = _siren_desc(meta, wvec, xf, pe, None if split is None else split.stacked, chunks)
+        check(lib.rcb_siren_reduce_chunks(C.byref(d2), ptr(part), ptr(sse_part), _dev_ptr_strided(dw), ptr(sse), stream_ptr()),
+              "rcb_siren_reduce_chunks")
     return (sse, dw, dpe, split) if want_split else (sse, dw, dpe)
 
 

@@ -287,6 +287,47 @@ def test_siren_wide_bf16_pe_storage_and_split_output():
         assert torch.equal(split[k], want[k])
 
 
+@pytest.mark.parametrize("width,prec", [(32, 1), (32, 2), (48, 1), (64, 2)])
+def test_siren_pixel_chunks_equal_whole_row_launch(width, prec):
+    """rcb_siren_desc.pixel_chunks (launches with few rows): outputs and the pe gradient are bit-identical to the one-
+    workgroup-per-row launch (disjoint pixels); the weight gradient and the loss are the same sums in a different
+    (fixed) association; the reduction also emits the split-bf16 form."""
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=1000, N=3, S=2, hidden=width)
+    dims, D, xf, pe, wv, y = _siren_case(seed=17, **case)
+    meta = SirenMeta(2, 1000, 16, 16, 3, width, 3, precision=prec)
+    assert ops.siren_pixel_chunks(6, meta) == 1                       # opt-in (keeps bitwise batch invariance by default)
+    ops.PIXEL_CHUNKS_AUTO = True
+    try:
+        assert ops.siren_pixel_chunks(6, meta) == (4 if width == 32 else 1) and ops.siren_pixel_chunks(4096, meta) == 1
+        assert ops.siren_pixel_chunks(6, SirenMeta(2, 1000, 16, 16, 3, 32, 3, precision=0)) == 1
+    finally:
+        ops.PIXEL_CHUNKS_AUTO = False
+    pe16 = g(pe).bfloat16()
+    scale = 1.0 / 6000
+    y1 = ops.siren_fwd(g(xf), pe16, g(wv), meta, pixel_chunks=1)
+    for c in (2, 4, 32):
+        assert torch.equal(ops.siren_fwd(g(xf), pe16, g(wv), meta, pixel_chunks=c), y1)
+    s1, w1, d1, sp1 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_split=True, pixel_chunks=1)
+    for c in (2, 5):
+        sc, wc, dc, spc = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_split=True, pixel_chunks=c)
+        assert torch.equal(dc, d1)
+        assert rel_err(sc, s1) < 1e-6 and rel_err(wc, w1) < 2e-6
+        n_wide, wlen = ops.siren_wide_layers(meta)
+        lo0 = dims[1] * (dims[0] + 1) if width != 32 else 0
+        want = ops.split_bf16([wc[:, lo0 + k * wlen:lo0 + (k + 1) * wlen] for k in range(n_wide)], "cols", 0b010)
+        assert torch.equal(spc.stacked, want.stacked)
+        s2, w2, d2 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, pixel_chunks=c)
+        assert torch.equal(w2, wc) and torch.equal(s2, sc)                       # deterministic
+    dy = 1e-3 * torch.randn(6, 1000, 3, device=DEV)
+    wb1, db1 = ops.siren_bwd(g(xf), pe16, g(wv), dy, meta, pixel_chunks=1)
+    wb4, db4 = ops.siren_bwd(g(xf), pe16, g(wv), dy, meta, pixel_chunks=4)
+    assert torch.equal(db4, db1) and rel_err(wb4, wb1) < 2e-6
+    with pytest.raises(ops.RcbError):
+        ops.siren_fwd(g(xf), pe16, g(wv), meta, pixel_chunks=33)                 # more chunks than 32-pixel tiles
+    with pytest.raises(ops.RcbError):
+        ops.siren_fwd(g(xf), g(pe), g(wv), SirenMeta(2, 1000, 16, 16, 3, 32, 3, precision=0), pixel_chunks=2)
+
+
 def test_siren_per_inr_coordinates_and_strided_rows():
     """xf given per INR ([N,P,F]) and wvec rows with a padded stride."""
     case = dict(F=16, E=16, n_hidden=3, C=3, P=64, N=3, S=1)
