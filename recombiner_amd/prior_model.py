@@ -55,6 +55,12 @@ class Upsample(nn.Module):
         x = self.act2(self.conv2(self.up2(x)))
         return self.conv3(self.up3(x))
 
+    def __getstate__(self):
+        # the fast evaluation paths cache their wrappers on the module (`_rcb_*`, upsample_fast.py); they share this module's
+        # parameters and must neither travel in a checkpoint pickle (the reference could not load it) nor be carried over
+        # by copy.deepcopy (the copy would keep evaluating the ORIGINAL's parameters)
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_rcb_")}
+
 
 def _zeros_state(t):
     return torch.zeros_like(t, memory_format=torch.contiguous_format)

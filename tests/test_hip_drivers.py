@@ -84,3 +84,29 @@ def test_prior_training_checkpoint_and_compression(tmp_path):
     assert os.path.getsize(path_bs) == len(blob)
     with pytest.raises(ValueError):
         bitstream.decode(cfg, "cifar", ck, blob, Xd, 3, device=DEV)       # wrong number of datapoints
+
+
+def test_patched_2d_prior_training_checkpoint_and_compression_in_the_bf16_mode(tmp_path):
+    """the drivers on a (reduced) patched 2-D preset in the 16-bit mode: the stitched-grid path caches its wrappers on the
+    Upsample module, which must not break the checkpoint (the module itself is pickled, main_prior_training.py:334-335);
+    the checkpoint then drives a compression of one datapoint whose bitstream decodes to the encoder's reconstruction."""
+    from recombiner_amd import bitstream
+    cfg = dict(config.configs["kodak"], pixel_sizes=[32, 32], patch_nums=[2, 2],
+               hierarchical_patch_nums={"level2": [1, 2], "level3": [2, 2]})
+    n = 8                                                   # two datapoints of 2 x 2 patches
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3, seed=2)
+    path = os.path.join(tmp_path, "PRIOR2D.pkl")
+    out = drivers.train_prior(cfg, "kodak", X.to(DEV)[None].expand(n, -1, -1), Y, max_bitrate=0.5, device=DEV, n_em_iter=2,
+                              first_epochs=5, epochs=5, lr=2e-3, checkpoint_path=path, checkpoint_every=1, precision=1,
+                              log=lambda *a: None)
+    assert np.isfinite(out["elbo"]).all()
+    assert any(k.startswith("_rcb_") for k in out["upsample_net"].__dict__)       # the stitched-grid wrapper is cached there
+    ck = drivers.load_checkpoint(path)
+    assert len(ck) == 8 and type(ck[7]).__name__ == "Upsample" and not any(k.startswith("_rcb_") for k in ck[7].__dict__)
+    Xd = X.to(DEV)[None].expand(4, -1, -1)
+    dist, model = drivers.compress(cfg, "kodak", ck, Xd, Y[:4], device=DEV, n_epochs=4, finetune_epochs=1, precision=1)
+    assert np.isfinite(dist).all()
+    blob = bitstream.encode(model)
+    y_dec = bitstream.decode(cfg, "kodak", ck, blob, Xd, 4, device=DEV, precision=1)
+    with torch.no_grad():
+        assert float((y_dec - model.predict(Xd)).abs().max()) < 1e-5

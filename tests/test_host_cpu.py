@@ -126,3 +126,26 @@ def test_bitstream_container_round_trip_and_rejects_corruption():
         B.pack_indices([np.zeros((1, 1))] * 4)                          # at most three levels
     with pytest.raises(ValueError):
         B.unpack_indices(B.MAGIC + b"\x01\x00\x04\x10" + b"\0" * 40)   # header claiming four levels
+
+
+def test_upsample_pickles_and_deep_copies_without_its_fast_path_caches():
+    """the 16-bit modes cache their evaluation wrappers on the Upsample module; a checkpoint pickle (drivers.save_checkpoint
+    writes the module itself, as main_prior_training.py:334-335 does) must stay loadable by the reference and a deep copy must
+    not keep evaluating the original's parameters"""
+    import copy
+    import io
+    import pickle
+    from recombiner_amd import prior_model as PM
+    from recombiner_amd.upsample_fast import phase_module, stitched2d_module
+    net = PM.Upsample(2, [2, 1, 1], [4, 2, 2])
+    assert phase_module(net) is not None and callable(stitched2d_module(net))
+    assert any(k.startswith("_rcb_") for k in net.__dict__)
+    blob = pickle.dumps(net)
+    assert b"upsample_fast" not in blob and b"_rcb_" not in blob
+    back = pickle.load(io.BytesIO(blob))
+    assert not any(k.startswith("_rcb_") for k in back.__dict__)
+    for a, b in zip(net.state_dict().values(), back.state_dict().values()):
+        assert torch.equal(a, b)
+    twin = copy.deepcopy(net)
+    assert not any(k.startswith("_rcb_") for k in twin.__dict__)
+    assert phase_module(twin).net is twin and phase_module(net).net is net
