@@ -480,7 +480,9 @@ class PriorBNNmodel(nn.Module):
                         graphs = []
                         for seg in (seg1a, seg1b, seg2, seg3):
                             g = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(g, pool=pool):
+                            # thread_local: the process group's own threads (RCCL watchdog: event queries) must not be able
+                            # to invalidate a capture in progress on this thread
+                            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                                 seg()
                             graphs.append(g)
                         ws["graphs"] = ("segments", graphs)
