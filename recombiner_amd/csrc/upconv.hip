@@ -974,21 +974,28 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
 __global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int row,
                                                                   int wsz, float* __restrict__ dweff,
                                                                   float* __restrict__ dbias) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= row) return;
-  const float* p = partial + j;
-  float s[8];
+  // 64 outputs per block; wave k sums the slabs k, k + 4, ... (coalesced 256-byte rows), the four wave sums are added in
+  // wave order: a fixed association (bitwise reproducible) with 4x the parallelism of one thread per output
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < row) {
+    const float* p = partial + j;
+    int w = wave;
+    for (; w + 12 < nblk; w += 16) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s[u] = 0.f;
-  int w = 0;
-  for (; w + 8 <= nblk; w += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += p[(long long)(w + u) * row];
+      for (int u = 0; u < 4; ++u) s[u] += p[(long long)(w + 4 * u) * row];
+    }
+    for (; w < nblk; w += 4) s[0] += p[(long long)w * row];
   }
-  for (; w < nblk; ++w) s[0] += p[(long long)w * row];
-  const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  if (j < wsz) dweff[j] = tot;
-  else if (dbias) dbias[j - wsz] = tot;
+  part[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (wave == 0 && j < row) {
+    const float tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (j < wsz) dweff[j] = tot;
+    else if (dbias) dbias[j - wsz] = tot;
+  }
 }
 
 template <typename K, typename A>
@@ -1111,7 +1118,7 @@ extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const vo
   if (!hit) return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
-  upconv_wgrad_reduce_kernel<<<(row + 255) / 256, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
+  upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -1134,7 +1141,7 @@ extern "C" int rcb_upconv_bwd_fused(const void* dy, const float* weff, const voi
   int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * 64) * 2, st, done);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
-  upconv_wgrad_reduce_kernel<<<(row + 255) / 256, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
+  upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
