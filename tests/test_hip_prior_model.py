@@ -291,3 +291,35 @@ def test_sharded_training_rehearsal_two_ranks_one_gpu():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "REHEARSAL OK ws=2" in out.stdout
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 258])
+def test_odd_batch_sizes_in_the_throughput_mode(n):
+    """batch sizes that are no multiple of the kernels' pass sizes (4 INRs per stage-2 pass, 4-element groups of the flat
+    posterior / reparam paths, 256 persistent workgroups): the bf16 step must capture, replay and agree with the fp32
+    parity mode on the same injected noise to 16-bit operand rounding."""
+    from recombiner_amd import config, utils
+    cfg = config.configs["cifar"]
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3, seed=3)
+    res = {}
+    for prec in (0, 1):
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device=DEV)
+        m.precision = prec
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(m.dims).to(DEV)
+        torch.manual_seed(124)
+        up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        m.noise_source = lambda shape: torch.randn(shape, device=DEV, generator=gen)
+        D, s0 = m._d_net, 0.0211547
+        pri = [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV), torch.zeros(2, 2, 128, device=DEV),
+               torch.full((2, 2, 128), s0, device=DEV)] + [None] * 4
+        _, _, elbo = m.train(8, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *pri, lt, up, 1e-8, training_mappings=True)
+        res[prec] = np.array(elbo)
+    assert np.isfinite(res[1]).all() and len(res[1]) == 8
+    np.testing.assert_allclose(res[1], res[0], rtol=2e-3)
+    # and the production path (in-kernel noise) at this size
+    m.noise_source = None
+    _, _, e2 = m.train(8, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *pri, lt, up, 1e-8, training_mappings=True)
+    assert np.isfinite(e2).all()
