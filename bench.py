@@ -41,6 +41,7 @@ def parse():
                     help="bf16 = bf16 MFMA operands / fp32 accumulate / fp32 master weights (BASELINE config[1]); "
                          "fp32 = exact-parity mode (fp32 MFMA, MIOpen upsample net)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (per-kernel table, REC roofline, PSNR@bpp run)")
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
     ap.add_argument("--lowp-gemm", action="store_true", help="bf16-operand A-transform GEMMs (experimental)")
     ap.add_argument("--no-split-gemm", action="store_true", help="plain fp32 A-transform GEMMs instead of split-bf16 fwd/dgrad")
@@ -93,23 +94,56 @@ def cpu_baseline(cfg, seconds_target=15.0):
                       f"torch CPU fp32, {threads} threads"}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a CHILD
+    process and exit with its code.  Nothing in this parent has touched the GPU yet (device_count() does not initialise
+    it), and the parent is not replaced (no exec)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    rehearsal = os.environ.get("RCB_DIST_BACKEND", "nccl") != "nccl"
+    if ndev < a.gpus and not rehearsal:
+        sys.exit(f"bench.py: --gpus {a.gpus} requested but only {ndev} GPU(s) are visible: one rank per GPU over RCCL "
+                 f"needs {a.gpus} devices (RCB_DIST_BACKEND=gloo rehearses the sharded code path on fewer; never for numbers)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {ws} rank(s)")
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("RCB_DIST_BACKEND", "nccl")
+    if ws > 1 and backend == "nccl" and ndev < ws:
+        sys.exit(f"bench.py: {ws} RCCL ranks need {ws} GPUs, {ndev} visible")
     dev = torch.device("cuda", local % max(ndev, 1))
     torch.cuda.set_device(dev)
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL over xGMI on ROCm.  RCB_DIST_BACKEND=gloo exists only to rehearse the N>1 code path on a
         # box with fewer GPUs than ranks (ranks then share a device); it is never used for reported numbers.
-        backend = os.environ.get("RCB_DIST_BACKEND", "nccl")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+        # n_gpus of the JSON line = the ranks the communicator itself reports, proven by a collective
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        ws_seen = int(one.item())
+        if ws_seen != a.gpus or torch.distributed.get_world_size() != a.gpus:
+            sys.exit(f"bench.py: communicator has {ws_seen} ranks, --gpus {a.gpus}")
 
     from recombiner_amd import config, ops, tuning, utils
     tuned = False if a.no_tuned_gemms else tuning.enable_tuned_gemms()
@@ -135,6 +169,12 @@ def main():
     lt = PM.LinearTransform(m.dims).to(dev)
     torch.manual_seed(124)
     up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(dev)
+    if ws > 1:
+        # the shared mappings' gradients are summed over all ranks every step (the only per-step collective); the mappings
+        # themselves start from rank 0's values
+        m.dp_group = torch.distributed.group.WORLD
+        for prm in list(lt.parameters()) + list(up.parameters()):
+            torch.distributed.broadcast(prm.data, 0)
     torch.manual_seed(1000 + rank)
     s0 = 0.0211547
     D = m._d_net

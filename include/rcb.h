@@ -262,22 +262,60 @@ int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int3
                     double* m2, double* sig2, rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K9: A* / relative-entropy-coding candidate scoring (test_model.py:501-533, 586-595), batched
+ * K9: A* / relative-entropy-coding candidate scoring (test_model.py:501-533 sample_group, :535-584
+ * h_/hh_ copies) and the commit of the chosen sample (test_model.py:586-619 compress_group), batched
  * over jobs.  Job b encodes columns [start[b], start[b]+glen[b]) of row row[b]:
- *   z_k   = p_loc + p_scale * xi_k                     (fp64; xi = table for group length glen)
+ *   z_k    = p_loc + p_scale * xi_k                    (fp64: multiply, then add; xi = table of that group length)
  *   logw_k = sum_j logN(z_kj; loc, scale) - logN(z_kj; p_loc, p_scale) + gumbel[k]
- *   idx   = first argmax_k logw_k ;  z_out = z_idx
- * loc/scale/p_loc/p_scale are fp32 (scale = softplus(log_scale)/6 precomputed by the caller),
- * tables[g] points to a [K, g] fp64 row-major table (or NULL if unused), gumbel is [K] fp64.
- * Outputs: idx[b] (int32), z_out[b, max_glen] fp64, best[b, 2] = (max, runner-up) log-weights;
- * logw_job0 (nullable, [K]) receives all log-weights of job 0 for testing.
+ *   idx    = first argmax_k logw_k
+ * loc/scale/p_loc/p_scale are fp32 (scale = softplus(log_scale)/6 precomputed by the caller).  Group lengths are
+ * unbounded (the reference packs parameters until 16 bits of KL are reached, prior_model.py:301-316).
+ * Candidate tables: the reference table (scrambled Sobol -> scipy norm.ppf, test_model.py:493-498) is fp32-precision
+ * data in an fp64 container, so it is held as fp32, TRANSPOSED: tables_t[g] -> [g][K] (candidate index contiguous).
+ * tables_t and table_absmax are DEVICE arrays of max_glen + 1 entries (NULL / 0 for unused lengths); the job arrays are
+ * DEVICE arrays too, so an encode round needs no host round trip.  Jobs outside the matrix, with an unknown group
+ * length or a missing table are rejected on the device: idx = -1, nothing committed.
+ *
+ * mode RCB_REC_EXACT: the reference arithmetic op for op (one workgroup per job).
+ * mode RCB_REC_FAST : logw as a quadratic in xi (two fp64 FMAs per candidate and element, eight jobs share every table
+ *   load), then a per-job certificate: if the gap between the two best fast scores exceeds a rigorous bound on
+ *   |fast - exact| the exact arg-max is provably the same index; the remaining jobs (flagged in `uncertified`) are
+ *   re-scored by the exact kernel inside the same call.  Indices are identical to RCB_REC_EXACT by construction.
+ * Outputs: idx[n_jobs]; best[n_jobs, 2] (nullable) = (max, runner-up) log-weights; uncertified[n_jobs] (nullable);
+ * logw_job0 (nullable, [K]) = all log-weights of job 0, always from the exact scorer.
+ * `workspace`: rcb_rec_workspace_bytes(...) bytes, 16-byte aligned, caller-allocated.
+ *
+ * rcb_rec_commit: z = p_loc + p_scale * xi[idx] (fp64, mul then add) -> z_out[b, max_glen] (nullable, fp64),
+ * enc_sample[row, start + j] = (float) z, enc_mask[row, start + j] = 1, and per (row, group = job_group[b]):
+ * done = 1, beta = 0, idx_groupwise = idx  (each nullable).  The decoder rebuilds its samples with the same kernel.
  * ------------------------------------------------------------------------------------------- */
-int rcb_rec_score_argmax(const float* loc, const float* scale, int32_t cols, const float* p_loc,
-                         const float* p_scale, const double* const* tables, int32_t max_glen,
-                         const double* gumbel, int32_t n_candidates, const int32_t* job_row,
-                         const int32_t* job_start, const int32_t* job_glen, int32_t n_jobs,
-                         int32_t* idx, double* z_out, double* best, double* logw_job0,
-                         rcb_stream_t stream);
+#define RCB_REC_EXACT 0
+#define RCB_REC_FAST 1
+
+typedef struct rcb_rec_desc {
+  const float* loc;            /* [rows, cols] posterior means (group order)          (nullable for rcb_rec_commit) */
+  const float* scale;          /* [rows, cols] posterior standard deviations           (nullable for rcb_rec_commit) */
+  const float* p_loc;          /* [cols] */
+  const float* p_scale;        /* [cols] */
+  int32_t rows, cols;
+  const float* const* tables_t; /* device array [max_glen + 1] of device pointers to fp32 [g][K] tables */
+  const double* table_absmax;  /* device array [max_glen + 1]: max |xi| of each table  (nullable for rcb_rec_commit) */
+  int32_t max_glen;
+  const double* gumbel;        /* [K] fp64 (test_model.py:441-457)                      (nullable for rcb_rec_commit) */
+  double gumbel_absmax;
+  int32_t n_candidates;        /* K */
+  const int32_t* job_row;      /* device arrays [n_jobs]; sorting the jobs by glen lets eight jobs share table loads */
+  const int32_t* job_start;
+  const int32_t* job_glen;
+  int32_t n_jobs;
+} rcb_rec_desc;
+
+int64_t rcb_rec_workspace_bytes(int32_t n_jobs, int32_t max_glen, int32_t n_candidates);
+int rcb_rec_score_argmax(const rcb_rec_desc* desc, int32_t mode, void* workspace, int64_t workspace_bytes, int32_t* idx,
+                         double* best, uint8_t* uncertified, double* logw_job0, rcb_stream_t stream);
+int rcb_rec_commit(const rcb_rec_desc* desc, const int32_t* idx, const int32_t* job_group, int32_t n_groups,
+                   double* z_out, float* enc_sample, float* enc_mask, uint8_t* done, float* beta,
+                   int32_t* idx_groupwise, rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1: the `nearest-upsample(2) -> conv3x3(pad 1)` stages of the upsampling net (prior_model.py:52-54:

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("RCB_LIB") or os.path.join(_HERE, "lib", "librcb_hip.s
 
 EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
-           "rcb_col_moments", "rcb_rec_score_argmax", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
+           "rcb_col_moments", "rcb_rec_score_argmax", "rcb_rec_commit", "rcb_rec_workspace_bytes", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
            "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad",
            "rcb_upconv_dgrad_partial_rows", "rcb_split_bf16", "rcb_debug_generic_kernels_only", "rcb_philox_normal",
@@ -35,6 +35,14 @@ class Level(C.Structure):
                 ("enc_mask", C.c_void_p), ("row_map", C.c_void_p), ("row_perm", C.c_void_p),
                 ("col_map", C.c_void_p), ("eps", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("cols_out", C.c_int32)]
+
+
+class RecDesc(C.Structure):
+    _fields_ = [("loc", C.c_void_p), ("scale", C.c_void_p), ("p_loc", C.c_void_p), ("p_scale", C.c_void_p),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("tables_t", C.c_void_p), ("table_absmax", C.c_void_p),
+                ("max_glen", C.c_int32), ("gumbel", C.c_void_p), ("gumbel_absmax", C.c_double),
+                ("n_candidates", C.c_int32), ("job_row", C.c_void_p), ("job_start", C.c_void_p),
+                ("job_glen", C.c_void_p), ("n_jobs", C.c_int32)]
 
 
 class SplitItem(C.Structure):
@@ -73,6 +81,7 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.rcb_last_error_string.restype = C.c_char_p
         lib.rcb_upconv_wgrad_workspace.restype = C.c_int64
+        lib.rcb_rec_workspace_bytes.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RcbError(f"{LIB_PATH} does not export {name}")

@@ -99,26 +99,19 @@ def apply_indices(model, levels):
     for lv, idx in zip(lvls, levels):
         if tuple(idx.shape) != (lv.rows, lv.n_groups):
             raise ValueError("level %r: index array %s, model needs %s" % (lv.pre, idx.shape, (lv.rows, lv.n_groups)))
+        if idx.min() < 0 or idx.max() >= K:
+            raise ValueError("level %r: index outside [0, %d)" % (lv.pre, K))
         dev = lv.loc.device
-        p_scale = ops.softplus_scale(lv.p_log_scale).double()
-        p_loc = lv.p_loc.double()
-        lens = lv.end - lv.start
-        sample = torch.empty(lv.rows, lv.D, device=dev, dtype=torch.float32)
-        idx_t = torch.from_numpy(idx).to(dev)
-        for g_len in np.unique(lens):
-            tab = model._table(lv, int(g_len), K)                          # [K, g_len] fp64
-            groups = np.nonzero(lens == g_len)[0]
-            cols = torch.from_numpy((lv.start[groups][:, None] + np.arange(int(g_len))[None, :]).reshape(-1)).to(dev)
-            t = tab[idx_t[:, torch.from_numpy(groups).to(dev)]]            # [rows, n_g, g_len]
-            z = t.reshape(lv.rows, -1) * p_scale[cols][None, :]            # fp64 multiply, then add (as the scoring kernel)
-            z = z + p_loc[cols][None, :]
-            sample[:, cols] = z.to(torch.float32)
-        lv.sample.copy_(sample)
-        lv.mask.fill_(1)
-        lv.mask_groupwise[:] = True
-        lv.idx_groupwise[:] = idx
-        lv.d_done.fill_(1)
-        lv.kl_beta.zero_()
+        tables = model._rec_tables(lv, lv.end - lv.start, K)
+        # every (row, group) pair is one job of the encoder's own commit kernel (rcb_rec_commit): fp64 multiply, then add,
+        # rounded to fp32 -- the decoder's parameters are the encoder's bit for bit by construction
+        rows = np.repeat(np.arange(lv.rows), lv.n_groups)
+        groups = np.tile(np.arange(lv.n_groups), lv.rows)
+        jobs, order = ops.RecJobs.from_host(dev, rows, lv.start[groups], (lv.end - lv.start)[groups], group=groups,
+                                            rows=lv.rows, cols=lv.D, sort=False)
+        idx_t = torch.from_numpy(np.ascontiguousarray(idx.reshape(-1)).astype(np.int32)).to(dev)
+        ops.rec_commit(lv.p_loc, ops.softplus_scale(lv.p_log_scale), tables, jobs, idx_t, n_groups=lv.n_groups,
+                       enc_sample=lv.sample, enc_mask=lv.mask, done=lv.d_done, beta=lv.kl_beta, idx_groupwise=lv.d_idx)
 
 
 def decode(config, dataset, checkpoint, blob, x, n_datapoints, device="cuda", seed=42, precision=0):

@@ -23,6 +23,10 @@ def world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def is_dist() -> bool:
+    return bool(td.is_available() and td.is_initialized())
+
+
 def shard_range(n_datapoints: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous block of whole datapoints for `rank` (remainder spread over the first ranks)."""
     base, rem = divmod(n_datapoints, world_size)

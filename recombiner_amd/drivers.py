@@ -12,6 +12,7 @@ contents (main_prior_training.py:284-335) -- so priors interchange with the refe
 Under torch.distributed the INRs of `train_prior` are the local shard; the prior refit, the KL that drives
 beta and the grouping statistics are all-reduced (recombiner_amd.dist).
 """
+import copy
 import pickle
 
 import numpy as np
@@ -63,6 +64,13 @@ def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em
     m.precision = precision
     lt = LinearTransform(m.dims).to(device)
     up = Upsample(config['data_dim'], config['paddings'], config['layerwise_scale_factors']).to(device)
+    if dist.is_dist():
+        # sharded: this model's mapping gradients are summed over `group` (None = every rank), nothing else is; the
+        # shared mappings start from rank 0's values rather than from an assumption about identical seeds
+        m.dp_group = group if group is not None else torch.distributed.group.WORLD
+        if training_mappings:
+            for prm in list(lt.parameters()) + list(up.parameters()):
+                torch.distributed.broadcast(prm.data, torch.distributed.get_global_rank(m.dp_group, 0), group=m.dp_group)
     budget_max, budget_min = bit_budgets(config, dataset, max_bitrate)
     assert budget_min <= budget_max
     s0 = F.softplus(torch.tensor(-2.), beta=1, threshold=20) / 6
@@ -134,15 +142,15 @@ def build_checkpoint(m, lt, up, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc,
 
 
 def save_checkpoint(path, ck):
+    """Writes the eight pickles.  The two modules are pickled as CPU *copies*: moving the live modules to the CPU and
+    back (what main_prior_training.py:334-338 does) re-allocates their parameter storages, i.e. the addresses the
+    captured training graphs read and update (PriorBNNmodel.train re-captures if that ever happens, see its key)."""
     lt, up = ck[6], ck[7]
-    dev = next(lt.parameters()).device
     with open(path, "wb") as f:
         for obj in ck[:6]:
             pickle.dump(obj, f)
-        pickle.dump(lt.cpu(), f)
-        pickle.dump(up.cpu(), f)
-    lt.to(dev)
-    up.to(dev)
+        pickle.dump(copy.deepcopy(lt).cpu(), f)
+        pickle.dump(copy.deepcopy(up).cpu(), f)
 
 
 def load_checkpoint(path):

@@ -491,45 +491,166 @@ def softplus_scale(log_scale):
     return out
 
 
-def rec_score_argmax(loc, scale, p_loc, p_scale, tables: dict, gumbel, job_row, job_start, job_glen,
-                     want_logw0=False):
-    """Batched A* scoring.  tables: {group_len: fp64 [K, g] GPU tensor}.  job_* are host int arrays.
-    -> (idx int32 [B] (GPU), z fp64 [B, max_g] (GPU), best fp64 [B,2] (GPU), logw0 or None)."""
+class RecTables:
+    """Candidate tables of the A* coder on the device, one per group length: the reference's fp64 [K, g] table
+    (test_model.py:493-498) held as fp32 TRANSPOSED [g, K] -- its values are fp32-precision ndtri widened to fp64, so the
+    narrowing is exact (checked on insertion) -- plus the device-side pointer / max |xi| arrays the kernels index by group
+    length (include/rcb.h, rcb_rec_desc)."""
+
+    def __init__(self, device, n_candidates):
+        self.device, self.K = torch.device(device), int(n_candidates)
+        self.t = {}            # g -> fp32 [g, K]
+        self.absmax = {}
+        self._dev = None       # (max_glen, pointer array int64 [max_glen + 1], absmax fp64 [max_glen + 1])
+
+    def __contains__(self, g):
+        return int(g) in self.t
+
+    def add(self, g, table):
+        """table: fp64 (or fp32) [K, g] tensor, any device."""
+        g = int(g)
+        if tuple(table.shape) != (self.K, g):
+            raise RcbError(f"candidate table for group length {g} must be [{self.K}, {g}], got {tuple(table.shape)}")
+        t32 = table.to(f32)
+        if not torch.equal(t32.to(table.dtype), table):
+            raise RcbError("candidate table is not exactly representable in fp32 (the reference's tables are fp32-precision "
+                           "data, SURVEY A16): refusing to round it")
+        self.t[g] = t32.t().contiguous().to(self.device)
+        self.absmax[g] = float(table.abs().max())
+        self._dev = None
+
+    @classmethod
+    def from_dict(cls, tables: dict, device, n_candidates):
+        rt = cls(device, n_candidates)
+        for g, t in tables.items():
+            rt.add(g, t)
+        return rt
+
+    def device_arrays(self):
+        if self._dev is None:
+            mg = max(self.t)
+            ptrs = np.zeros(mg + 1, dtype=np.int64)
+            amax = np.zeros(mg + 1, dtype=np.float64)
+            for g, t in self.t.items():
+                ptrs[g] = t.data_ptr()
+                amax[g] = self.absmax[g]
+            self._dev = (mg, torch.from_numpy(ptrs).to(self.device), torch.from_numpy(amax).to(self.device))
+        return self._dev
+
+
+class RecJobs:
+    """(row, start, glen[, group]) arrays of a batch of encodes on the device (int32)."""
+
+    def __init__(self, row, start, glen, group=None):
+        self.row, self.start, self.glen, self.group = row, start, glen, group
+        self.n = int(row.shape[0])
+
+    @classmethod
+    def from_host(cls, device, row, start, glen, group=None, rows=None, cols=None, sort=True):
+        """host arrays, validated here (device-built job lists are validated inside the kernels); sorted by group
+        length so that the fast scorer's eight-job workgroups share table loads.  Returns (jobs, order) with
+        order[i] = position of sorted job i in the caller's arrays."""
+        row, start, glen = (np.asarray(v, dtype=np.int64).reshape(-1) for v in (row, start, glen))
+        if row.shape[0] == 0:
+            raise RcbError("rec: no jobs")
+        if glen.min() < 1:
+            raise RcbError("rec: group length < 1")
+        if rows is not None and ((row < 0).any() or (row >= rows).any() or (start < 0).any() or (start + glen > cols).any()):
+            raise RcbError("job outside the parameter matrix")
+        order = np.argsort(glen, kind="stable") if sort else np.arange(row.shape[0])
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a[order]).astype(np.int32)).to(device)
+        grp = None if group is None else dev(np.asarray(group, dtype=np.int64).reshape(-1))
+        return cls(dev(row), dev(start), dev(glen), grp), order
+
+
+def _rec_desc(loc, scale, p_loc, p_scale, tables: RecTables, gumbel, gumbel_absmax, jobs: RecJobs):
+    mg, ptrs, amax = tables.device_arrays()
+    rows, cols = (loc.shape if loc is not None else (int(1 << 30), p_loc.shape[0]))
+    d = _lib.RecDesc(addr(None if loc is None else loc.detach(), f32), addr(scale, f32), addr(p_loc, f32), addr(p_scale, f32),
+                     int(rows), int(cols), addr(ptrs, torch.int64), addr(amax, f64), int(mg),
+                     addr(gumbel, f64), float(gumbel_absmax), int(tables.K), addr(jobs.row, i32), addr(jobs.start, i32),
+                     addr(jobs.glen, i32), jobs.n)
+    return d, (ptrs, amax)
+
+
+REC_EXACT, REC_FAST = 0, 1
+
+
+def rec_score(loc, scale, p_loc, p_scale, tables: RecTables, gumbel, jobs: RecJobs, mode=REC_FAST, want_logw0=False,
+              gumbel_absmax=None):
+    """Batched A* scoring, everything on the device (rcb_rec_score_argmax).
+    -> (idx int32 [B], best fp64 [B, 2], uncertified uint8 [B] (jobs the exact scorer had to decide), logw0 or None)."""
     lib = _lib.load()
-    job_row = np.asarray(job_row, dtype=np.int32)
-    job_start = np.asarray(job_start, dtype=np.int32)
-    job_glen = np.asarray(job_glen, dtype=np.int32)
-    B = int(job_row.shape[0])
-    rows, cols = loc.shape
-    K = int(gumbel.shape[0])
-    if B == 0:
-        raise RcbError("rec_score_argmax: no jobs")
-    max_g = int(job_glen.max())
-    if job_glen.min() < 1 or max_g > 32:
-        raise RcbError("group length outside 1..32")
-    if (job_row < 0).any() or (job_row >= rows).any() or (job_start < 0).any() or (job_start + job_glen > cols).any():
-        raise RcbError("job outside the parameter matrix")
-    tab = (C.c_void_p * (max_g + 1))()
-    for g in range(max_g + 1):
-        tab[g] = None
-    for g in np.unique(job_glen):
-        t = tables.get(int(g))
-        if t is None or tuple(t.shape) != (K, int(g)) or t.dtype != f64:
-            raise RcbError(f"missing / malformed candidate table for group length {int(g)}")
-        tab[int(g)] = ptr(t, f64).value
+    if loc.dim() != 2 or tuple(scale.shape) != tuple(loc.shape) or p_loc.numel() != loc.shape[1] or p_scale.numel() != loc.shape[1]:
+        raise RcbError("rec_score: loc / scale [rows, cols] and priors [cols] expected")
+    K = tables.K
+    if gumbel.numel() != K:
+        raise RcbError(f"rec_score: {gumbel.numel()} Gumbel values for {K} candidates")
+    if gumbel_absmax is None:
+        gumbel_absmax = float(gumbel.abs().max())
+    d, keep = _rec_desc(loc, scale, p_loc, p_scale, tables, gumbel, gumbel_absmax, jobs)
     dev = loc.device
-    jr = torch.from_numpy(job_row).to(dev)
-    js = torch.from_numpy(job_start).to(dev)
-    jg = torch.from_numpy(job_glen).to(dev)
+    B = jobs.n
+    n_ws = int(lib.rcb_rec_workspace_bytes(B, d.max_glen, K))
+    if n_ws < 0:
+        raise RcbError("rcb_rec_workspace_bytes rejected the shape")
+    ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
     idx = torch.empty(B, device=dev, dtype=i32)
-    z = torch.zeros(B, max_g, device=dev, dtype=f64)
     best = torch.empty(B, 2, device=dev, dtype=f64)
+    unc = torch.empty(B, device=dev, dtype=torch.uint8)
     logw0 = torch.empty(K, device=dev, dtype=f64) if want_logw0 else None
-    check(lib.rcb_rec_score_argmax(ptr(loc.detach(), f32), ptr(scale, f32), cols, ptr(p_loc, f32), ptr(p_scale, f32),
-                                   tab, max_g, ptr(gumbel, f64), K, ptr(jr, i32), ptr(js, i32), ptr(jg, i32), B,
-                                   ptr(idx), ptr(z), ptr(best), ptr(logw0, f64, True), stream_ptr()),
-          "rcb_rec_score_argmax")
-    return idx, z, best, logw0
+    check(lib.rcb_rec_score_argmax(C.byref(d), int(mode), ptr(ws), C.c_int64(n_ws), ptr(idx), ptr(best), ptr(unc),
+                                   ptr(logw0, f64, True), stream_ptr()), "rcb_rec_score_argmax")
+    return idx, best, unc, logw0
+
+
+def rec_commit(p_loc, p_scale, tables: RecTables, jobs: RecJobs, idx, n_groups=0, want_z=False, enc_sample=None,
+               enc_mask=None, done=None, beta=None, idx_groupwise=None):
+    """z = p_loc + p_scale * xi[idx] per job (fp64 mul, add) and the state update of compress_group (rcb_rec_commit).
+    enc_sample / enc_mask: fp32 [rows, cols]; done uint8 / beta fp32 / idx_groupwise int32: [rows, n_groups]."""
+    lib = _lib.load()
+    rows = enc_sample.shape[0] if enc_sample is not None else (done.shape[0] if done is not None else 1 << 30)
+    mg, ptrs, amax = tables.device_arrays()
+    d = _lib.RecDesc(None, None, addr(p_loc, f32), addr(p_scale, f32), int(rows), int(p_loc.numel()), addr(ptrs, torch.int64),
+                     addr(amax, f64), int(mg), None, 0.0, int(tables.K), addr(jobs.row, i32), addr(jobs.start, i32),
+                     addr(jobs.glen, i32), jobs.n)
+    z = torch.zeros(jobs.n, mg, device=p_loc.device, dtype=f64) if want_z else None
+    for t_, shape in ((enc_sample, (rows, p_loc.numel())), (enc_mask, (rows, p_loc.numel())), (done, (rows, n_groups)),
+                      (beta, (rows, n_groups)), (idx_groupwise, (rows, n_groups))):
+        if t_ is not None and tuple(t_.shape) != tuple(shape):
+            raise RcbError(f"rec_commit: state tensor of shape {tuple(t_.shape)}, expected {tuple(shape)}")
+    check(lib.rcb_rec_commit(C.byref(d), ptr(idx, i32), ptr(jobs.group, i32, True), int(n_groups), ptr(z, f64, True),
+                             ptr(enc_sample, f32, True), ptr(enc_mask, f32, True), ptr(done, torch.uint8, True),
+                             ptr(beta, f32, True), ptr(idx_groupwise, i32, True), stream_ptr()), "rcb_rec_commit")
+    return z
+
+
+def rec_score_argmax(loc, scale, p_loc, p_scale, tables, gumbel, job_row, job_start, job_glen, want_logw0=False,
+                     mode=REC_FAST):
+    """Convenience form with host job arrays (validated here).  tables: RecTables or {group_len: fp64 [K, g] tensor}.
+    -> (idx int32 [B] (GPU), z fp64 [B, max_g] (GPU), best fp64 [B,2] (GPU), logw0 or None), in the caller's job order."""
+    dev = loc.device
+    K = int(gumbel.shape[0])
+    rows, cols = loc.shape
+    if not isinstance(tables, RecTables):
+        need = set(int(g) for g in np.unique(np.asarray(job_glen)))
+        for g in need:
+            t = tables.get(g)
+            if t is None or tuple(t.shape) != (K, g):
+                raise RcbError(f"missing / malformed candidate table for group length {g}")
+        tables = RecTables.from_dict({g: tables[g] for g in need}, dev, K)
+    else:
+        for g in np.unique(np.asarray(job_glen)):
+            if int(g) not in tables:
+                raise RcbError(f"missing / malformed candidate table for group length {int(g)}")
+    jobs, order = RecJobs.from_host(dev, job_row, job_start, job_glen, rows=rows, cols=cols, sort=not want_logw0)
+    idx, best, _, logw0 = rec_score(loc, scale, p_loc, p_scale, tables, gumbel, jobs, mode, want_logw0)
+    z = rec_commit(p_loc, p_scale, tables, jobs, idx, want_z=True)
+    inv = torch.from_numpy(np.argsort(order)).to(dev)
+    max_g = int(np.max(job_glen))
+    return idx[inv], z[inv][:, :max_g].contiguous(), best[inv], logw0
 
 
 # ----------------------------------------------------------------------------------------------

@@ -244,8 +244,11 @@ class PriorBNNmodel(nn.Module):
         conv = [p for p in upsample_net.parameters()]
         slices = self._layer_slices()
         D = self._d_net
+        # Gradients of the shared mappings are summed over ranks only when the caller asked for it by setting `dp_group`
+        # (drivers.train_prior and bench.py do): an initialised process group alone must not couple models that merely
+        # live in the same job (several priors / bit-rates trained side by side).
         world, rank_id = 1, 0
-        if self.dp_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if self.dp_group is not None:
             world = torch.distributed.get_world_size(self.dp_group)
             rank_id = torch.distributed.get_rank(self.dp_group)      # ranks must not draw the same noise
 
@@ -258,7 +261,10 @@ class PriorBNNmodel(nn.Module):
         key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.patch,
-               tuple(None if q is None else tuple(q.shape) for q in priors))
+               tuple(None if q is None else tuple(q.shape) for q in priors),
+               # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
+               # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
+               tuple(q.data_ptr() for q in A + conv), tuple(q.data_ptr() for q in self.parameters()))
         ws = self._ws if graphable else None
         if ws is not None and (ws["key"] != key or ws["rows"] < n_epoch):
             ws = None
@@ -464,12 +470,14 @@ class PriorBNNmodel(nn.Module):
                     gr[3].replay()
 
         if graphable and (ws["graphs"] is not None or n_epoch > n_warm):
-            try:
-                left = n_epoch
-                if ws["graphs"] is None:               # first call with this workspace: warm up eagerly, then capture
-                    for _ in range(n_warm):
-                        body()
-                    torch.cuda.synchronize()
+            left = n_epoch
+            failure = None
+            if ws["graphs"] is None:               # first call with this workspace: warm up eagerly, then capture
+                for _ in range(n_warm):
+                    body()
+                left -= n_warm
+                torch.cuda.synchronize()
+                try:
                     if flat is None:                   # one rank (or frozen mappings): the whole step is one graph
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph):      # records the step; nothing executes during capture
@@ -486,17 +494,27 @@ class PriorBNNmodel(nn.Module):
                                 seg()
                             graphs.append(g)
                         ws["graphs"] = ("segments", graphs)
-                    left -= n_warm
+                except Exception as exc:     # capture is an optimisation: fall back to eager stepping
+                    failure = exc
+                    torch.cuda.synchronize()
+                if flat is not None:
+                    # every rank must take the same route from here on: replayed segments and eager steps issue the same
+                    # collectives, but a rank that alone drops to eager would also alone flip `use_graph` for later calls.
+                    # No collective was issued during the capture attempt (they sit between the segments), so the ranks are
+                    # still aligned and can agree here.
+                    ok = torch.tensor([0 if failure is not None else 1], device=dev, dtype=torch.int32)
+                    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.dp_group)
+                    if int(ok.item()) == 0 and failure is None:
+                        failure = RuntimeError("capture failed on another rank")
+            if failure is None:
                 replay(left)
-            except Exception as exc:     # capture is an optimisation: fall back to eager stepping
+            else:
                 import warnings
-                warnings.warn(f"HIP graph capture of the training step failed ({exc}); running eagerly")
+                warnings.warn(f"HIP graph capture of the training step failed ({failure}); running eagerly")
                 ws["graphs"] = None
                 self._ws = None
                 self.use_graph = False
-                torch.cuda.synchronize()
-                done = int(step_t.item())
-                for _ in range(n_epoch - done):
+                for _ in range(left):
                     body()
         else:
             it = range(n_epoch)

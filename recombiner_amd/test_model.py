@@ -71,14 +71,25 @@ class _Lvl:
         self.kl_beta = (torch.zeros(rows, self.n_groups) + initial_beta).to(dev, torch.float32).contiguous()
         self.perm_g2p = _column_row_perms(rows, D) if perm else None
         self.perm_p2g = np.argsort(self.perm_g2p, axis=0) if perm else None
-        self.mask_groupwise = np.zeros([rows, self.n_groups], dtype=bool)
-        self.idx_groupwise = np.zeros([rows, self.n_groups])
+        # encode progress lives on the device (an encode round never waits for the host); the reference's numpy views
+        # (compressed_mask_groupwise: bool, compressed_idx_groupwise: float64, test_model.py:220-237) are materialised on access
         self.d_done = torch.zeros(rows, self.n_groups, dtype=torch.uint8, device=dev)
+        self.d_idx = torch.zeros(rows, self.n_groups, dtype=torch.int32, device=dev)
         self.mask = torch.zeros(rows, D, device=dev)
         self.sample = torch.zeros(rows, D, device=dev)
         self.sample_std = 1e-15 + torch.zeros(rows, D, device=dev)
-        self.tables = {}
+        self.tables = {}             # (g, K) -> fp64 [K, g] host tensor, as the reference computes it
+        self.rec_tables = None       # ops.RecTables: the same tables on the device, fp32 transposed
+        self.d_glen = self.d_end - self.d_start
         self.compressed_num = None
+
+    @property
+    def mask_groupwise(self):
+        return self.d_done.cpu().numpy().astype(bool)
+
+    @property
+    def idx_groupwise(self):
+        return self.d_idx.cpu().numpy().astype(np.float64)
 
     def spec(self, n_inr, cols_out, row_map):
         return LevelSpec(self.loc, self.log_scale, cols_out, n_inr, row_map=row_map, row_perm=self.perm_g2p,
@@ -330,65 +341,75 @@ class TestBNNmodel(nn.Module):
         return torch.clamp(torch.from_numpy(norm.ppf(u)), -100, 100)
 
     def _table(self, lv, g, K):
+        """fp64 [K, g] table of the reference (host tensor), cached per (g, K); also registered with the level's device tables"""
         key = (int(g), int(K))
         if key not in lv.tables:
-            lv.tables[key] = self.get_sobol_normal_sample(int(g), int(K)).to(self.loc.device).contiguous()
+            lv.tables[key] = self.get_sobol_normal_sample(int(g), int(K)).contiguous()
+        if lv.rec_tables is None or lv.rec_tables.K != int(K):
+            lv.rec_tables = ops.RecTables(self.loc.device, int(K))
+        if int(g) not in lv.rec_tables:
+            lv.rec_tables.add(int(g), lv.tables[key])
         return lv.tables[key]
+
+    def _rec_tables(self, lv, lens, K):
+        for g in np.unique(np.asarray(lens)):
+            self._table(lv, int(g), K)
+        return lv.rec_tables
+
+    def _gumbel(self, K):
+        if self.g_samples is None:
+            self.get_gumbel_sample()
+        if getattr(self, "_g_absmax", None) is None:
+            self._g_absmax = float(self.g_samples.abs().max())
+        return self.g_samples[:K], self._g_absmax
 
     def get_sample(self, group_idx, group_sample_size):
         lv = self._l1
-        return self._table(lv, lv.end[group_idx] - lv.start[group_idx], group_sample_size)
+        return self._table(lv, lv.end[group_idx] - lv.start[group_idx], group_sample_size).to(self.loc.device)
 
     def h_get_sample(self, group_idx, group_sample_size):
         lv = self._l2
-        return self._table(lv, lv.end[group_idx] - lv.start[group_idx], group_sample_size)
+        return self._table(lv, lv.end[group_idx] - lv.start[group_idx], group_sample_size).to(self.loc.device)
 
     def hh_get_sample(self, group_idx, group_sample_size):
         lv = self._l3
-        return self._table(lv, lv.end[group_idx] - lv.start[group_idx], group_sample_size)
+        return self._table(lv, lv.end[group_idx] - lv.start[group_idx], group_sample_size).to(self.loc.device)
 
     # ---- A17 / A18 ----------------------------------------------------------------------------------------------
-    def _encode_jobs(self, lv, rows, groups, K, want_logw=False):
-        """score + commit a batch of (row, group) encodes of one level in one launch."""
-        rows = np.asarray(rows, dtype=np.int64)
-        groups = np.asarray(groups, dtype=np.int64)
-        starts = lv.start[groups]
-        lens = lv.end[groups] - starts
-        if self.g_samples is None:
-            self.get_gumbel_sample()
-        tables = {int(g): self._table(lv, g, K) for g in np.unique(lens)}
+    def _encode_jobs(self, lv, rows, groups, K, want_z=False):
+        """score + commit a batch of (row, group) encodes of one level: rows / groups are host arrays or device int tensors.
+        Everything runs on the device and nothing is read back (-> idx int32 device tensor in job order after sorting by
+        group length, z or None)."""
+        dev = lv.loc.device
+        tables = self._rec_tables(lv, lv.end - lv.start, K)      # every length of the level: all of them get encoded
+        gum, gmax = self._gumbel(K)
+        if not torch.is_tensor(groups):
+            groups = torch.as_tensor(np.asarray(groups, dtype=np.int64), device=dev)
+        if not torch.is_tensor(rows):
+            rows = torch.as_tensor(np.asarray(rows, dtype=np.int64), device=dev)
+        groups = groups.to(torch.int64)
+        glen = lv.d_glen[groups]
+        order = torch.sort(glen, stable=True)[1]          # eight jobs of one group length share the fast scorer's table loads
+        groups, glen = groups[order], glen[order]
+        jobs = ops.RecJobs(rows.to(torch.int32)[order].contiguous(), lv.d_start[groups].contiguous(), glen.contiguous(),
+                           groups.to(torch.int32).contiguous())
         scale = ops.softplus_scale(lv.log_scale)
         p_scale = ops.softplus_scale(lv.p_log_scale)
-        idx, z, best, logw = ops.rec_score_argmax(lv.loc, scale, lv.p_loc, p_scale, tables, self.g_samples[:K], rows,
-                                                  starts, lens, want_logw0=want_logw)
-        idx_h = idx.cpu().numpy()
+        idx, _, _, _ = ops.rec_score(lv.loc, scale, lv.p_loc, p_scale, tables, gum, jobs, ops.REC_FAST, gumbel_absmax=gmax)
         # commit: index, masks, encoded sample (fp32), beta = 0  (test_model.py:586-595)
-        lv.idx_groupwise[rows, groups] = idx_h
-        lv.mask_groupwise[rows, groups] = True
-        dev = lv.loc.device
-        r_t = torch.from_numpy(rows).to(dev)
-        g_t = torch.from_numpy(groups).to(dev)
-        lv.d_done[r_t, g_t] = 1
-        lv.kl_beta[r_t, g_t] = 0
-        max_g = z.shape[1]
-        col = torch.from_numpy(starts).to(dev)[:, None] + torch.arange(max_g, device=dev)[None, :]
-        ok = torch.arange(max_g, device=dev)[None, :] < torch.from_numpy(lens).to(dev)[:, None]
-        rr = r_t[:, None].expand_as(col)[ok]
-        cc = col[ok]
-        lv.sample[rr, cc] = z[ok].to(torch.float32)
-        lv.mask[rr, cc] = 1
-        return idx_h, z, best, logw
+        z = ops.rec_commit(lv.p_loc, p_scale, tables, jobs, idx, n_groups=lv.n_groups, want_z=want_z, enc_sample=lv.sample,
+                           enc_mask=lv.mask, done=lv.d_done, beta=lv.kl_beta, idx_groupwise=lv.d_idx)
+        return idx, z
 
     def _sample_group(self, lv, row_idx, group_idx, group_sample_size):
-        """A* scoring of one group without committing it -> (i, z_i fp64, log_w fp64 [K])."""
+        """A* scoring of one group without committing it -> (i, z_i fp64, log_w fp64 [K]); the reference arithmetic op for op."""
         s, e = int(lv.start[group_idx]), int(lv.end[group_idx])
-        if self.g_samples is None:
-            self.get_gumbel_sample()
-        tables = {e - s: self._table(lv, e - s, group_sample_size)}
+        K = int(group_sample_size)
+        tables = self._rec_tables(lv, [e - s], K)
+        gum, _ = self._gumbel(K)
         idx, z, best, logw = ops.rec_score_argmax(lv.loc, ops.softplus_scale(lv.log_scale), lv.p_loc,
-                                                  ops.softplus_scale(lv.p_log_scale), tables,
-                                                  self.g_samples[:group_sample_size], [row_idx], [s], [e - s],
-                                                  want_logw0=True)
+                                                  ops.softplus_scale(lv.p_log_scale), tables, gum, [row_idx], [s], [e - s],
+                                                  want_logw0=True, mode=ops.REC_EXACT)
         return int(idx.item()), z[0, :e - s], logw
 
     def sample_group(self, row_idx, group_idx, group_sample_size):
@@ -402,9 +423,9 @@ class TestBNNmodel(nn.Module):
 
     def _compress_group(self, lv, row_idx, group_idx):
         K = int(np.ceil(2 ** self.bit_per_group))
-        idx, z, _, _ = self._encode_jobs(lv, [row_idx], [group_idx], K)
+        idx, z = self._encode_jobs(lv, [row_idx], [group_idx], K, want_z=True)
         s, e = int(lv.start[group_idx]), int(lv.end[group_idx])
-        return int(idx[0]), z[0, :e - s]
+        return int(idx[0].item()), z[0, :e - s]
 
     def compress_group(self, row_idx, group_idx):
         return self._compress_group(self._l1, row_idx, group_idx)
@@ -455,7 +476,8 @@ class TestBNNmodel(nn.Module):
         # workspace that survives across calls (Adam state is re-zeroed = a fresh optimiser, the step counter
         # restarts): its stable addresses let the two captured step graphs be reused by every fine-tune call
         key = (x.data_ptr(), y.data_ptr(), tuple(x.shape), S, float(lr), float(eps_adam), self.precision,
-               self.loc.data_ptr(), self.log_scale.data_ptr(), bool(self.split_gemm), self.split_terms)
+               self.loc.data_ptr(), self.log_scale.data_ptr(), bool(self.split_gemm), self.split_terms,
+               tuple(q.data_ptr() for q in A), tuple(q.data_ptr() for q in self.upsample_net.parameters()))
         ws = self._ws
         if ws is None or ws["key"] != key or ws["tab"].shape[0] < n_epochs:
             ws = dict(key=key, tab=ops.adam_table(lr, max(n_epochs, 2048)).to(dev),
@@ -591,13 +613,13 @@ class TestBNNmodel(nn.Module):
 
     def _encode_round(self, lv, largest_kl_first, round_idx):
         """one group for every row of the level, scored in one batched launch."""
-        rows = np.arange(lv.rows)
+        rows = torch.arange(lv.rows, device=lv.loc.device)
         if largest_kl_first:
             bits = self._group_kls(lv) / LN2
             bits = torch.where(lv.d_done.bool(), torch.full_like(bits, -1e10), bits)
-            groups = torch.argmax(bits, dim=1).cpu().numpy()
+            groups = torch.argmax(bits, dim=1)                  # stays on the device: the round needs no host round trip
         else:
-            groups = np.full(lv.rows, round_idx)
+            groups = torch.full((lv.rows,), int(round_idx), device=lv.loc.device, dtype=torch.int64)
         K = int(np.ceil(2 ** self.bit_per_group))
         self._encode_jobs(lv, rows, groups, K)
 

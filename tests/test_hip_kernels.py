@@ -700,9 +700,13 @@ def test_rec_score_exact_against_golden_encodes():
     pscale = O.st(pls)
     # put the first golden encode as job 0 so that its log-weights can be compared too
     idx, z, best, lw0 = ops.rec_score_argmax(g(loc), g(scale), g(pl), g(pscale), tables, g(gum), rows, starts, lens,
-                                             want_logw0=True)
+                                             want_logw0=True, mode=ops.REC_EXACT)
     idx = idx.cpu().numpy()
     assert np.array_equal(idx, enc[:, 2].astype(int)), (idx, enc[:, 2])
+    # the fast scorer (quadratic form + certificate, what compress_posteriors runs): same indices, same samples
+    idx_f, z_f, best_f, _ = ops.rec_score_argmax(g(loc), g(scale), g(pl), g(pscale), tables, g(gum), rows, starts, lens)
+    assert np.array_equal(idx_f.cpu().numpy(), idx) and torch.equal(z_f, z)
+    np.testing.assert_allclose((best_f[:, 0] - best_f[:, 1]).cpu().numpy(), enc[:, 3], rtol=1e-6, atol=1e-9)
     margins = (best[:, 0] - best[:, 1]).cpu().numpy()
     np.testing.assert_allclose(margins, enc[:, 3], rtol=1e-6, atol=1e-9)
     r0, g0 = rows[0], grps[0]
@@ -737,3 +741,91 @@ def test_rec_score_batch_vs_oracle_random():
         i, zi, lw = O.rec_score(tabs_cpu[gl], loc[r, s:s + gl], scale[r, s:s + gl], pl[s:s + gl], ps[s:s + gl], gum)
         assert idx[b] == i, (b, idx[b], i)
         np.testing.assert_allclose(z[b, :gl].cpu().numpy(), zi.numpy(), rtol=1e-15)
+
+
+def _rec_problem(seed, N, D, lens_pool, n_jobs, ratio):
+    """random posteriors / priors with posterior-to-prior scale ratio around `ratio` and (row, start, len) jobs"""
+    gen = torch.Generator().manual_seed(seed)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    ps = 0.015 + 0.01 * torch.rand(D, generator=gen)
+    loc = pl[None] + ps[None] * 1.5 * torch.randn(N, D, generator=gen)
+    scale = ps[None] * ratio * (0.5 + torch.rand(N, D, generator=gen))
+    rs = np.random.RandomState(seed)
+    jr = rs.randint(N, size=n_jobs)
+    jg = np.asarray(lens_pool)[rs.randint(len(lens_pool), size=n_jobs)]
+    js = np.array([rs.randint(D - gl + 1) for gl in jg])
+    return loc, scale, pl, ps, jr, js, jg
+
+
+def test_rec_fast_scorer_equals_exact_scorer_on_many_random_jobs():
+    """12 288 random jobs (group lengths 1..12, posterior scales from 0.03x to 1x the prior's): the certified fast scorer
+    must return exactly the indices of the op-for-op scorer, and must have had to fall back only rarely."""
+    K = 65536
+    gum = g(torch.from_numpy(O.gumbel_table(42)))
+    tabs = ops.RecTables("cuda", K)
+    for gl in range(1, 13):
+        tabs.add(gl, O.sobol_normal_table(gl))
+    n_unc = 0
+    for seed, ratio in ((1, 0.03), (2, 0.2), (3, 1.0)):
+        loc, scale, pl, ps, jr, js, jg = _rec_problem(seed, 64, 600, list(range(1, 13)), 4096, ratio)
+        args = (g(loc), g(scale), g(pl), g(ps), tabs, gum)
+        jobs, _ = ops.RecJobs.from_host("cuda", jr, js, jg, rows=64, cols=600)
+        i_exact, b_exact, _, _ = ops.rec_score(*args, jobs, ops.REC_EXACT)
+        i_fast, b_fast, unc, _ = ops.rec_score(*args, jobs, ops.REC_FAST)
+        assert torch.equal(i_exact, i_fast)
+        assert int(i_exact.min()) >= 0 and int(i_exact.max()) < K
+        # the fast scores themselves agree with the exact ones far inside the certified bound
+        err = float((b_fast[:, 0] - b_exact[:, 0]).abs().max())
+        assert err < 1e-7, err
+        n_unc += int(unc.sum())
+    assert n_unc <= 12, n_unc        # <= 0.1 %: the certificate is tight enough to be useful
+
+
+def test_rec_long_groups_against_oracle():
+    """groups of several hundred parameters (low bit-rates pack that many: prior_model.py:301-316 has no size cap),
+    a length that is no multiple of anything, and a batch mixing lengths 1 .. 333 -- against the fp64 oracle"""
+    K = 65536
+    gum_c = torch.from_numpy(O.gumbel_table(42))
+    lens = [1, 33, 64, 200, 333]
+    tabs_c = {gl: O.sobol_normal_table(gl) for gl in lens}
+    tabs = ops.RecTables.from_dict(tabs_c, "cuda", K)
+    loc, scale, pl, ps, jr, js, jg = _rec_problem(5, 6, 700, lens, 40, 0.9)
+    # long groups only make sense when every element carries a fraction of a bit: posteriors close to the prior
+    loc = pl[None] + 0.05 * (loc - pl[None])
+    for mode in (ops.REC_EXACT, ops.REC_FAST):
+        idx, z, best, _ = ops.rec_score_argmax(g(loc), g(scale), g(pl), g(ps), tabs, g(gum_c), jr, js, jg, mode=mode)
+        idx = idx.cpu().numpy()
+        for b, (r, s, gl) in enumerate(zip(jr, js, jg)):
+            i, zi, lw = O.rec_score(tabs_c[gl], loc[r, s:s + gl], scale[r, s:s + gl], pl[s:s + gl], ps[s:s + gl], gum_c)
+            assert idx[b] == i, (mode, b, gl, idx[b], i)
+            np.testing.assert_allclose(z[b, :gl].cpu().numpy(), zi.numpy(), rtol=1e-15)
+            # log(sigma) is taken in fp32 (torch Normal.log_prob on fp32 scales) and device and host logf differ by an ulp here
+            # and there: a candidate-INDEPENDENT shift of ~1e-7 per element that cannot move the arg-max.  Differences between
+            # candidates are free of it: the gap to the runner-up agrees to fp64 rounding.
+            top2 = torch.topk(lw, 2).values
+            assert float(best[b, 0] - best[b, 1]) == pytest.approx(float(top2[0] - top2[1]), abs=2e-10 * gl)
+            assert float(best[b, 0]) == pytest.approx(float(lw.max()), abs=2e-6 + 2e-7 * gl)
+
+
+def test_rec_rejects_bad_jobs_on_the_device_and_refuses_inexact_tables():
+    K = 4096
+    gum = g(torch.from_numpy(O.gumbel_table(42)[:K].copy()))
+    t3 = O.sobol_normal_table(3)[:K].contiguous()
+    tabs = ops.RecTables.from_dict({3: t3}, "cuda", K)
+    with pytest.raises(ops.RcbError):
+        tabs.add(2, torch.full((K, 2), 0.1, dtype=torch.float64))            # 0.1 is no fp32 number
+    loc, scale, pl, ps, _, _, _ = _rec_problem(7, 4, 50, [3], 1, 0.5)
+    i32 = torch.int32
+    # device-built job list with a row / a window outside the matrix and a length without table: idx = -1, nothing written
+    jobs = ops.RecJobs(torch.tensor([0, 9, 1, 2], dtype=i32, device="cuda"), torch.tensor([0, 0, 49, 5], dtype=i32, device="cuda"),
+                       torch.tensor([3, 3, 3, 2], dtype=i32, device="cuda"), torch.tensor([0, 0, 0, 0], dtype=i32, device="cuda"))
+    for mode in (ops.REC_EXACT, ops.REC_FAST):
+        idx, _, _, _ = ops.rec_score(g(loc), g(scale), g(pl), g(ps), tabs, gum, jobs, mode)
+        idx = idx.cpu().numpy()
+        assert idx[0] >= 0 and (idx[1:] == -1).all(), idx
+    sample = torch.zeros(4, 50, device="cuda")
+    idx_t = torch.tensor([5, 5, 5, 5], dtype=i32, device="cuda")
+    ops.rec_commit(g(pl), g(ps), tabs, jobs, idx_t, n_groups=1, enc_sample=sample)
+    assert int((sample != 0).sum()) == 3 and int((sample[0, :3] != 0).sum()) == 3
+    with pytest.raises(ops.RcbError):                                          # host job lists are validated on the host
+        ops.rec_score_argmax(g(loc), g(scale), g(pl), g(ps), tabs, gum, [9], [0], [3])

@@ -180,6 +180,43 @@ def test_cached_graph_is_reused_with_new_priors_and_beta():
     assert abs(e2[0]) > 10 * abs(e1[-1])
 
 
+def test_graph_survives_a_checkpoint_that_moves_the_live_mappings():
+    """main_prior_training.py:334-338 pickles `linear_transform.cpu()` / `upsample_net.cpu()` and moves them back: that
+    re-allocates every parameter storage while id(module) stays equal.  A cached step graph would go on reading and
+    Adam-updating the freed storages (the live mappings would silently stop training): the workspace key holds the storage
+    addresses, so the next train() call re-captures.  Twin: the same calls with the mappings never moved."""
+    import copy
+    d = load("prior_cifar.npz")
+    _, geo, _, p, A, upo, X, Y, pri = prior_inputs(d)
+    prg = [None if q is None else q.to(DEV) for q in pri]
+    res = []
+    for move in (True, False):
+        cfg, n, m, lt, up = build(d)
+        m.precision = 1
+        x, y = X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV)
+        torch.manual_seed(7)
+        m.train(8, 1e-3, x, y, *prg, lt, up, 1e-4, training_mappings=True)
+        assert m._ws is not None and m._ws["graphs"] is not None
+        ws_before = m._ws
+        if move:
+            keep = [torch.empty(1 << 20, device=DEV) for _ in range(4)]      # occupy the allocator's free blocks ...
+            ptrs = [q.data_ptr() for q in list(lt.parameters()) + list(up.parameters())]
+            lt.cpu(); up.cpu()
+            junk = [torch.full((q.numel(),), 7.0, device=DEV) for q in list(lt.parameters()) + list(up.parameters())]
+            lt.to(DEV); up.to(DEV)                                          # ... so the parameters land somewhere else
+            assert [q.data_ptr() for q in list(lt.parameters()) + list(up.parameters())] != ptrs
+            del keep, junk
+        a_mid = lt.A[0].detach().clone()
+        m._rng_ctr_init = 8                   # a re-captured workspace continues the noise counter where the old one stood
+        m._train_calls -= 1 if move else 0    # ... and derives the same noise seed
+        m.train(8, 1e-3, x, y, *prg, lt, up, 1e-4, training_mappings=True)
+        assert (m._ws is not ws_before) == move
+        assert float((lt.A[0] - a_mid).abs().max()) > 1e-5                  # the LIVE mappings kept training
+        res.append((lt.A[0].detach().clone(), up.conv3.weight.detach().clone(), m.loc.detach().clone()))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize("name,n_data", [("cifar", 32), ("protein", 32), ("kodak", 1), ("audio", 1), ("video", 1)])
 def test_every_preset_captures_and_replays_in_the_throughput_mode(name, n_data):
     """production path (no injected noise) of every reference preset in the bf16 mode: the step must capture as a HIP
@@ -291,6 +328,30 @@ def test_sharded_training_rehearsal_two_ranks_one_gpu():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "REHEARSAL OK ws=2" in out.stdout
+    # and the shards train exactly like one process holding all INRs (same parameters, data and injected noise)
+    assert "SHARDED == UNSHARDED OK ws=2" in out.stdout
+
+
+def test_bench_gpus_flag_launches_ranks():
+    """`python bench.py --gpus 2` (no launcher) must start two ranks itself and report n_gpus = 2 -- here over gloo with
+    both ranks on the one GPU of the box (the rehearsal switch) -- and must refuse the RCCL form on a one-GPU box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RCB_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--inrs", "64",
+           "--no-cpu-baseline", "--no-extras"]
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, env=base, capture_output=True, text=True, timeout=600)
+        assert out.returncode != 0 and "--gpus 2 requested" in out.stderr
+    out = subprocess.run(cmd, env=dict(base, RCB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["inrs_per_gpu"] == 64 and rec["value"] > 0
 
 
 @pytest.mark.parametrize("n", [1, 3, 5, 258])

@@ -149,3 +149,19 @@ def test_upsample_pickles_and_deep_copies_without_its_fast_path_caches():
     twin = copy.deepcopy(net)
     assert not any(k.startswith("_rcb_") for k in twin.__dict__)
     assert phase_module(twin).net is twin and phase_module(net).net is net
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts N RCCL ranks itself; with fewer GPUs than ranks it must fail loudly instead of
+    silently running one rank and printing n_gpus: 1 (no GPU call happens before the check: device_count() only)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RCB_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 64 requested" in out.stderr and "{" not in out.stdout
+    # a launcher that started a different number of ranks than --gpus says is refused as well
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "launcher started 1 rank" in out.stderr

@@ -20,6 +20,7 @@ def run(use_graph, rank, n, steps):
                          cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42 + rank, device="cuda")
     m.precision = 1
     m.use_graph = use_graph
+    m.dp_group = dist.group.WORLD         # sharded training is opt-in: the model's mapping gradients are summed over this group
     torch.manual_seed(123)
     lt = PM.LinearTransform(m.dims).cuda()
     torch.manual_seed(124)
@@ -32,6 +33,59 @@ def run(use_graph, rank, n, steps):
                             training_mappings=True)
     flat = torch.cat([p.detach().reshape(-1) for p in list(lt.parameters()) + list(up.parameters())])
     return flat, m.loc.detach().clone(), mse
+
+
+def equivalence(rank, ws, n, steps, precision):
+    """`ws` shards of n INRs must train exactly like ONE process with ws * n INRs on the same parameters, data and
+    injected noise (main_prior_training.py:157-172 / prior_model.py:224-250 semantics: the loss is a sum of per-INR terms,
+    the mapping gradients a sum over all INRs): per-INR posteriors of shard r == rows [r n, (r+1) n) of the single-process
+    model, shared mappings equal, to the rounding of the differently associated gradient sum."""
+    cfg = config.configs["cifar"]
+    N = ws * n
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], N, 3, seed=5)
+    D, s0 = 3267, 0.0211547
+    gen = torch.Generator().manual_seed(77)
+    noise = [(torch.randn(N, 1, 512, generator=gen), torch.randn(N, 1, D, generator=gen)) for _ in range(steps)]
+
+    def train(lo, hi, group):
+        k = hi - lo
+        full = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], N, cfg["data_dim"], cfg["pixel_sizes"],
+                                cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device="cuda")
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], k, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device="cuda")
+        with torch.no_grad():
+            for name in ("loc", "log_scale", "lpe_loc", "lpe_log_scale"):
+                getattr(m, name).copy_(getattr(full, name)[lo:hi])
+        m.precision = precision
+        m.dp_group = group
+        q = [e[lo:hi] for pair in noise for e in pair]
+        m.noise_source = lambda shape: q.pop(0)
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(m.dims).cuda()
+        torch.manual_seed(124)
+        up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).cuda()
+        pri = [torch.zeros(D).cuda(), torch.full((D,), s0).cuda(), torch.zeros(2, 2, 128).cuda(),
+               torch.full((2, 2, 128), s0).cuda(), None, None, None, None]
+        _, _, elbo = m.train(steps, 1e-3, X.cuda()[None].expand(k, -1, -1), Y[lo:hi].cuda(), *pri, lt, up, 1e-8,
+                             training_mappings=True)
+        maps = torch.cat([p.detach().reshape(-1) for p in list(lt.parameters()) + list(up.parameters())])
+        return maps, m.loc.detach().clone(), m.lpe_loc.detach().flatten(1).clone(), torch.tensor(elbo, dtype=torch.float64)
+
+    maps_s, loc_s, lpe_s, elbo_s = train(rank * n, (rank + 1) * n, dist.group.WORLD)
+    maps_1, loc_1, lpe_1, elbo_1 = train(0, N, None)                # every rank: the whole problem, no communication
+    sl = slice(rank * n, (rank + 1) * n)
+    # Adam normalises the gradient, so a mapping entry whose summed gradient is ~0 may move by lr in either direction when
+    # the sum is associated differently: bound the bulk tightly and the worst entry by lr * steps
+    lr = 1e-3
+    for name, a, b in (("mappings", maps_s, maps_1), ("loc", loc_s, loc_1[sl]), ("lpe", lpe_s, lpe_1[sl])):
+        d = (a - b).abs()
+        frac = float((d > 2e-5).float().mean())
+        assert float(d.max()) <= 2.01 * lr * steps and frac < (2e-3 if precision == 0 else 5e-2), (name, float(d.max()), frac)
+    tot = elbo_s.cuda()
+    dist.all_reduce(tot)                                            # the ELBO log is a sum over INRs
+    err = float(((tot.cpu() - elbo_1).abs() / elbo_1.abs()).max())
+    assert err < (1e-5 if precision == 0 else 1e-3), err
+    return err
 
 
 if __name__ == "__main__":
@@ -54,6 +108,11 @@ if __name__ == "__main__":
     assert rel < 5e-3 and rel_loc < 5e-2, (rel, rel_loc)
     # 3. finite, and both paths report the same loss
     assert torch.isfinite(graph).all() and abs(mse_g - mse_e) <= 2e-2 * abs(mse_e), (mse_e, mse_g)
+    # 4. ws shards of n INRs == one process with ws * n INRs (injected noise), exact-parity mode and 16-bit mode
+    eq32 = equivalence(rank, ws, 24, 4, 0)
+    eq16 = equivalence(rank, ws, 24, 4, 1)
+    if rank == 0:
+        print("SHARDED == UNSHARDED OK ws=%d  ELBO rel err %.1e (fp32) %.1e (bf16)" % (ws, eq32, eq16), flush=True)
     if rank == 0:
         print("REHEARSAL OK ws=%d  graph-vs-eager rel %.2e (mappings) %.2e (loc)  mse %.4f / %.4f" % (ws, rel, rel_loc, mse_e, mse_g),
               flush=True)
