@@ -405,11 +405,16 @@ def build_test_model(cfg, name, n, pm, pri, lt, up, initial_beta=1e-5):
     return tm, groups, kw
 
 
-def gen_test_cases(out):
+def gen_test_cases(out, names=("cifar", "patch2d", "patch1d")):
+    """names may carry a width suffix ("patch3d_w64": the reference classes with hidden_dims = [64] * 3, BASELINE
+    configs[4]); the dataset string and the geometry come from the part before it."""
     P, NI = presets()
-    for name in ["cifar", "patch2d", "patch1d"]:
-        cfg = P[name]
-        n = {"cifar": 4, "patch2d": 8, "patch1d": 8}[name]  # 2 datapoints for the patched presets
+    for full_name in names:
+        name, _, wtag = full_name.partition("_w")
+        cfg = dict(P[name])
+        if wtag:
+            cfg["hidden_dims"] = [int(wtag)] * 3
+        n = {"cifar": 4, "patch2d": 8, "patch1d": 8, "patch3d": 8}[name]  # 2 datapoints for the patched presets
         d = Bag({"cfg": np.array(jsonable(cfg)), "n": np.array(n)})
         pm = build_prior(cfg, n)
         lt, up = build_maps(cfg, pm.dims)
@@ -459,10 +464,12 @@ def gen_test_cases(out):
             if cfg["patch"]:
                 tm.h_loc.add_(0.004 * torch.randn(tm.h_loc.shape, generator=g))
                 tm.hh_loc.add_(0.004 * torch.randn(tm.hh_loc.shape, generator=g))
-        d["t_loc"], d["t_log_scale"] = tnp(tm.loc), tnp(tm.log_scale)
+        # the posteriors the cases start from are inputs: always stored whole (dict.__setitem__ bypasses the subsampling)
+        dict.__setitem__(d, "t_loc", tnp(tm.loc))
+        dict.__setitem__(d, "t_log_scale", tnp(tm.log_scale))
         if cfg["patch"]:
-            d["t_h_loc"], d["t_h_log_scale"] = tnp(tm.h_loc), tnp(tm.h_log_scale)
-            d["t_hh_loc"], d["t_hh_log_scale"] = tnp(tm.hh_loc), tnp(tm.hh_log_scale)
+            for k_ in ("h_loc", "h_log_scale", "hh_loc", "hh_log_scale"):
+                dict.__setitem__(d, "t_" + k_, tnp(getattr(tm, k_)))
         # A12 predict, S=1 and S=5
         for S in (1, 5):
             with NoiseTap() as tap, torch.no_grad():
@@ -511,11 +518,11 @@ def gen_test_cases(out):
         if cfg["patch"]:
             d["train_h_loc"], d["train_hh_loc"] = tnp(tm.h_loc), tnp(tm.hh_loc)
             d["train_h_log_scale"], d["train_hh_log_scale"] = tnp(tm.h_log_scale), tnp(tm.hh_log_scale)
-        np.savez_compressed(os.path.join(out, f"test_{name}.npz"), **d)
-        print("test", name, "ok", flush=True)
+        np.savez_compressed(os.path.join(out, f"test_{full_name}.npz"), **d)
+        print("test", full_name, "ok", flush=True)
 
         # A20/A21 mini end-to-end (only for cifar and patch1d: cheap)
-        if name in ("cifar", "patch1d"):
+        if full_name in ("cifar", "patch1d"):
             e = Bag({"cfg": d["cfg"], "n": d["n"]})
             tm2, _, _ = build_test_model(cfg, name, n, pm, pri, lt, up)
             import io
@@ -537,6 +544,231 @@ def gen_test_cases(out):
                 e["final_pred"] = tnp(tm2.predict(X))
             np.savez_compressed(os.path.join(out, f"e2e_{name}.npz"), **e)
             print("e2e", name, "ok", flush=True)
+
+        # 3-D patched geometry: the head of a compression run -- 12 optimisation epochs, then the first encode rounds of the
+        # top level (level 3) exactly as compress_posteriors' loop body runs them (test_model.py:700-722): the row's
+        # largest-KL group -> hh_compress_group -> fine-tune.  (The complete run is hours of CPU time at 6144 pixels.)
+        if name == "patch3d":
+            e = Bag({"cfg": d["cfg"], "n": d["n"]})
+            tm2, _, _ = build_test_model(cfg, name, n, pm, pri, lt, up)
+            import io
+            import contextlib
+            with contextlib.redirect_stderr(io.StringIO()):
+                tm2.optimize_posteriors(X, y, n_epochs=12, lr=2e-4, verbose=False)
+            e["opt_loc"], e["opt_log_scale"] = tnp(tm2.loc), tnp(tm2.log_scale)
+            e["opt_hh_loc"], e["opt_h_loc"] = tnp(tm2.hh_loc), tnp(tm2.h_loc)
+            e["opt_beta"] = tnp(tm2.kl_beta)
+            rounds = []
+            for _i in range(3):
+                for row in range(tm2.hh_loc.shape[0]):
+                    _, _, kls = tm2.update_annealing_factors(False)
+                    kls = kls / np.log(2.)
+                    kls[tm2.hh_compressed_mask_groupwise] = -1e10
+                    grp = int(np.argmax(kls[row]))
+                    tm2.hh_compress_group(row, grp)
+                    rounds.append((row, grp, tm2.hh_compressed_idx_groupwise[row, grp]))
+                opt = torch.optim.Adam(tm2.parameters(), lr=2e-4)
+                tm2.train(X, y, n_epochs=2, optimizer=opt, verbose=False)
+            e["hh_rounds"] = np.array(rounds, dtype=np.float64)
+            e["hh_loc_after"] = tnp(tm2.hh_loc)
+            e["loc_after"] = tnp(tm2.loc)
+            with torch.no_grad():
+                e["final_pred"] = tnp(tm2.predict(X, random_seed=11))
+            np.savez_compressed(os.path.join(out, f"e2e_{full_name}.npz"), **e)
+            print("e2e head", full_name, "ok", flush=True)
+
+
+def gen_long_groups(out):
+    """A17 on groups of hundreds of parameters: what low bit-rates produce (group_parameters packs until 16 bits of KL are
+    reached, prior_model.py:301-316, no size cap).  The reference's own sample_group on a CIFAR test model whose grouping
+    comes from ~0.05 bits per parameter."""
+    P, _ = presets()
+    cfg = P["cifar"]
+    n = 3
+    pm = build_prior(cfg, n)
+    lt, up = build_maps(cfg, pm.dims)
+    D = pm.loc.shape[1] + int(np.prod(pm.lpe_loc.shape[1:]))
+    rng = np.random.RandomState(4)
+    bits = rng.gamma(0.7, 0.05 / 0.7, size=D).astype(np.float32)
+    G = ref_prior.get_grouping_by_kl(bits.copy())
+    g = torch.Generator().manual_seed(31)
+    p_loc = 0.01 * torch.randn(D, generator=g)
+    p_ls = -2.0 + 0.3 * torch.randn(D, generator=g)
+    p2g = G[4]
+    tm = ref_test.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["upsample_factors"],
+                               cfg["latent_dim"], cfg["data_dim"], cfg["pixel_sizes"], False, None, None, "cifar",
+                               linear_transform=lt, upsample_net=up, device="cpu", initial_beta=1e-5,
+                               p_loc=p_loc[p2g], p_log_scale=p_ls[p2g], init_log_scale=torch.full((D,), -2.2)[p2g],
+                               param_to_group=p2g, group_to_param=G[3], n_groups=G[5], group_start_index=G[1],
+                               group_end_index=G[2], group_idx=G[0])
+    with torch.no_grad():      # posteriors a fraction of a bit per parameter away from the prior
+        tm.loc.add_(0.004 * torch.randn(tm.loc.shape, generator=g))
+        tm.log_scale.add_(0.2 * torch.randn(tm.log_scale.shape, generator=g))
+    d = {"bits": bits, "n_groups": np.array(G[5]), "start": np.asarray(G[1]), "end": np.asarray(G[2]),
+         "p_loc": tnp(tm.p_loc), "p_log_scale": tnp(tm.p_log_scale)}
+    lens = np.asarray(G[2]) - np.asarray(G[1])
+    picks = [(0, int(np.argmax(lens))), (1, int(np.argmin(lens))), (2, int(G[5]) // 2)]
+    enc = []
+    for row, grp in picks:
+        i, z, lw = tm.sample_group(row, grp, 65536)
+        s_, e_ = int(G[1][grp]), int(G[2][grp])
+        top2 = torch.topk(lw, 2).values
+        enc.append((row, grp, i, float(top2[0] - top2[1]), e_ - s_))
+        d[f"enc_{row}_{grp}_loc"] = tnp(tm.loc[row, s_:e_])
+        d[f"enc_{row}_{grp}_log_scale"] = tnp(tm.log_scale[row, s_:e_])
+        d[f"enc_{row}_{grp}_z"] = tnp(z)
+        d[f"enc_{row}_{grp}_lw_head"] = tnp(lw[:256])
+    d["enc_table"] = np.array(enc, dtype=np.float64)
+    np.savez_compressed(os.path.join(out, "rec_long_groups.npz"), **d)
+    print("long groups ok: lengths", [int(e[4]) for e in enc], flush=True)
+
+
+def smooth_images(n, pixel_sizes, seed):
+    """low-frequency synthetic images in [0.1, 0.9] (something an INR fits to > 25 dB): per channel a few 2-D sinusoids"""
+    rng = np.random.RandomState(seed)
+    h, w = pixel_sizes
+    yy, xx = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    out = np.zeros([n, h * w, 3], dtype=np.float32)
+    for i in range(n):
+        for c in range(3):
+            img = np.zeros([h, w])
+            for _ in range(3):
+                fx, fy = rng.uniform(-2.5, 2.5, size=2)
+                img += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * (fx * xx + fy * yy) + rng.uniform(0, 2 * np.pi))
+            img = 0.5 + 0.4 * img / np.abs(img).max()
+            out[i, :, c] = img.reshape(-1)
+    return torch.from_numpy(out)
+
+
+def structured_A(dims):
+    """a well-conditioned, exactly reproducible stand-in for LEARNED mappings (the fixture cannot carry 13 MB of trained
+    A): identity plus a small circulant pattern.  tests/golden_util.py::structured_A restates it."""
+    mats = []
+    for i in range(1, len(dims)):
+        L = dims[i] * (dims[i - 1] + 1)
+        r = torch.arange(L)
+        base = torch.tensor([0.5, -0.25, 0.125, 0.375, -0.5, 0.25, -0.125, -0.375]) / 8
+        mats.append(torch.eye(L) + base[(r[:, None] + 3 * r[None, :]) % 8] / L)
+    return mats
+
+
+def gen_checkpoint_and_psnr(out):
+    """N2 + the PSNR@bpp half of the metric.  The reference's EM loop (main_prior_training.py:112-172: train -> beta rule ->
+    prior refit) on 16 smooth synthetic images with its own classes, its checkpoint written in its own layout
+    (main_prior_training.py:284-335: eight sequential pickles, the two modules pickled as `prior_model.*`), then the
+    reference's compression of 4 other images from that file (main_compression.py:37-167): optimise, A*-encode every
+    group, fine-tune in between.  Stored: the checkpoint (gzip), the test images' seed, per-image PSNR, bpp, all indices,
+    and a predict() output on injected noise for the interchange test."""
+    import gzip
+    import io
+    import pickle
+    import contextlib
+    import time
+    P, _ = presets()
+    cfg = P["cifar"]
+    n_train, n_test = 16, 32      # 32 test images: per-image PSNR varies by ~0.3 dB between equally valid runs (every A* index is a
+    #                               random draw), the mean over 32 by ~0.05 dB
+    _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
+    Ytr = smooth_images(n_train, cfg["pixel_sizes"], 100)
+    Yte = smooth_images(n_test, cfg["pixel_sizes"], 200)
+    X = x[None].repeat(n_train, 1, 1)
+    pm = build_prior(cfg, n_train)
+    lt, up = build_maps(cfg, pm.dims)
+    with torch.no_grad():
+        for a, b in zip(lt.A, structured_A(pm.dims)):
+            a.copy_(b)
+    s0 = torch.nn.functional.softplus(torch.tensor(-2.0)) / 6
+    pri = [torch.zeros(pm.loc.shape[1]), torch.ones(pm.loc.shape[1]) * s0,
+           torch.zeros(pm.lpe_loc.shape[1:]), torch.ones(pm.lpe_loc.shape[1:]) * s0, None, None, None, None]
+    max_bitrate = 3.0
+    px = np.prod(cfg["pixel_sizes"])
+    budget_max = max_bitrate * px
+    budget_min = max(cfg["lowest_bitrate"], max_bitrate - cfg["bitrate_range"]) * px
+    kl_beta, n_epoch = 1e-8, 200
+    t0 = time.time()
+    torch.manual_seed(0)
+    for it in range(14):
+        # mappings frozen: A is the structured stand-in, Upsample stays at its seeded initialisation
+        _, kl, _ = pm.train(n_epoch, 2e-3, X, Ytr, *pri, lt, up, kl_beta, training_mappings=False)
+        n_epoch = 100
+        kls = kl / np.log(2.)
+        if kls > budget_max:
+            kl_beta *= 1.5
+        if kls < budget_min:
+            kl_beta /= 1.5
+        kl_beta = min(max(kl_beta, 1e-20), 1)
+        with torch.no_grad():                                 # main_prior_training.py:157-172
+            pri[0] = pm.loc.clone().detach().mean(0)
+            pri[1] = ((pm.st(pm.log_scale.clone().detach()) ** 2).mean(0) + pm.loc.clone().detach().var(0)) ** 0.5
+            pri[2] = pm.lpe_loc.clone().detach().mean(0)
+            pri[3] = ((pm.st(pm.lpe_log_scale.clone().detach()) ** 2).mean(0) + pm.lpe_loc.clone().detach().var(0)) ** 0.5
+        print("  EM %d: %.1f bits/INR, beta %.2e (%.0f s)" % (it, kls, kl_beta, time.time() - t0), flush=True)
+    # checkpoint, in the reference's order (main_prior_training.py:186-335)
+    with torch.no_grad():
+        avg_ls = torch.cat([pm.log_scale.clone().detach().mean(0), pm.lpe_log_scale.clone().detach().mean([0]).flatten()])
+        q_loc = torch.cat([pm.loc.flatten(start_dim=1), pm.lpe_loc.flatten(start_dim=1)], -1)
+        q_scale = torch.cat([pm.st(pm.log_scale).flatten(start_dim=1), pm.st(pm.lpe_log_scale).flatten(start_dim=1)], -1)
+        p_loc = torch.cat([pri[0].flatten(), pri[2].flatten()])
+        p_scale = torch.cat([pri[1].flatten(), pri[3].flatten()])
+        G = ref_prior.get_grouping(q_loc, q_scale, p_loc, p_scale)
+    none8 = (None,) * 8
+    buf = io.BytesIO()
+    pickle.dump(tuple(G), buf)
+    pickle.dump((p_loc.cpu(), p_scale.cpu(), kl_beta, avg_ls), buf)
+    pickle.dump(none8, buf)
+    pickle.dump((None, None, kl_beta, None), buf)
+    pickle.dump(none8, buf)
+    pickle.dump((None, None, kl_beta, None), buf)
+    pickle.dump(lt.cpu(), buf)
+    pickle.dump(up.cpu(), buf)
+    with gzip.open(os.path.join(out, "PRIOR_ref_smooth_cifar.pkl.gz"), "wb", compresslevel=9) as f:
+        f.write(buf.getvalue())
+    print("  checkpoint: %d groups, %.2f MB pickled" % (G[5], len(buf.getvalue()) / 1e6), flush=True)
+
+    # compression from that file, the way main_compression.py:37-167 does it
+    f = io.BytesIO(buf.getvalue())
+    group_idx, group_start_index, group_end_index, group2param, param2group, n_groups, group_kls, weights = pickle.load(f)
+    prior_loc, prior_scale, kl_beta_l, average_training_log_scale = pickle.load(f)
+    for _ in range(4):
+        pickle.load(f)
+    linear_transform = pickle.load(f)
+    upsample_net = pickle.load(f)
+    _p_locs = prior_loc.clone()[param2group]
+    _p_log_scales = torch.log(torch.exp(prior_scale * 6) - 1).clone()[param2group]
+    _avg = average_training_log_scale[param2group].cpu().detach()
+    tm = ref_test.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n_test, cfg["upsample_factors"],
+                               cfg["latent_dim"], cfg["data_dim"], cfg["pixel_sizes"], False, None, None, "cifar",
+                               linear_transform=linear_transform, upsample_net=upsample_net, p_loc=_p_locs,
+                               p_log_scale=_p_log_scales, init_log_scale=_avg, param_to_group=param2group,
+                               group_to_param=group2param, n_groups=n_groups, group_start_index=group_start_index,
+                               group_end_index=group_end_index, group_idx=group_idx, w0=30., c=6., random_seed=42,
+                               device="cpu", kl_upper_buffer=0., kl_lower_buffer=0.4, kl_adjust_gap=10,
+                               initial_beta=kl_beta_l, beta_step_size=0.05)
+    Xte = x[None].repeat(n_test, 1, 1)
+    d = Bag({"cfg": np.array(jsonable(cfg)), "n_test": np.array(n_test), "train_seed": np.array(100), "test_seed": np.array(200),
+             "Y_test": tnp(Yte), "n_groups": np.array(n_groups), "bpp": np.array(tm.bpp), "kl_beta": np.array(kl_beta_l),
+             "p_loc": tnp(prior_loc), "p_scale": tnp(prior_scale)})
+    with NoiseTap() as tap, torch.no_grad():
+        yp = tm.predict(Xte, random_seed=3, sample_size=1)
+    d["pred0"] = tnp(yp)
+    store_noise(d, "pred0_eps", 3, tap.log, False)
+    n_opt, n_ft = 400, 6
+    d["n_opt"], d["n_ft"], d["lr"] = np.array(n_opt), np.array(n_ft), np.array(2e-3)
+    with contextlib.redirect_stderr(io.StringIO()):
+        tm.optimize_posteriors(Xte, Yte, n_epochs=n_opt, lr=2e-3, verbose=False)
+        d["opt_loc"], d["opt_log_scale"] = tnp(tm.loc), tnp(tm.log_scale)
+        with torch.no_grad():
+            d["psnr_after_opt"] = np.asarray(ref_utils.metric(Yte.numpy(), tm.predict(Xte).numpy(), "cifar"))
+        print("  optimised (%.0f s): PSNR" % (time.time() - t0), d["psnr_after_opt"], flush=True)
+        dist = tm.compress_posteriors(Xte, Yte, n_epochs_finetune=n_ft, h_n_epochs_finetune=None, hh_n_epochs_finetune=None,
+                                      verbose=False, lr=2e-3, fine_tune_gap=1)
+    d["psnr"] = np.asarray(dist)
+    d["idx"] = tm.compressed_idx_groupwise
+    d["final_sample"] = tnp(tm.compressed_sample)
+    with torch.no_grad():
+        d["final_pred"] = tnp(tm.predict(Xte))
+    np.savez_compressed(os.path.join(out, "psnr_smooth_cifar.npz"), **d)
+    print("checkpoint + PSNR ok: bpp %.3f, PSNR" % tm.bpp, d["psnr"], "(%.0f s)" % (time.time() - t0), flush=True)
 
 
 def gen_metrics(out):
@@ -609,4 +841,11 @@ if __name__ == "__main__":
         gen_test_cases(a.out)
     if "wide" in todo:
         gen_wide_cases(a.out)
+    # round-2 additions (not in the default list: the round-1 fixtures above are not rewritten)
+    if "test3d" in todo:
+        gen_test_cases(a.out, names=("patch3d", "patch3d_w64"))
+    if "long" in todo:
+        gen_long_groups(a.out)
+    if "ckpt" in todo:
+        gen_checkpoint_and_psnr(a.out)
     print("done")

@@ -12,8 +12,12 @@ contents (main_prior_training.py:284-335) -- so priors interchange with the refe
 Under torch.distributed the INRs of `train_prior` are the local shard; the prior refit, the KL that drives
 beta and the grouping statistics are all-reduced (recombiner_amd.dist).
 """
+import contextlib
 import copy
+import gzip
 import pickle
+import sys
+import types
 
 import numpy as np
 import torch
@@ -141,12 +145,51 @@ def build_checkpoint(m, lt, up, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc,
     return [g1, (pl.cpu(), ps.cpu(), kl_beta, avg_ls), g2, l2, g3, l3, lt, up]
 
 
+_REF_CLASSES = {"LinearTransform": LinearTransform, "Upsample": Upsample}
+
+
+@contextlib.contextmanager
+def _reference_class_paths():
+    """While active, LinearTransform / Upsample pickle as `prior_model.LinearTransform` / `prior_model.Upsample` -- the
+    paths the reference's own pickles carry (main_prior_training.py:334-335) and main_compression.py:44-45 resolves --
+    whatever is on sys.path.  (pickle checks that the named module really holds the class: a stand-in module is
+    registered for the duration and whatever was there is put back.)"""
+    stand_in = types.ModuleType("prior_model")
+    saved_mod = sys.modules.get("prior_model")
+    saved_paths = {n: c.__module__ for n, c in _REF_CLASSES.items()}
+    for n, c in _REF_CLASSES.items():
+        setattr(stand_in, n, c)
+        c.__module__ = "prior_model"
+    sys.modules["prior_model"] = stand_in
+    try:
+        yield
+    finally:
+        for n, c in _REF_CLASSES.items():
+            c.__module__ = saved_paths[n]
+        if saved_mod is None:
+            sys.modules.pop("prior_model", None)
+        else:
+            sys.modules["prior_model"] = saved_mod
+
+
+class _CheckpointUnpickler(pickle.Unpickler):
+    """`prior_model.LinearTransform` / `prior_model.Upsample` resolve to the MI355X classes (same attribute, sub-module and
+    parameter names as the reference's, prior_model.py:16-59), so a checkpoint written by the reference loads without the
+    reference -- or `dropin/` -- on sys.path."""
+
+    def find_class(self, module, name):
+        if module in ("prior_model", "recombiner_amd.prior_model") and name in _REF_CLASSES:
+            return _REF_CLASSES[name]
+        return super().find_class(module, name)
+
+
 def save_checkpoint(path, ck):
-    """Writes the eight pickles.  The two modules are pickled as CPU *copies*: moving the live modules to the CPU and
-    back (what main_prior_training.py:334-338 does) re-allocates their parameter storages, i.e. the addresses the
-    captured training graphs read and update (PriorBNNmodel.train re-captures if that ever happens, see its key)."""
+    """Writes the eight pickles (main_prior_training.py:284-335), loadable by the reference's main_compression.py.
+    The two modules are pickled as CPU *copies*: moving the live modules to the CPU and back (what the reference does,
+    :334-338) re-allocates their parameter storages, i.e. the addresses the captured training graphs read and update
+    (PriorBNNmodel.train re-captures if that ever happens, see its workspace key)."""
     lt, up = ck[6], ck[7]
-    with open(path, "wb") as f:
+    with open(path, "wb") as f, _reference_class_paths():
         for obj in ck[:6]:
             pickle.dump(obj, f)
         pickle.dump(copy.deepcopy(lt).cpu(), f)
@@ -154,11 +197,14 @@ def save_checkpoint(path, ck):
 
 
 def load_checkpoint(path):
-    """-> list of the eight objects (main_compression.py:37-45)."""
+    """-> list of the eight objects (main_compression.py:37-45); `path` may be gzip-compressed (test fixtures)."""
     out = []
     with open(path, "rb") as f:
-        for _ in range(8):
-            out.append(pickle.load(f))
+        magic = f.read(2)
+    opener = gzip.open if magic == b"\x1f\x8b" else open
+    with opener(path, "rb") as f:
+        for _ in range(8):          # eight independent pickle streams: a fresh unpickler (memo) for each
+            out.append(_CheckpointUnpickler(f).load())
     return out
 
 

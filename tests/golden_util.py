@@ -139,3 +139,32 @@ def assert_close_mostly(actual, expected, rtol, atol, max_frac=1e-3, hard_atol=7
     bad = diff > (atol + rtol * np.abs(e))
     assert bad.mean() <= max_frac, (what, float(bad.mean()))
     assert diff.max() <= hard_atol, (what, float(diff.max()))
+
+
+def xy_of(d, y_seed=5):
+    """(X [P, F], Y [n, P, C]) of a test_*.npz / e2e case: stored whole, or -- large geometries -- rebuilt (Fourier features of
+    the coordinate grid; targets = torch.manual_seed(5), rand) and verified against the stored subsample + moments."""
+    cfg = cfg_of(d)
+    n = int(d["n"])
+    X = t(d, "X")
+    if X is None:
+        X = O.fourier_features(cfg["pixel_sizes"], cfg["fourier_dim"])
+        check(d, "X", X, rtol=0, atol=1e-6)
+    Y = t(d, "Y")
+    if Y is None:
+        torch.manual_seed(y_seed)
+        Y = torch.rand(n, X.shape[0], cfg["output_dim"])
+        check(d, "Y", Y, rtol=0, atol=0)
+    return X, Y
+
+
+def structured_A(dims):
+    """the stand-in for learned mappings of the checkpoint fixture (oracle/make_golden.py::structured_A): identity plus a
+    small circulant pattern -- restated here so that the test can verify what the reference-written pickle carries"""
+    mats = []
+    for i in range(1, len(dims)):
+        L = dims[i] * (dims[i - 1] + 1)
+        r = torch.arange(L)
+        base = torch.tensor([0.5, -0.25, 0.125, 0.375, -0.5, 0.25, -0.125, -0.375]) / 8
+        mats.append(torch.eye(L) + base[(r[:, None] + 3 * r[None, :]) % 8] / L)
+    return mats

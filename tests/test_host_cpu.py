@@ -165,3 +165,72 @@ def test_bench_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "launcher started 1 rank" in out.stderr
+
+
+REF_DIR = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DIR), reason="needs the reference checkout (build container only)")
+def test_reference_unpickles_a_checkpoint_written_by_the_product(tmp_path):
+    """N2, product -> reference: a checkpoint written by drivers.save_checkpoint is read by the REFERENCE's own
+    main_compression.py load sequence (eight plain pickle.load calls with the reference's prior_model on the path), the
+    two modules come back as the reference's classes (without the product's fast-path caches), and the reference's
+    TestBNNmodel built from them runs predict().  Runs in a child process (the module name `prior_model` must be the
+    reference's there); skipped where the reference is absent."""
+    import subprocess
+    import sys
+    from recombiner_amd import drivers
+    cfg = config.configs["cifar"]
+    dims = [cfg["input_dim"]] + cfg["hidden_dims"] + [cfg["output_dim"]]
+    torch.manual_seed(3)
+    lt = PM.LinearTransform(dims)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"])
+    from recombiner_amd.upsample_fast import phase_module
+    phase_module(up)                                                  # the fast-path cache must not travel
+    D = 3267 + 512
+    g1 = PM.get_grouping_by_kl(np.random.RandomState(0).gamma(0.7, 4.0, size=D).astype(np.float32))
+    gen = torch.Generator().manual_seed(1)
+    p_loc, p_scale = 0.01 * torch.randn(D, generator=gen), 0.02 + 0.01 * torch.rand(D, generator=gen)
+    avg_ls = -4 + 0.1 * torch.randn(D, generator=gen)
+    ck = [g1, (p_loc, p_scale, 3e-7, avg_ls), (None,) * 8, (None, None, 3e-7, None), (None,) * 8, (None, None, 3e-7, None), lt, up]
+    path = os.path.join(tmp_path, "PRIOR.pkl")
+    drivers.save_checkpoint(path, ck)
+    assert PM.LinearTransform.__module__ == "recombiner_amd.prior_model" and "prior_model" not in sys.modules
+    child = r"""
+import pickle, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import prior_model, test_model, config
+assert prior_model.__file__.startswith(%r)
+with open(%r, "rb") as f:
+    group_idx, gs, ge, g2p, p2g, n_groups, gk, w = pickle.load(f)
+    prior_loc, prior_scale, kl_beta, avg_ls = pickle.load(f)
+    for _ in range(4):
+        pickle.load(f)
+    linear_transform = pickle.load(f)
+    upsample_net = pickle.load(f)
+assert type(linear_transform) is prior_model.LinearTransform and type(upsample_net) is prior_model.Upsample
+assert not any(k.startswith("_rcb_") for k in upsample_net.__dict__)
+c = config.configs["cifar"]
+tm = test_model.TestBNNmodel(c["input_dim"], c["hidden_dims"], c["output_dim"], 2, c["upsample_factors"], c["latent_dim"],
+                             c["data_dim"], c["pixel_sizes"], False, None, None, "cifar", linear_transform=linear_transform,
+                             upsample_net=upsample_net, p_loc=prior_loc.clone()[p2g],
+                             p_log_scale=torch.log(torch.exp(prior_scale * 6) - 1).clone()[p2g], init_log_scale=avg_ls[p2g],
+                             param_to_group=p2g, group_to_param=g2p, n_groups=n_groups, group_start_index=gs,
+                             group_end_index=ge, group_idx=group_idx, device="cpu", initial_beta=kl_beta)
+x = torch.from_numpy(np.load(%r))
+with torch.no_grad():
+    y = tm.predict(x[None].repeat(2, 1, 1), random_seed=3)
+np.save(%r, y.numpy())
+print("REF LOAD OK", n_groups)
+""" % (REF_DIR, REF_DIR, path, os.path.join(tmp_path, "x.npy"), os.path.join(tmp_path, "y.npy"))
+    X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], 1, 3, seed=0)
+    np.save(os.path.join(tmp_path, "x.npy"), X.numpy())
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert out.returncode == 0 and "REF LOAD OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    y_ref = np.load(os.path.join(tmp_path, "y.npy"))
+    assert y_ref.shape == (2, 1024, 3) and np.isfinite(y_ref).all() and float(np.abs(y_ref).max()) > 0
+    # and the same file read back by the product's loader gives the objects that were written
+    back = drivers.load_checkpoint(path)
+    assert all(torch.equal(a, b) for a, b in zip(back[6].A, lt.A)) and torch.equal(back[7].conv3.weight, up.conv3.weight)
+    assert np.array_equal(back[0][4], g1[4]) and back[1][2] == 3e-7

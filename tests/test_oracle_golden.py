@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import (DATASET_OF, GOLDEN, O, cfg_of, check, level_kwargs, load, prior_inputs,
+from golden_util import (DATASET_OF, xy_of, GOLDEN, O, cfg_of, check, level_kwargs, load, prior_inputs,
                          regen_noise, regen_noise_per_epoch, stats_of, t)
 
 PRIOR_CASES = ["cifar", "protein", "patch2d", "patch1d", "patch3d"]
@@ -158,7 +158,7 @@ def build_test_model(d, name):
     n = int(d["n"])
     A = O.make_linear_transform(geo.dims, seed=123)
     up = O.UpsampleNet(geo.data_dim, geo.paddings, geo.layerwise_scale_factors, seed=124)
-    m = O.TestTimeModel(geo, n, DATASET_OF[name], A, up, level_kwargs(d, ""),
+    m = O.TestTimeModel(geo, n, DATASET_OF[name.partition("_w")[0]], A, up, level_kwargs(d, ""),
                         level_kwargs(d, "h_") if geo.patch else None,
                         level_kwargs(d, "hh_") if geo.patch else None, initial_beta=1e-5)
     return geo, n, m
@@ -171,7 +171,7 @@ def set_test_posteriors(d, geo, m):
         m.l3.loc, m.l3.log_scale = t(d, "t_hh_loc").clone(), t(d, "t_hh_log_scale").clone()
 
 
-@pytest.mark.parametrize("name", ["cifar", "patch2d", "patch1d"])
+@pytest.mark.parametrize("name", ["cifar", "patch2d", "patch1d", "patch3d", "patch3d_w64"])
 def test_test_model(name):
     d = load(f"test_{name}.npz")
     geo, n, m = build_test_model(d, name)
@@ -180,8 +180,8 @@ def test_test_model(name):
         assert np.array_equal(m.l1.row_perm_g2p, d["perm_x_g2p"].astype(np.int64))
         assert np.array_equal(m.l2.row_perm_g2p, d["h_perm_x_g2p"].astype(np.int64))
     set_test_posteriors(d, geo, m)
-    X = t(d, "X")[None].repeat(n, 1, 1)
-    Y = t(d, "Y")
+    X, Y = xy_of(d)
+    X = X[None].repeat(n, 1, 1)
     for S in (1, 5):
         eps = regen_noise(d, f"pred_S{S}_eps")
         with torch.no_grad():
@@ -252,3 +252,20 @@ def test_end_to_end_compress(name):
     assert done.sum() == rounds * n
     agree = (lv.idx[done] == e["idx"][done]).mean()
     assert agree == 1.0, agree
+
+
+def test_rec_long_groups():
+    """the reference's sample_group on groups of 338 / 360 parameters (rec_long_groups.npz): exact index, sample, margin"""
+    d = load("rec_long_groups.npz")
+    gum = torch.from_numpy(O.gumbel_table(42))
+    for row, grp, idx, margin, gl in d["enc_table"]:
+        row, grp, gl = int(row), int(grp), int(gl)
+        s0 = int(d["start"][grp])
+        assert int(d["end"][grp]) - s0 == gl
+        i, z, lw = O.rec_score(O.sobol_normal_table(gl), t(d, f"enc_{row}_{grp}_loc"), O.st(t(d, f"enc_{row}_{grp}_log_scale")),
+                               t(d, "p_loc")[s0:s0 + gl], O.st(t(d, "p_log_scale")[s0:s0 + gl]), gum)
+        assert i == int(idx)
+        np.testing.assert_allclose(z.numpy(), d[f"enc_{row}_{grp}_z"], rtol=1e-12)
+        np.testing.assert_allclose(lw[:256].numpy(), d[f"enc_{row}_{grp}_lw_head"], rtol=1e-9, atol=1e-9)
+        top2 = torch.topk(lw, 2).values
+        np.testing.assert_allclose(float(top2[0] - top2[1]), margin, rtol=1e-6, atol=1e-9)
