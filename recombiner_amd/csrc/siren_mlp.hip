@@ -72,7 +72,20 @@ __global__ void __launch_bounds__(256) siren_kernel(SirenArgs a) {
   // ---- stage weights -------------------------------------------------------------------
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
-    for (int i = tid; i < a.dnet; i += 256) wl[i] = src[i];
+    // loads in batches of eight before their LDS stores (a plain `wl[i] = src[i]` loop serialises one HBM round trip per element)
+    for (int i0 = tid; i0 < a.dnet; i0 += 8 * 256) {
+      float stage[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + 256 * k;
+        stage[k] = src[i < a.dnet ? i : a.dnet - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + 256 * k;
+        if (i < a.dnet) wl[i] = stage[k];
+      }
+    }
     __syncthreads();
     if (MODE != MODE_FWD) {
 #pragma unroll

@@ -19,6 +19,21 @@
 
 using namespace rcb;
 
+// Diagnostic build only (-DRCB_SIREN_STAMPS, tools/siren_stamps.py): wave 0 of every workgroup records s_memtime at its
+// phase boundaries into a device array read back through rcb_debug_read_stamps.  Nothing of this exists in the library.
+#ifdef RCB_SIREN_STAMPS
+__device__ unsigned long long g_siren_stamps[8192 * 16];
+#define RCB_STAMP(k)                                                                                      \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_siren_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int rcb_debug_read_stamps(unsigned long long* dst, int n_entries) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_siren_stamps), sizeof(unsigned long long) * n_entries);
+}
+#else
+#define RCB_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 using namespace rcb::op16;
 
@@ -90,14 +105,31 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   T* bufA = reinterpret_cast<T*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
   T* bufB = bufA + 32 * G::TSA;
 
+  RCB_STAMP(0);
   // ---- stage weights, build MFMA A-fragments, clear the zero padding of bufB ---------------------
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
-    for (int i = tid; i < DNET; i += 256) wl[i] = src[i];
+    {
+      // all loads first, then the LDS stores: written as `wl[i] = src[i]` in a loop the compiler waits for every load before
+      // its store -- 13 serialized HBM round trips, 17 % of the whole kernel by the in-kernel stamps (tools/siren_stamps.py)
+      constexpr int NLD = (DNET + 255) / 256;
+      float stage[NLD];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        stage[k] = src[i < DNET ? i : DNET - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        if (i < DNET) wl[i] = stage[k];
+      }
+    }
     if (32 * NB0 > IN0) {
       for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
     }
     __syncthreads();
+    RCB_STAMP(1);
     // the sine layers work in revolutions: w0 / 2 pi is folded into their forward fragments (below) and biases (here),
     // so the accumulator feeds v_sin / v_cos directly -- no scaling multiply per activation
     if (tid < HID) {
@@ -150,6 +182,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     }
     __syncthreads();
   }
+  RCB_STAMP(2);
   auto FA = [&](int slot) -> bf16x8 {
     union { bf16x8 v; uint4 u; } fr;
     fr.u = frags[slot * 64 + lane];
@@ -222,6 +255,10 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   const int t0 = (int)((long long)chunk * ntiles / a.chunks), t1 = (int)((long long)(chunk + 1) * ntiles / a.chunks);
   if (t0 + wave < t1) fetch(t0 + wave);
   for (int t = t0 + wave; t < t1; t += 4) {
+#ifdef RCB_SIREN_STAMPS
+    if (t == t0 + wave) RCB_STAMP(14);
+    if (t == t0 + wave + 4) RCB_STAMP(15);
+#endif
     const int p = t * 32 + q;
     const bool valid = p < P;
     const int pc = valid ? p : P - 1;                       // clamped: loads never leave the arrays
@@ -301,6 +338,9 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       }
       continue;
     }
+#ifdef RCB_SIREN_STAMPS
+    if (t == t0 + wave) RCB_STAMP(8);
+#endif
     // ---- output gradient (branch-free: selects on the prefetched targets) ---------------------------------
     f32x16 dz;
 #pragma unroll
@@ -321,6 +361,9 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     // ---- backward ----------------------------------------------------------------------------------
 #pragma unroll
     for (int l = NL - 1; l >= 0; --l) {
+#ifdef RCB_SIREN_STAMPS
+      if (t == t0 + wave) RCB_STAMP(9 + (NL - 1 - l));
+#endif
       bf16x8 dzb[2] = {pack8<T>(dz, 0), pack8<T>(dz, 1)};
       // (1) weight gradient: [pixel][feature] images -> transposed reads
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -421,11 +464,13 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     }
   }
   if (MODE == MODE_FWD) return;
+  RCB_STAMP(3);
 
   // ---- deterministic cross-wave reduction of the weight gradients -------------------------------------
   // per wave scratch: layer l as [out o][in i] rows of stride (32*NBl + 1) (conflict-free for the
   // lane = i writes and for the o-fastest reads below), followed by 32 bias slots
   __syncthreads();
+  RCB_STAMP(4);
   float* part = smem + wave * G::RED_WAVE;
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
@@ -446,6 +491,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     }
   }
   __syncthreads();
+  RCB_STAMP(5);
   {
     float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
     // layer by layer with compile-time shapes (constant divisors, no layer search per element)
@@ -474,6 +520,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       }
     }
   }
+  RCB_STAMP(6);
   if (MODE == MODE_LOSS) {
     float v = wave_sum(sse_local);
     __syncthreads();
@@ -481,6 +528,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     __syncthreads();
     if (tid == 0) a.sse[(long long)chunk * a.G + g] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
   }
+  RCB_STAMP(7);
 }
 
 template <typename T, int NH, int F, int E, int C, int MODE>

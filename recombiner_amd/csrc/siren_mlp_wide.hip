@@ -113,7 +113,22 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
   // ---- stage weights, build the MFMA A-fragments, clear the image buffers ---------------------------------------------
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
-    for (int i = tid; i < DNET; i += 256) wl[i] = src[i];
+    {
+      // all loads first, then the LDS stores: written as `wl[i] = src[i]` in a loop the compiler waits for every load before
+      // its store -- 13 serialized HBM round trips, 17 % of the whole kernel by the in-kernel stamps (tools/siren_stamps.py)
+      constexpr int NLD = (DNET + 255) / 256;
+      float stage[NLD];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        stage[k] = src[i < DNET ? i : DNET - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        if (i < DNET) wl[i] = stage[k];
+      }
+    }
     for (int i = lane; i < 32 * (G::TSA + G::TSBB); i += 64) bufA[i] = (T)0.f;
     __syncthreads();
     if (tid < W) {

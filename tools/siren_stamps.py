@@ -1,0 +1,56 @@
+"""Phase breakdown of the fused bf16 SIREN kernel from in-kernel s_memtime stamps (DIAGNOSTIC build, -DRCB_SIREN_STAMPS:
+built here into gpurun_out/librcb_stamps.so, loaded through RCB_LIB; the shipped library carries no stamps).
+    python tools/siren_stamps.py            (on the GPU box)"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out_dir = os.path.join(ROOT, "gpurun_out")
+os.makedirs(out_dir, exist_ok=True)
+lib = os.path.join(out_dir, "librcb_stamps.so")
+from recombiner_amd import build as B  # noqa: E402
+cmd = [B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DRCB_SIREN_STAMPS", "-Wno-unused-result"] + \
+      [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-o", lib]
+subprocess.check_call(cmd)
+os.environ["RCB_LIB"] = lib
+import torch  # noqa: E402
+from recombiner_amd import _lib, ops, utils  # noqa: E402
+from recombiner_amd.ops import SirenMeta  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+X, Y = utils.synthetic_inputs([32, 32], 16, n, 3, seed=0)
+meta = SirenMeta(1, 1024, 16, 16, 3, 32, 3, precision=1)
+Xd, Yd = X.cuda(), Y.cuda()
+pe = (torch.randn(n, 1024, 16, device="cuda") * 0.1).bfloat16()
+wv = (torch.rand(n, meta.d_net, device="cuda") * 2 - 1) * 0.02
+for _ in range(5):
+    ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta)
+torch.cuda.synchronize()
+L = _lib.load()
+nb = min(n, 8192)
+buf = (C.c_uint64 * (nb * 16))()
+rc = L.rcb_debug_read_stamps(buf, nb * 16)
+assert rc == 0, rc
+st = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 16).astype(np.int64)
+names = ["wvec -> LDS (+sync)", "fragment build (+sync)", "tile loop (wave 0: 8 tiles)", "wait for the other waves", "partials -> LDS (+sync)",
+         "reduce + dw / split stores", "sse reduce"]
+tot = (st[:, 7] - st[:, 0]).astype(np.float64)
+print("workgroups %d; s_memtime ticks (100 MHz constant clock? no: shader clock on gfx9) per workgroup: median %.0f" % (nb, np.median(tot)))
+for k, nm in enumerate(names):
+    d = (st[:, k + 1] - st[:, k]).astype(np.float64)
+    print("  %-32s median %8.0f  (%5.1f %% of the workgroup)   p10 %8.0f  p90 %8.0f" % (nm, np.median(d), 100 * np.median(d) / np.median(tot),
+                                                                                       np.percentile(d, 10), np.percentile(d, 90)))
+# first tile of wave 0: 14 = tile start, 8 = after forward, 9..12 = before backward layer 3,2,1,0, 15 = start of the wave's second tile
+t = st
+seg = [("forward (3 sine layers + output)", 14, 8), ("loss / dz", 8, 9), ("backward layer 3", 9, 10), ("backward layer 2", 10, 11),
+       ("backward layer 1", 11, 12), ("backward layer 0 (+dpe)", 12, 15)]
+tile = (t[:, 15] - t[:, 14]).astype(np.float64)
+print("first tile of wave 0: median %.0f ticks" % np.median(tile))
+for nm, a, b in seg:
+    d = (t[:, b] - t[:, a]).astype(np.float64)
+    print("  %-34s median %7.0f  (%5.1f %%)" % (nm, np.median(d), 100 * np.median(d) / np.median(tile)))
