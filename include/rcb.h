@@ -74,6 +74,10 @@ typedef struct {
                           * otherwise leave most of the 256 CUs idle).  y_out / dpe are unaffected; dwvec and sse then
                           * receive PARTIAL results: dwvec [c][n_rows][w_row_stride], sse [c][n_rows], to be summed in
                           * chunk order by rcb_siren_reduce_chunks; dw_split must be NULL (the reduction emits it)  */
+  const void* xf_bf16;   /* nullable, bf16 operand mode with pe_bf16 = 1: a bf16 copy of xf (same shape, same strides in
+                          * elements).  The coordinate grid is constant for a whole run and the kernel rounds it to bf16 for
+                          * its MFMA operand anyway: given the copy, both input halves are loaded as operand bits (no
+                          * unpack / re-round per tile).  Results are bit-identical with and without it.            */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */

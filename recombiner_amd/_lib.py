@@ -27,7 +27,8 @@ class SirenDesc(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("samples", C.c_int32), ("n_pix", C.c_int32), ("fourier_dim", C.c_int32),
                 ("pe_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
                 ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
-                ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_split", C.c_void_p), ("pixel_chunks", C.c_int32)]
+                ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_split", C.c_void_p), ("pixel_chunks", C.c_int32),
+                ("xf_bf16", C.c_void_p)]
 
 
 class Level(C.Structure):

@@ -29,6 +29,7 @@ struct SirenArgs {
   int pe_bf16;        // pe / dpe hold bf16 elements (16-bit kernels only)
   void* dw_split;     // nullable: split-bf16 copy of the wide layers' weight gradients (see rcb_siren_desc)
   int chunks;         // >= 1: workgroups per row of wvec (pixel tiles split; dwvec / sse hold per-chunk partials)
+  const void* xf16;   // nullable: bf16 copy of xf, same shape and strides (rcb_siren_desc.xf_bf16)
 };
 
 // row of accumulator register r for lane half h (32x32 MFMA C/D layout)

@@ -406,6 +406,7 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   a.chunks = chunks;
   a.pe_bf16 = d->pe_bf16;
   a.dw_split = d->dw_split;
+  a.xf16 = d->xf_bf16;
   a.G = d->n_rows;
   a.S = d->samples;
   a.P = d->n_pix;

@@ -82,7 +82,7 @@ struct Geo {
   static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4);
 };
 
-template <typename T, int NH, int F, int E, int C, int MODE>
+template <typename T, int NH, int F, int E, int C, int MODE, bool IN16>
 __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   using G = Geo<NH, F, E, C>;
   using bf16x8 = typename Op16<T>::v8;
@@ -206,10 +206,25 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   constexpr bool VEC4 = (F % 4 == 0) && (E % 4 == 0) && (F % 8 == 0) && (E % 8 == 0);
   // raw fp32 input rows of the NEXT tile are fetched while the current tile computes (HBM/L2 latency
   // is otherwise exposed at only 2 waves per SIMD)
-  float4 raw[2 * K0S];
+  // IN16 (chosen by the launcher: bf16 operands, pe stored as bf16, a bf16 copy of xf supplied, 16-byte rows): both input
+  // halves arrive as 16-bit rows and the loaded bits ARE the tile's B operand -- no widening to fp32 and re-rounding per
+  // tile (24 VALU instructions and 8 registers less; same-box A/B: -15 % kernel time)
+  float4 raw[IN16 ? 1 : 2 * K0S];
+  uint4 raw16[IN16 ? K0S : 1];
   auto fetch = [&](int tile) {
     const int pp = tile * 32 + q;
     const int pcl = pp < P ? pp : P - 1;
+    if constexpr (IN16) {
+      const __bf16* s16 = (h == 0) ? (reinterpret_cast<const __bf16*>(a.xf16) + (long long)n * a.xf_stride + (long long)pcl * F)
+                                   : (reinterpret_cast<const __bf16*>(a.pe) + ((long long)g * P + pcl) * E);
+      const int kh16 = (h == 0) ? KH0 : KH1;
+#pragma unroll
+      for (int s = 0; s < K0S; ++s) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (8 * s + 8 <= kh16) u = reinterpret_cast<const uint4*>(s16)[s];
+        raw16[s] = u;
+      }
+    } else {
     const float* src = (h == 0) ? (a.xf + (long long)n * a.xf_stride + (long long)pcl * F)
                                 : (a.pe + ((long long)g * P + pcl) * E);
     const int kh = (h == 0) ? KH0 : KH1;
@@ -250,6 +265,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         raw[2 * s + 1] = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
+    }
   };
   // this workgroup's share of the 32-pixel tiles (all of them unless rcb_siren_desc.pixel_chunks > 1)
   const int t0 = (int)((long long)chunk * ntiles / a.chunks), t1 = (int)((long long)(chunk + 1) * ntiles / a.chunks);
@@ -266,9 +282,15 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     bf16x8 xin[K0S];
 #pragma unroll
     for (int s = 0; s < K0S; ++s) {
-      const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
-      xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
-      xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
+      if constexpr (IN16) {
+        union { uint4 u; bf16x8 v; } cv;
+        cv.u = raw16[s];
+        xin[s] = cv.v;
+      } else {
+        const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
+        xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
+        xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
+      }
     }
     // targets / upstream gradient of this tile, issued early
     float yv[16];
@@ -365,7 +387,54 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       if (t == t0 + wave) RCB_STAMP(9 + (NL - 1 - l));
 #endif
       bf16x8 dzb[2] = {pack8<T>(dz, 0), pack8<T>(dz, 1)};
-      // (1) weight gradient: [pixel][feature] images -> transposed reads
+      // (1) data gradient FIRST: dz -> dh -> dz of the next layer is the serial chain of the backward pass; the weight
+      // gradient below (LDS transpose + MFMAs nothing waits for) then fills the latency of these MFMAs instead of delaying them
+      if (l > 0) {
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+        if (l == NL - 1) {
+          dh = Op16<T>::mfma(FA(NFA + 0), dzb[0], dh);
+        } else {
+          constexpr int dummy = 0;
+          const int base = NFA + 1 + 2 * ((NH - 1) - l);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) dh = Op16<T>::mfma(FA(base + s), dzb[s], dh);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (float)Cs[l - 1][r >> 3][r & 7];     // w0 is in the fragments
+      } else if (a.dpe != nullptr) {
+        f32x16 dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+        const int base = NFA + 1 + 2 * (NH - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dx = Op16<T>::mfma(FA(base + s), dzb[s], dx);
+        if (valid) {
+          float* dst = a.dpe + ((long long)g * P + p) * E;
+          if (E % 8 == 0 && a.pe_bf16) {
+            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
+#pragma unroll
+            for (int g4 = 0; g4 < E / 8; ++g4) {
+              typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
+                                              (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
+              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
+            }
+          } else if (E % 8 == 0) {
+#pragma unroll
+            for (int g4 = 0; g4 < E / 8; ++g4)
+              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
+                                                                             dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              int e = rho(r, h);
+              if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
+            }
+          }
+        }
+      }
+      // (2) weight gradient: [pixel][feature] images -> transposed reads (uses the packed copy dzb and the stored activations)
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       {
         union { bf16x8 v; bf16x4 hlf[2]; } u;
@@ -413,52 +482,6 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
           const int gi = (l == 0) ? blk : (l + NB0 - 1);
 #pragma unroll
           for (int s = 0; s < 2; ++s) gW[gi] = Op16<T>::mfma(av[s], read_tr<T>(bufB, G::TSBB, s, lane, 32 * blk), gW[gi]);
-        }
-      }
-      // (2) data gradient
-      if (l > 0) {
-        f32x16 dh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-        if (l == NL - 1) {
-          dh = Op16<T>::mfma(FA(NFA + 0), dzb[0], dh);
-        } else {
-          constexpr int dummy = 0;
-          const int base = NFA + 1 + 2 * ((NH - 1) - l);
-#pragma unroll
-          for (int s = 0; s < 2; ++s) dh = Op16<T>::mfma(FA(base + s), dzb[s], dh);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (float)Cs[l - 1][r >> 3][r & 7];     // w0 is in the fragments
-      } else if (a.dpe != nullptr) {
-        f32x16 dx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
-        const int base = NFA + 1 + 2 * (NH - 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) dx = Op16<T>::mfma(FA(base + s), dzb[s], dx);
-        if (valid) {
-          float* dst = a.dpe + ((long long)g * P + p) * E;
-          if (E % 8 == 0 && a.pe_bf16) {
-            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
-#pragma unroll
-            for (int g4 = 0; g4 < E / 8; ++g4) {
-              typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
-                                              (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
-              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
-            }
-          } else if (E % 8 == 0) {
-#pragma unroll
-            for (int g4 = 0; g4 < E / 8; ++g4)
-              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
-                                                                             dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              int e = rho(r, h);
-              if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
-            }
-          }
         }
       }
     }
@@ -531,11 +554,11 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   RCB_STAMP(7);
 }
 
-template <typename T, int NH, int F, int E, int C, int MODE>
+template <typename T, int NH, int F, int E, int C, int MODE, bool IN16>
 int launch_one(const SirenArgs& a, hipStream_t st) {
   using G = Geo<NH, F, E, C>;
   static bool attr_done = false;
-  auto kfn = siren_bf16_kernel<T, NH, F, E, C, MODE>;
+  auto kfn = siren_bf16_kernel<T, NH, F, E, C, MODE, IN16>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -549,9 +572,12 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
 
 template <typename T, int NH, int F, int E, int C>
 int launch_mode(int mode, const SirenArgs& a, hipStream_t st) {
-  if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, MODE_FWD>(a, st);
-  if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, MODE_BWD>(a, st);
-  return launch_one<T, NH, F, E, C, MODE_LOSS>(a, st);
+  // both input halves as operand bits: bf16 operands, pe stored as bf16, a bf16 copy of xf supplied, 16-byte rows
+  constexpr bool can16 = Op16<T>::IS_BF16 && (E % 8 == 0) && (F % 8 == 0) && E > 0;
+  if (can16 && a.pe_bf16 && a.xf16 != nullptr && mode == MODE_LOSS) return launch_one<T, NH, F, E, C, MODE_LOSS, can16>(a, st);
+  if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, MODE_FWD, false>(a, st);
+  if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, MODE_BWD, false>(a, st);
+  return launch_one<T, NH, F, E, C, MODE_LOSS, false>(a, st);
 }
 
 }  // namespace

@@ -13,6 +13,7 @@ template <> struct Op16<__bf16> {
   typedef __bf16 v2 __attribute__((ext_vector_type(2)));
   static constexpr float GRAD_SCALE = 1.0f;
   static constexpr float W_SCALE = 1.0f;
+  static constexpr bool IS_BF16 = true;
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ float dot2(v2 a, v2 b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
 };
@@ -20,6 +21,7 @@ template <> struct Op16<_Float16> {
   typedef _Float16 v8 __attribute__((ext_vector_type(8)));
   typedef _Float16 v4 __attribute__((ext_vector_type(4)));
   typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr bool IS_BF16 = false;
   static constexpr float GRAD_SCALE = 1024.0f;
   // effective INR weights (h_w @ A) are ~1e-4: scaled by 2^10 into f16's normal range; the factor is
   // folded into the sine argument / cosine multipliers, biases are pre-scaled in the accumulator

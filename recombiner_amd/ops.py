@@ -5,6 +5,7 @@ hot path runs in librcb_hip.so.  Every wrapper raises if the library is missing 
 not on the GPU -- there is no CPU fallback.
 """
 import ctypes as C
+import os as _os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -74,6 +75,25 @@ def siren_pixel_chunks(G, meta: SirenMeta):
     return max(1, min(4 if G <= 128 else 2, ntiles // 8))
 
 
+_XF16_CACHE = {}
+
+
+def _xf_bf16(xf):
+    """bf16 copy of the coordinate features with the same shape / strides in elements (rcb_siren_desc.xf_bf16), cached per
+    storage: the grid is constant for a whole run.  Only for shared grids ([P, F] or a stride-0 expansion of one)."""
+    if xf.dim() == 3 and xf.stride(0) != 0:
+        return None
+    base = xf if xf.dim() == 2 else xf[0]
+    key = (base.data_ptr(), tuple(base.shape), base._version, str(base.device))
+    hit = _XF16_CACHE.get(key)
+    if hit is None:
+        if len(_XF16_CACHE) > 16:
+            _XF16_CACHE.clear()
+        hit = base.to(bf16).contiguous()
+        _XF16_CACHE[key] = hit
+    return hit
+
+
 def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
@@ -84,7 +104,12 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1):
         raise RcbError("rows of wvec must be a multiple of samples")
     d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
-                  meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split), int(chunks))
+                  meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split), int(chunks), None)
+    if meta.precision == 1 and pe is not None and pe.dtype == bf16 and not _os.environ.get("RCB_SIREN_NO_XF16"):   # (A/B switch)
+        x16 = _xf_bf16(xf)
+        if x16 is not None:
+            d.xf_bf16 = x16.data_ptr()
+            d._keep = x16
     return d, G
 
 

@@ -4,9 +4,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 PAT=${2:-upconv}
 rm -rf gpurun_out/ab_new gpurun_out/ab_prev
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_new -- python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline > gpurun_out/ab_new.json 2> gpurun_out/ab_new.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_new -- python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/ab_new.json 2> gpurun_out/ab_new.err
 export RCB_LIB=$1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_prev -- python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline > gpurun_out/ab_prev.json 2> gpurun_out/ab_prev.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_prev -- python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/ab_prev.json 2> gpurun_out/ab_prev.err
 unset RCB_LIB
 python3 - "$PAT" <<'PY'
 import csv, glob, sys

@@ -37,14 +37,19 @@ buf = (C.c_uint64 * (nb * 16))()
 rc = L.rcb_debug_read_stamps(buf, nb * 16)
 assert rc == 0, rc
 st = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 16).astype(np.int64)
-names = ["wvec -> LDS (+sync)", "fragment build (+sync)", "tile loop (wave 0: 8 tiles)", "wait for the other waves", "partials -> LDS (+sync)",
-         "reduce + dw / split stores", "sse reduce"]
-tot = (st[:, 7] - st[:, 0]).astype(np.float64)
-print("workgroups %d; s_memtime ticks (100 MHz constant clock? no: shader clock on gfx9) per workgroup: median %.0f" % (nb, np.median(tot)))
+# persistent kernel: the stamps of a workgroup's LAST row survive.  1 = row start (its weights were requested during the row
+# before), 2 = fragments stored (+sync), 3 = wave 0 done with its tiles, 4 = all waves done, 5 = partials in LDS and the next
+# row's weights requested (+sync), 6 = gradients summed and stored, 7 = row end (+sync)
+names = ["fragments: wait for the prefetched weights, convert, store (+sync)", "tile loop (wave 0: 8 tiles)", "wait for the other waves",
+         "partials -> LDS, request next weights (+sync)", "reduce + dw / split stores", "sse, sync"]
+nb = min(nb, 512)
+st = st[:nb]
+tot = (st[:, 7] - st[:, 1]).astype(np.float64)
+print("workgroups %d; shader-clock ticks per row (last row of each workgroup): median %.0f" % (nb, np.median(tot)))
 for k, nm in enumerate(names):
-    d = (st[:, k + 1] - st[:, k]).astype(np.float64)
-    print("  %-32s median %8.0f  (%5.1f %% of the workgroup)   p10 %8.0f  p90 %8.0f" % (nm, np.median(d), 100 * np.median(d) / np.median(tot),
-                                                                                       np.percentile(d, 10), np.percentile(d, 90)))
+    d = (st[:, k + 2] - st[:, k + 1]).astype(np.float64)
+    print("  %-72s median %8.0f  (%5.1f %%)   p10 %8.0f  p90 %8.0f" % (nm, np.median(d), 100 * np.median(d) / np.median(tot),
+                                                                      np.percentile(d, 10), np.percentile(d, 90)))
 # first tile of wave 0: 14 = tile start, 8 = after forward, 9..12 = before backward layer 3,2,1,0, 15 = start of the wave's second tile
 t = st
 seg = [("forward (3 sine layers + output)", 14, 8), ("loss / dz", 8, 9), ("backward layer 3", 9, 10), ("backward layer 2", 10, 11),
@@ -54,3 +59,7 @@ print("first tile of wave 0: median %.0f ticks" % np.median(tile))
 for nm, a, b in seg:
     d = (t[:, b] - t[:, a]).astype(np.float64)
     print("  %-34s median %7.0f  (%5.1f %%)" % (nm, np.median(d), 100 * np.median(d) / np.median(tile)))
+# whole-kernel view: every workgroup starts at launch; the kernel ends with the slowest one
+life = (st[:, 7] - st[:, 0]).astype(np.float64)
+print("workgroup lifetime (launch -> last row done), ticks: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f  (max / median = %.3f)" % (
+    life.min(), np.percentile(life, 10), np.median(life), np.percentile(life, 90), life.max(), life.max() / np.median(life)))
