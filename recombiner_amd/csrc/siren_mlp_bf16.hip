@@ -308,7 +308,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     // next tile's rows are requested after the targets, so the wait at the loss does not cover them
     fetch(t + 4 < t1 ? t + 4 : t);
     // ---- forward ----------------------------------------------------------------------------------
-    bf16x8 S[NH][2], Cs[NH][2];
+    // cosines: packed bf16 (8 registers per layer; unpacked again for dz = dh * cos) or, in the IN16 variant whose register
+    // budget allows it, the fp32 values themselves (16 per layer, no pack / unpack: -72 VALU instructions per tile; the
+    // product then uses the unrounded cosine)
+    constexpr bool COS32 = IN16;
+    bf16x8 S[NH][2], Cs[COS32 ? 1 : NH][2];
+    f32x16 Cf[COS32 ? NH : 1];
     f32x16 acc;
 #pragma unroll
     for (int l = 0; l < NH; ++l) {
@@ -332,8 +337,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       S[l][0] = pack8<T>(sv, 0);
       S[l][1] = pack8<T>(sv, 1);
       if (MODE != MODE_FWD) {
-        Cs[l][0] = pack8<T>(cv, 0);
-        Cs[l][1] = pack8<T>(cv, 1);
+        if constexpr (COS32) {
+          Cf[l] = cv;
+        } else {
+          Cs[l][0] = pack8<T>(cv, 0);
+          Cs[l][1] = pack8<T>(cv, 1);
+        }
       }
     }
     {
@@ -402,7 +411,10 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
           for (int s = 0; s < 2; ++s) dh = Op16<T>::mfma(FA(base + s), dzb[s], dh);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz[r] = dh[r] * (float)Cs[l - 1][r >> 3][r & 7];     // w0 is in the fragments
+        for (int r = 0; r < 16; ++r) {     // w0 is in the fragments
+          if constexpr (COS32) dz[r] = dh[r] * Cf[l - 1][r];
+          else dz[r] = dh[r] * (float)Cs[l - 1][r >> 3][r & 7];
+        }
       } else if (a.dpe != nullptr) {
         f32x16 dx;
 #pragma unroll

@@ -79,19 +79,23 @@ _XF16_CACHE = {}
 
 
 def _xf_bf16(xf):
-    """bf16 copy of the coordinate features with the same shape / strides in elements (rcb_siren_desc.xf_bf16), cached per
-    storage: the grid is constant for a whole run.  Only for shared grids ([P, F] or a stride-0 expansion of one)."""
+    """bf16 copy of the coordinate features with the same shape / strides in elements (rcb_siren_desc.xf_bf16), cached: the
+    grid is constant for a whole run.  Only for shared grids ([P, F] or a stride-0 expansion of one).  The cache entry keeps
+    a reference to the source tensor: while it is held, the allocator cannot hand the address to other data, so
+    (address, shape, version counter) identifies the contents."""
     if xf.dim() == 3 and xf.stride(0) != 0:
         return None
     base = xf if xf.dim() == 2 else xf[0]
     key = (base.data_ptr(), tuple(base.shape), base._version, str(base.device))
     hit = _XF16_CACHE.get(key)
-    if hit is None:
-        if len(_XF16_CACHE) > 16:
+    if hit is not None:
+        return hit[1]
+    copy = base.to(bf16).contiguous()
+    if not torch.cuda.is_current_stream_capturing():      # (a copy made inside a capture lives in that graph's memory pool)
+        if len(_XF16_CACHE) >= 16:
             _XF16_CACHE.clear()
-        hit = base.to(bf16).contiguous()
-        _XF16_CACHE[key] = hit
-    return hit
+        _XF16_CACHE[key] = (base, copy)
+    return copy
 
 
 def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1):
