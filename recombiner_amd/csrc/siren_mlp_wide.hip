@@ -87,7 +87,7 @@ struct GeoW {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <typename T, int NH, int F, int E, int C, int W, int MODE>
+template <typename T, int NH, int F, int E, int C, int W, int MODE, bool IN16>
 __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
   using G = GeoW<NH, F, E, C, W>;
   using bf16x8 = typename Op16<T>::v8;
@@ -234,10 +234,23 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
 
   const int ntiles = (P + 31) >> 5;
   constexpr bool VEC4 = (F % 8 == 0) && (E % 8 == 0);
-  float4 raw[2 * K0S];
+  // IN16 (as in the width-32 kernel): both input halves arrive as bf16 rows and the loaded bits are the layer-0 B operand
+  float4 raw[IN16 ? 1 : 2 * K0S];
+  uint4 raw16[IN16 ? K0S : 1];
   auto fetch = [&](int tile) {
     const int pp = tile * 32 + q;
     const int pcl = pp < P ? pp : P - 1;
+    if constexpr (IN16) {
+      const __bf16* s16 = (h == 0) ? (reinterpret_cast<const __bf16*>(a.xf16) + (long long)n * a.xf_stride + (long long)pcl * F)
+                                   : (reinterpret_cast<const __bf16*>(a.pe) + ((long long)g * P + pcl) * E);
+      const int kh16 = (h == 0) ? KH0 : KH1;
+#pragma unroll
+      for (int s = 0; s < K0S; ++s) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (8 * s + 8 <= kh16) u = reinterpret_cast<const uint4*>(s16)[s];
+        raw16[s] = u;
+      }
+    } else {
     const float* src = (h == 0) ? (a.xf + (long long)n * a.xf_stride + (long long)pcl * F)
                                 : (a.pe + ((long long)g * P + pcl) * E);
     const int kh = (h == 0) ? KH0 : KH1;
@@ -277,6 +290,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
         raw[2 * s + 1] = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
+    }
   };
   // this workgroup's share of the 32-pixel tiles (all of them unless rcb_siren_desc.pixel_chunks > 1)
   const int t0 = (int)((long long)chunk * ntiles / a.chunks), t1 = (int)((long long)(chunk + 1) * ntiles / a.chunks);
@@ -288,9 +302,15 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
     bf16x8 xin[K0S];
 #pragma unroll
     for (int s = 0; s < K0S; ++s) {
-      const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
-      xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
-      xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
+      if constexpr (IN16) {
+        union { uint4 u; bf16x8 v; } cv;
+        cv.u = raw16[s];
+        xin[s] = cv.v;
+      } else {
+        const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
+        xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
+        xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
+      }
     }
     float yv[16];
     if (MODE != MODE_FWD) {
@@ -389,7 +409,56 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2 * HB; ++ks)
         if (ks < KSO) dzb[ks] = pack8<T>(dz[ks >> 1], ks & 1);
-      // (1) weight gradient: [pixel][feature] images of dZ and of the layer input -> transposed reads
+      // (1) data gradient FIRST (the serial chain of the backward pass; the weight gradient below fills its MFMA latency --
+      // at one wave per SIMD nothing else would)
+      if (l > 0) {
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib) {
+          f32x16 dh;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+          if (l == NL - 1) {
+            dh = Op16<T>::mfma(FA(G::FBO + ib), dzb[0], dh);
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) dh = Op16<T>::mfma(FA(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks), dzb[ks], dh);
+          }
+          // dz of layer l-1, tile ib (written after every use of the old dz tiles: dzb holds their packed copies)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dz[ib][r] = (2 * ib + (r >> 3) < KSH) ? dh[r] * (float)Cs[l - 1][2 * ib + (r >> 3)][r & 7] : 0.f;
+        }
+      } else if (a.dpe != nullptr) {
+        f32x16 dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(FA(G::FBX + ks), dzb[ks], dx);
+        if (valid) {
+          float* dst = a.dpe + ((long long)g * P + p) * E;
+          if (E % 8 == 0 && a.pe_bf16) {
+            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
+#pragma unroll
+            for (int g4 = 0; g4 < E / 8; ++g4) {
+              typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
+                                              (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
+              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
+            }
+          } else if (E % 8 == 0) {
+#pragma unroll
+            for (int g4 = 0; g4 < E / 8; ++g4)
+              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
+                                                                             dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              int e = rho(r, h);
+              if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
+            }
+          }
+        }
+      }
+      // (2) weight gradient: [pixel][feature] images of dZ and of the layer input -> transposed reads
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       {
         union { bf16x8 v; bf16x4 hlf[2]; } u;
@@ -455,54 +524,6 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
           }
         }
       }
-      // (2) data gradient
-      if (l > 0) {
-#pragma unroll
-        for (int ib = 0; ib < HB; ++ib) {
-          f32x16 dh;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-          if (l == NL - 1) {
-            dh = Op16<T>::mfma(FA(G::FBO + ib), dzb[0], dh);
-          } else {
-#pragma unroll
-            for (int ks = 0; ks < KSH; ++ks) dh = Op16<T>::mfma(FA(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks), dzb[ks], dh);
-          }
-          // dz of layer l-1, tile ib (written after every use of the old dz tiles: dzb holds their packed copies)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            dz[ib][r] = (2 * ib + (r >> 3) < KSH) ? dh[r] * (float)Cs[l - 1][2 * ib + (r >> 3)][r & 7] : 0.f;
-        }
-      } else if (a.dpe != nullptr) {
-        f32x16 dx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(FA(G::FBX + ks), dzb[ks], dx);
-        if (valid) {
-          float* dst = a.dpe + ((long long)g * P + p) * E;
-          if (E % 8 == 0 && a.pe_bf16) {
-            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
-#pragma unroll
-            for (int g4 = 0; g4 < E / 8; ++g4) {
-              typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
-                                              (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
-              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
-            }
-          } else if (E % 8 == 0) {
-#pragma unroll
-            for (int g4 = 0; g4 < E / 8; ++g4)
-              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
-                                                                             dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              int e = rho(r, h);
-              if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
-            }
-          }
-        }
-      }
     }
   }
   if (MODE == MODE_FWD) return;
@@ -564,11 +585,11 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
   }
 }
 
-template <typename T, int NH, int F, int E, int C, int W, int MODE>
+template <typename T, int NH, int F, int E, int C, int W, int MODE, bool IN16>
 int launch_one(const SirenArgs& a, hipStream_t st) {
   using G = GeoW<NH, F, E, C, W>;
   static bool attr_done = false;
-  auto kfn = siren_wide_kernel<T, NH, F, E, C, W, MODE>;
+  auto kfn = siren_wide_kernel<T, NH, F, E, C, W, MODE, IN16>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -582,9 +603,11 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
 
 template <typename T, int NH, int F, int E, int C, int W>
 int launch_mode(int mode, const SirenArgs& a, hipStream_t st) {
-  if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, W, MODE_FWD>(a, st);
-  if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, W, MODE_BWD>(a, st);
-  return launch_one<T, NH, F, E, C, W, MODE_LOSS>(a, st);
+  constexpr bool can16 = Op16<T>::IS_BF16 && (E % 8 == 0) && (F % 8 == 0) && E > 0;
+  if (can16 && a.pe_bf16 && a.xf16 != nullptr && mode == MODE_LOSS) return launch_one<T, NH, F, E, C, W, MODE_LOSS, can16>(a, st);
+  if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, W, MODE_FWD, false>(a, st);
+  if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, W, MODE_BWD, false>(a, st);
+  return launch_one<T, NH, F, E, C, W, MODE_LOSS, false>(a, st);
 }
 
 }  // namespace
