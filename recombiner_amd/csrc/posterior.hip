@@ -476,8 +476,12 @@ __device__ __forceinline__ void adam_apply(float& p, float g, float& m, float& v
   const float bc2_sqrt = s.dyn ? s.dyn[1] : s.bc2_sqrt;
   m = add_rn(m, mul_rn(s.w1, sub_rn(g, m)));                    // exp_avg.lerp_(grad, 1-beta1)
   v = add_rn(mul_rn(v, s.beta2), mul_rn(mul_rn(s.w2, g), g));  // mul_(beta2).addcmul_(g, g, 1-beta2)
-  float denom = add_rn(div_rn(sqrtf(v), bc2_sqrt), s.eps);
-  p = add_rn(p, mul_rn(-step_size, div_rn(m, denom)));          // addcdiv_(exp_avg, denom, -step_size)
+  // sqrt: hardware v_sqrt_f32 with one residual step (<= 1 ulp, 0 -> 0); the two divisions by reciprocal + residual
+  // (rcb_common.h); the operation ORDER stays torch's
+  float sq = __builtin_amdgcn_sqrtf(v);
+  if (sq > 0.0f) sq = __builtin_fmaf(__builtin_fmaf(-sq, sq, v), 0.5f * __builtin_amdgcn_rcpf(sq), sq);
+  float denom = add_rn(div_fast(sq, bc2_sqrt), s.eps);
+  p = add_rn(p, mul_rn(-step_size, div_fast(m, denom)));        // addcdiv_(exp_avg, denom, -step_size)
 }
 
 struct PostBwdArgs {
@@ -488,9 +492,9 @@ struct PostBwdArgs {
 // KL part of the gradient and the chain rule through softplus, with explicitly unfused roundings: the generic and the
 // flat kernel must produce the same bits, and the reference computes these with separate torch ops anyway
 __device__ __forceinline__ void kl_grad_add(float loc, float sig, float pl, float sp, float w, float& g_mu, float& g_sig) {
-  const float inv_var_p = 1.0f / mul_rn(sp, sp);
+  const float inv_var_p = div_fast(1.0f, mul_rn(sp, sp));
   g_mu = add_rn(g_mu, mul_rn(w, mul_rn(sub_rn(loc, pl), inv_var_p)));
-  g_sig = add_rn(g_sig, mul_rn(w, sub_rn(mul_rn(sig, inv_var_p), 1.0f / sig)));
+  g_sig = add_rn(g_sig, mul_rn(w, sub_rn(mul_rn(sig, inv_var_p), div_fast(1.0f, sig))));
 }
 
 __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
