@@ -45,6 +45,126 @@ def test_upsample_hip_forward_backward(S, N, stage1_bf16, pe_bf16):
     assert max(errs) < (8e-2 if stage1_bf16 else 6e-2)
 
 
+def _bf(x):
+    """round to bf16, keep fp64"""
+    return x.to(torch.bfloat16).double()
+
+
+def _phase_eval(x, We, b):
+    """`nearest-upsample(2) -> conv3x3(pad 1)` in sub-pixel form, written from the definition: x [B, G, G, Ci] (fp64),
+    We [ty, tx, ci, a, c, co], b [co] -> [B, 2G, 2G, co]; output pixel (2i+a, 2j+c) reads source pixels (i+a+ty-1, j+c+tx-1)"""
+    B, G = x.shape[0], x.shape[1]
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    out = torch.zeros(B, 2 * G, 2 * G, We.shape[-1], dtype=x.dtype, device=x.device)
+    for a in range(2):
+        for c in range(2):
+            acc = 0
+            for ty in range(2):
+                for tx in range(2):
+                    acc = acc + xp[:, a + ty:a + ty + G, c + tx:c + tx + G, :] @ We[ty, tx, :, a, c, :]
+            out[:, a::2, c::2, :] = acc + b
+    return out
+
+
+def _eff23(W):
+    """effective weights of a (x2, 3x3, pad 1) stage from the conv weight [co, ci, 3, 3]: kernel tap k of output phase a lands
+    on source tap t with  a = 0: {0} -> t 0, {1, 2} -> t 1;  a = 1: {0, 1} -> t 0, {2} -> t 1"""
+    R = torch.zeros(2, 2, 3, dtype=W.dtype, device=W.device)      # [a, t, k]
+    R[0, 0, 0] = R[0, 1, 1] = R[0, 1, 2] = 1
+    R[1, 0, 0] = R[1, 0, 1] = R[1, 1, 2] = 1
+    return torch.einsum("ayk,cxl,oikl->yxiaco", R, R, W)
+
+
+def _eff1(W1):
+    """stage 1 (x4, 5x5, pad 2) on the 2 x 2 latent grid as one dense map [2*2*128, 8*8*64]"""
+    M = torch.zeros(8, 2, 5, dtype=W1.dtype, device=W1.device)       # [y, s, k]: tap k of output row y reads source row s
+    for y in range(8):
+        for k in range(5):
+            u = y + k - 2
+            if 0 <= u < 8:
+                M[y, u // 4, k] = 1
+    return torch.einsum("ysk,xtl,oikl->stiyxo", M, M, W1).reshape(512, 4096)
+
+
+def test_phase_conv_kernels_against_rounded_operand_reference():
+    """The hand-written phase-conv kernels (shipped 16-bit mode: bf16 stage 1, bf16 intermediates) against an fp64
+    evaluation of the SAME arithmetic -- operands rounded to bf16 exactly where the kernels round them (inputs, effective
+    weights after the tap sums, z1, the activations a1 / h2, the gradients dz2 / dz1 and the bf16 GEMM results of stage 1)
+    -- so that only the fp32 accumulation order differs: tolerances at rounding level instead of the 2e-2 / 8e-2 a
+    full-precision yardstick needs.  The evaluator itself is tied to the reference: without any rounding it reproduces the
+    oracle's UpsampleNet (nearest-upsample + conv, fp64) to 1e-12, forward and gradients."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_cpu as O
+    torch.manual_seed(11)
+    B = 6
+    net = PM.Upsample(2, [2, 1, 1], [4, 2, 2]).to(DEV)
+    W1, b1, W2, b2, W3, b3 = [p_.detach().double() for p_ in (net.conv1.weight, net.conv1.bias, net.conv2.weight, net.conv2.bias,
+                                                               net.conv3.weight, net.conv3.bias)]
+    lpe = 0.1 * torch.randn(1, B, 2, 2, 128, device=DEV)
+    g16 = (0.01 * torch.randn(B, 1, 1024, 16, device=DEV)).bfloat16()
+    lk = lambda t_: torch.where(t_ > 0, t_, 0.01 * t_)       # noqa: E731
+    dlk = lambda t_: torch.where(t_ > 0, torch.ones_like(t_), torch.full_like(t_, 0.01))      # noqa: E731
+
+    # ---- 1. the evaluator, unrounded, IS the reference's upsampling net ------------------------------------------------
+    W1r, W2r, W3r = (w.clone().requires_grad_(True) for w in (W1, W2, W3))
+    x64 = lpe[0].double().clone().requires_grad_(True)
+    z1 = (x64.reshape(B, 512) @ _eff1(W1r) + b1.repeat(64)).view(B, 8, 8, 64)
+    pe_ev = _phase_eval(lk(_phase_eval(lk(z1), _eff23(W2r), b2)), _eff23(W3r), b3)
+    up = O.UpsampleNet(2, [2, 1, 1], [4, 2, 2])
+    up.weights = [w.cpu().clone().requires_grad_(True) for w in (W1, b1, W2, b2, W3, b3)]
+    xo = lpe[0].double().cpu().clone().requires_grad_(True)
+    pe_or = up(xo.movedim(-1, 1)).movedim(1, -1)
+    assert rel(pe_ev.cpu(), pe_or) < 1e-12
+    ge = torch.autograd.grad(pe_ev, [x64, W1r, W2r, W3r], g16.double().view(B, 32, 32, 16))
+    go_ = torch.autograd.grad(pe_or, [xo, up.weights[0], up.weights[2], up.weights[4]], g16.double().cpu().view(B, 32, 32, 16))
+    for a_, b_ in zip(ge, go_):
+        assert rel(a_.cpu(), b_) < 1e-11
+
+    # ---- 2. the kernels' arithmetic in fp64, rounded where they round ------------------------------------------------------
+    We1, We2, We3 = _eff1(W1), _eff23(W2), _eff23(W3)
+    lpe_r, We1_r = _bf(lpe[0].double().reshape(B, 512)), _bf(We1)
+    z1 = _bf(lpe_r @ We1_r + _bf(b1).repeat(64)).view(B, 8, 8, 64)
+    a1 = _bf(lk(z1))
+    We2_r, We3_r = _bf(We2).requires_grad_(True), _bf(We3).requires_grad_(True)
+    a1g = a1.clone().requires_grad_(True)
+    b2g, b3g = b2.clone().requires_grad_(True), b3.clone().requires_grad_(True)
+    pre2 = _phase_eval(a1g, We2_r, b2g)
+    h2 = _bf(lk(pre2)).detach()
+    h2g = h2.clone().requires_grad_(True)
+    pe_ref = _phase_eval(h2g, We3_r, b3g)
+    # backward, stage by stage
+    dh2, dWe3, db3 = torch.autograd.grad(pe_ref, [h2g, We3_r, b3g], g16.double().view(B, 32, 32, 16))
+    dz2 = _bf(dh2 * dlk(h2))
+    da1, dWe2, db2 = torch.autograd.grad(pre2, [a1g, We2_r, b2g], dz2)
+    dz1 = _bf(da1 * dlk(z1)).reshape(B, 4096)
+    dlpe_ref = _bf(dz1 @ We1_r.t())
+    dWe1 = _bf(lpe_r.t() @ dz1)
+    db1_ref = dz1.view(B, 64, 64).sum((0, 1))
+    W1g, W2g, W3g = (w.clone().requires_grad_(True) for w in (W1, W2, W3))
+    dW1_ref, = torch.autograd.grad(_eff1(W1g), [W1g], dWe1)
+    dW2_ref, = torch.autograd.grad(_eff23(W2g), [W2g], dWe2)
+    dW3_ref, = torch.autograd.grad(_eff23(W3g), [W3g], dWe3)
+
+    # ---- 3. the kernels ----------------------------------------------------------------------------------------------------
+    lpe_k = lpe.clone().requires_grad_(True)
+    params = [net.conv1.weight, net.conv1.bias, net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias]
+    pe32 = upsample_cifar_hip(net, lpe_k, True, False)                       # fp32 pe: the last rounding is not in the way
+    assert rel(pe32.view(B, 32, 32, 16), pe_ref) < 1.5e-3, rel(pe32.view(B, 32, 32, 16), pe_ref)      # (a few z1 / h2 elements land on the other side of a bf16 rounding boundary)
+    pe16 = upsample_cifar_hip(net, lpe_k, True, True)
+    assert rel(pe16.view(B, 32, 32, 16), pe_ref) < 4.5e-3                  # one bf16 ulp of the largest element
+    gk = torch.autograd.grad(pe16, [lpe_k] + params, g16)
+    names = ["dlpe", "dW1", "db1", "dW2", "db2", "dW3", "db3"]
+    refs = [dlpe_ref.view(1, B, 2, 2, 128), dW1_ref, db1_ref, dW2_ref, db2, dW3_ref, db3]
+    # dlpe and dW1 pass through a bf16-output GEMM: one bf16 ulp; the others are fp32 sums of identical products
+    tols = [5e-3, 2e-3, 1e-3, 1e-3, 5e-4, 1.5e-3, 1e-5]        # measured: 1.8e-3 4.6e-4 1.8e-4 2.0e-4 2.7e-5 3.5e-4 5.0e-8
+    errs = [rel(a_, b_) for a_, b_ in zip(gk, refs)]
+    print("phase-conv kernels vs rounded-operand fp64 reference:", " ".join("%s %.1e" % (n_, e_) for n_, e_ in zip(names, errs)))
+    for n_, e_, t_ in zip(names, errs, tols):
+        assert e_ < t_, (n_, e_, t_)
+
+
 def test_phase_form_is_exact_on_gpu():
     torch.manual_seed(1)
     net = PM.Upsample(2, [2, 1, 1], [4, 2, 2]).to(DEV).double()
