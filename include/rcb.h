@@ -398,6 +398,27 @@ int rcb_tile_crop(const void* tiles, void* img, int32_t n, int32_t H, int32_t W,
 int rcb_tile_fold(const void* tiles, void* img, int32_t n, int32_t H, int32_t W, int32_t C, int32_t Ty, int32_t Tx,
                   int32_t T, int32_t off, rcb_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * N1, grids of any dimension (nd = 1 audio / protein, 3 video; 2 is valid too): the `nearest-upsample(2) -> conv(3, pad 1)`
+ * stages of the upsampling net (prior_model.py:52-54 with Conv1d / Conv3d) as direct sub-pixel convolutions on bf16 MFMA,
+ * channel-last bf16 tensors, Cin = 64, Cout = 64 or 16 -- no window matrix.  x [B][g0][g1][g2][64] (axes k >= nd of
+ * size 1), y [B][2 g...][Cout] (active axes doubled).
+ *   rcb_phaseconv_pack : conv weight [Cout][64][3]^nd fp32 -> bf16 MFMA fragments of the pre-summed phase weights for the
+ *                        forward and / or the data-gradient kernel (rcb_phaseconv_pack_uint4(nd, cout, which) 16-byte
+ *                        units each; which 0 = forward, 1 = data gradient; either pointer may be NULL)
+ *   rcb_phaseconv_fwd  : y = bias + sum over the 2^nd source taps of every phase (+ LeakyReLU(0.01) if leaky_out);
+ *                        x holds ACTIVATIONS (post-LeakyReLU: the producer applies it)
+ *   rcb_phaseconv_dgrad: dx = LeakyReLU'(x_act) * (transposed stage applied to dy [B][2 g...][Cout]); x_act = the stored
+ *                        activations of the stage input (sign = derivative; NULL: no factor)
+ * The weight gradient of these stages stays a GEMM over 3^nd-pixel windows (rcb_window_gather) for now.               */
+int64_t rcb_phaseconv_pack_uint4(int32_t nd, int32_t cout, int32_t which);
+int rcb_phaseconv_pack(const float* conv_weight, int32_t nd, int32_t cout, void* fwd_frags, void* dgrad_frags,
+                       rcb_stream_t stream);
+int rcb_phaseconv_fwd(const void* x, const void* fwd_frags, const float* bias, void* y, int32_t B, int32_t g0, int32_t g1,
+                      int32_t g2, int32_t nd, int32_t cout, int32_t leaky_out, rcb_stream_t stream);
+int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, const void* x_act, void* dx, int32_t B, int32_t g0,
+                        int32_t g1, int32_t g2, int32_t nd, int32_t cout, rcb_stream_t stream);
+
 /* 3^d-pixel windows of a channel-last bf16 grid x [B][g0][g1][g2][C] (nd = 1..3 windowed axes, unused trailing axes of size 1,
  * C % 8 == 0): the operand of the one-GEMM-per-stage phase form of the 1-D / 3-D upsampling nets (prior_model.py:23-59 with
  * Conv1d / Conv3d; every phase of the reference's stages reads inside the 3-pixel window around its source pixel).

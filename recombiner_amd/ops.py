@@ -825,6 +825,55 @@ def window_fold(dcols, shape):
     return dx
 
 
+# ---------------------------------------------------------------------------------------------------
+# direct sub-pixel convolutions for grids of any dimension (rcb_phaseconv_*)
+# ---------------------------------------------------------------------------------------------------
+def _pc_geo(shape):
+    nd = len(shape) - 2
+    if nd < 1 or nd > 3 or shape[-1] != 64:
+        raise RcbError("phaseconv: [B, *grid (1-3 axes), 64] expected")
+    return nd, list(shape[1:-1]) + [1] * (3 - nd)
+
+
+def phaseconv_pack(W, want_fwd=True, want_dgrad=True):
+    """conv weight [Cout, 64, 3, ...] (fp32) -> (fwd fragments, dgrad fragments) as uint8 tensors (rcb_phaseconv_pack)"""
+    lib = _lib.load()
+    nd, cout = W.dim() - 2, W.shape[0]
+    if W.shape[1] != 64 or any(k != 3 for k in W.shape[2:]) or cout not in (16, 64):
+        raise RcbError("phaseconv_pack: conv weight [16 | 64, 64, 3, ...] expected")
+    out = []
+    for which, want in ((0, want_fwd), (1, want_dgrad)):
+        n = int(lib.rcb_phaseconv_pack_uint4(nd, cout, which))
+        out.append(torch.empty(n * 16, device=W.device, dtype=torch.uint8) if want else None)
+    check(lib.rcb_phaseconv_pack(ptr(W.detach().contiguous(), f32), nd, cout, ptr(out[0], None, True), ptr(out[1], None, True),
+                                 stream_ptr()), "rcb_phaseconv_pack")
+    return out[0], out[1]
+
+
+def phaseconv_fwd(x, frags, bias, cout, leaky_out):
+    """x [B, *g, 64] bf16 activations -> y [B, *(2 g), cout] bf16 (rcb_phaseconv_fwd)"""
+    if x.dtype != bf16 or not x.is_contiguous():
+        raise RcbError("phaseconv_fwd: contiguous bf16 input expected")
+    nd, g = _pc_geo(x.shape)
+    y = torch.empty([x.shape[0]] + [2 * v for v in x.shape[1:-1]] + [cout], device=x.device, dtype=bf16)
+    check(_lib.load().rcb_phaseconv_fwd(ptr(x), ptr(frags), ptr(bias.detach().contiguous(), f32), ptr(y), x.shape[0], g[0], g[1], g[2],
+                                        nd, cout, int(bool(leaky_out)), stream_ptr()), "rcb_phaseconv_fwd")
+    return y
+
+
+def phaseconv_dgrad(dy, frags, x_act):
+    """dy [B, *(2 g), cout] bf16, x_act [B, *g, 64] bf16 (stage input activations) -> dx [B, *g, 64] bf16, times LeakyReLU'(x_act)"""
+    if dy.dtype != bf16 or not dy.is_contiguous() or x_act.dtype != bf16 or not x_act.is_contiguous():
+        raise RcbError("phaseconv_dgrad: contiguous bf16 tensors expected")
+    nd, g = _pc_geo(x_act.shape)
+    if list(dy.shape[1:-1]) != [2 * v for v in x_act.shape[1:-1]] or dy.shape[0] != x_act.shape[0]:
+        raise RcbError("phaseconv_dgrad: dy grid must be twice the input grid")
+    dx = torch.empty_like(x_act)
+    check(_lib.load().rcb_phaseconv_dgrad(ptr(dy), ptr(frags), ptr(x_act), ptr(dx), x_act.shape[0], g[0], g[1], g[2], nd, dy.shape[-1],
+                                          stream_ptr()), "rcb_phaseconv_dgrad")
+    return dx
+
+
 UPCONV_PACK_UINT4 = 22528
 
 

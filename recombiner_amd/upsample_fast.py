@@ -195,6 +195,75 @@ class _WindowGemmFn(torch.autograd.Function):
         return dx, dW, db
 
 
+def _unshuffle(t, nd):
+    """[B, 2 g..., C] -> [B * prod(g), 2^nd * C]: the phases of every source pixel side by side (axis 0 most significant),
+    i.e. the column order of PhaseStage.big_weight"""
+    B, C = t.shape[0], t.shape[-1]
+    g = [v // 2 for v in t.shape[1:-1]]
+    v = t.view([B] + [u for k in range(nd) for u in (g[k], 2)] + [C])
+    perm = [0] + [1 + 2 * k for k in range(nd)] + [2 + 2 * k for k in range(nd)] + [1 + 2 * nd]
+    return v.permute(perm).reshape(B * int(np.prod(g)), (2 ** nd) * C)
+
+
+def _window_wgrad(x_act, dy, stage, W):
+    """weight and bias gradient of one (x2, 3, pad 1) stage from its input activations and the gradient of its linear output:
+    dWbig = cols(x)^T @ dy over 3^d-pixel windows (rcb_window_gather; the contraction over all grid positions split into
+    batched chunks so that the library GEMM fills the chip), mapped back to the conv weight through the transpose of
+    PhaseStage.big_weight"""
+    from . import ops
+    nd = x_act.dim() - 2
+    cols = ops.window_gather(x_act)
+    dyu = _unshuffle(dy, nd)
+    rows, parts = cols.shape[0], 1
+    while parts < 64 and rows % (2 * parts) == 0 and rows // (2 * parts) >= 2048 and \
+            parts * (cols.shape[1] // 64 + 1) * (dyu.shape[1] // 64 + 1) < 512:
+        parts *= 2
+    if parts > 1:
+        dWbig = torch.bmm(cols.view(parts, rows // parts, -1).transpose(1, 2), dyu.view(parts, rows // parts, -1),
+                          out_dtype=torch.float32).sum(0)
+    else:
+        dWbig = torch.mm(cols.t(), dyu, out_dtype=torch.float32)
+    with torch.enable_grad():
+        Wd = W.detach().requires_grad_(True)
+        (dW,) = torch.autograd.grad(stage.big_weight(Wd), [Wd], dWbig)
+    db = dy.reshape(-1, dy.shape[-1]).sum(0, dtype=torch.float32)
+    return dW, db
+
+
+class _PhaseConv23Fn(torch.autograd.Function):
+    """stages 2 and 3 of the upsampling net on a grid of any dimension through the direct sub-pixel kernels
+    (rcb_phaseconv_fwd / _dgrad): z1 [B, *g, 64] (bf16 PRE-activation of stage 1) -> pe [B, *(4 g), 16] (bf16, linear).
+    Activations are stored post-LeakyReLU (x1, h2); the data-gradient kernels multiply by LeakyReLU' = sign of the stored
+    value.  Weight gradients: GEMMs over 3^d-pixel windows of the stored activations (the direct weight-gradient kernel is
+    the open item)."""
+
+    @staticmethod
+    def forward(ctx, z1, W2, b2, W3, b3, stage2, stage3):
+        from . import ops
+        x1 = F.leaky_relu(z1, 0.01).contiguous()
+        f2, d2 = ops.phaseconv_pack(W2)
+        f3, d3 = ops.phaseconv_pack(W3)
+        h2 = ops.phaseconv_fwd(x1, f2, b2, 64, True)
+        pe = ops.phaseconv_fwd(h2, f3, b3, 16, False)
+        ctx.save_for_backward(x1, h2, d2, d3, W2, W3)
+        ctx.stages = (stage2, stage3)
+        return pe
+
+    @staticmethod
+    def backward(ctx, dpe):
+        from . import ops
+        x1, h2, d2, d3, W2, W3 = ctx.saved_tensors
+        stage2, stage3 = ctx.stages
+        dpe = dpe.to(torch.bfloat16).contiguous()
+        dh2 = ops.phaseconv_dgrad(dpe, d3, h2)                   # gradient of stage 2's PRE-activation (LeakyReLU' inside)
+        dz1 = ops.phaseconv_dgrad(dh2, d2, x1) if ctx.needs_input_grad[0] else None
+        dW2 = db2 = dW3 = db3 = None
+        if any(ctx.needs_input_grad[1:5]):
+            dW3, db3 = _window_wgrad(h2, dpe, stage3, W3)
+            dW2, db2 = _window_wgrad(x1, dh2, stage2, W2)
+        return dz1, dW2, db2, dW3, db3, None, None
+
+
 class UpsampleFast(torch.nn.Module):
     """Drop-in evaluation of an `Upsample` module (same parameters, shared storage) in phase form.
     Input/outputs are channel-FIRST like the reference module so it can replace it anywhere."""
@@ -213,10 +282,22 @@ class UpsampleFast(torch.nn.Module):
                 if any(shift[a] > shift[a + 1] for a in range(f - 1)):
                     raise ValueError("unsupported upsample/conv geometry")
         self.window_gemm = True      # one GEMM per stage over 3^d-pixel windows (False: one GEMM per window-shift group)
+        self.direct = True           # stages 2 and 3 through the direct sub-pixel kernels (rcb_phaseconv_*) where they apply
         self.gemm_dtype = None       # operand / activation type of the window GEMMs (None: the input's)
+
+    def _direct_ok(self, x):
+        """stages 2 and 3 are (x2, 3, pad 1) with 64 -> 64 -> 16 channels (every reference net) and the tensors are bf16 GPU"""
+        n = self.net
+        return (self.direct and x.is_cuda and self.gemm_dtype == torch.bfloat16 and all(f == 2 for st in self.stages[1:] for f in st.f)
+                and all(st.k == 3 and st.pad == 1 for st in self.stages[1:]) and n.conv2.weight.shape[:2] == (64, 64)
+                and n.conv3.weight.shape[:2] == (16, 64))
 
     def forward_channel_last(self, x):
         n = self.net
+        if self.window_gemm and self.stages[0].window3() and self._direct_ok(x):
+            z1 = self.stages[0].forward_gemm(x, n.conv1.weight, n.conv1.bias, torch.bfloat16)
+            return _PhaseConv23Fn.apply(z1.contiguous(), n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias,
+                                        self.stages[1], self.stages[2])
         if self.window_gemm and all(st.window3() for st in self.stages):
             dt = self.gemm_dtype
             x = F.leaky_relu(self.stages[0].forward_gemm(x, n.conv1.weight, n.conv1.bias, dt), 0.01)

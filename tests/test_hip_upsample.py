@@ -410,3 +410,45 @@ def test_window_gather_and_fold_kernels(shape):
         ops.window_gather(x.float())
     with pytest.raises(ops.RcbError):
         ops.window_fold(d[:-1], shape)
+
+
+# ---------------------------------------------------------------------------------------------------
+# direct sub-pixel convolutions for 1-D / 3-D (and 2-D) grids: rcb_phaseconv_*
+# ---------------------------------------------------------------------------------------------------
+def _stage_ref(x, W, b, nd, leaky):
+    """the reference's stage, channel-last: nearest-upsample(2) -> conv(3, pad 1) (-> LeakyReLU), fp64"""
+    import torch.nn.functional as F
+    conv = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[nd]
+    y = conv(F.interpolate(x.movedim(-1, 1), scale_factor=2, mode="nearest"), W, b, padding=1).movedim(1, -1)
+    return F.leaky_relu(y, 0.01) if leaky else y
+
+
+@pytest.mark.parametrize("shape,cout,leaky", [((3, 70), 64, True), ((2, 45), 16, False), ((2, 5, 33), 64, True), ((2, 3, 4, 40), 64, True),
+                                              ((1, 2, 3, 32), 16, False), ((2, 6, 32, 32), 64, True)])
+def test_phaseconv_forward_and_data_gradient(shape, cout, leaky):
+    """rcb_phaseconv_fwd / _dgrad on 1-D, 2-D and 3-D grids (ragged last tiles, borders on every axis) against the stage
+    as the reference defines it (nearest-upsample + ConvNd, fp64) evaluated on the same bf16-rounded operands: what differs
+    is the bf16 rounding of the pre-summed phase weights (<= 2^-9 relative per weight) and the fp32 accumulation order."""
+    from recombiner_amd import ops
+    torch.manual_seed(sum(shape) + cout)
+    nd = len(shape) - 1
+    B, g = shape[0], list(shape[1:])
+    W = (torch.randn(cout, 64, *([3] * nd), device=DEV) * (0.5 / (64 * 3 ** nd) ** 0.5))
+    b = torch.randn(cout, device=DEV) * 0.1
+    x = torch.nn.functional.leaky_relu(torch.randn(B, *g, 64, device=DEV), 0.01).bfloat16()      # an activation tensor
+    ff, fd = ops.phaseconv_pack(W)
+    y = ops.phaseconv_fwd(x, ff, b, cout, leaky)
+    assert list(y.shape) == [B] + [2 * v for v in g] + [cout]
+    x64 = x.double().requires_grad_(True)
+    ref = _stage_ref(x64, W.double(), b.double(), nd, leaky)
+    e_fwd = rel(y, ref)
+    assert e_fwd < 6e-3, e_fwd                 # bf16 output + bf16 effective weights
+    # data gradient of the linear part, times LeakyReLU'(stage input): what the kernel returns for upstream dy
+    dy = (torch.randn_like(y.float()) * 0.1).bfloat16()
+    lin = _stage_ref(x64, W.double(), b.double(), nd, False)
+    gx, = torch.autograd.grad(lin, [x64], dy.double())
+    want = gx * torch.where(x.double() > 0, 1.0, 0.01)
+    dx = ops.phaseconv_dgrad(dy, fd, x)
+    e_bwd = rel(dx, want)
+    assert e_bwd < 8e-3, e_bwd
+    print("phaseconv %s cout %d: fwd %.1e dgrad %.1e" % (shape, cout, e_fwd, e_bwd))
