@@ -125,13 +125,21 @@ __global__ void pc_pack_dgrad_kernel(const float* __restrict__ W, int cout, uint
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------------
+// One workgroup = 8 waves = all 2^ND phases of TPB = 8 / 2^ND consecutive tiles of one row (blockIdx.y = 32-channel output
+// block).  The 3^(ND-1) source rows the phases share -- (32 TPB + 2) pixels each, one pixel of halo -- are staged ONCE in
+// LDS with coalesced 16-byte loads (8 lanes per pixel); the B fragments (16 bytes of one shifted pixel per lane) are then
+// ds_read_b128 from an image whose 16-byte chunk index is XORed with (pixel >> 1) & 7: conflict-free for the 16-lane groups
+// of the instruction.  (Read straight from global memory the same fragments cost one cache-line lookup per lane: the first
+// version of this kernel was bound by exactly that, at 5x the time.)
 template <int ND, int COUT, int ACT>
-__global__ void __launch_bounds__(256) pc_fwd_kernel(PcArgs p) {
-  constexpr int NP = 1 << ND, MB = (COUT + 31) / 32, NROLE = NP * MB;
+__global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
+  constexpr int NP = 1 << ND, MB = (COUT + 31) / 32, TPB = 8 / NP;
+  constexpr int NROW = ND == 1 ? 1 : (ND == 2 ? 3 : 9), PW = 32 * TPB + 2, NCH = NROW * PW * 8, NIT = (NCH + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+  uint4* img = reinterpret_cast<uint4*>(pc_smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
-  const int role = blockIdx.y * 4 + wave;
-  if (role >= NROLE) return;
-  const int a = role / MB, mb = role % MB;
+  const int a = wave % NP, tsub = wave / NP, mb = blockIdx.y;
+  const int role = a * MB + mb;
   bf16x8 wf[NP][4];
 #pragma unroll
   for (int t = 0; t < NP; ++t)
@@ -149,43 +157,80 @@ __global__ void __launch_bounds__(256) pc_fwd_kernel(PcArgs p) {
   }
   const int g[3] = {p.g0, p.g1, p.g2};
   const int gl = g[ND - 1];
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    int rest = tile / p.tiles_per_row;
-    const int ts = tile - rest * p.tiles_per_row;
-    int idx[3] = {0, 0, 0};
-    idx[ND - 1] = 32 * ts + q;
+  const int groups_per_row = (p.tiles_per_row + TPB - 1) / TPB;
+  const int n_groups = (p.n_tiles / p.tiles_per_row) * groups_per_row;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    int rest = grp / groups_per_row;
+    const int tg = grp - rest * groups_per_row;
+    int lead[3] = {0, 0, 0};
 #pragma unroll
     for (int ax = ND - 2; ax >= 0; --ax) {
-      idx[ax] = rest % g[ax];
+      lead[ax] = rest % g[ax];
       rest /= g[ax];
     }
     const int b = rest;
-    const bool valid = idx[ND - 1] < gl;
+    const int l0 = 32 * TPB * tg;                 // first pixel of the group along the last active axis
+    // ---- stage the shared source rows (all loads first, then the LDS stores) ------------------------------------------
+    uint4 stg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < NCH) {
+        const int c = e & 7, pp = (e >> 3) % PW, r = (e >> 3) / PW;
+        bool inb = true;
+        long long off = b;
+        if (ND == 3) {
+          const int s0 = lead[0] + r / 3 - 1, s1 = lead[1] + r % 3 - 1;
+          inb = s0 >= 0 && s0 < g[0] && s1 >= 0 && s1 < g[1];
+          off = (off * g[0] + s0) * g[1] + s1;
+        } else if (ND == 2) {
+          const int s0 = lead[0] + r - 1;
+          inb = s0 >= 0 && s0 < g[0];
+          off = off * g[0] + s0;
+        }
+        const int sl = l0 - 1 + pp;
+        inb = inb && sl >= 0 && sl < gl;
+        if (inb) v = reinterpret_cast<const uint4*>(p.x + (off * gl + sl) * CIN)[c];
+      }
+      stg[it] = v;
+    }
+    __syncthreads();                               // every wave is done reading the previous group's image
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      if (e < NCH) {
+        const int c = e & 7, pix = e >> 3, pp = pix % PW;
+        img[pix * 8 + (c ^ ((pp >> 1) & 7))] = stg[it];
+      }
+    }
+    __syncthreads();
+    // ---- this wave's phase of its tile -----------------------------------------------------------------------------------
+    const int ts = tg * TPB + tsub;
+    if (ts >= p.tiles_per_row) continue;           // (no barrier below this point inside the iteration)
+    const int il = 32 * ts + q;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bv[r];
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
-      bool inb = true;
-      long long off = b;
+      int r = 0;
+      if (ND == 3) r = (((a >> 2) & 1) + ((t >> 2) & 1)) * 3 + (((a >> 1) & 1) + ((t >> 1) & 1));
+      if (ND == 2) r = ((a >> 1) & 1) + ((t >> 1) & 1);
+      const int pp = 32 * tsub + q + (a & 1) + (t & 1);
+      const uint4* src = img + (r * PW + pp) * 8;
+      const int sw = (pp >> 1) & 7;
+      Frag f[4];
 #pragma unroll
-      for (int ax = 0; ax < ND; ++ax) {
-        const int s = idx[ax] + ((a >> (ND - 1 - ax)) & 1) + ((t >> (ND - 1 - ax)) & 1) - 1;
-        inb = inb && s >= 0 && s < g[ax];
-        off = off * g[ax] + s;
-      }
-      const uint4* src = reinterpret_cast<const uint4*>(p.x + off * CIN + 8 * h);
+      for (int c = 0; c < 4; ++c) f[c].u = src[(2 * c + h) ^ sw];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        Frag f;
-        f.u = inb ? src[2 * c] : make_uint4(0, 0, 0, 0);
-        acc = mfma16(wf[t][c], f.v, acc);
-      }
+      for (int c = 0; c < 4; ++c) acc = mfma16(wf[t][c], f[c].v, acc);
     }
-    if (!valid) continue;
+    if (il >= gl) continue;
     long long oo = b;
 #pragma unroll
-    for (int ax = 0; ax < ND; ++ax) oo = oo * (2 * g[ax]) + 2 * idx[ax] + ((a >> (ND - 1 - ax)) & 1);
+    for (int ax = 0; ax < ND - 1; ++ax) oo = oo * (2 * g[ax]) + 2 * lead[ax] + ((a >> (ND - 1 - ax)) & 1);
+    oo = oo * (2 * gl) + 2 * il + (a & 1);
     __bf16* dst = p.y + oo * COUT + 32 * mb + 4 * h;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -204,65 +249,152 @@ __global__ void __launch_bounds__(256) pc_fwd_kernel(PcArgs p) {
 }
 
 // ---- data gradient -------------------------------------------------------------------------------------------------------
+// One workgroup = 4 waves = four consecutive tiles (in row-major tile order: rows may be as short as one tile) x both
+// 32-channel input blocks; wave (mb, pair) owns two tiles, so every streamed weight fragment (the 4^ND x COUT/16 fragments
+// of a block fit neither in registers nor, in 3-D at COUT = 64, in LDS) feeds two MFMAs; the fragments of the next pass
+// are requested before the MFMAs of the current one.  The upstream gradient is staged through LDS per tile as one dy row
+// segment (66 pixels: 2 x 32 + 2) and one 16-channel block at a time, double-buffered: coalesced 16-byte loads in, and the
+// B fragments (pixel 2 j + u of the segment, stride-2 over the lanes) out by ds_read_b128 from an image whose chunk index
+// is XORed with (pixel >> 3) & 3 -- conflict-free for the stride-2 pattern (checked exhaustively off line).
 template <int ND, int COUT>
 __global__ void __launch_bounds__(256) pc_dgrad_kernel(PcArgs p) {
-  constexpr int NU = 1 << (2 * ND), CB = COUT / 16;
+  constexpr int NU = 1 << (2 * ND), CB = COUT / 16, NLEAD = 1 << (2 * (ND - 1)), PWD = 66, TCH = 136, NCHK = 4 * TCH;
+  constexpr int NIT = (4 * PWD * 2 + 255) / 256;
+  __shared__ uint4 img[2][NCHK];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
-  const int mb = wave & 1;
+  const int mb = wave & 1, pair = wave >> 1;
   const int g[3] = {p.g0, p.g1, p.g2};
   const int gl = g[ND - 1];
   const uint4* __restrict__ fr = p.frags + (long long)mb * NU * CB * 64 + lane;
-  for (int tile = 2 * blockIdx.x + (wave >> 1); tile < p.n_tiles; tile += 2 * gridDim.x) {
-    int rest = tile / p.tiles_per_row;
-    const int ts = tile - rest * p.tiles_per_row;
-    int idx[3] = {0, 0, 0};
-    idx[ND - 1] = 32 * ts + q;
+  const int n_groups = (p.n_tiles + 3) / 4;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // staging role of this thread: chunk e -> (tile slot, pixel of its segment, 16-byte half)
+    int s_slot[NIT], s_pp[NIT], s_c[NIT];
+    long long s_base[NIT];
+    int s_lead0[NIT], s_lead1[NIT], s_j0[NIT];
+    bool s_on[NIT];
 #pragma unroll
-    for (int ax = ND - 2; ax >= 0; --ax) {
-      idx[ax] = rest % g[ax];
-      rest /= g[ax];
+    for (int it = 0; it < NIT; ++it) {
+      const int e = threadIdx.x + 256 * it;
+      s_on[it] = e < 4 * PWD * 2;
+      const int ee = s_on[it] ? e : 0;
+      s_slot[it] = ee / (PWD * 2);
+      const int rem = ee - s_slot[it] * (PWD * 2);
+      s_pp[it] = rem >> 1;
+      s_c[it] = rem & 1;
+      const int tile = grp * 4 + s_slot[it];
+      s_on[it] = s_on[it] && tile < p.n_tiles;
+      int rest = min(tile, p.n_tiles - 1) / p.tiles_per_row;
+      s_j0[it] = 32 * (min(tile, p.n_tiles - 1) - rest * p.tiles_per_row);
+      int l0 = 0, l1 = 0;
+      if (ND == 3) {
+        l1 = rest % g[1];
+        rest /= g[1];
+        l0 = rest % g[0];
+        rest /= g[0];
+      } else if (ND == 2) {
+        l0 = rest % g[0];
+        rest /= g[0];
+      }
+      s_lead0[it] = l0;
+      s_lead1[it] = l1;
+      s_base[it] = rest;                            // batch index
     }
-    const int b = rest;
-    const bool valid = idx[ND - 1] < gl;
-    f32x16 acc;
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int u = 0; u < NU; ++u) {
-      bool inb = true;
-      long long off = b;
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int ax = 0; ax < ND; ++ax) {
-        const int s = 2 * idx[ax] + ((u >> (2 * (ND - 1 - ax))) & 3) - 1;
-        inb = inb && s >= 0 && s < 2 * g[ax];
-        off = off * (2 * g[ax]) + s;
+      for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    uint4 stg[NIT];
+    auto fetch = [&](int pass) {
+      const int cb = pass / NLEAD, ld = pass % NLEAD;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        bool inb = s_on[it];
+        long long off = s_base[it];
+        if (ND == 3) {
+          const int s0 = 2 * s_lead0[it] + ((ld >> 2) & 3) - 1, s1 = 2 * s_lead1[it] + (ld & 3) - 1;
+          inb = inb && s0 >= 0 && s0 < 2 * g[0] && s1 >= 0 && s1 < 2 * g[1];
+          off = (off * (2 * g[0]) + s0) * (2 * g[1]) + s1;
+        } else if (ND == 2) {
+          const int s0 = 2 * s_lead0[it] + (ld & 3) - 1;
+          inb = inb && s0 >= 0 && s0 < 2 * g[0];
+          off = off * (2 * g[0]) + s0;
+        }
+        const int sl = 2 * s_j0[it] - 1 + s_pp[it];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (inb && sl >= 0 && sl < 2 * gl) v = reinterpret_cast<const uint4*>(p.x + (off * (2 * gl) + sl) * COUT + 16 * cb)[s_c[it]];
+        stg[it] = v;
       }
-      const uint4* src = reinterpret_cast<const uint4*>(p.x + off * COUT + 8 * h);
+    };
+    auto stash = [&](int buf) {
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        Frag f, w;
-        f.u = inb ? src[2 * cb] : make_uint4(0, 0, 0, 0);
-        w.u = fr[(u * CB + cb) * 64];
-        acc = mfma16(w.v, f.v, acc);
+      for (int it = 0; it < NIT; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        if (e < 4 * PWD * 2) {
+          const int L = s_pp[it] * 2 + s_c[it];
+          img[buf][s_slot[it] * TCH + (L ^ ((s_pp[it] >> 3) & 3))] = stg[it];
+        }
+      }
+    };
+    constexpr int NPASS = CB * NLEAD;
+    Frag wnext[4];
+    auto fetch_w = [&](int pass) {
+      const int cb = pass / NLEAD, ld = pass % NLEAD;
+#pragma unroll
+      for (int dl = 0; dl < 4; ++dl) wnext[dl].u = fr[((ld * 4 + dl) * CB + cb) * 64];
+    };
+    fetch(0);
+    fetch_w(0);
+    __syncthreads();                               // the previous group's last pass is done with both buffers
+    stash(0);
+    __syncthreads();
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int buf = pass & 1;
+      Frag w[4];
+#pragma unroll
+      for (int dl = 0; dl < 4; ++dl) w[dl] = wnext[dl];
+      if (pass + 1 < NPASS) {
+        fetch(pass + 1);
+        fetch_w(pass + 1);
+      }
+#pragma unroll
+      for (int dl = 0; dl < 4; ++dl) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pp = 2 * q + dl;
+          Frag f;
+          f.u = img[buf][(2 * pair + k) * TCH + ((pp * 2 + h) ^ ((pp >> 3) & 3))];
+          acc[k] = mfma16(w[dl].v, f.v, acc[k]);
+        }
+      }
+      if (pass + 1 < NPASS) {
+        stash(buf ^ 1);                            // (buffer buf ^ 1 was last read in pass - 1: every wave passed the barrier since)
+        __syncthreads();
       }
     }
-    if (!valid) continue;
-    long long oo = b;
 #pragma unroll
-    for (int ax = 0; ax < ND; ++ax) oo = oo * g[ax] + idx[ax];
-    const long long e0 = oo * CIN + 32 * mb + 4 * h;
+    for (int k = 0; k < 2; ++k) {
+      const int tile = grp * 4 + 2 * pair + k;
+      if (tile >= p.n_tiles) continue;
+      int rest = tile / p.tiles_per_row;
+      const int il = 32 * (tile - rest * p.tiles_per_row) + q;
+      if (il >= gl) continue;
+      // rest = flattened (batch, leading indices): exactly the row index of dx
+      const long long e0 = ((long long)rest * gl + il) * CIN + 32 * mb + 4 * h;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      bf16x4 ob;
-      bf16x4 xa;
-      if (p.xact) xa = *reinterpret_cast<const bf16x4*>(p.xact + e0 + 8 * g4);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 ob;
+        bf16x4 xa;
+        if (p.xact) xa = *reinterpret_cast<const bf16x4*>(p.xact + e0 + 8 * g4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float v = acc[4 * g4 + k];
-        if (p.xact) v *= ((float)xa[k] > 0.f ? 1.0f : SLOPE);
-        ob[k] = (__bf16)v;
+        for (int kk = 0; kk < 4; ++kk) {
+          float v = acc[k][4 * g4 + kk];
+          if (p.xact) v *= ((float)xa[kk] > 0.f ? 1.0f : SLOPE);
+          ob[kk] = (__bf16)v;
+        }
+        *reinterpret_cast<bf16x4*>(p.y + e0 + 8 * g4) = ob;
       }
-      *reinterpret_cast<bf16x4*>(p.y + e0 + 8 * g4) = ob;
     }
   }
 }
@@ -300,8 +432,8 @@ extern "C" int rcb_phaseconv_pack(const float* conv_weight, int32_t nd, int32_t 
   hipStream_t s = (hipStream_t)stream;
 #define RCB_PACK(NDv)                                                                                            \
   if (nd == NDv) {                                                                                               \
-    if (fwd_frags) pc_pack_fwd_kernel<NDv><<<64, 256, 0, s>>>(conv_weight, cout, static_cast<uint4*>(fwd_frags));       \
-    if (dgrad_frags) pc_pack_dgrad_kernel<NDv><<<64, 256, 0, s>>>(conv_weight, cout, static_cast<uint4*>(dgrad_frags)); \
+    if (fwd_frags) pc_pack_fwd_kernel<NDv><<<cdiv(rcb_phaseconv_pack_uint4(NDv, cout, 0), 256), 256, 0, s>>>(conv_weight, cout, static_cast<uint4*>(fwd_frags));       \
+    if (dgrad_frags) pc_pack_dgrad_kernel<NDv><<<cdiv(rcb_phaseconv_pack_uint4(NDv, cout, 1), 256), 256, 0, s>>>(conv_weight, cout, static_cast<uint4*>(dgrad_frags)); \
   }
   RCB_PACK(1)
   RCB_PACK(2)
@@ -322,14 +454,16 @@ extern "C" int rcb_phaseconv_fwd(const void* x, const void* fwd_frags, const flo
   p.frags = static_cast<const uint4*>(fwd_frags);
   p.bias = bias;
   p.y = static_cast<__bf16*>(y);
-  const int nrole = (1 << nd) * ((cout + 31) / 32);
-  int gx = p.n_tiles < 2048 ? p.n_tiles : 2048;      // waves keep their fragments across the tiles they walk
-  dim3 grid(gx, (nrole + 3) / 4);
+  const int tpb = 8 >> nd;                            // tiles per workgroup (8 waves = all phases of tpb tiles of one row)
+  const long long groups = (long long)(p.n_tiles / p.tiles_per_row) * ((p.tiles_per_row + tpb - 1) / tpb);
+  int gx = (int)(groups < 1024 ? groups : 1024);      // waves keep their fragments across the groups they walk
+  dim3 grid(gx, (cout + 31) / 32);
+  const size_t lds = (size_t)(nd == 1 ? 1 : (nd == 2 ? 3 : 9)) * (32 * tpb + 2) * 128;
   hipStream_t s = (hipStream_t)stream;
 #define RCB_FWD(NDv, Cv)                                                                  \
   if (nd == NDv && cout == Cv) {                                                          \
-    if (leaky_out) pc_fwd_kernel<NDv, Cv, 1><<<grid, 256, 0, s>>>(p);                     \
-    else pc_fwd_kernel<NDv, Cv, 0><<<grid, 256, 0, s>>>(p);                               \
+    if (leaky_out) pc_fwd_kernel<NDv, Cv, 1><<<grid, 512, lds, s>>>(p);                   \
+    else pc_fwd_kernel<NDv, Cv, 0><<<grid, 512, lds, s>>>(p);                             \
   }
   RCB_FWD(1, 64) RCB_FWD(1, 16) RCB_FWD(2, 64) RCB_FWD(2, 16) RCB_FWD(3, 64) RCB_FWD(3, 16)
 #undef RCB_FWD
@@ -348,8 +482,8 @@ extern "C" int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, cons
   p.frags = static_cast<const uint4*>(dgrad_frags);
   p.xact = static_cast<const __bf16*>(x_act);
   p.y = static_cast<__bf16*>(dx);
-  int gx = (p.n_tiles + 1) / 2;
-  if (gx > 4096) gx = 4096;
+  const int groups = (p.n_tiles + 3) / 4;             // four consecutive tiles per workgroup
+  int gx = groups < 4096 ? groups : 4096;
   hipStream_t s = (hipStream_t)stream;
 #define RCB_DG(NDv, Cv) \
   if (nd == NDv && cout == Cv) pc_dgrad_kernel<NDv, Cv><<<gx, 256, 0, s>>>(p);
