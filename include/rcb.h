@@ -410,7 +410,10 @@ int rcb_tile_fold(const void* tiles, void* img, int32_t n, int32_t H, int32_t W,
  *                        x holds ACTIVATIONS (post-LeakyReLU: the producer applies it)
  *   rcb_phaseconv_dgrad: dx = LeakyReLU'(x_act) * (transposed stage applied to dy [B][2 g...][Cout]); x_act = the stored
  *                        activations of the stage input (sign = derivative; NULL: no factor)
- * The weight gradient of these stages stays a GEMM over 3^nd-pixel windows (rcb_window_gather) for now.               */
+ *   rcb_phaseconv_wgrad: dW [Cout][64][3]^nd and dbias [Cout] (fp32) from the stage input activations and the gradient of
+ *                        its linear output: contraction over all positions with both MFMA operands read transposed from
+ *                        LDS images; per-workgroup fp32 slabs added in a fixed order (no atomics); `workspace`:
+ *                        rcb_phaseconv_wgrad_workspace(nd, cout) floats, caller-allocated                              */
 int64_t rcb_phaseconv_pack_uint4(int32_t nd, int32_t cout, int32_t which);
 int rcb_phaseconv_pack(const float* conv_weight, int32_t nd, int32_t cout, void* fwd_frags, void* dgrad_frags,
                        rcb_stream_t stream);
@@ -418,6 +421,9 @@ int rcb_phaseconv_fwd(const void* x, const void* fwd_frags, const float* bias, v
                       int32_t g2, int32_t nd, int32_t cout, int32_t leaky_out, rcb_stream_t stream);
 int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, const void* x_act, void* dx, int32_t B, int32_t g0,
                         int32_t g1, int32_t g2, int32_t nd, int32_t cout, rcb_stream_t stream);
+int64_t rcb_phaseconv_wgrad_workspace(int32_t nd, int32_t cout);
+int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW, float* dbias, float* workspace, int64_t workspace_floats,
+                        int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t nd, int32_t cout, rcb_stream_t stream);
 
 /* 3^d-pixel windows of a channel-last bf16 grid x [B][g0][g1][g2][C] (nd = 1..3 windowed axes, unused trailing axes of size 1,
  * C % 8 == 0): the operand of the one-GEMM-per-stage phase form of the 1-D / 3-D upsampling nets (prior_model.py:23-59 with

@@ -399,6 +399,244 @@ __global__ void __launch_bounds__(256) pc_dgrad_kernel(PcArgs p) {
   }
 }
 
+// ---- weight gradient -------------------------------------------------------------------------------------------------------
+//   dWeff[a][t][ci][co] = sum_{b, i} x[b, i + a + t - 1, ci] dy[b, 2 i + a, co]        dbias[co] = sum dy
+// The contraction runs over positions, i.e. over the lanes' axis of both operands: the [pixel][channel] images of a tile
+// are staged in LDS (64-byte rows: 32 channels of this workgroup's block) and both MFMA operands are read TRANSPOSED with
+// ds_read_b64_tr_b16 (four consecutive pixels x 64 bytes per 32-lane group: every bank once, no swizzle needed).
+// grid.y = (32-channel input block mb) x (32-column output block nb); a workgroup = 8 waves walks its share of the tiles:
+//   3-D: wave = phase a, its 8 taps;   2-D: wave = (phase, tap pair);   1-D: waves 0..3 = (phase, tap)
+// so a wave reads its dy operand once per k-step and one shifted x operand per tap.  Per tile: the 3^(ND-1) x 34-pixel
+// source rows and the 2^ND phase images of dy.  Sums stay in registers across the walk and leave as one fp32 slab per
+// workgroup; pc_wgrad_finish_kernel adds the slabs in a fixed order (no atomics: bitwise reproducible) and folds the phase
+// weights back onto the conv taps (transpose of the tap sums of the forward pass).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_read_plain(const __bf16* img, int ks, int lane) {
+  const int h = lane >> 5, fb = (lane >> 4) & 1, i = lane & 15, q4 = i >> 2, p4 = i & 3;
+  union { s16x4 v[2]; bf16x8 b; } u;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const __bf16* ptr = img + (16 * ks + 8 * h + 4 * w + q4) * 32 + 16 * fb + 4 * p4;
+    u.v[w] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  }
+  return u.b;
+}
+
+struct WgArgs {
+  const __bf16* x;    // [B][g...][64] stage input activations
+  const __bf16* dy;   // [B][2g...][COUT]
+  float* partial;     // [gridDim.x][gridDim.y][combos][32][32] (+ [gridDim.x][COUT] bias partials behind)
+  float* bias_part;
+  int B, g0, g1, g2, tiles_per_row, n_tiles;
+};
+
+template <int ND, int COUT>
+__global__ void __launch_bounds__(512) pc_wgrad_kernel(WgArgs p) {
+  constexpr int NP = 1 << ND, NBLK = (COUT + 31) / 32, NROW = ND == 1 ? 1 : (ND == 2 ? 3 : 9), PWX = 34;
+  constexpr int TPW = ND == 3 ? 8 : (ND == 2 ? 2 : 1), TG = NP / TPW;       // taps per wave, tap groups per phase
+  constexpr int NWAVE = NP * TG;                                           // active waves (8, 8, 4)
+  constexpr int NXC = NROW * PWX * 4;                                      // 16-byte chunks of the x image
+  constexpr int DYROWS = 1 << (ND - 1), NCD = COUT == 16 ? 2 : 4;           // dy rows per tile, chunks per dy pixel (this block)
+  constexpr int NDC = DYROWS * 64 * NCD;
+  constexpr int NITX = (NXC + 511) / 512, NITD = (NDC + 511) / 512;
+  __shared__ uint4 ximg[2][NROW * PWX * 4];
+  __shared__ uint4 dyimg[2][NP * 32 * 4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+  const int mb = blockIdx.y / NBLK, nb = blockIdx.y % NBLK;
+  const int a = wave / TG, tgp = wave % TG;
+  const int g[3] = {p.g0, p.g1, p.g2};
+  const int gl = g[ND - 1];
+  for (int e = threadIdx.x; e < 2 * NP * 32 * 4; e += 512) (&dyimg[0][0])[e] = make_uint4(0, 0, 0, 0);   // (padding columns at COUT = 16 stay zero)
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  float dbsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
+  uint4 sx[NITX], sd[NITD];
+  auto fetch = [&](int tile) {
+    int rest = tile / p.tiles_per_row;
+    const int l0 = 32 * (tile - rest * p.tiles_per_row);
+    int lead[3] = {0, 0, 0};
+#pragma unroll
+    for (int ax = ND - 2; ax >= 0; --ax) {
+      lead[ax] = rest % g[ax];
+      rest /= g[ax];
+    }
+    const int b = rest;
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < NXC) {
+        const int c = e & 3, pp = (e >> 2) % PWX, r = (e >> 2) / PWX;
+        bool inb = true;
+        long long off = b;
+        if (ND == 3) {
+          const int s0 = lead[0] + r / 3 - 1, s1 = lead[1] + r % 3 - 1;
+          inb = s0 >= 0 && s0 < g[0] && s1 >= 0 && s1 < g[1];
+          off = (off * g[0] + s0) * g[1] + s1;
+        } else if (ND == 2) {
+          const int s0 = lead[0] + r - 1;
+          inb = s0 >= 0 && s0 < g[0];
+          off = off * g[0] + s0;
+        }
+        const int sl = l0 - 1 + pp;
+        if (inb && sl >= 0 && sl < gl) v = reinterpret_cast<const uint4*>(p.x + (off * gl + sl) * CIN + 32 * mb)[c];
+      }
+      sx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < NDC) {
+        const int c = e % NCD, d = (e / NCD) & 63, rr = e / (NCD * 64);
+        long long off = b;
+        if (ND == 3) off = (off * (2 * g[0]) + 2 * lead[0] + (rr >> 1)) * (2 * g[1]) + 2 * lead[1] + (rr & 1);
+        else if (ND == 2) off = off * (2 * g[0]) + 2 * lead[0] + rr;
+        const int sl = 2 * l0 + d;
+        if (sl < 2 * gl) v = reinterpret_cast<const uint4*>(p.dy + (off * (2 * gl) + sl) * COUT + 32 * nb)[c];
+      }
+      sd[it] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      if (e < NXC) ximg[buf][e] = sx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      if (e < NDC) {
+        const int c = e % NCD, d = (e / NCD) & 63, rr = e / (NCD * 64);
+        dyimg[buf][((rr * 2 + (d & 1)) * 32 + (d >> 1)) * 4 + c] = sd[it];
+        if (mb == 0) {
+          Frag f;
+          f.u = sd[it];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
+        }
+      }
+    }
+  };
+  // tile n + 1 travels from global memory while tile n is multiplied; one barrier per tile (two image buffers)
+  int tile = blockIdx.x, buf = 0;
+  if (tile < p.n_tiles) fetch(tile);
+  __syncthreads();                                 // zero-fill of the dy images is complete
+  if (tile < p.n_tiles) stash(0);
+  __syncthreads();
+  for (; tile < p.n_tiles; tile += gridDim.x, buf ^= 1) {
+    const int next = tile + gridDim.x;
+    if (next < p.n_tiles) fetch(next);
+    if (wave < NWAVE) {
+      const __bf16* dyi = reinterpret_cast<const __bf16*>(&dyimg[buf][0]) + a * 32 * 32;
+      const __bf16* xi = reinterpret_cast<const __bf16*>(&ximg[buf][0]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 bop = tr_read_plain(dyi, ks, lane);
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          const int t = tgp * TPW + k;
+          int r = 0;
+          if (ND == 3) r = (((a >> 2) & 1) + ((t >> 2) & 1)) * 3 + (((a >> 1) & 1) + ((t >> 1) & 1));
+          if (ND == 2) r = ((a >> 1) & 1) + ((t >> 1) & 1);
+          const int sl = (a & 1) + (t & 1);
+          const bf16x8 aop = tr_read_plain(xi + (r * PWX + sl) * 32, ks, lane);
+          acc[k] = mfma16(aop, bop, acc[k]);
+        }
+      }
+    }
+    if (next < p.n_tiles) stash(buf ^ 1);          // (buffer buf ^ 1 was last read before the previous barrier)
+    __syncthreads();
+  }
+  // ---- slabs -----------------------------------------------------------------------------------------------------------
+  if (wave < NWAVE) {
+    float* slab = p.partial + ((long long)blockIdx.x * gridDim.y + blockIdx.y) * (NP * NP) * 1024;
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int combo = a * NP + tgp * TPW + k;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(combo * 32 + rho(r, h)) * 32 + (lane & 31)] = acc[k][r];
+    }
+  }
+  if (mb == 0) {       // bias partials: thread e owns the channels 8 (e % NCD) .. + 7 of this block in every chunk it staged
+    __shared__ float red_sm[512 * 8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red_sm[threadIdx.x * 8 + j] = dbsum[j];
+    __syncthreads();
+    if (threadIdx.x < 8 * NCD) {
+      const int c = threadIdx.x / 8, j = threadIdx.x % 8;
+      float sacc = 0.f;
+      for (int t = c; t < 512; t += NCD) sacc += red_sm[t * 8 + j];          // fixed order: deterministic
+      if (8 * c + j < (COUT < 32 ? COUT : 32)) p.bias_part[(long long)blockIdx.x * COUT + 32 * nb + 8 * c + j] = sacc;
+    }
+  }
+}
+
+// sum of the slabs in a fixed order (one thread per element of dWeff, coalesced over the slabs) ...
+__global__ void __launch_bounds__(256) pc_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_part,
+                                                              int n_slabs, long long slab_floats, int cout,
+                                                              float* __restrict__ weff_sum, float* __restrict__ db) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e < slab_floats) {
+    // sixteen slabs in flight per thread (the sum over 128 slabs is otherwise a chain of dependent L2 round trips); the
+    // association is fixed: slab g goes to accumulator g % 16, the accumulators are added pairwise in index order
+    float sa[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sa[k] = 0.f;
+    int gI = 0;
+    for (; gI + 15 < n_slabs; gI += 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sa[k] += partial[(long long)(gI + k) * slab_floats + e];
+    }
+    for (int k = 0; gI < n_slabs; ++gI, ++k) sa[k] += partial[(long long)gI * slab_floats + e];
+#pragma unroll
+    for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+      for (int k = 0; k < st; ++k) sa[k] += sa[k + st];
+    weff_sum[e] = sa[0];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < cout) {
+    float s = 0.f;
+    for (int gI = 0; gI < n_slabs; ++gI) s += bias_part[(long long)gI * cout + threadIdx.x];
+    db[threadIdx.x] = s;
+  }
+}
+
+// ... and the fold of the phase weights back onto the conv taps (transpose of the tap sums of the forward pass):
+//   dW[co][ci][k...] = sum over phases a of dWeff[a][t(a, k)]      (tap k of phase a reads source tap t(a, k))
+template <int ND>
+__global__ void __launch_bounds__(256) pc_wgrad_fold_kernel(const float* __restrict__ weff_sum, int cout, float* __restrict__ dW) {
+  constexpr int NP = 1 << ND, KK = ND == 1 ? 3 : (ND == 2 ? 9 : 27);
+  const int nblk = (cout + 31) / 32;
+  const int total = cout * CIN * KK;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int kk = e % KK, ci = (e / KK) % CIN, co = e / (KK * CIN);
+  const int y = (ci >> 5) * nblk + (co >> 5);
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < NP; ++a) {
+    int t = 0, rem = kk;
+#pragma unroll
+    for (int ax = ND - 1; ax >= 0; --ax) {
+      const int k = rem % 3;
+      rem /= 3;
+      const int ak = (a >> (ND - 1 - ax)) & 1;
+      const int tk = ak == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0);
+      t |= tk << (ND - 1 - ax);
+    }
+    s += weff_sum[(((long long)y * (NP * NP) + a * NP + t) * 32 + (ci & 31)) * 32 + (co & 31)];
+  }
+  dW[e] = s;
+}
+
 int check_pc(const char* who, int nd, int B, int g0, int g1, int g2, int cout, PcArgs& p) {
   RCB_REQUIRE(nd >= 1 && nd <= 3 && B > 0 && g0 > 0 && g1 > 0 && g2 > 0 && (nd > 1 || g1 == 1) && (nd > 2 || g2 == 1), RCB_ERR_SHAPE,
               "%s: B=%d grid=%dx%dx%d nd=%d (axes >= nd must have size 1)", who, B, g0, g1, g2, nd);
@@ -489,6 +727,55 @@ extern "C" int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, cons
   if (nd == NDv && cout == Cv) pc_dgrad_kernel<NDv, Cv><<<gx, 256, 0, s>>>(p);
   RCB_DG(1, 64) RCB_DG(1, 16) RCB_DG(2, 64) RCB_DG(2, 16) RCB_DG(3, 64) RCB_DG(3, 16)
 #undef RCB_DG
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+constexpr int kWgSlots = 128;      // workgroups per (mb, nb) block of the weight gradient = slabs to add
+
+extern "C" int64_t rcb_phaseconv_wgrad_workspace(int32_t nd, int32_t cout) {
+  if (nd < 1 || nd > 3 || (cout != 16 && cout != 64)) return -1;
+  const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
+  const int64_t slab = (int64_t)ny * np * np * 1024;
+  return (int64_t)kWgSlots * (slab + cout) + slab;
+}
+
+extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW, float* dbias, float* workspace,
+                                   int64_t workspace_floats, int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t nd,
+                                   int32_t cout, rcb_stream_t stream) {
+  RCB_REQUIRE(x_act && dy && dW && dbias && workspace, RCB_ERR_ARG, "phaseconv_wgrad: null pointer");
+  PcArgs pc;
+  memset(&pc, 0, sizeof(pc));
+  int rc = check_pc("phaseconv_wgrad", nd, B, g0, g1, g2, cout, pc);
+  if (rc) return rc;
+  RCB_REQUIRE(workspace_floats >= rcb_phaseconv_wgrad_workspace(nd, cout), RCB_ERR_SHAPE, "phaseconv_wgrad: workspace too small");
+  const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
+  const long long slab = (long long)ny * np * np * 1024;
+  const int gx = pc.n_tiles < kWgSlots ? pc.n_tiles : kWgSlots;
+  WgArgs w;
+  w.x = static_cast<const __bf16*>(x_act);
+  w.dy = static_cast<const __bf16*>(dy);
+  w.partial = workspace;
+  w.bias_part = workspace + (long long)kWgSlots * slab;
+  float* weff_sum = w.bias_part + (long long)kWgSlots * cout;
+  w.B = B;
+  w.g0 = g0;
+  w.g1 = g1;
+  w.g2 = g2;
+  w.tiles_per_row = pc.tiles_per_row;
+  w.n_tiles = pc.n_tiles;
+  dim3 grid(gx, ny);
+  hipStream_t s = (hipStream_t)stream;
+  const int kk = nd == 1 ? 3 : (nd == 2 ? 9 : 27);
+  const int fin = cdiv((long long)cout * CIN * kk, 256);
+#define RCB_WG(NDv, Cv)                                                                                              \
+  if (nd == NDv && cout == Cv) {                                                                                     \
+    pc_wgrad_kernel<NDv, Cv><<<grid, 512, 0, s>>>(w);                                                                \
+    pc_wgrad_reduce_kernel<<<cdiv(slab, 256), 256, 0, s>>>(w.partial, w.bias_part, gx, slab, cout, weff_sum, dbias); \
+    pc_wgrad_fold_kernel<NDv><<<fin, 256, 0, s>>>(weff_sum, cout, dW);                                               \
+  }
+  RCB_WG(1, 64) RCB_WG(1, 16) RCB_WG(2, 64) RCB_WG(2, 16) RCB_WG(3, 64) RCB_WG(3, 16)
+#undef RCB_WG
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

@@ -874,6 +874,24 @@ def phaseconv_dgrad(dy, frags, x_act):
     return dx
 
 
+def phaseconv_wgrad(x_act, dy):
+    """x_act [B, *g, 64], dy [B, *(2 g), cout] (bf16) -> (dW [cout, 64, 3, ...] fp32, dbias [cout] fp32) (rcb_phaseconv_wgrad)"""
+    lib = _lib.load()
+    if dy.dtype != bf16 or not dy.is_contiguous() or x_act.dtype != bf16 or not x_act.is_contiguous():
+        raise RcbError("phaseconv_wgrad: contiguous bf16 tensors expected")
+    nd, g = _pc_geo(x_act.shape)
+    cout = dy.shape[-1]
+    if list(dy.shape[1:-1]) != [2 * v for v in x_act.shape[1:-1]] or dy.shape[0] != x_act.shape[0]:
+        raise RcbError("phaseconv_wgrad: dy grid must be twice the input grid")
+    n_ws = int(lib.rcb_phaseconv_wgrad_workspace(nd, cout))
+    ws = torch.empty(n_ws, device=dy.device, dtype=f32)
+    dW = torch.empty([cout, 64] + [3] * nd, device=dy.device, dtype=f32)
+    db = torch.empty(cout, device=dy.device, dtype=f32)
+    check(lib.rcb_phaseconv_wgrad(ptr(x_act), ptr(dy), ptr(dW), ptr(db), ptr(ws), C.c_int64(n_ws), x_act.shape[0], g[0], g[1], g[2],
+                                  nd, cout, stream_ptr()), "rcb_phaseconv_wgrad")
+    return dW, db
+
+
 UPCONV_PACK_UINT4 = 22528
 
 

@@ -234,8 +234,9 @@ class _PhaseConv23Fn(torch.autograd.Function):
     """stages 2 and 3 of the upsampling net on a grid of any dimension through the direct sub-pixel kernels
     (rcb_phaseconv_fwd / _dgrad): z1 [B, *g, 64] (bf16 PRE-activation of stage 1) -> pe [B, *(4 g), 16] (bf16, linear).
     Activations are stored post-LeakyReLU (x1, h2); the data-gradient kernels multiply by LeakyReLU' = sign of the stored
-    value.  Weight gradients: GEMMs over 3^d-pixel windows of the stored activations (the direct weight-gradient kernel is
-    the open item)."""
+    value.  Weight gradients: rcb_phaseconv_wgrad (contraction over all positions, both operands read transposed from LDS
+    images, deterministic slab sums)."""
+    direct_wgrad = True
 
     @staticmethod
     def forward(ctx, z1, W2, b2, W3, b3, stage2, stage3):
@@ -259,8 +260,12 @@ class _PhaseConv23Fn(torch.autograd.Function):
         dz1 = ops.phaseconv_dgrad(dh2, d2, x1) if ctx.needs_input_grad[0] else None
         dW2 = db2 = dW3 = db3 = None
         if any(ctx.needs_input_grad[1:5]):
-            dW3, db3 = _window_wgrad(h2, dpe, stage3, W3)
-            dW2, db2 = _window_wgrad(x1, dh2, stage2, W2)
+            if _PhaseConv23Fn.direct_wgrad:
+                dW3, db3 = ops.phaseconv_wgrad(h2, dpe)
+                dW2, db2 = ops.phaseconv_wgrad(x1, dh2)
+            else:                                      # (A/B: GEMMs over 3^d-pixel windows)
+                dW3, db3 = _window_wgrad(h2, dpe, stage3, W3)
+                dW2, db2 = _window_wgrad(x1, dh2, stage2, W2)
         return dz1, dW2, db2, dW3, db3, None, None
 
 

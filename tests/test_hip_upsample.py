@@ -451,4 +451,13 @@ def test_phaseconv_forward_and_data_gradient(shape, cout, leaky):
     dx = ops.phaseconv_dgrad(dy, fd, x)
     e_bwd = rel(dx, want)
     assert e_bwd < 8e-3, e_bwd
-    print("phaseconv %s cout %d: fwd %.1e dgrad %.1e" % (shape, cout, e_fwd, e_bwd))
+    # weight and bias gradient: contraction over every position of the batch
+    Wd, bd = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    lin2 = _stage_ref(x.double(), Wd, bd, nd, False)
+    gW, gb = torch.autograd.grad(lin2, [Wd, bd], dy.double())
+    dW, db = ops.phaseconv_wgrad(x, dy)
+    e_w, e_b = rel(dW, gW), rel(db, gb)
+    assert e_w < 2e-3 and e_b < 1e-5, (e_w, e_b)             # identical bf16 operands: fp32 accumulation order only
+    dW2, db2 = ops.phaseconv_wgrad(x, dy)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)      # no atomics: bitwise reproducible
+    print("phaseconv %s cout %d: fwd %.1e dgrad %.1e wgrad %.1e dbias %.1e" % (shape, cout, e_fwd, e_bwd, e_w, e_b))
