@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
-from .upsample_fast import (hip_path_supported, hip_stitched_supported, phase_form_preferred, phase_module,
+from .upsample_fast import (hip_path_supported, tiled_2d_preferred, phase_form_preferred, phase_module,
                             stitched2d_module, upsample_cifar_hip)
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs
 
@@ -147,7 +147,7 @@ class PriorBNNmodel(nn.Module):
                                                       self.data_dim):
             return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
         net = upsample_net
-        if self.precision != 0 and hip_stitched_supported(upsample_net, self.patch, self.data_dim):
+        if self.precision != 0 and tiled_2d_preferred(upsample_net, self.patch, self.data_dim):
             net = stitched2d_module(upsample_net)                  # stitched 2-D grid: phase-conv kernels on overlapping tiles
         elif self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
             net = phase_module(upsample_net) or upsample_net       # torch-level phase form: same function, fewer flops

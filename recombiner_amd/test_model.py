@@ -20,7 +20,7 @@ from torch.optim import Adam
 
 from . import ops
 from .ops import LevelSpec, SirenMeta
-from .upsample_fast import (hip_path_supported, hip_stitched_supported, phase_form_preferred, phase_module,
+from .upsample_fast import (hip_path_supported, tiled_2d_preferred, phase_form_preferred, phase_module,
                             stitched2d_module, upsample_cifar_hip)
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs, metric
 
@@ -251,7 +251,7 @@ class TestBNNmodel(nn.Module):
                 self._weff_cache = {}        # the mappings are frozen for this model's lifetime (test_model.py:117-126)
             return upsample_cifar_hip(self.upsample_net, lpe, self.stage1_bf16, self.pe_bf16, self._weff_cache)
         net = self.upsample_net
-        if self.precision != 0 and hip_stitched_supported(self.upsample_net, self.patch, self.data_dim):
+        if self.precision != 0 and tiled_2d_preferred(self.upsample_net, self.patch, self.data_dim):
             net = stitched2d_module(self.upsample_net)
         elif self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
             net = phase_module(self.upsample_net) or self.upsample_net

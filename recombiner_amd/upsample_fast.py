@@ -492,6 +492,16 @@ class _UpsampleStitched23Fn(torch.autograd.Function):
         return dz1, None, None, dW2, db2, dW3, db3
 
 
+# Stitched 2-D grids (Kodak): the direct sub-pixel kernels of any dimension (rcb_phaseconv_*, via phase_module) work on the
+# whole grid and need no tile copies -- same-box 0.93 vs 0.98 ms per step for two photos, 1.29 vs 1.35 at width 48 -- so they
+# are the default; the overlapping-tile route through the fixed-size CIFAR kernels stays selectable (and tested).
+PREFER_TILED_2D = False
+
+
+def tiled_2d_preferred(net, patch, data_dim):
+    return PREFER_TILED_2D and hip_stitched_supported(net, patch, data_dim)
+
+
 def hip_stitched_supported(net, patch, data_dim):
     try:
         ok = (data_dim == 2 and bool(patch) and isinstance(net.conv1, torch.nn.Conv2d)
