@@ -8,12 +8,28 @@
 // for lane half h, element j.  W = 48 therefore costs 3 k-steps and 24 (not 32) sin/cos per pixel and layer: no
 // transcendental is spent on padding.  The weight fragments of every (row tile, k-step) are pre-swizzled once per INR
 // into LDS in that k order, in the forward (W^T, sine layers scaled by w0 / 2 pi) and the data-gradient orientation.
-// Weight gradients: OB x IB accumulator tiles per layer (224 accumulator registers at W = 64, three hidden layers), so the
-// kernel runs one wave per SIMD with the unified 512-register file; the cross-wave reduction goes through LDS one layer
-// at a time (deterministic, no atomics).
+// Weight gradients: OB x IB accumulator tiles per layer (12, or 14 with two input blocks, at W = 64): too many for one
+// wave at two waves per SIMD, so they are dealt to the four waves of the workgroup (see the kernel's comment) and each
+// wave contracts its tiles over the images of all four pixel tiles of a pass: complete sums, fixed order, no atomics.
+#include <type_traits>
+
 #include "siren_op16.h"
 
 using namespace rcb;
+
+// Diagnostic build only (-DRCB_SIREN_STAMPS, tools/siren_stamps.py wide): see siren_mlp_bf16.hip
+#ifdef RCB_SIREN_STAMPS
+__device__ unsigned long long g_wide_stamps[8192 * 16];
+#define RCB_WSTAMP(k)                                                                                      \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int rcb_debug_read_stamps_wide(unsigned long long* dst, int n_entries) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * n_entries);
+}
+#else
+#define RCB_WSTAMP(k) do { } while (0)
+#endif
 
 namespace {
 using namespace rcb::op16;
@@ -24,16 +40,16 @@ template <int NH, int F, int E, int C, int W>
 struct GeoW {
   static_assert(W % 16 == 0 && W > 32 && W <= 64, "hidden width 48 or 64");
   static_assert(C <= 16, "the output gradient is one k-step");
+  static_assert(E <= 16, "the data-gradient fragments onto the upsampled features are stored for 16 rows");
   static constexpr int NL = NH + 1;
   static constexpr int IN0 = F + E;
   static constexpr int K0S = (cmax(F, E) + 7) / 8;
   static constexpr int NB0 = (IN0 + 31) / 32;
   static constexpr int HB = (W + 31) / 32;
   static constexpr int KSH = W / 16;
+  static_assert(HB == 2 && NB0 <= 2, "gradient tiles are dealt to four waves as 2 x 2");
   __host__ __device__ static constexpr int lin(int l) { return l == 0 ? IN0 : W; }
   __host__ __device__ static constexpr int lout(int l) { return l == NL - 1 ? C : W; }
-  __host__ __device__ static constexpr int ib(int l) { return l == 0 ? NB0 : HB; }     // 32-feature input blocks
-  __host__ __device__ static constexpr int ob(int l) { return l == NL - 1 ? 1 : HB; }  // 32-feature output blocks
   __host__ __device__ static constexpr int off(int l) {
     int o = 0;
     for (int i = 0; i < l; ++i) o += lout(i) * (lin(i) + 1);
@@ -52,43 +68,43 @@ struct GeoW {
     for (int i = 0; i < l; ++i) k += (lsize(i) == WMAX) ? 1 : 0;
     return k;
   }
-  // weight-gradient accumulator tiles: layer l owns ob(l) x ib(l) tiles starting at gbase(l)
-  __host__ __device__ static constexpr int gbase(int l) {
-    int o = 0;
-    for (int i = 0; i < l; ++i) o += ob(i) * ib(i);
-    return o;
-  }
-  static constexpr int NT = gbase(NL);
-  // fragment slots (1 KB each)
+  // fragment slots (1 KB each; the FBX slots at the end hold 16 rows = 512 B each)
   static constexpr int FA0 = 0;                                  // + mb * K0S + s
   static constexpr int FAH = FA0 + HB * K0S;                     // + ((l - 1) * HB + mb) * KSH + ks
   static constexpr int FAO = FAH + (NH - 1) * HB * KSH;          // + ks
   static constexpr int FBO = FAO + KSH;                          // + ib
   static constexpr int FBH = FBO + HB;                           // + (((NH - 1) - l) * HB + ib) * KSH + ks
-  static constexpr int FBX = FBH + (NH - 1) * HB * KSH;          // + ks
-  static constexpr int NFR = FBX + KSH;
+  static constexpr int NFR = FBH + (NH - 1) * HB * KSH;          // full slots
   static constexpr int NSINE = FAO;                              // slots below carry w0 / 2 pi
-  // LDS map (bytes)
-  static constexpr int FR_OFF = ((DNET * 4 + 15) / 16) * 16;
-  static constexpr int TILE_OFF = FR_OFF + NFR * 1024;
+  // LDS map (bytes): biases | fragments | half-height FBX fragments | per-wave image pairs (= weight staging area)
+  static constexpr int BIAS_STRIDE = 64;
+  static constexpr int FR_OFF = NL * BIAS_STRIDE * 4;
+  static constexpr int FX_OFF = FR_OFF + NFR * 1024;             // + ks * 512
+  static constexpr int TILE_OFF = FX_OFF + KSH * 512;
   static constexpr int TSA = 32 * HB;                            // dZ image row stride (elements)
   static constexpr int TSBB = 32 * cmax(HB, NB0);                // input image row stride
   static constexpr int WAVE_TILE = 32 * (TSA + TSBB) * 2;
-  static constexpr int LDS_MAIN = TILE_OFF + 4 * WAVE_TILE;
-  // cross-wave reduction scratch of ONE layer: [out][in] rows of stride 32 ib + 1, then 32 ob bias slots
-  __host__ __device__ static constexpr int rsize(int l) { return lout(l) * (32 * ib(l) + 1) + 32 * ob(l); }
-  __host__ __device__ static constexpr int rmax() {
-    int w = 0;
-    for (int l = 0; l < NL; ++l) w = rsize(l) > w ? rsize(l) : w;
-    return w;
+  static constexpr int LDS_BYTES = TILE_OFF + 4 * WAVE_TILE;
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  // the fp32 weights are staged through the image area in at most two parts: layers [0, LSPLIT) and [LSPLIT, NL)
+  static constexpr int CAP = 4 * WAVE_TILE / 4;                  // floats
+  __host__ __device__ static constexpr int lsplit() {
+    int l = 0;
+    while (l < NL && off(l + 1) <= CAP) ++l;
+    return l;
   }
-  static constexpr int RED_WAVE = rmax();
-  static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4);
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static constexpr int LSPLIT = lsplit();
+  static_assert(LSPLIT >= 1 && DNET - off(LSPLIT) <= CAP, "weights stage in two parts");
+  static_assert(32 * 33 * 4 <= WAVE_TILE, "a wave transposes one gradient tile through its image area");
 };
 
+// Two workgroups of four waves per CU (two waves per SIMD, 256 registers each).  The weight-gradient tiles are DEALT to the
+// waves instead of every wave accumulating all of them: per layer each wave stores the dZ / input images of its pixel tile,
+// the workgroup synchronises, and the owner of gradient tile (ob, ib) contracts it over the images of all four pixel tiles.
+// A wave thus holds 3 (4 with two input blocks) accumulator tiles instead of 12 (14), the tiles come out complete (no
+// cross-wave reduction in the epilogue) and are summed over the pixel tiles in ascending order.
 template <typename T, int NH, int F, int E, int C, int W, int MODE, bool IN16>
-__global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
+__global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
   using G = GeoW<NH, F, E, C, W>;
   using bf16x8 = typename Op16<T>::v8;
   using bf16x4 = typename Op16<T>::v4;
@@ -96,139 +112,153 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
   constexpr float GS = Op16<T>::GRAD_SCALE;
   constexpr float WS = Op16<T>::W_SCALE;
   constexpr int NL = G::NL, IN0 = G::IN0, K0S = G::K0S, NB0 = G::NB0, HB = G::HB, KSH = G::KSH, DNET = G::DNET;
+  constexpr int BST = G::BIAS_STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* smem = reinterpret_cast<float*>(smem_raw);
+  float* bias = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int q = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
   const int g = blockIdx.x % a.G, chunk = blockIdx.x / a.G;     // chunk-major: partial buffers are [chunk][g]
   const int n = g / a.S;
   const int P = a.P;
 
-  float* wl = smem;
   uint4* frags = reinterpret_cast<uint4*>(smem_raw + G::FR_OFF);
-  T* bufA = reinterpret_cast<T*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
+  uint4* fragsx = reinterpret_cast<uint4*>(smem_raw + G::FX_OFF);
+  T* images = reinterpret_cast<T*>(smem_raw + G::TILE_OFF);
+  T* bufA = images + wave * (G::WAVE_TILE / 2);
   T* bufB = bufA + 32 * G::TSA;
 
-  // ---- stage weights, build the MFMA A-fragments, clear the image buffers ---------------------------------------------
+  // ---- stage the weights (in one or two parts through the image area), build the MFMA A-fragments --------------------
+  RCB_WSTAMP(0);
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
-    {
-      // all loads first, then the LDS stores: written as `wl[i] = src[i]` in a loop the compiler waits for every load before
-      // its store -- 13 serialized HBM round trips, 17 % of the whole kernel by the in-kernel stamps (tools/siren_stamps.py)
-      constexpr int NLD = (DNET + 255) / 256;
-      float stage[NLD];
+    float* wst = reinterpret_cast<float*>(smem_raw + G::TILE_OFF);
+    const int lane = lane0, fq = lane & 31, fh = lane >> 5;
+    auto part = [&](auto lo_c, auto hi_c) {
+      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+      constexpr int BASE = G::off(LO), LEN = G::off(HI) - BASE;
+      {
+        // all loads first, then the LDS stores (a load-store loop waits for every load before its store)
+        constexpr int NLD = (LEN + 255) / 256;
+        float stage[NLD];
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int i = tid + 256 * k;
-        stage[k] = src[i < DNET ? i : DNET - 1];
+        for (int k = 0; k < NLD; ++k) {
+          const int i = tid + 256 * k;
+          stage[k] = src[BASE + (i < LEN ? i : LEN - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+          const int i = tid + 256 * k;
+          if (i < LEN) wst[i] = stage[k];
+        }
+      }
+      __syncthreads();
+      const float* wl = wst - BASE;                               // wl[G::off(l) + ...] as in the parameter vector
+#pragma unroll
+      for (int l = LO; l < HI; ++l)
+        if (tid < G::lout(l)) bias[l * BST + tid] = wl[G::off(l) + tid] * (l < NH ? a.k_hi : 1.0f);   // sine layers work in revolutions
+      auto put = [&](int slot, auto&& elem) {
+        union { bf16x8 v; uint4 u; } fr;
+        // sine-layer forward fragments carry w0 / 2 pi, the fragments producing a hidden layer's data gradient carry w0
+        const float sc = (slot < G::NSINE) ? WS * a.k_hi : (slot >= G::FBO) ? a.w0 : WS;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fr.v[j] = (T)(elem(j) * sc);
+        frags[slot * 64 + lane] = fr.u;
+      };
+      int dealt = 0;                                              // fragments of this part go round the waves
+      auto mine = [&]() { return ((dealt++) & 3) == wave; };
+      if (LO == 0) {
+        // forward, layer 0: half-wave 0 contracts the F Fourier features, half-wave 1 the E upsampled features
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+          for (int s = 0; s < K0S; ++s) {
+            if (!mine()) continue;
+            put(G::FA0 + mb * K0S + s, [&](int j) {
+              const int kk = 8 * s + j, out = 32 * mb + fq;
+              const int row = (fh == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
+              return (row >= 0 && out < W) ? wl[G::off(0) + W + row * W + out] : 0.f;
+            });
+          }
+        // data gradient through layer 0 onto the E upsampled features: 16 rows stored
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) {
+          if (!mine()) continue;
+          union { bf16x8 v; uint4 u; } fr;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fr.v[j] = (T)((fq < E ? wl[G::off(0) + W + (F + fq) * W + featk(ks, fh, j)] : 0.f) * WS);
+          if (fq < 16) fragsx[ks * 32 + fh * 16 + fq] = fr.u;
+        }
       }
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) {
-        const int i = tid + 256 * k;
-        if (i < DNET) wl[i] = stage[k];
+      for (int l = (LO > 1 ? LO : 1); l < (HI < NH ? HI : NH); ++l) {
+        // forward, hidden layer l
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+          for (int ks = 0; ks < KSH; ++ks) {
+            if (!mine()) continue;
+            put(G::FAH + ((l - 1) * HB + mb) * KSH + ks, [&](int j) {
+              const int out = 32 * mb + fq;
+              return out < W ? wl[G::off(l) + W + featk(ks, fh, j) * W + out] : 0.f;
+            });
+          }
+        // data gradient through hidden layer l
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+          for (int ks = 0; ks < KSH; ++ks) {
+            if (!mine()) continue;
+            put(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks, [&](int j) {
+              const int m = 32 * ib + fq;
+              return m < W ? wl[G::off(l) + W + m * W + featk(ks, fh, j)] : 0.f;
+            });
+          }
       }
-    }
-    for (int i = lane; i < 32 * (G::TSA + G::TSBB); i += 64) bufA[i] = (T)0.f;
-    __syncthreads();
-    if (tid < W) {
+      if (HI == NL) {
+        // forward, output layer
 #pragma unroll
-      for (int l = 0; l < NH; ++l) wl[G::off(l) + tid] *= a.k_hi;    // sine layers work in revolutions
-    }
-    const int fq = lane & 31, fh = lane >> 5;
-    auto put = [&](int slot, auto&& elem) {
-      union { bf16x8 v; uint4 u; } fr;
-      // sine-layer forward fragments carry w0 / 2 pi, the fragments producing a hidden layer's data gradient carry w0
-      const float sc = (slot < G::NSINE) ? WS * a.k_hi : (slot >= G::FBO && slot < G::FBX) ? a.w0 : WS;
+        for (int ks = 0; ks < KSH; ++ks) {
+          if (!mine()) continue;
+          put(G::FAO + ks, [&](int j) { return fq < C ? wl[G::off(NH) + C + featk(ks, fh, j) * C + fq] : 0.f; });
+        }
+        // data gradient through the output layer (k = output channel, one step)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) fr.v[j] = (T)(elem(j) * sc);
-      frags[slot * 64 + lane] = fr.u;
+        for (int ib = 0; ib < HB; ++ib) {
+          if (!mine()) continue;
+          put(G::FBO + ib, [&](int j) {
+            const int m = 32 * ib + fq, k = fk(0, fh, j);
+            return (m < W && k < C) ? wl[G::off(NH) + C + m * C + k] : 0.f;
+          });
+        }
+      }
+      __syncthreads();
     };
-    // forward, layer 0: half-wave 0 contracts the F Fourier features, half-wave 1 the E upsampled features
-#pragma unroll
-    for (int mb = 0; mb < HB; ++mb)
-#pragma unroll
-      for (int s = 0; s < K0S; ++s) {
-        const int slot = G::FA0 + mb * K0S + s;
-        if ((slot & 3) != wave) continue;
-        put(slot, [&](int j) {
-          const int kk = 8 * s + j, out = 32 * mb + fq;
-          const int row = (fh == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
-          return (row >= 0 && out < W) ? wl[G::off(0) + W + row * W + out] : 0.f;
-        });
-      }
-    // forward, hidden layers 1 .. NH-1
-#pragma unroll
-    for (int l = 1; l < NH; ++l)
-#pragma unroll
-      for (int mb = 0; mb < HB; ++mb)
-#pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) {
-          const int slot = G::FAH + ((l - 1) * HB + mb) * KSH + ks;
-          if ((slot & 3) != wave) continue;
-          put(slot, [&](int j) {
-            const int out = 32 * mb + fq;
-            return out < W ? wl[G::off(l) + W + featk(ks, fh, j) * W + out] : 0.f;
-          });
-        }
-    // forward, output layer
-#pragma unroll
-    for (int ks = 0; ks < KSH; ++ks) {
-      const int slot = G::FAO + ks;
-      if ((slot & 3) != wave) continue;
-      put(slot, [&](int j) { return fq < C ? wl[G::off(NH) + C + featk(ks, fh, j) * C + fq] : 0.f; });
+    if constexpr (G::LSPLIT == NL) {
+      part(std::integral_constant<int, 0>{}, std::integral_constant<int, NL>{});
+    } else {
+      part(std::integral_constant<int, 0>{}, std::integral_constant<int, G::LSPLIT>{});
+      part(std::integral_constant<int, G::LSPLIT>{}, std::integral_constant<int, NL>{});
     }
-    // data gradient through the output layer (k = output channel, one step)
-#pragma unroll
-    for (int ib = 0; ib < HB; ++ib) {
-      const int slot = G::FBO + ib;
-      if ((slot & 3) != wave) continue;
-      put(slot, [&](int j) {
-        const int m = 32 * ib + fq, k = fk(0, fh, j);
-        return (m < W && k < C) ? wl[G::off(NH) + C + m * C + k] : 0.f;
-      });
-    }
-    // data gradient through hidden layers NH-1 .. 1
-#pragma unroll
-    for (int l = NH - 1; l >= 1; --l)
-#pragma unroll
-      for (int ib = 0; ib < HB; ++ib)
-#pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) {
-          const int slot = G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks;
-          if ((slot & 3) != wave) continue;
-          put(slot, [&](int j) {
-            const int m = 32 * ib + fq;
-            return m < W ? wl[G::off(l) + W + m * W + featk(ks, fh, j)] : 0.f;
-          });
-        }
-    // data gradient through layer 0 onto the E upsampled features
-#pragma unroll
-    for (int ks = 0; ks < KSH; ++ks) {
-      const int slot = G::FBX + ks;
-      if ((slot & 3) != wave) continue;
-      put(slot, [&](int j) { return fq < E ? wl[G::off(0) + W + (F + fq) * W + featk(ks, fh, j)] : 0.f; });
-    }
-    __syncthreads();
   }
-  auto FA = [&](int slot) -> bf16x8 {
-    union { bf16x8 v; uint4 u; } fr;
-    fr.u = frags[slot * 64 + lane];
-    return fr.v;
-  };
+  RCB_WSTAMP(2);
 
-  f32x16 gW[G::NT];
-  float gb[NL][HB];
+  // this wave's weight-gradient tiles: hidden layer l (1 .. NH-1): tile (wave >> 1, wave & 1); layer 0: the same with two
+  // input blocks, (wave, 0) on waves 0 / 1 with one; output layer: (0, wave - 2) on waves 2 / 3
+  constexpr int NHID = NH - 1;
+  f32x16 gH[NHID > 0 ? NHID : 1], g0, gO_own;
+  f32x16& gO = (NB0 == 1) ? g0 : gO_own;                          // one input block: layer-0 tiles on waves 0 / 1 only
+  float bH[NHID > 0 ? NHID : 1], b0 = 0.f, bO = 0.f;
   float sse_local = 0.f;
   if (MODE != MODE_FWD) {
 #pragma unroll
-    for (int i = 0; i < G::NT; ++i)
+    for (int r = 0; r < 16; ++r) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gW[i][r] = 0.f;
+      for (int i = 0; i < NHID; ++i) gH[i][r] = 0.f;
+      g0[r] = 0.f;
+      gO_own[r] = 0.f;
+    }
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-      for (int b = 0; b < HB; ++b) gb[l][b] = 0.f;
+    for (int i = 0; i < NHID; ++i) bH[i] = 0.f;
   }
   constexpr int KH0 = F, KH1 = E;
 
@@ -237,7 +267,7 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
   // IN16 (as in the width-32 kernel): both input halves arrive as bf16 rows and the loaded bits are the layer-0 B operand
   float4 raw[IN16 ? 1 : 2 * K0S];
   uint4 raw16[IN16 ? K0S : 1];
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int tile, int q, int h) {
     const int pp = tile * 32 + q;
     const int pcl = pp < P ? pp : P - 1;
     if constexpr (IN16) {
@@ -292,189 +322,227 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
     }
     }
   };
-  // this workgroup's share of the 32-pixel tiles (all of them unless rcb_siren_desc.pixel_chunks > 1)
+  // this workgroup's share of the 32-pixel tiles (all of them unless rcb_siren_desc.pixel_chunks > 1); every wave makes
+  // the same number of passes (the passes synchronise), a wave without a tile in the last pass only contracts
   const int t0 = (int)((long long)chunk * ntiles / a.chunks), t1 = (int)((long long)(chunk + 1) * ntiles / a.chunks);
-  if (t0 + wave < t1) fetch(t0 + wave);
-  for (int t = t0 + wave; t < t1; t += 4) {
-    const int p = t * 32 + q;
-    const bool valid = p < P;
-    const int pc = valid ? p : P - 1;
-    bf16x8 xin[K0S];
+  if (t0 + wave < t1) fetch(t0 + wave, lane0 & 31, lane0 >> 5);
+  // fp32 inputs are converted as soon as they have arrived (end of the pass that requested them): 4 registers per k-step
+  // cross the pass boundary instead of 8
+  bf16x8 xnext[IN16 ? 1 : K0S];
+  auto convert_inputs = [&]() {
+    if constexpr (!IN16) {
 #pragma unroll
-    for (int s = 0; s < K0S; ++s) {
-      if constexpr (IN16) {
-        union { uint4 u; bf16x8 v; } cv;
-        cv.u = raw16[s];
-        xin[s] = cv.v;
-      } else {
+      for (int s = 0; s < K0S; ++s) {
         const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
-        xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
-        xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
+        xnext[s][0] = (T)v0.x; xnext[s][1] = (T)v0.y; xnext[s][2] = (T)v0.z; xnext[s][3] = (T)v0.w;
+        xnext[s][4] = (T)v1.x; xnext[s][5] = (T)v1.y; xnext[s][6] = (T)v1.z; xnext[s][7] = (T)v1.w;
       }
     }
-    float yv[16];
-    if (MODE != MODE_FWD) {
-      const long long ybase = ((MODE == MODE_LOSS ? (long long)n : (long long)g) * P + pc) * C;
+  };
+  if (t0 + wave < t1) convert_inputs();
+  // lane-dependent LDS offsets that stay in registers for the whole kernel (everything else lane-dependent is re-derived per
+  // pass, see below).  Image rows are 64 elements (TSA == TSBB) with the 8-byte chunks swizzled by (pixel >> 1) & 7 (swz()):
+  //   wr_off[2 par + e]: this lane's store of features 16 ks + 4 h + 8 e .. + 3, ks = 2 (ks >> 1) + par, + 32 (ks >> 1)
+  //   rd_off[wq]:        this lane's transposed 8-byte read of pixels 8 h + 4 wq + 0..3 (+ 16 s), + feature block, + tile
+  static_assert(G::TSA == 64 && G::TSBB == 64, "one swizzle pattern for both images");
+  int wr_off[4], rd_off[2];
+  {
+    const int q0 = lane0 & 31, h0 = lane0 >> 5, key = (q0 >> 1) & 7;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        yv[r] = 0.f;
-        if (rho(r, 0) < C || rho(r, 1) < C) {
-          const int row = rho(r, h);
-          yv[r] = a.yin[ybase + (row < C ? row : 0)];
-        }
-      }
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) wr_off[2 * par + e] = q0 * 64 + (((4 * par + h0 + 2 * e) ^ key) << 2);
+    const int fb = (lane0 >> 4) & 1, q4 = (lane0 & 15) >> 2, p4 = lane0 & 3;
+#pragma unroll
+    for (int wq = 0; wq < 2; ++wq) {
+      const int pix = 8 * h0 + 4 * wq + q4;
+      rd_off[wq] = pix * 64 + (((4 * fb + p4) ^ ((pix >> 1) & 7)) << 2);
     }
-    fetch(t + 4 < t1 ? t + 4 : t);
-    // ---- forward ----------------------------------------------------------------------------------------------------
+  }
+  const uint4* fr_lane = frags + lane0;                           // + slot * 64
+  const float* bias_lane = bias + 4 * (lane0 >> 5);               // + l * BST + 32 mb + (r & 3) + 8 (r >> 2)
+  // transposed operand of k-step s (pixels 16 s + 8 h + 0..7) of feature block fblk of pixel tile w's image `img` (0 / 1).
+  // The two per-lane LDS byte addresses are kept opaque: everything added below then fits the 16-bit offset field of the
+  // read (left to itself the compiler folds the image area's own offset in, exceeds the field and keeps ~40 derived bases)
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  unsigned rd_addr[2];
+#pragma unroll
+  for (int wq = 0; wq < 2; ++wq) {
+    rd_addr[wq] = (unsigned)(size_t)((__attribute__((address_space(3))) T*)images) + 2u * (unsigned)rd_off[wq];
+    asm volatile("" : "+v"(rd_addr[wq]));
+  }
+  auto tr_read = [&](int w, int img, int s, int fblk) -> bf16x8 {
+    union { s16x4 v[2]; bf16x8 b; } u;
+#pragma unroll
+    for (int wq = 0; wq < 2; ++wq) {
+      const unsigned addr = (rd_addr[wq] + 2u * (unsigned)fblk) + 2u * (unsigned)(w * (G::WAVE_TILE / 2) + img * 32 * G::TSA + s * 16 * 64);
+      u.v[wq] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)addr);
+    }
+    return u.b;
+  };
+  int lane_v = lane0;
+  // one pass = four pixel tiles, one per wave.  FULL: every wave has a tile (all passes but possibly the chunk's last): no
+  // wave-level conditionals in the hot loop
+  auto pass = [&](int tb, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    // the remaining lane-dependent addresses (global rows, layer-0 image stores) are re-derived in every pass: hoisted out
+    // of the loop they are ~90 live registers that the allocator spills
+    asm volatile("" : "+v"(lane_v));
+    const int lane = lane_v, q = lane & 31, h = lane >> 5;
+    auto FA = [&](int slot) -> bf16x8 {
+      union { bf16x8 v; uint4 u; } fr;
+      fr.u = fr_lane[slot * 64];
+      return fr.v;
+    };
+    auto FX = [&](int ks) -> bf16x8 {
+      union { bf16x8 v; uint4 u; } fr;
+      fr.u = make_uint4(0, 0, 0, 0);
+      if (q < 16) fr.u = fragsx[ks * 32 + h * 16 + q];
+      return fr.v;
+    };
+    const int t = tb + wave;
+    const bool active = FULL || t < t1;                           // wave-uniform
+    const int p = t * 32 + q;
+    const bool valid = active && p < P;
+    const int pc = p < P ? p : P - 1;
+    if (tb == t0) RCB_WSTAMP(14);
+    if (tb == t0 + 4) RCB_WSTAMP(15);
+    bf16x8 xin[K0S];
     bf16x8 S[NH][KSH], Cs[NH][KSH];
+    bf16x8 dzb[2 * HB];
+    float yv[16];
+    if (active) {
 #pragma unroll
-    for (int l = 0; l < NH; ++l) {
-      const float* Bl = wl + G::off(l);
-#pragma unroll
-      for (int mb = 0; mb < HB; ++mb) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = (32 * mb + 16 * (r >> 3) < W) ? Bl[32 * mb + rho(r, h)] * WS : 0.f;
-        if (l == 0) {
-#pragma unroll
-          for (int s = 0; s < K0S; ++s) acc = Op16<T>::mfma(FA(G::FA0 + mb * K0S + s), xin[s], acc);
+      for (int s = 0; s < K0S; ++s) {
+        if constexpr (IN16) {
+          union { uint4 u; bf16x8 v; } cv;
+          cv.u = raw16[s];
+          xin[s] = cv.v;
         } else {
-#pragma unroll
-          for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(FA(G::FAH + ((l - 1) * HB + mb) * KSH + ks), S[l - 1][ks], acc);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (2 * mb + s >= KSH) continue;               // rows beyond the layer width: no transcendental spent
-          bf16x8 sp, cp;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float tt = (WS == 1.0f) ? acc[8 * s + j] : acc[8 * s + j] * (1.0f / WS);
-            sp[j] = (T)__builtin_amdgcn_sinf(tt);
-            if (MODE != MODE_FWD) cp[j] = (T)__builtin_amdgcn_cosf(tt);
-          }
-          S[l][2 * mb + s] = sp;
-          if (MODE != MODE_FWD) Cs[l][2 * mb + s] = cp;
+          xin[s] = xnext[s];
         }
       }
-    }
-    f32x16 acc;
-    {
-      const float* Bl = wl + G::off(NL - 1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] * WS : 0.f) : 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(FA(G::FAO + ks), S[NH - 1][ks], acc);
-      if (WS != 1.0f) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (rho(r, 0) < C || rho(r, 1) < C) acc[r] *= (1.0f / WS);
-      }
-    }
-    if (MODE == MODE_FWD) {
-      if (valid) {
+      if (MODE != MODE_FWD) {
+        const long long ybase = ((MODE == MODE_LOSS ? (long long)n : (long long)g) * P + pc) * C;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          yv[r] = 0.f;
           if (rho(r, 0) < C || rho(r, 1) < C) {
-            int row = rho(r, h);
-            if (row < C) a.yout[((long long)g * P + p) * C + row] = acc[r];
+            const int row = rho(r, h);
+            yv[r] = a.yin[ybase + (row < C ? row : 0)];
           }
         }
       }
-      continue;
-    }
-    // ---- output gradient --------------------------------------------------------------------------------------------
-    f32x16 dz[HB];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = 0.f;
-      if (rho(r, 0) < C || rho(r, 1) < C) {
-        const bool ok = valid && rho(r, h) < C;
-        if (MODE == MODE_LOSS) {
-          float diff = ok ? (acc[r] - yv[r]) : 0.f;
-          sse_local += diff * diff;
-          v = (2.0f * GS) * a.dy_scale * diff;
-        } else {
-          v = ok ? yv[r] * GS : 0.f;
-        }
+      if (MODE == MODE_FWD && t + 4 < t1) {
+        fetch(t + 4, q, h);
+        convert_inputs();
       }
-      dz[0][r] = v;
-    }
-    // ---- backward ---------------------------------------------------------------------------------------------------
+      // ---- forward --------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int l = NL - 1; l >= 0; --l) {
-      const int OBl = (l == NL - 1) ? 1 : HB;
-      const int KSO = (l == NL - 1) ? 2 : KSH;            // k-steps over this layer's output features
-      const int IBl = (l == 0) ? NB0 : HB;
-      bf16x8 dzb[2 * HB];
+      for (int l = 0; l < NH; ++l) {
+        const float* Bl = bias_lane + l * BST;                   // Bl[rho(r, 0)] is the bias of accumulator row rho(r, h)
 #pragma unroll
-      for (int ks = 0; ks < 2 * HB; ++ks)
-        if (ks < KSO) dzb[ks] = pack8<T>(dz[ks >> 1], ks & 1);
-      // (1) data gradient FIRST (the serial chain of the backward pass; the weight gradient below fills its MFMA latency --
-      // at one wave per SIMD nothing else would)
-      if (l > 0) {
+        for (int mb = 0; mb < HB; ++mb) {
+          f32x16 acc;
 #pragma unroll
-        for (int ib = 0; ib < HB; ++ib) {
-          f32x16 dh;
+          for (int r = 0; r < 16; ++r) acc[r] = (32 * mb + 16 * (r >> 3) < W) ? Bl[32 * mb + rho(r, 0)] * WS : 0.f;
+          if (l == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dh[r] = 0.f;
-          if (l == NL - 1) {
-            dh = Op16<T>::mfma(FA(G::FBO + ib), dzb[0], dh);
+            for (int s = 0; s < K0S; ++s) acc = Op16<T>::mfma(FA(G::FA0 + mb * K0S + s), xin[s], acc);
           } else {
 #pragma unroll
-            for (int ks = 0; ks < KSH; ++ks) dh = Op16<T>::mfma(FA(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks), dzb[ks], dh);
+            for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(FA(G::FAH + ((l - 1) * HB + mb) * KSH + ks), S[l - 1][ks], acc);
           }
-          // dz of layer l-1, tile ib (written after every use of the old dz tiles: dzb holds their packed copies)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (2 * mb + s >= KSH) continue;               // rows beyond the layer width: no transcendental spent
+            bf16x8 sp, cp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float tt = (WS == 1.0f) ? acc[8 * s + j] : acc[8 * s + j] * (1.0f / WS);
+              sp[j] = (T)__builtin_amdgcn_sinf(tt);
+              if (MODE != MODE_FWD) cp[j] = (T)__builtin_amdgcn_cosf(tt);
+            }
+            S[l][2 * mb + s] = sp;
+            if (MODE != MODE_FWD) Cs[l][2 * mb + s] = cp;
+          }
+        }
+      }
+      f32x16 acc;
+      {
+        const float* Bl = bias + (NL - 1) * BST;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] * WS : 0.f) : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(FA(G::FAO + ks), S[NH - 1][ks], acc);
+        if (WS != 1.0f) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            dz[ib][r] = (2 * ib + (r >> 3) < KSH) ? dh[r] * (float)Cs[l - 1][2 * ib + (r >> 3)][r & 7] : 0.f;
+            if (rho(r, 0) < C || rho(r, 1) < C) acc[r] *= (1.0f / WS);
         }
-      } else if (a.dpe != nullptr) {
-        f32x16 dx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(FA(G::FBX + ks), dzb[ks], dx);
+      }
+      if (MODE == MODE_FWD) {
         if (valid) {
-          float* dst = a.dpe + ((long long)g * P + p) * E;
-          if (E % 8 == 0 && a.pe_bf16) {
-            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
 #pragma unroll
-            for (int g4 = 0; g4 < E / 8; ++g4) {
-              typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
-                                              (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
-              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
-            }
-          } else if (E % 8 == 0) {
-#pragma unroll
-            for (int g4 = 0; g4 < E / 8; ++g4)
-              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
-                                                                             dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              int e = rho(r, h);
-              if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
+          for (int r = 0; r < 16; ++r) {
+            if (rho(r, 0) < C || rho(r, 1) < C) {
+              int row = rho(r, h);
+              if (row < C) a.yout[((long long)g * P + p) * C + row] = acc[r];
             }
           }
         }
+      } else {
+        // ---- output gradient ----------------------------------------------------------------------------------------
+        if (tb == t0) RCB_WSTAMP(8);
+        f32x16 dz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.f;
+          if (rho(r, 0) < C || rho(r, 1) < C) {
+            const bool ok = valid && rho(r, h) < C;
+            if (MODE == MODE_LOSS) {
+              float diff = ok ? (acc[r] - yv[r]) : 0.f;
+              sse_local += diff * diff;
+              v = (2.0f * GS) * a.dy_scale * diff;
+            } else {
+              v = ok ? yv[r] * GS : 0.f;
+            }
+          }
+          dz[r] = v;
+        }
+        dzb[0] = pack8<T>(dz, 0);
+        dzb[1] = pack8<T>(dz, 1);
       }
-      // (2) weight gradient: [pixel][feature] images of dZ and of the layer input -> transposed reads
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      {
+    }
+    if (MODE == MODE_FWD) return;
+    // ---- backward: per layer  images -> sync -> data gradient (own tile) + weight gradient (own gradient tiles, all
+    // pixel tiles of the pass) -> sync -----------------------------------------------------------------------------------
+#pragma unroll
+    for (int l = NL - 1; l >= 0; --l) {
+      const int KSO = (l == NL - 1) ? 2 : KSH;            // k-steps over this layer's output features
+      if (tb == t0) RCB_WSTAMP(9 + (NL - 1 - l));
+      if (!FULL && !active && l == NL - 1) {
+        // a wave without a pixel tile in the chunk's last pass: zero images, so that the owners contract four tiles always
+        uint4* z = reinterpret_cast<uint4*>(bufA);
+#pragma unroll
+        for (int k = 0; k < G::WAVE_TILE / 1024; ++k) z[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+      }
+      if (active) {
+        if (l == 0 && t + 4 < t1) fetch(t + 4, q, h);     // next pass's inputs: in flight behind the last layer
         union { bf16x8 v; bf16x4 hlf[2]; } u;
 #pragma unroll
         for (int ks = 0; ks < 2 * HB; ++ks) {
           if (ks >= KSO) continue;
           u.v = dzb[ks];
-          *reinterpret_cast<bf16x4*>(bufA + swz(q, 16 * ks + 4 * h, G::TSA)) = u.hlf[0];
-          *reinterpret_cast<bf16x4*>(bufA + swz(q, 16 * ks + 8 + 4 * h, G::TSA)) = u.hlf[1];
+          *reinterpret_cast<bf16x4*>(bufA + 32 * (ks >> 1) + wr_off[2 * (ks & 1)]) = u.hlf[0];
+          *reinterpret_cast<bf16x4*>(bufA + 32 * (ks >> 1) + wr_off[2 * (ks & 1) + 1]) = u.hlf[1];
         }
         if (l > 0) {
 #pragma unroll
           for (int ks = 0; ks < KSH; ++ks) {
             u.v = S[l - 1][ks];
-            *reinterpret_cast<bf16x4*>(bufB + swz(q, 16 * ks + 4 * h, G::TSBB)) = u.hlf[0];
-            *reinterpret_cast<bf16x4*>(bufB + swz(q, 16 * ks + 8 + 4 * h, G::TSBB)) = u.hlf[1];
+            *reinterpret_cast<bf16x4*>(bufB + 32 * (ks >> 1) + wr_off[2 * (ks & 1)]) = u.hlf[0];
+            *reinterpret_cast<bf16x4*>(bufB + 32 * (ks >> 1) + wr_off[2 * (ks & 1) + 1]) = u.hlf[1];
           }
         } else {
           const int base = (h == 0) ? 0 : F;
@@ -492,97 +560,197 @@ __global__ void __launch_bounds__(256, 1) siren_wide_kernel(SirenArgs a) {
                 if (8 * s + j + 1 < kh) *reinterpret_cast<bf16x2*>(bufB + swz(q, base + 8 * s + j, G::TSBB)) = x.pr[j >> 1];
             }
           }
-          if (32 * NB0 > IN0) {
-            // the hidden layers' input images overwrote the padding columns [IN0, 32 NB0): finite values that only reach
-            // accumulator columns which are never stored
+          // image columns [IN0, 32 NB0) keep whatever the hidden layers / the weight staging left there: they only reach
+          // accumulator columns that are never stored (likewise feature columns >= W of either image at width 48)
+        }
+      }
+      __syncthreads();
+      // (1) data gradient of this wave's pixel tile
+      if (active) {
+        if (l > 0) {
+          bf16x8 nz[2 * HB];
+          f32x16 dh[HB];
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[ib][r] = 0.f;
+          if (l == NL - 1) {
+#pragma unroll
+            for (int ib = 0; ib < HB; ++ib) dh[ib] = Op16<T>::mfma(FA(G::FBO + ib), dzb[0], dh[ib]);
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks)                     // the two chains alternate
+#pragma unroll
+              for (int ib = 0; ib < HB; ++ib)
+                dh[ib] = Op16<T>::mfma(FA(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks), dzb[ks], dh[ib]);
+          }
+#pragma unroll
+          for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              if (2 * ib + s >= KSH) continue;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) nz[2 * ib + s][j] = (T)(dh[ib][8 * s + j] * (float)Cs[l - 1][2 * ib + s][j]);
+            }
+#pragma unroll
+          for (int ks = 0; ks < KSH; ++ks) dzb[ks] = nz[ks];
+        } else if (a.dpe != nullptr) {
+          f32x16 dx;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(FX(ks), dzb[ks], dx);
+          if (valid) {
+            float* dst = a.dpe + ((long long)g * P + p) * E;
+            if (E % 8 == 0 && a.pe_bf16) {
+              __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
+#pragma unroll
+              for (int g4 = 0; g4 < E / 8; ++g4) {
+                typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
+                                                (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
+                *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
+              }
+            } else if (E % 8 == 0) {
+#pragma unroll
+              for (int g4 = 0; g4 < E / 8; ++g4)
+                *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
+                                                                               dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                int e = rho(r, h);
+                if (e < E) dst[e] = dx[r] * (1.0f / (GS * WS));
+              }
+            }
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // (2) weight gradient of this wave's tile of the layer over the images of every pixel tile of the pass
       {
-        bf16x8 av[HB][2];
-#pragma unroll
-        for (int ob = 0; ob < HB; ++ob) {
-          if (ob >= OBl) continue;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) av[ob][s] = read_tr<T>(bufA, G::TSA, s, lane, 32 * ob);
-          gb[l][ob] = sum8_16<T>(av[ob][0], gb[l][ob]);
-          gb[l][ob] = sum8_16<T>(av[ob][1], gb[l][ob]);
+        bool own;
+        int ob, ib;
+        if (l == NL - 1) {
+          own = wave >= 2; ob = 0; ib = wave - 2;
+        } else if (l == 0 && NB0 == 1) {
+          own = wave < 2; ob = wave; ib = 0;
+        } else {
+          own = true; ob = wave >> 1; ib = wave & 1;
         }
+        if (own) {
+          f32x16& acc = (l == NL - 1) ? gO : (l == 0) ? g0 : gH[l > 0 && l < NL - 1 ? l - 1 : 0];
+          float& bsum = (l == NL - 1) ? bO : (l == 0) ? b0 : bH[l > 0 && l < NL - 1 ? l - 1 : 0];
+          // bias gradient = row sums of dZ^T: the two owners of a row block (ib = 0 / 1) sum one k-step each; layer 0 with a
+          // single input block has one owner per row block, which sums both
+          const bool both = (l == 0 && NB0 == 1);
 #pragma unroll
-        for (int ib = 0; ib < cmax(HB, NB0); ++ib) {
-          if (ib >= IBl) continue;
-          bf16x8 bv[2];
+          for (int w = 0; w < 4; ++w) {
+            bf16x8 av[2], bv[2];
 #pragma unroll
-          for (int s = 0; s < 2; ++s) bv[s] = read_tr<T>(bufB, G::TSBB, s, lane, 32 * ib);
+            for (int s2 = 0; s2 < 2; ++s2) av[s2] = tr_read(w, 0, s2, 32 * ob);
 #pragma unroll
-          for (int ob = 0; ob < HB; ++ob) {
-            if (ob >= OBl) continue;
-            const int gi = G::gbase(l) + ob * IBl + ib;
+            for (int s2 = 0; s2 < 2; ++s2) bv[s2] = tr_read(w, 1, s2, 32 * ib);
+            if (both) {
+              bsum = sum8_16<T>(av[0], bsum);
+              bsum = sum8_16<T>(av[1], bsum);
+            } else {
+              union { bf16x8 v; unsigned u[4]; } a0, a1, pick;
+              a0.v = av[0];
+              a1.v = av[1];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) gW[gi] = Op16<T>::mfma(av[ob][s], bv[s], gW[gi]);
+              for (int k = 0; k < 4; ++k) pick.u[k] = ib ? a1.u[k] : a0.u[k];   // wave-uniform select
+              bsum = sum8_16<T>(pick.v, bsum);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) acc = Op16<T>::mfma(av[s2], bv[s2], acc);
           }
         }
       }
+      __syncthreads();
     }
-  }
+    if (t + 4 < t1) convert_inputs();
+  };
+  int tb = t0;
+  for (; tb + 4 <= t1; tb += 4) pass(tb, std::true_type{});
+  if (tb < t1) pass(tb, std::false_type{});
   if (MODE == MODE_FWD) return;
+  RCB_WSTAMP(3);
 
-  // ---- deterministic cross-wave reduction of the weight gradients, one layer at a time -----------------------------------
-  float* part = smem + wave * G::RED_WAVE;
-  float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
+  // ---- every gradient tile is complete in its owner's registers: transpose through the wave's own image area and store --
+  const int lane = lane0, q = lane & 31, h = lane >> 5;
+  {
+    // bias gradients: the two owners of a row block hold one k-step's sums each; the ib = 1 owner hands its part over through
+    // LDS (the fragment area is no longer read) and the ib = 0 owner stores own + partner
+    float* xch = reinterpret_cast<float*>(smem_raw + G::FR_OFF);  // [slot][wave][32]
+    constexpr int NSLOT = NHID + 2;
+    auto half_sum = [&](float v) { return v + __shfl_xor(v, 32, 64); };
+    float bsumH[NHID > 0 ? NHID : 1];
 #pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    const int no = G::lout(l), IBl = G::ib(l), OBl = G::ob(l);
-    const int rs = 32 * IBl + 1;
-    __syncthreads();                                   // the tile loop / the previous layer's sums are done with LDS
+    for (int i = 0; i < NHID; ++i) bsumH[i] = half_sum(bH[i]);
+    float bsum0 = half_sum(b0), bsumO = half_sum(bO);
+    if (h == 0) {
 #pragma unroll
-    for (int ob = 0; ob < HB; ++ob) {
-      if (ob >= OBl) continue;
-      const float bt = gb[l][ob] + __shfl_xor(gb[l][ob], 32, 64);
-      if (h == 0) part[no * rs + 32 * ob + q] = bt;
-#pragma unroll
-      for (int ib = 0; ib < cmax(HB, NB0); ++ib) {
-        if (ib >= IBl) continue;
-        const int gi = G::gbase(l) + ob * IBl + ib;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (32 * ob + rho(r, 0) < no || 32 * ob + rho(r, 1) < no) {
-            const int o = 32 * ob + rho(r, h);
-            if (o < no) part[o * rs + 32 * ib + q] = gW[gi][r];
-          }
-        }
-      }
+      for (int i = 0; i < NHID; ++i) xch[(i * 4 + wave) * 32 + q] = bsumH[i];
+      xch[(NHID * 4 + wave) * 32 + q] = bsum0;
+      xch[((NHID + 1) * 4 + wave) * 32 + q] = bsumO;
     }
     __syncthreads();
-    const int ol = G::off(l);
-    const int size = no * (G::lin(l) + 1);
-    for (int e = tid; e < size; e += 256) {
-      int src;
-      if (e < no) {
-        src = no * rs + e;                 // bias
-      } else {
-        const int i = (e - no) / no, o = (e - no) - i * no;
-        src = o * rs + i;
+    const int partner = (wave | 1) * 32 + q;                      // read by the ib = 0 owners only
+#pragma unroll
+    for (int i = 0; i < NHID; ++i) bsumH[i] += xch[i * 4 * 32 + partner];
+    if (NB0 == 2) bsum0 += xch[NHID * 4 * 32 + partner];
+    bsumO += xch[(NHID + 1) * 4 * 32 + partner];
+    static_assert(NSLOT * 4 * 32 * 4 <= G::NFR * 1024, "exchange area");
+
+    float* scr = reinterpret_cast<float*>(bufA);
+    float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
+    auto store_tile = [&](auto l_c, int ob, int ib, const f32x16& acc, float bt, bool with_bias) {
+      constexpr int l = decltype(l_c)::value;
+      constexpr int no = G::lout(l), ni = G::lin(l), ol = G::off(l);
+      constexpr bool SPLIT = (G::lsize(l) == G::WMAX) && ((G::WMAX & 1) == 0);
+      __bf16* sp = (SPLIT && a.dw_split != nullptr)
+                       ? reinterpret_cast<__bf16*>(a.dw_split) + ((long long)G::wide_index(l) * a.G + g) * (3 * G::WMAX) : nullptr;
+      auto emit = [&](int e, float v) {
+        dst[ol + e] = v;
+        if (SPLIT && sp != nullptr) {
+          const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+          sp[e] = hi;
+          sp[G::WMAX + e] = lo;
+          sp[2 * G::WMAX + e] = hi;
+        }
+      };
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[q * 33 + rho(r, h)] = acc[r] * (1.0f / GS);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int o = 32 * ob + q;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int il = 2 * k + h, i = 32 * ib + il;
+        if (i < ni && o < no) emit(no + i * no + o, scr[il * 33 + q]);
       }
-      const float v = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
-      dst[ol + e] = v;
-      if (size == G::WMAX && (G::WMAX & 1) == 0 && a.dw_split != nullptr) {
-        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-        __bf16* o = reinterpret_cast<__bf16*>(a.dw_split) + ((long long)G::wide_index(l) * a.G + g) * (3 * G::WMAX) + e;
-        o[0] = hi;
-        o[G::WMAX] = lo;
-        o[2 * G::WMAX] = hi;
-      }
+      if (with_bias && h == 0 && o < no) emit(o, bt * (1.0f / GS));
+    };
+    if constexpr (NHID >= 1) store_tile(std::integral_constant<int, 1>{}, wave >> 1, wave & 1, gH[0], bsumH[0], (wave & 1) == 0);
+    if constexpr (NHID >= 2) store_tile(std::integral_constant<int, 2>{}, wave >> 1, wave & 1, gH[1], bsumH[1], (wave & 1) == 0);
+    if constexpr (NHID >= 3) store_tile(std::integral_constant<int, 3>{}, wave >> 1, wave & 1, gH[2], bsumH[2], (wave & 1) == 0);
+    static_assert(NHID <= 3, "hidden-layer tiles are stored by the three calls above");
+    if (NB0 == 1) {
+      if (wave < 2) store_tile(std::integral_constant<int, 0>{}, wave, 0, g0, bsum0, true);
+    } else {
+      store_tile(std::integral_constant<int, 0>{}, wave >> 1, wave & 1, g0, bsum0, (wave & 1) == 0);
     }
+    if (wave >= 2) store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, gO, bsumO, wave == 2);
   }
+  RCB_WSTAMP(6);
   if (MODE == MODE_LOSS) {
     float v = wave_sum(sse_local);
+    float* red = reinterpret_cast<float*>(smem_raw);              // the bias table is no longer read
     __syncthreads();
-    if (lane == 0) smem[wave] = v;
+    if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (tid == 0) a.sse[(long long)chunk * a.G + g] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
+    if (tid == 0) a.sse[(long long)chunk * a.G + g] = ((red[0] + red[1]) + red[2]) + red[3];
   }
+  RCB_WSTAMP(7);
 }
 
 template <typename T, int NH, int F, int E, int C, int W, int MODE, bool IN16>
@@ -592,7 +760,7 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
   auto kfn = siren_wide_kernel<T, NH, F, E, C, W, MODE, IN16>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+                                       G::LDS_BYTES);
     if (e != hipSuccess) return fail((int)e, "siren(wide): hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }

@@ -22,9 +22,12 @@ import torch  # noqa: E402
 from recombiner_amd import _lib, ops, utils  # noqa: E402
 from recombiner_amd.ops import SirenMeta  # noqa: E402
 
+WIDE = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "wide" else 0      # python tools/siren_stamps.py wide 64 [n]
+if WIDE:
+    del sys.argv[1:3]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 X, Y = utils.synthetic_inputs([32, 32], 16, n, 3, seed=0)
-meta = SirenMeta(1, 1024, 16, 16, 3, 32, 3, precision=1)
+meta = SirenMeta(1, 1024, 16, 16, 3, WIDE or 32, 3, precision=1)
 Xd, Yd = X.cuda(), Y.cuda()
 pe = (torch.randn(n, 1024, 16, device="cuda") * 0.1).bfloat16()
 wv = (torch.rand(n, meta.d_net, device="cuda") * 2 - 1) * 0.02
@@ -34,7 +37,7 @@ torch.cuda.synchronize()
 L = _lib.load()
 nb = min(n, 8192)
 buf = (C.c_uint64 * (nb * 16))()
-rc = L.rcb_debug_read_stamps(buf, nb * 16)
+rc = (L.rcb_debug_read_stamps_wide if WIDE else L.rcb_debug_read_stamps)(buf, nb * 16)
 assert rc == 0, rc
 st = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 16).astype(np.int64)
 # persistent kernel: the stamps of a workgroup's LAST row survive.  1 = row start (its weights were requested during the row
@@ -52,6 +55,11 @@ for k, nm in enumerate(names):
                                                                       np.percentile(d, 10), np.percentile(d, 90)))
 # first tile of wave 0: 14 = tile start, 8 = after forward, 9..12 = before backward layer 3,2,1,0, 15 = start of the wave's second tile
 t = st
+if WIDE:
+    # wide kernel: 0 = launch, 2 = fragments built, 3 = passes done, 6 = gradient tiles stored, 7 = end
+    for nm, a_, b_ in [("weights staged, fragments built", 0, 2), ("passes over the pixel tiles", 2, 3), ("gradient tiles -> HBM", 3, 6), ("sse", 6, 7)]:
+        d = (st[:, b_] - st[:, a_]).astype(np.float64)
+        print("  wide: %-50s median %8.0f  (%5.1f %% of %0.f)" % (nm, np.median(d), 100 * np.median(d) / np.median(st[:, 7] - st[:, 0]), np.median(st[:, 7] - st[:, 0])))
 seg = [("forward (3 sine layers + output)", 14, 8), ("loss / dz", 8, 9), ("backward layer 3", 9, 10), ("backward layer 2", 10, 11),
        ("backward layer 1", 11, 12), ("backward layer 0 (+dpe)", 12, 15)]
 tile = (t[:, 15] - t[:, 14]).astype(np.float64)
