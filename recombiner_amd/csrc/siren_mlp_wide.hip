@@ -27,8 +27,23 @@ __device__ unsigned long long g_wide_stamps[8192 * 16];
 extern "C" int rcb_debug_read_stamps_wide(unsigned long long* dst, int n_entries) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * n_entries);
 }
+// barriers of the pass loop with the time wave 0 spends in them summed (stamp slot 5) and the passes' forward time (slot 4)
+#define RCB_WBARRIER()                                                        \
+  do {                                                                        \
+    const unsigned long long tb_ = __builtin_amdgcn_s_memtime();              \
+    __syncthreads();                                                          \
+    bar_acc += __builtin_amdgcn_s_memtime() - tb_;                            \
+  } while (0)
+#define RCB_WACC_DECL unsigned long long bar_acc = 0
+#define RCB_WACC_STORE()                                                      \
+  do {                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 16 + 5] = bar_acc; \
+  } while (0)
 #else
 #define RCB_WSTAMP(k) do { } while (0)
+#define RCB_WBARRIER() __syncthreads()
+#define RCB_WACC_DECL
+#define RCB_WACC_STORE() do { } while (0)
 #endif
 
 namespace {
@@ -133,29 +148,30 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
     const float* src = a.wvec + (long long)g * a.w_stride;
     float* wst = reinterpret_cast<float*>(smem_raw + G::TILE_OFF);
     const int lane = lane0, fq = lane & 31, fh = lane >> 5;
-    auto part = [&](auto lo_c, auto hi_c) {
+    // all global loads of a part first, into registers (a load-store loop waits for every load before its store); the second
+    // part's loads are issued before the first part's fragments are built and stay in flight behind that work
+    auto load_part = [&](auto lo_c, auto hi_c, float* stage) {
+      constexpr int BASE = G::off(decltype(lo_c)::value), LEN = G::off(decltype(hi_c)::value) - BASE;
+#pragma unroll
+      for (int k = 0; k < (LEN + 255) / 256; ++k) {
+        const int i = tid + 256 * k;
+        stage[k] = src[BASE + (i < LEN ? i : LEN - 1)];
+      }
+    };
+    auto part = [&](auto lo_c, auto hi_c, const float* stage, auto&& between) {
       constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
       constexpr int BASE = G::off(LO), LEN = G::off(HI) - BASE;
-      {
-        // all loads first, then the LDS stores (a load-store loop waits for every load before its store)
-        constexpr int NLD = (LEN + 255) / 256;
-        float stage[NLD];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-          const int i = tid + 256 * k;
-          stage[k] = src[BASE + (i < LEN ? i : LEN - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-          const int i = tid + 256 * k;
-          if (i < LEN) wst[i] = stage[k];
-        }
+      for (int k = 0; k < (LEN + 255) / 256; ++k) {
+        const int i = tid + 256 * k;
+        if (i < LEN) wst[i] = stage[k];
       }
+      between();
       __syncthreads();
       const float* wl = wst - BASE;                               // wl[G::off(l) + ...] as in the parameter vector
 #pragma unroll
       for (int l = LO; l < HI; ++l)
-        if (tid < G::lout(l)) bias[l * BST + tid] = wl[G::off(l) + tid] * (l < NH ? a.k_hi : 1.0f);   // sine layers work in revolutions
+        if (tid < G::lout(l)) bias[l * BST + tid] = (wl[G::off(l) + tid] * (l < NH ? a.k_hi : 1.0f)) * WS;   // sine layers work in revolutions
       auto put = [&](int slot, auto&& elem) {
         union { bf16x8 v; uint4 u; } fr;
         // sine-layer forward fragments carry w0 / 2 pi, the fragments producing a hidden layer's data gradient carry w0
@@ -233,11 +249,17 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
       }
       __syncthreads();
     };
+    using L0c = std::integral_constant<int, 0>;
+    using LSc = std::integral_constant<int, G::LSPLIT>;
+    using LNc = std::integral_constant<int, NL>;
+    float stage_a[(G::off(G::LSPLIT) + 255) / 256];
+    load_part(L0c{}, LSc{}, stage_a);
     if constexpr (G::LSPLIT == NL) {
-      part(std::integral_constant<int, 0>{}, std::integral_constant<int, NL>{});
+      part(L0c{}, LNc{}, stage_a, [] {});
     } else {
-      part(std::integral_constant<int, 0>{}, std::integral_constant<int, G::LSPLIT>{});
-      part(std::integral_constant<int, G::LSPLIT>{}, std::integral_constant<int, NL>{});
+      float stage_b[(DNET - G::off(G::LSPLIT) + 255) / 256];
+      part(L0c{}, LSc{}, stage_a, [&] { load_part(LSc{}, LNc{}, stage_b); });
+      part(LSc{}, LNc{}, stage_b, [] {});
     }
   }
   RCB_WSTAMP(2);
@@ -383,6 +405,7 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
   int lane_v = lane0;
   // one pass = four pixel tiles, one per wave.  FULL: every wave has a tile (all passes but possibly the chunk's last): no
   // wave-level conditionals in the hot loop
+  RCB_WACC_DECL;
   auto pass = [&](int tb, auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
     // the remaining lane-dependent addresses (global rows, layer-0 image stores) are re-derived in every pass: hoisted out
@@ -437,44 +460,75 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
         fetch(t + 4, q, h);
         convert_inputs();
       }
-      // ---- forward --------------------------------------------------------------------------------------------------
-#pragma unroll
-      for (int l = 0; l < NH; ++l) {
-        const float* Bl = bias_lane + l * BST;                   // Bl[rho(r, 0)] is the bias of accumulator row rho(r, h)
+      // ---- forward: software-pipelined by hand -- the bias / fragment reads of a layer are issued before the sine / cosine
+      // work of the layer before it (scheduling barriers keep them there), and the two row blocks' MFMA chains alternate
+      constexpr int KMAX = cmax(K0S, KSH);
+      bf16x8 fr[HB][KMAX];
+      f32x16 acc2[HB];
+      auto issue = [&](int l) {
+        const float* Bl = bias_lane + l * BST;                   // Bl[rho(r, 0)] is the (pre-scaled) bias of row rho(r, h)
 #pragma unroll
         for (int mb = 0; mb < HB; ++mb) {
-          f32x16 acc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = (32 * mb + 16 * (r >> 3) < W) ? Bl[32 * mb + rho(r, 0)] * WS : 0.f;
-          if (l == 0) {
+          for (int r = 0; r < 16; ++r) acc2[mb][r] = (32 * mb + 16 * (r >> 3) < W) ? Bl[32 * mb + rho(r, 0)] : 0.f;
 #pragma unroll
-            for (int s = 0; s < K0S; ++s) acc = Op16<T>::mfma(FA(G::FA0 + mb * K0S + s), xin[s], acc);
-          } else {
+          for (int k = 0; k < KMAX; ++k)
+            if (k < (l == 0 ? K0S : KSH)) fr[mb][k] = FA(l == 0 ? G::FA0 + mb * K0S + k : G::FAH + ((l - 1) * HB + mb) * KSH + k);
+        }
+      };
+      f32x16 acc;
+      bf16x8 fro[KSH];
+      issue(0);
 #pragma unroll
-            for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(FA(G::FAH + ((l - 1) * HB + mb) * KSH + ks), S[l - 1][ks], acc);
-          }
+      for (int l = 0; l < NH; ++l) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+          for (int mb = 0; mb < HB; ++mb)
+            if (k < (l == 0 ? K0S : KSH)) acc2[mb] = Op16<T>::mfma(fr[mb][k], l == 0 ? xin[k < K0S ? k : 0] : S[l > 0 ? l - 1 : 0][k < KSH ? k : 0], acc2[mb]);
+        f32x16 cur[HB];
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb) cur[mb] = acc2[mb];
+        __builtin_amdgcn_sched_barrier(0);
+        if (l + 1 < NH) {
+          issue(l + 1);
+        } else {
+          const float* Bl = bias + (NL - 1) * BST;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] : 0.f) : 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KSH; ++ks) fro[ks] = FA(G::FAO + ks);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             if (2 * mb + s >= KSH) continue;               // rows beyond the layer width: no transcendental spent
             bf16x8 sp, cp;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float tt = (WS == 1.0f) ? acc[8 * s + j] : acc[8 * s + j] * (1.0f / WS);
+              const float tt = (WS == 1.0f) ? cur[mb][8 * s + j] : cur[mb][8 * s + j] * (1.0f / WS);
               sp[j] = (T)__builtin_amdgcn_sinf(tt);
               if (MODE != MODE_FWD) cp[j] = (T)__builtin_amdgcn_cosf(tt);
             }
             S[l][2 * mb + s] = sp;
-            if (MODE != MODE_FWD) Cs[l][2 * mb + s] = cp;
+            if (MODE != MODE_FWD) {
+              // pinned in its packed form: left alone, the compiler keeps the 8 fp32 sine arguments alive instead and
+              // evaluates cos (and its rounding, value by value) in the backward pass
+              union { bf16x8 v; unsigned u[4]; } pin;
+              pin.v = cp;
+              asm volatile("" : "+v"(pin.u[0]), "+v"(pin.u[1]), "+v"(pin.u[2]), "+v"(pin.u[3]));
+              Cs[l][2 * mb + s] = pin.v;
+            }
           }
         }
       }
-      f32x16 acc;
+      __builtin_amdgcn_sched_barrier(0);
       {
-        const float* Bl = bias + (NL - 1) * BST;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] * WS : 0.f) : 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(FA(G::FAO + ks), S[NH - 1][ks], acc);
+        for (int ks = 0; ks < KSH; ++ks) acc = Op16<T>::mfma(fro[ks], S[NH - 1][ks], acc);
         if (WS != 1.0f) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
@@ -564,9 +618,29 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
           // accumulator columns that are never stored (likewise feature columns >= W of either image at width 48)
         }
       }
-      __syncthreads();
+      // the data-gradient fragments do not depend on the images: their reads are in flight across the barrier
+      bf16x8 fb[HB][KSH];
+      auto load_fb = [&]() {
+#pragma unroll
+        for (int ib = 0; ib < HB; ++ib)
+#pragma unroll
+          for (int ks = 0; ks < KSH; ++ks) {
+            if (l == NL - 1) {
+              if (ks == 0) fb[ib][0] = FA(G::FBO + ib);
+            } else if (l > 0) {
+              fb[ib][ks] = FA(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks);
+            } else if (ib == 0 && a.dpe != nullptr) {
+              fb[0][ks] = FX(ks);
+            }
+          }
+      };
+      // (with 16-bit inputs and one input block the register budget allows it; the other instances read after the barrier)
+      constexpr bool FB_EARLY = IN16 && NB0 == 1;
+      if (FB_EARLY && active) load_fb();
+      RCB_WBARRIER();
       // (1) data gradient of this wave's pixel tile
       if (active) {
+        if (!FB_EARLY) load_fb();
         if (l > 0) {
           bf16x8 nz[2 * HB];
           f32x16 dh[HB];
@@ -576,22 +650,22 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
             for (int r = 0; r < 16; ++r) dh[ib][r] = 0.f;
           if (l == NL - 1) {
 #pragma unroll
-            for (int ib = 0; ib < HB; ++ib) dh[ib] = Op16<T>::mfma(FA(G::FBO + ib), dzb[0], dh[ib]);
+            for (int ib = 0; ib < HB; ++ib) dh[ib] = Op16<T>::mfma(fb[ib][0], dzb[0], dh[ib]);
           } else {
 #pragma unroll
             for (int ks = 0; ks < KSH; ++ks)                     // the two chains alternate
 #pragma unroll
-              for (int ib = 0; ib < HB; ++ib)
-                dh[ib] = Op16<T>::mfma(FA(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks), dzb[ks], dh[ib]);
+              for (int ib = 0; ib < HB; ++ib) dh[ib] = Op16<T>::mfma(fb[ib][ks], dzb[ks], dh[ib]);
           }
 #pragma unroll
-          for (int ib = 0; ib < HB; ++ib)
+          for (int ib = 0; ib < HB; ++ib) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              if (2 * ib + s >= KSH) continue;
+            for (int r = 0; r < 16; ++r)                         // products in place, then packed pairwise
+              dh[ib][r] = (2 * ib + (r >> 3) < KSH) ? dh[ib][r] * (float)Cs[l - 1][2 * ib + (r >> 3)][r & 7] : 0.f;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) nz[2 * ib + s][j] = (T)(dh[ib][8 * s + j] * (float)Cs[l - 1][2 * ib + s][j]);
-            }
+            for (int s = 0; s < 2; ++s)
+              if (2 * ib + s < KSH) nz[2 * ib + s] = pack8<T>(dh[ib], s);
+          }
 #pragma unroll
           for (int ks = 0; ks < KSH; ++ks) dzb[ks] = nz[ks];
         } else if (a.dpe != nullptr) {
@@ -599,7 +673,7 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) dx[r] = 0.f;
 #pragma unroll
-          for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(FX(ks), dzb[ks], dx);
+          for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(fb[0][ks], dzb[ks], dx);
           if (valid) {
             float* dst = a.dpe + ((long long)g * P + p) * E;
             if (E % 8 == 0 && a.pe_bf16) {
@@ -665,7 +739,7 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
           }
         }
       }
-      __syncthreads();
+      RCB_WBARRIER();
     }
     if (t + 4 < t1) convert_inputs();
   };
@@ -674,6 +748,7 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
   if (tb < t1) pass(tb, std::false_type{});
   if (MODE == MODE_FWD) return;
   RCB_WSTAMP(3);
+  RCB_WACC_STORE();
 
   // ---- every gradient tile is complete in its owner's registers: transpose through the wave's own image area and store --
   const int lane = lane0, q = lane & 31, h = lane >> 5;
@@ -693,13 +768,20 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
       xch[(NHID * 4 + wave) * 32 + q] = bsum0;
       xch[((NHID + 1) * 4 + wave) * 32 + q] = bsumO;
     }
+    float sse_wave = 0.f;
+    if (MODE == MODE_LOSS) {
+      sse_wave = wave_sum(sse_local);
+      if (lane == 0) xch[NSLOT * 4 * 32 + wave] = sse_wave;
+    }
     __syncthreads();
+    if (MODE == MODE_LOSS && tid == 0)
+      a.sse[(long long)chunk * a.G + g] = ((xch[NSLOT * 4 * 32] + xch[NSLOT * 4 * 32 + 1]) + xch[NSLOT * 4 * 32 + 2]) + xch[NSLOT * 4 * 32 + 3];
     const int partner = (wave | 1) * 32 + q;                      // read by the ib = 0 owners only
 #pragma unroll
     for (int i = 0; i < NHID; ++i) bsumH[i] += xch[i * 4 * 32 + partner];
     if (NB0 == 2) bsum0 += xch[NHID * 4 * 32 + partner];
     bsumO += xch[(NHID + 1) * 4 * 32 + partner];
-    static_assert(NSLOT * 4 * 32 * 4 <= G::NFR * 1024, "exchange area");
+    static_assert((NSLOT * 4 * 32 + 4) * 4 <= G::NFR * 1024, "exchange area");
 
     float* scr = reinterpret_cast<float*>(bufA);
     float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
@@ -742,14 +824,6 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
     if (wave >= 2) store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, gO, bsumO, wave == 2);
   }
   RCB_WSTAMP(6);
-  if (MODE == MODE_LOSS) {
-    float v = wave_sum(sse_local);
-    float* red = reinterpret_cast<float*>(smem_raw);              // the bias table is no longer read
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    if (tid == 0) a.sse[(long long)chunk * a.G + g] = ((red[0] + red[1]) + red[2]) + red[3];
-  }
   RCB_WSTAMP(7);
 }
 

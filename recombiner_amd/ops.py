@@ -58,19 +58,28 @@ def _xf_stride(xf, meta, n_inr):
     return int(xf.stride(0))
 
 
-# Opt-in: split the pixel tiles of a row over several workgroups when a launch has few rows (rcb_siren_desc.pixel_chunks).
-# Off by default: the partial sums change the association of the weight-gradient sums with the batch size, i.e. an INR's
-# gradient would no longer be bit-identical whether it is trained alone or in a large batch
-# (test_determinism_and_batch_invariance), for a gain that only matters below ~200 rows (tools/siren_chunks.py on MI355X,
-# 4096 pixels: 96 rows 85 -> 44 us with 4 chunks, 192 rows 90 -> 68 us; nothing at width 48 / 64).
+# Rows of many pixels are cut into pieces of 32 .. 63 of the 32-pixel tiles, one workgroup each (rcb_siren_desc.pixel_chunks;
+# partial weight gradients summed in a fixed order by rcb_siren_reduce_chunks).  The rule looks at the geometry only, never at
+# the number of rows in the launch: an INR's gradient stays bit-identical whether it is trained alone or in a large batch
+# (test_determinism_and_batch_invariance), and the patched presets (Kodak 4096, video 6144 pixels per patch: a few hundred rows
+# for 256 CUs x 2 workgroups) fill the chip.
+LONG_ROW_TILES = 64
+
+# Opt-in on top of that: also split SHORTER rows when a launch has few of them.  Off by default because that rule does depend on
+# the batch size (tools/siren_chunks.py on MI355X, 4096 pixels: 96 rows 85 -> 44 us with 4 chunks, 192 rows 90 -> 68 us).
 PIXEL_CHUNKS_AUTO = False
 
 
 def siren_pixel_chunks(G, meta: SirenMeta):
-    """workgroups per row of wvec chosen for a launch of G rows: 1 unless PIXEL_CHUNKS_AUTO is set and the launch is a
-    width-32 16-bit one with fewer than 256 rows; every chunk keeps at least 8 of the 32-pixel tiles (2 per wave)"""
+    """workgroups per row of wvec chosen for a launch of G rows (16-bit kernels): rows of at least LONG_ROW_TILES tiles are
+    always cut into ntiles // 32 pieces; with PIXEL_CHUNKS_AUTO a width-32 launch of fewer than 256 shorter rows is split as
+    well, every chunk keeping at least 8 tiles (2 per wave)"""
     ntiles = (meta.n_pix + 31) // 32
-    if not PIXEL_CHUNKS_AUTO or meta.precision == 0 or meta.hidden != 32 or G >= 256 or ntiles < 16:
+    if meta.precision == 0:
+        return 1
+    if ntiles >= LONG_ROW_TILES:
+        return ntiles // 32
+    if not PIXEL_CHUNKS_AUTO or meta.hidden != 32 or G >= 256 or ntiles < 16:
         return 1
     return max(1, min(4 if G <= 128 else 2, ntiles // 8))
 

@@ -60,6 +60,8 @@ if WIDE:
     for nm, a_, b_ in [("weights staged, fragments built", 0, 2), ("passes over the pixel tiles", 2, 3), ("gradient tiles -> HBM", 3, 6), ("sse", 6, 7)]:
         d = (st[:, b_] - st[:, a_]).astype(np.float64)
         print("  wide: %-50s median %8.0f  (%5.1f %% of %0.f)" % (nm, np.median(d), 100 * np.median(d) / np.median(st[:, 7] - st[:, 0]), np.median(st[:, 7] - st[:, 0])))
+    print("  wide: wave 0 inside the passes' barriers, summed       median %8.0f  (%5.1f %% of the passes)" % (
+        np.median(st[:, 5]), 100 * np.median(st[:, 5]) / np.median(st[:, 3] - st[:, 2])))
 seg = [("forward (3 sine layers + output)", 14, 8), ("loss / dz", 8, 9), ("backward layer 3", 9, 10), ("backward layer 2", 10, 11),
        ("backward layer 1", 11, 12), ("backward layer 0 (+dpe)", 12, 15)]
 tile = (t[:, 15] - t[:, 14]).astype(np.float64)
