@@ -1,5 +1,7 @@
 // Declarations shared by the fp32 and bf16 SIREN kernels.
 #pragma once
+#include <cstdlib>
+
 #include "rcb_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,8 +45,14 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);
 int siren_wide_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // hidden width 48 / 64
 
-// the 16-bit kernel family of a descriptor: width 32 or the wide kernel
+// the 16-bit kernel family of a descriptor: width 32 (siren_mlp_bf16.hip) or the kernel with dealt gradient tiles for widths
+// 48 / 64 (siren_mlp_wide.hip; in a -DRCB_SIREN_DEALT32 build RCB_SIREN_W32_DEALT=1 sends the width-32 loss / backward
+// launches there too, for A/B runs)
 inline int siren_16bit_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
+#ifdef RCB_SIREN_DEALT32
+  static const bool dealt32 = getenv("RCB_SIREN_W32_DEALT") != nullptr;
+  if (dealt32 && mode != MODE_FWD) return siren_wide_dispatch(mode, d, a, st);
+#endif
   return d->hidden > HID ? siren_wide_dispatch(mode, d, a, st) : siren_bf16_dispatch(mode, d, a, st);
 }
 

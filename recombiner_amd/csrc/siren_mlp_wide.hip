@@ -53,7 +53,7 @@ __device__ __forceinline__ constexpr int featk(int ks, int h, int j) { return 16
 
 template <int NH, int F, int E, int C, int W>
 struct GeoW {
-  static_assert(W % 16 == 0 && W > 32 && W <= 64, "hidden width 48 or 64");
+  static_assert(W % 16 == 0 && W >= 32 && W <= 64, "hidden width 32, 48 or 64");
   static_assert(C <= 16, "the output gradient is one k-step");
   static_assert(E <= 16, "the data-gradient fragments onto the upsampled features are stored for 16 rows");
   static constexpr int NL = NH + 1;
@@ -62,7 +62,8 @@ struct GeoW {
   static constexpr int NB0 = (IN0 + 31) / 32;
   static constexpr int HB = (W + 31) / 32;
   static constexpr int KSH = W / 16;
-  static_assert(HB == 2 && NB0 <= 2, "gradient tiles are dealt to four waves as 2 x 2");
+  static_assert(NB0 <= 2, "at most two 32-feature input blocks");
+  static_assert(HB == 2 || NH <= 3, "width 32: layer l's gradient tiles belong to wave l");
   __host__ __device__ static constexpr int lin(int l) { return l == 0 ? IN0 : W; }
   __host__ __device__ static constexpr int lout(int l) { return l == NL - 1 ? C : W; }
   __host__ __device__ static constexpr int off(int l) {
@@ -99,8 +100,13 @@ struct GeoW {
   static constexpr int TSA = 32 * HB;                            // dZ image row stride (elements)
   static constexpr int TSBB = 32 * cmax(HB, NB0);                // input image row stride
   static constexpr int WAVE_TILE = 32 * (TSA + TSBB) * 2;
-  static constexpr int LDS_BYTES = TILE_OFF + 4 * WAVE_TILE;
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  // after the passes: bias / loss exchange at FR_OFF, then one 32 x 33 float transposition area per wave
+  static constexpr int XCH_BYTES = 4096;
+  static constexpr int SCR_OFF = FR_OFF + XCH_BYTES;
+  static constexpr int SCR_WAVE = 32 * 33 * 4;
+  static constexpr int LDS_BYTES = cmax(TILE_OFF + 4 * WAVE_TILE, SCR_OFF + 4 * SCR_WAVE);
+  static constexpr int WG_PER_CU = HB == 1 ? 3 : 2;              // waves per SIMD = workgroups per CU (4 waves each)
+  static_assert(WG_PER_CU * LDS_BYTES <= 160 * 1024, "workgroups per CU");
   // the fp32 weights are staged through the image area in at most two parts: layers [0, LSPLIT) and [LSPLIT, NL)
   static constexpr int CAP = 4 * WAVE_TILE / 4;                  // floats
   __host__ __device__ static constexpr int lsplit() {
@@ -110,7 +116,6 @@ struct GeoW {
   }
   static constexpr int LSPLIT = lsplit();
   static_assert(LSPLIT >= 1 && DNET - off(LSPLIT) <= CAP, "weights stage in two parts");
-  static_assert(32 * 33 * 4 <= WAVE_TILE, "a wave transposes one gradient tile through its image area");
 };
 
 // Two workgroups of four waves per CU (two waves per SIMD, 256 registers each).  The weight-gradient tiles are DEALT to the
@@ -119,7 +124,7 @@ struct GeoW {
 // A wave thus holds 3 (4 with two input blocks) accumulator tiles instead of 12 (14), the tiles come out complete (no
 // cross-wave reduction in the epilogue) and are summed over the pixel tiles in ascending order.
 template <typename T, int NH, int F, int E, int C, int W, int MODE, bool IN16>
-__global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
+__global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_wide_kernel(SirenArgs a) {
   using G = GeoW<NH, F, E, C, W>;
   using bf16x8 = typename Op16<T>::v8;
   using bf16x4 = typename Op16<T>::v4;
@@ -264,23 +269,27 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
   }
   RCB_WSTAMP(2);
 
-  // this wave's weight-gradient tiles: hidden layer l (1 .. NH-1): tile (wave >> 1, wave & 1); layer 0: the same with two
-  // input blocks, (wave, 0) on waves 0 / 1 with one; output layer: (0, wave - 2) on waves 2 / 3
+  // this wave's weight-gradient tiles.  Two row blocks (width 48 / 64): hidden layer l (1 .. NH-1): tile (wave >> 1, wave & 1);
+  // layer 0: the same with two input blocks, (wave, 0) on waves 0 / 1 with one; output layer: (0, wave - 2) on waves 2 / 3.
+  // One row block (width 32): wave l owns layer l, i.e. one tile, or two for layer 0 with two input blocks (gT).
   constexpr int NHID = NH - 1;
-  f32x16 gH[NHID > 0 ? NHID : 1], g0, gO_own;
+  constexpr int NGH = (HB == 2 && NHID > 0) ? NHID : 1;
+  f32x16 gH[NGH], g0, gO_own, gT[NB0];
   f32x16& gO = (NB0 == 1) ? g0 : gO_own;                          // one input block: layer-0 tiles on waves 0 / 1 only
-  float bH[NHID > 0 ? NHID : 1], b0 = 0.f, bO = 0.f;
+  float bH[NGH], b0 = 0.f, bO = 0.f, bT = 0.f;
   float sse_local = 0.f;
   if (MODE != MODE_FWD) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #pragma unroll
-      for (int i = 0; i < NHID; ++i) gH[i][r] = 0.f;
+      for (int i = 0; i < NGH; ++i) gH[i][r] = 0.f;
       g0[r] = 0.f;
       gO_own[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NB0; ++i) gT[i][r] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < NHID; ++i) bH[i] = 0.f;
+    for (int i = 0; i < NGH; ++i) bH[i] = 0.f;
   }
   constexpr int KH0 = F, KH1 = E;
 
@@ -363,41 +372,48 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
   };
   if (t0 + wave < t1) convert_inputs();
   // lane-dependent LDS offsets that stay in registers for the whole kernel (everything else lane-dependent is re-derived per
-  // pass, see below).  Image rows are 64 elements (TSA == TSBB) with the 8-byte chunks swizzled by (pixel >> 1) & 7 (swz()):
-  //   wr_off[2 par + e]: this lane's store of features 16 ks + 4 h + 8 e .. + 3, ks = 2 (ks >> 1) + par, + 32 (ks >> 1)
-  //   rd_off[wq]:        this lane's transposed 8-byte read of pixels 8 h + 4 wq + 0..3 (+ 16 s), + feature block, + tile
-  static_assert(G::TSA == 64 && G::TSBB == 64, "one swizzle pattern for both images");
-  int wr_off[4], rd_off[2];
-  {
+  // pass, see below).  Image rows are TSA / TSBB elements with the 8-byte chunks swizzled by (pixel >> 1) & 7 (swz()):
+  //   wr_off[img][2 par + e]: this lane's store of features 16 ks + 4 h + 8 e .. + 3, ks = 2 (ks >> 1) + par, + 32 (ks >> 1)
+  //   rd_addr[img][wq]:       this lane's transposed 8-byte read of pixels 8 h + 4 wq + 0..3 (+ 16 s), + feature block, + tile
+  constexpr bool ONE_STRIDE = (G::TSA == G::TSBB);
+  constexpr int NIMG = ONE_STRIDE ? 1 : 2;
+  int wr_off[NIMG][4], rd_off[NIMG][2];
+#pragma unroll
+  for (int im = 0; im < NIMG; ++im) {
+    const int stride = im == 0 ? G::TSA : G::TSBB;
     const int q0 = lane0 & 31, h0 = lane0 >> 5, key = (q0 >> 1) & 7;
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) wr_off[2 * par + e] = q0 * 64 + (((4 * par + h0 + 2 * e) ^ key) << 2);
+      for (int e = 0; e < 2; ++e) wr_off[im][2 * par + e] = q0 * stride + (((4 * par + h0 + 2 * e) ^ key) << 2);
     const int fb = (lane0 >> 4) & 1, q4 = (lane0 & 15) >> 2, p4 = lane0 & 3;
 #pragma unroll
     for (int wq = 0; wq < 2; ++wq) {
       const int pix = 8 * h0 + 4 * wq + q4;
-      rd_off[wq] = pix * 64 + (((4 * fb + p4) ^ ((pix >> 1) & 7)) << 2);
+      rd_off[im][wq] = pix * stride + (((4 * fb + p4) ^ ((pix >> 1) & 7)) << 2);
     }
   }
   const uint4* fr_lane = frags + lane0;                           // + slot * 64
   const float* bias_lane = bias + 4 * (lane0 >> 5);               // + l * BST + 32 mb + (r & 3) + 8 (r >> 2)
   // transposed operand of k-step s (pixels 16 s + 8 h + 0..7) of feature block fblk of pixel tile w's image `img` (0 / 1).
-  // The two per-lane LDS byte addresses are kept opaque: everything added below then fits the 16-bit offset field of the
+  // The per-lane LDS byte addresses are kept opaque: everything added below then fits the 16-bit offset field of the
   // read (left to itself the compiler folds the image area's own offset in, exceeds the field and keeps ~40 derived bases)
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-  unsigned rd_addr[2];
+  unsigned rd_addr[NIMG][2];
 #pragma unroll
-  for (int wq = 0; wq < 2; ++wq) {
-    rd_addr[wq] = (unsigned)(size_t)((__attribute__((address_space(3))) T*)images) + 2u * (unsigned)rd_off[wq];
-    asm volatile("" : "+v"(rd_addr[wq]));
-  }
-  auto tr_read = [&](int w, int img, int s, int fblk) -> bf16x8 {
-    union { s16x4 v[2]; bf16x8 b; } u;
+  for (int im = 0; im < NIMG; ++im)
 #pragma unroll
     for (int wq = 0; wq < 2; ++wq) {
-      const unsigned addr = (rd_addr[wq] + 2u * (unsigned)fblk) + 2u * (unsigned)(w * (G::WAVE_TILE / 2) + img * 32 * G::TSA + s * 16 * 64);
+      rd_addr[im][wq] = (unsigned)(size_t)((__attribute__((address_space(3))) T*)images) + 2u * (unsigned)rd_off[im][wq];
+      asm volatile("" : "+v"(rd_addr[im][wq]));
+    }
+  auto tr_read = [&](int w, int img, int s, int fblk) -> bf16x8 {
+    union { s16x4 v[2]; bf16x8 b; } u;
+    const int stride = img == 0 ? G::TSA : G::TSBB;
+#pragma unroll
+    for (int wq = 0; wq < 2; ++wq) {
+      const unsigned addr = (rd_addr[ONE_STRIDE ? 0 : img][wq] + 2u * (unsigned)fblk) +
+                            2u * (unsigned)(w * (G::WAVE_TILE / 2) + img * 32 * G::TSA + s * 16 * stride);
       u.v[wq] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)addr);
     }
     return u.b;
@@ -588,15 +604,15 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
         for (int ks = 0; ks < 2 * HB; ++ks) {
           if (ks >= KSO) continue;
           u.v = dzb[ks];
-          *reinterpret_cast<bf16x4*>(bufA + 32 * (ks >> 1) + wr_off[2 * (ks & 1)]) = u.hlf[0];
-          *reinterpret_cast<bf16x4*>(bufA + 32 * (ks >> 1) + wr_off[2 * (ks & 1) + 1]) = u.hlf[1];
+          *reinterpret_cast<bf16x4*>(bufA + 32 * (ks >> 1) + wr_off[0][2 * (ks & 1)]) = u.hlf[0];
+          *reinterpret_cast<bf16x4*>(bufA + 32 * (ks >> 1) + wr_off[0][2 * (ks & 1) + 1]) = u.hlf[1];
         }
         if (l > 0) {
 #pragma unroll
           for (int ks = 0; ks < KSH; ++ks) {
             u.v = S[l - 1][ks];
-            *reinterpret_cast<bf16x4*>(bufB + 32 * (ks >> 1) + wr_off[2 * (ks & 1)]) = u.hlf[0];
-            *reinterpret_cast<bf16x4*>(bufB + 32 * (ks >> 1) + wr_off[2 * (ks & 1) + 1]) = u.hlf[1];
+            *reinterpret_cast<bf16x4*>(bufB + 32 * (ks >> 1) + wr_off[NIMG - 1][2 * (ks & 1)]) = u.hlf[0];
+            *reinterpret_cast<bf16x4*>(bufB + 32 * (ks >> 1) + wr_off[NIMG - 1][2 * (ks & 1) + 1]) = u.hlf[1];
           }
         } else {
           const int base = (h == 0) ? 0 : F;
@@ -700,7 +716,25 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
         }
       }
       // (2) weight gradient of this wave's tile of the layer over the images of every pixel tile of the pass
-      {
+      if constexpr (HB == 1) {
+        if (wave == (l & 3)) {                             // one row block: the whole layer belongs to one wave
+          const int IBl = (l == 0) ? NB0 : 1;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            bf16x8 av[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) av[s2] = tr_read(w, 0, s2, 0);
+            bT = sum8_16<T>(av[0], bT);
+            bT = sum8_16<T>(av[1], bT);
+#pragma unroll
+            for (int ib = 0; ib < NB0; ++ib) {
+              if (ib >= IBl) continue;
+#pragma unroll
+              for (int s2 = 0; s2 < 2; ++s2) gT[ib] = Op16<T>::mfma(av[s2], tr_read(w, 1, s2, 32 * ib), gT[ib]);
+            }
+          }
+        }
+      } else {
         bool own;
         int ob, ib;
         if (l == NL - 1) {
@@ -753,18 +787,20 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
   // ---- every gradient tile is complete in its owner's registers: transpose through the wave's own image area and store --
   const int lane = lane0, q = lane & 31, h = lane >> 5;
   {
-    // bias gradients: the two owners of a row block hold one k-step's sums each; the ib = 1 owner hands its part over through
-    // LDS (the fragment area is no longer read) and the ib = 0 owner stores own + partner
-    float* xch = reinterpret_cast<float*>(smem_raw + G::FR_OFF);  // [slot][wave][32]
+    // bias gradients (two row blocks): the two owners of a row block hold one k-step's sums each; the ib = 1 owner hands its
+    // part over through LDS (the fragment area is no longer read) and the ib = 0 owner stores own + partner
+    float* xch = reinterpret_cast<float*>(smem_raw + G::FR_OFF);  // [slot][wave][32], then the four waves' loss sums
     constexpr int NSLOT = NHID + 2;
+    static_assert((NSLOT * 4 * 32 + 4) * 4 <= G::XCH_BYTES, "exchange area");
     auto half_sum = [&](float v) { return v + __shfl_xor(v, 32, 64); };
-    float bsumH[NHID > 0 ? NHID : 1];
+    float bsumH[NGH];
 #pragma unroll
-    for (int i = 0; i < NHID; ++i) bsumH[i] = half_sum(bH[i]);
+    for (int i = 0; i < NGH; ++i) bsumH[i] = half_sum(bH[i]);
     float bsum0 = half_sum(b0), bsumO = half_sum(bO);
-    if (h == 0) {
+    const float bsumT = half_sum(bT);
+    if (HB == 2 && h == 0) {
 #pragma unroll
-      for (int i = 0; i < NHID; ++i) xch[(i * 4 + wave) * 32 + q] = bsumH[i];
+      for (int i = 0; i < NGH; ++i) xch[(i * 4 + wave) * 32 + q] = bsumH[i];
       xch[(NHID * 4 + wave) * 32 + q] = bsum0;
       xch[((NHID + 1) * 4 + wave) * 32 + q] = bsumO;
     }
@@ -776,14 +812,15 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
     __syncthreads();
     if (MODE == MODE_LOSS && tid == 0)
       a.sse[(long long)chunk * a.G + g] = ((xch[NSLOT * 4 * 32] + xch[NSLOT * 4 * 32 + 1]) + xch[NSLOT * 4 * 32 + 2]) + xch[NSLOT * 4 * 32 + 3];
-    const int partner = (wave | 1) * 32 + q;                      // read by the ib = 0 owners only
+    if (HB == 2) {
+      const int partner = (wave | 1) * 32 + q;                    // read by the ib = 0 owners only
 #pragma unroll
-    for (int i = 0; i < NHID; ++i) bsumH[i] += xch[i * 4 * 32 + partner];
-    if (NB0 == 2) bsum0 += xch[NHID * 4 * 32 + partner];
-    bsumO += xch[(NHID + 1) * 4 * 32 + partner];
-    static_assert((NSLOT * 4 * 32 + 4) * 4 <= G::NFR * 1024, "exchange area");
+      for (int i = 0; i < NGH; ++i) bsumH[i] += xch[i * 4 * 32 + partner];
+      if (NB0 == 2) bsum0 += xch[NHID * 4 * 32 + partner];
+      bsumO += xch[(NHID + 1) * 4 * 32 + partner];
+    }
 
-    float* scr = reinterpret_cast<float*>(bufA);
+    float* scr = reinterpret_cast<float*>(smem_raw + G::SCR_OFF + wave * G::SCR_WAVE);   // (the images' area is dead)
     float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
     auto store_tile = [&](auto l_c, int ob, int ib, const f32x16& acc, float bt, bool with_bias) {
       constexpr int l = decltype(l_c)::value;
@@ -812,16 +849,26 @@ __global__ void __launch_bounds__(256, 2) siren_wide_kernel(SirenArgs a) {
       }
       if (with_bias && h == 0 && o < no) emit(o, bt * (1.0f / GS));
     };
-    if constexpr (NHID >= 1) store_tile(std::integral_constant<int, 1>{}, wave >> 1, wave & 1, gH[0], bsumH[0], (wave & 1) == 0);
-    if constexpr (NHID >= 2) store_tile(std::integral_constant<int, 2>{}, wave >> 1, wave & 1, gH[1], bsumH[1], (wave & 1) == 0);
-    if constexpr (NHID >= 3) store_tile(std::integral_constant<int, 3>{}, wave >> 1, wave & 1, gH[2], bsumH[2], (wave & 1) == 0);
-    static_assert(NHID <= 3, "hidden-layer tiles are stored by the three calls above");
-    if (NB0 == 1) {
-      if (wave < 2) store_tile(std::integral_constant<int, 0>{}, wave, 0, g0, bsum0, true);
+    if constexpr (HB == 2) {
+      if constexpr (NHID >= 1) store_tile(std::integral_constant<int, 1>{}, wave >> 1, wave & 1, gH[0], bsumH[0], (wave & 1) == 0);
+      if constexpr (NHID >= 2) store_tile(std::integral_constant<int, 2>{}, wave >> 1, wave & 1, gH[NHID >= 2 ? 1 : 0], bsumH[NHID >= 2 ? 1 : 0], (wave & 1) == 0);
+      if constexpr (NHID >= 3) store_tile(std::integral_constant<int, 3>{}, wave >> 1, wave & 1, gH[NHID >= 3 ? 2 : 0], bsumH[NHID >= 3 ? 2 : 0], (wave & 1) == 0);
+      static_assert(NHID <= 3, "hidden-layer tiles are stored by the three calls above");
+      if (NB0 == 1) {
+        if (wave < 2) store_tile(std::integral_constant<int, 0>{}, wave, 0, g0, bsum0, true);
+      } else {
+        store_tile(std::integral_constant<int, 0>{}, wave >> 1, wave & 1, g0, bsum0, (wave & 1) == 0);
+      }
+      if (wave >= 2) store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, gO, bsumO, wave == 2);
     } else {
-      store_tile(std::integral_constant<int, 0>{}, wave >> 1, wave & 1, g0, bsum0, (wave & 1) == 0);
+      if (wave == 0) {
+#pragma unroll
+        for (int ib = 0; ib < NB0; ++ib) store_tile(std::integral_constant<int, 0>{}, 0, ib, gT[ib], bsumT, ib == 0);
+      }
+      if constexpr (NL > 1) { if (wave == 1) store_tile(std::integral_constant<int, 1>{}, 0, 0, gT[0], bsumT, true); }
+      if constexpr (NL > 2) { if (wave == 2) store_tile(std::integral_constant<int, (NL > 2 ? 2 : 0)>{}, 0, 0, gT[0], bsumT, true); }
+      if constexpr (NL > 3) { if (wave == 3) store_tile(std::integral_constant<int, (NL > 3 ? 3 : 0)>{}, 0, 0, gT[0], bsumT, true); }
     }
-    if (wave >= 2) store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, gO, bsumO, wave == 2);
   }
   RCB_WSTAMP(6);
   RCB_WSTAMP(7);
@@ -860,6 +907,15 @@ int siren_wide_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStre
   if (d->n_hidden == NHv && d->fourier_dim == Fv && d->pe_dim == Ev && d->out_dim == Cv && d->hidden == Wv)          \
     return d->precision == 2 ? launch_mode<_Float16, NHv, Fv, Ev, Cv, Wv>(mode, a, st)                             \
                              : launch_mode<__bf16, NHv, Fv, Ev, Cv, Wv>(mode, a, st);
+#ifdef RCB_SIREN_DEALT32
+  // width 32 on this kernel (wave l owns layer l's gradient tile, three workgroups per CU): measured 0.284 ms against the
+  // 0.25 ms of siren_mlp_bf16.hip in the same back-to-back loop (4096 x 1024 px) -- eight barriers per pass are too many for
+  // its short layers -- so these instances are only built on request (-DRCB_SIREN_DEALT32, selected by RCB_SIREN_W32_DEALT=1)
+  RCB_CASE(3, 16, 16, 3, 32)
+  RCB_CASE(3, 16, 16, 1, 32)
+  RCB_CASE(3, 18, 16, 3, 32)
+  RCB_CASE(2, 16, 16, 3, 32)
+#endif
   RCB_CASE(3, 16, 16, 3, 48)   // kodak / cifar / protein geometry at width 48
   RCB_CASE(3, 16, 16, 3, 64)
   RCB_CASE(3, 18, 16, 3, 64)   // video geometry at width 64
