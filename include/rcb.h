@@ -45,7 +45,8 @@ const char* rcb_last_error_string(void);
  * `wvec` row g holds the layer vectors back to back, each `[bias(out) | W(in,out) row-major]`
  * (prior_model.py:125-126); rows are w_row_stride floats apart.  G = N*S; sample s of INR n is
  * row g = n*S + s; targets / xf are indexed by n = g / S.
- * Hidden width 32 (every precision mode) or 48 / 64 (16-bit modes), 1..4 hidden layers, out_dim <= 32, F + E <= 64.
+ * Hidden width 32, 48 or 64 in the 16-bit modes; any width up to 64 in the fp32 mode (32 on the matrix cores, the others on a
+ * plain-FMA parity kernel, reference prior_model.py:84-85); 1..4 hidden layers, out_dim <= 32, F + E <= 64.
  * precision: 0 = fp32 MFMA (exact fp32 products); 1 = bf16 operands, 2 = f16 operands (both fp32 accumulate;
  * f16 carries gradients scaled by 2^10 internally).
  * ------------------------------------------------------------------------------------------- */
@@ -56,7 +57,7 @@ typedef struct {
   int32_t fourier_dim;   /* F                                                       */
   int32_t pe_dim;        /* E                                                       */
   int32_t n_hidden;      /* number of hidden layers                                 */
-  int32_t hidden;        /* hidden width (32; 48 / 64 in the 16-bit modes)           */
+  int32_t hidden;        /* hidden width (16-bit modes: 32, 48, 64; fp32: 1 .. 64)   */
   int32_t out_dim;       /* C                                                       */
   int64_t xf_inr_stride; /* floats between INRs in xf; 0 = shared grid              */
   int64_t w_row_stride;  /* floats between rows of wvec and of dwvec                */

@@ -44,6 +44,7 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 
 int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);
 int siren_wide_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // hidden width 48 / 64
+int siren_generic_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // fp32, widths other than 32
 
 // the 16-bit kernel family of a descriptor: width 32 (siren_mlp_bf16.hip) or the kernel with dealt gradient tiles for widths
 // 48 / 64 (siren_mlp_wide.hip; in a -DRCB_SIREN_DEALT32 build RCB_SIREN_W32_DEALT=1 sends the width-32 loss / backward

@@ -348,6 +348,7 @@ int launch(const SirenArgs& a, size_t smem_bytes, hipStream_t st) {
 
 template <int MODE>
 int dispatch(const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
+  if (d->hidden != HID) return siren_generic_dispatch(MODE, d, a, st);   // fp32 at other widths: siren_mlp_generic.hip
   const int in0 = d->fourier_dim + d->pe_dim;
   const int ks = d->fourier_dim > d->pe_dim ? d->fourier_dim : d->pe_dim;
   const int nb0 = (in0 + 31) / 32;
@@ -381,8 +382,9 @@ int dispatch(const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
 
 int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d, RCB_ERR_ARG, "siren: null descriptor");
-  RCB_REQUIRE(d->hidden == HID || (d->precision >= 1 && (d->hidden == 48 || d->hidden == 64)), RCB_ERR_UNSUPPORTED,
-              "siren: hidden width %d (32 in every precision mode; 48 and 64 in the 16-bit modes)", d->hidden);
+  RCB_REQUIRE(d->hidden == HID || (d->precision >= 1 && (d->hidden == 48 || d->hidden == 64)) ||
+                  (d->precision == 0 && d->hidden >= 1 && d->hidden <= 64),
+              RCB_ERR_UNSUPPORTED, "siren: hidden width %d (fp32 mode: up to 64; 16-bit modes: 32, 48, 64)", d->hidden);
   RCB_REQUIRE(d->n_hidden >= 1 && d->n_hidden <= 4, RCB_ERR_UNSUPPORTED, "siren: n_hidden=%d", d->n_hidden);
   RCB_REQUIRE(d->out_dim >= 1 && d->out_dim <= 32, RCB_ERR_UNSUPPORTED, "siren: out_dim=%d", d->out_dim);
   RCB_REQUIRE(d->fourier_dim >= 1 && d->pe_dim >= 0 && d->fourier_dim + d->pe_dim <= 64, RCB_ERR_UNSUPPORTED,

@@ -253,6 +253,42 @@ def test_siren_wide_16bit_operands(case, prec):
     assert rel_err(dw2, wv_r.grad) < lim[2] and rel_err(dpe2, pe_r.grad) < lim[3]
 
 
+@pytest.mark.parametrize("case", WIDE_CASES + [dict(F=16, E=16, n_hidden=2, C=3, P=100, N=2, S=2, hidden=40)])
+def test_siren_other_widths_fp32(case):
+    """fp32 parity mode at hidden widths other than 32 (siren_mlp_generic.hip): forward, fused loss + backward and plain
+    backward against the fp32 torch restatement at fp32 tolerance; bitwise deterministic."""
+    S, N, P, C, W = case["S"], case["N"], case["P"], case["C"], case["hidden"]
+    dims, D, xf, pe, wv, y = _siren_case(seed=31, **case)
+    meta = SirenMeta(samples=S, n_pix=P, fourier_dim=case["F"], pe_dim=case["E"], n_hidden=case["n_hidden"], hidden=W,
+                     out_dim=C, precision=0)
+    assert meta.d_net == D
+    pe_r, wv_r = pe.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+    y_ref = _oracle_mlp(dims, xf, pe_r, wv_r, S)
+    tgt = y.repeat_interleave(S, 0)
+    scale = 1.0 / (S * P * C)
+    (((y_ref - tgt) ** 2).sum() * scale).backward()
+    y_hip = ops.siren_fwd(g(xf), g(pe), g(wv), meta)
+    sse, dw, dpe = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    e_y, e_w, e_p = rel_err(y_hip, y_ref.detach()), rel_err(dw, wv_r.grad), rel_err(dpe, pe_r.grad)
+    e_s = rel_err(sse, ((y_ref.detach() - tgt) ** 2).sum((1, 2)))
+    print("width %d fp32 rel err: y %.2e  sse %.2e  dW %.2e  dpe %.2e" % (W, e_y, e_s, e_w, e_p))
+    assert e_y < 3e-5 and e_s < 3e-6 and e_w < 3e-5 and e_p < 3e-5
+    lo = 0
+    for l in range(len(dims) - 1):
+        n = dims[l + 1] * (dims[l] + 1)
+        assert rel_err(dw[:, lo:lo + n], wv_r.grad[:, lo:lo + n]) < 5e-5, l
+        lo += n
+    sse_b, dw_b, dpe_b = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), scale, meta)
+    assert torch.equal(dw, dw_b) and torch.equal(dpe, dpe_b) and torch.equal(sse, sse_b)
+    gen = torch.Generator().manual_seed(3)
+    dy = 1e-3 * torch.randn(N * S, P, C, generator=gen)
+    pe_r.grad = None
+    wv_r.grad = None
+    _oracle_mlp(dims, xf, pe_r, wv_r, S).backward(dy)
+    dw2, dpe2 = ops.siren_bwd(g(xf), g(pe), g(wv), g(dy), meta)
+    assert rel_err(dw2, wv_r.grad) < 3e-5 and rel_err(dpe2, pe_r.grad) < 3e-5
+
+
 @pytest.mark.parametrize("W", [48, 64])
 def test_siren_wide_model_scale_weights_f16(W):
     """the regime of the real model (effective weights ~1e-4, biases ~1e-2) in f16: 5e-3 of the fp32 restatement, which

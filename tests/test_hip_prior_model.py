@@ -291,10 +291,12 @@ def test_wide_siren_variants_train_like_the_oracle(name, width, prec):
     assert_close_mostly(lt.A[1], A[1].detach(), rtol=0, atol=1.5e-4, max_frac=0.02, hard_atol=8.2e-4, what="A1")
 
 
-@pytest.mark.parametrize("case,prec", [("wide_patch2d_w48", 1), ("wide_patch3d_w64", 2), ("wide_cifar_w64", 1)])
+@pytest.mark.parametrize("case,prec", [("wide_patch2d_w48", 1), ("wide_patch3d_w64", 2), ("wide_cifar_w64", 1),
+                                       ("wide_patch2d_w48", 0), ("wide_patch3d_w64", 0), ("wide_cifar_w64", 0)])
 def test_wide_variants_against_reference_goldens(case, prec):
     """the same variants against vectors produced by the REFERENCE itself at widths 48 / 64 (oracle/make_golden.py
-    --only wide; the CPU suite pins the oracle to them exactly): 16-bit HIP path within operand rounding."""
+    --only wide; the CPU suite pins the oracle to them exactly): 16-bit HIP path within operand rounding, and the fp32
+    parity mode (siren_mlp_generic.hip: any hidden width up to 64) at the tolerances of the width-32 golden tests."""
     d = load(case + ".npz")
     cfg, n, m, lt, up = build(d)
     m.precision = prec
@@ -302,16 +304,20 @@ def test_wide_variants_against_reference_goldens(case, prec):
     feed(m, regen_noise(d, "tm1_eps"))
     prg = [None if q is None else q.to(DEV) for q in pri]
     mse, kl, elbo = m.train(2, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *prg, lt, up, 1e-4, training_mappings=True)
-    np.testing.assert_allclose([mse, kl], d["tm1_ret"], rtol=2e-3)
-    np.testing.assert_allclose(elbo, d["tm1_elbo"], rtol=2e-3)
+    np.testing.assert_allclose([mse, kl], d["tm1_ret"], rtol=2e-3 if prec else 2e-4)
+    np.testing.assert_allclose(elbo, d["tm1_elbo"], rtol=2e-3 if prec else 2e-4)
     got = m.loc.detach().cpu().numpy().reshape(-1)
     if "tm1_loc" in d.files:
         sub = d["tm1_loc"].reshape(-1)
     else:                                   # large entries are kept as a strided subsample (+ moments)
         sub, got = d["tm1_loc__sub"], got[::int(d["tm1_loc__stride"])]
     diff = np.abs(got - sub)
-    assert (diff > 1.5e-4).mean() < 0.02 and diff.max() < 8.2e-4          # Adam moves every element by <= lr per step
-    assert_close_mostly(lt.A[-1], d["tm1_A3"], rtol=0, atol=1.5e-4, max_frac=0.02, hard_atol=8.2e-4, what="A3")
+    if prec:
+        assert (diff > 1.5e-4).mean() < 0.02 and diff.max() < 8.2e-4          # Adam moves every element by <= lr per step
+        assert_close_mostly(lt.A[-1], d["tm1_A3"], rtol=0, atol=1.5e-4, max_frac=0.02, hard_atol=8.2e-4, what="A3")
+    else:                                   # fp32 mode: as test_train_3_steps
+        assert (diff > 3e-5 + 1e-4 * np.abs(sub)).mean() < 0.002, float(diff.max())
+        assert_close_mostly(lt.A[-1], d["tm1_A3"], rtol=1e-3, atol=3e-5, what="A3")
 
 
 def test_sharded_training_rehearsal_two_ranks_one_gpu():

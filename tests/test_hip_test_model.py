@@ -403,15 +403,17 @@ def test_wide_variant_test_time_training_and_bit_exact_decode(width, precision):
 # BASELINE configs[4]: the 3-D patched (video) geometry at test time -- fp32 parity mode above (NAMES), and here the
 # width-64 / f16 variant and the head of a compression run
 # ---------------------------------------------------------------------------------------------------
-def test_patch3d_width64_f16_test_time_path():
+@pytest.mark.parametrize("precision", [2, 0])
+def test_patch3d_width64_f16_test_time_path(precision):
     """TestBNNmodel at data_dim 3, hidden width 64, f16 operands (precision 2), against vectors of the REFERENCE classes run
     with hidden_dims = [64] * 3 (test_patch3d_w64.npz): constructor state exact; predict, KL, annealing and three
-    training epochs within 16-bit operand rounding; A* indices exact (scoring never leaves fp64)."""
+    training epochs within 16-bit operand rounding; A* indices exact (scoring never leaves fp64).  precision 0: the same in
+    the fp32 parity mode (fp32 SIREN at width 64: siren_mlp_generic.hip) at fp32 tolerances."""
     name = "patch3d_w64"
     d = load(f"test_{name}.npz")
     cfg, n, m = build(d, name)
     assert cfg["hidden_dims"] == [64, 64, 64] and cfg["data_dim"] == 3
-    m.precision = 2
+    m.precision = precision
     np.testing.assert_allclose(m.bpp, float(d["bpp"]), rtol=1e-12)
     assert np.array_equal(m.permute_patch_x_g2p, d["perm_x_g2p"].astype(np.int64))
     assert np.array_equal(m.h_permute_patch_x_g2p, d["h_perm_x_g2p"].astype(np.int64))
@@ -421,7 +423,10 @@ def test_patch3d_width64_f16_test_time_path():
         feed(m, regen_noise(d, f"pred_S{S}_eps"))
         with torch.no_grad():
             yp = m.predict(X, random_seed=None, sample_size=S)
-        check(d, f"pred_S{S}", yp, rtol=2e-2, atol=4e-3)                 # f16 operands, fp32 accumulation
+        if precision:
+            check(d, f"pred_S{S}", yp, rtol=2e-2, atol=4e-3)             # f16 operands, fp32 accumulation
+        else:
+            check(d, f"pred_S{S}", yp, rtol=2e-4, atol=2e-5)
     r = m.update_annealing_factors(False)
     for a, k in zip(r, ["kls", "h_kls", "hh_kls"]):
         np.testing.assert_allclose(a, d[k], rtol=2e-5, atol=1e-9)       # KL is fp32 / fp64 in every mode
@@ -443,7 +448,10 @@ def test_patch3d_width64_f16_test_time_path():
         else:
             exp, got = d[key + "__sub"], got[::int(d[key + "__stride"])]
         diff = np.abs(got - exp)
-        assert (diff > 1.5e-4).mean() < 0.03 and diff.max() < 1.25e-3, (key, float((diff > 1.5e-4).mean()), float(diff.max()))
+        if precision:
+            assert (diff > 1.5e-4).mean() < 0.03 and diff.max() < 1.25e-3, (key, float((diff > 1.5e-4).mean()), float(diff.max()))
+        else:
+            assert (diff > 3e-5 + 1e-4 * np.abs(exp)).mean() < 0.002, (key, float(diff.max()))
 
 
 @pytest.mark.parametrize("precision", [0, 1])
