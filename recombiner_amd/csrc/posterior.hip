@@ -513,13 +513,37 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
     int r0 = L.row_perm_inv ? L.row_perm_inv[o] : r;
     int mb = L.member_ptr ? L.member_ptr[r0] : r0;
     int me = L.member_ptr ? L.member_ptr[r0 + 1] : r0 + 1;
-    for (int q = mb; q < me; ++q) {
-      int n = L.member_idx ? L.member_idx[q] : q;
-      for (int s = 0; s < L.samples; ++s) {
-        long long e = ((long long)n * L.samples + s) * L.cols_out + d;
-        float go = L.d_out[e];
-        g_mu = add_rn(g_mu, go);
-        g_sig = add_rn(g_sig, mul_rn(go, L.eps[e]));
+    // the members' gradients, summed in member order.  One sample per member (training): loads in batches of eight -- a row
+    // of a coarse level has tens of members and the launch only a few workgroups, one dependent load after the other is pure
+    // latency
+    if (L.samples == 1) {
+      for (int q0 = mb; q0 < me; q0 += 8) {
+        float go[8], ep[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int q = q0 + u < me ? q0 + u : me - 1;
+          const int n = L.member_idx ? L.member_idx[q] : q;
+          const long long e = (long long)n * L.cols_out + d;
+          go[u] = L.d_out[e];
+          ep[u] = L.eps[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (q0 + u < me) {
+            g_mu = add_rn(g_mu, go[u]);
+            g_sig = add_rn(g_sig, mul_rn(go[u], ep[u]));
+          }
+        }
+      }
+    } else {
+      for (int q = mb; q < me; ++q) {
+        int n = L.member_idx ? L.member_idx[q] : q;
+        for (int s = 0; s < L.samples; ++s) {
+          long long e = ((long long)n * L.samples + s) * L.cols_out + d;
+          float go = L.d_out[e];
+          g_mu = add_rn(g_mu, go);
+          g_sig = add_rn(g_sig, mul_rn(go, L.eps[e]));
+        }
       }
     }
     if (L.enc_mask) {

@@ -79,7 +79,7 @@ struct Geo {
     return o;
   }
   static constexpr int RED_WAVE = roff(NL);
-  static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4);
+  static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4 + 16);   // + the four waves' loss sums
 };
 
 template <typename T, int NH, int F, int E, int C, int MODE, bool IN16>
@@ -525,8 +525,14 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       }
     }
   }
+  if (MODE == MODE_LOSS) {                                 // the loss sums travel with the same barrier
+    const float v = wave_sum(sse_local);
+    if (lane == 0) smem[4 * G::RED_WAVE + wave] = v;
+  }
   __syncthreads();
   RCB_STAMP(5);
+  if (MODE == MODE_LOSS && tid == 0)
+    a.sse[(long long)chunk * a.G + g] = ((smem[4 * G::RED_WAVE] + smem[4 * G::RED_WAVE + 1]) + smem[4 * G::RED_WAVE + 2]) + smem[4 * G::RED_WAVE + 3];
   {
     float* dst = a.dwvec + ((long long)chunk * a.G + g) * a.w_stride;
     // layer by layer with compile-time shapes (constant divisors, no layer search per element)
@@ -556,13 +562,6 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     }
   }
   RCB_STAMP(6);
-  if (MODE == MODE_LOSS) {
-    float v = wave_sum(sse_local);
-    __syncthreads();
-    if (lane == 0) smem[wave] = v;
-    __syncthreads();
-    if (tid == 0) a.sse[(long long)chunk * a.G + g] = ((smem[0] + smem[1]) + smem[2]) + smem[3];
-  }
   RCB_STAMP(7);
 }
 

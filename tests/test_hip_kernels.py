@@ -403,9 +403,9 @@ def test_siren_rejects_bad_arguments():
         ops.siren_fwd(xf, pe, torch.zeros(2, 100, device=DEV), meta)             # wrong d_net
     with pytest.raises(ops.RcbError):
         ops.siren_fwd(xf.cpu(), pe, torch.zeros(2, meta.d_net, device=DEV), meta)  # CPU tensor: no fallback
-    bad = SirenMeta(1, 64, 16, 16, 3, 48, 3)
+    bad = SirenMeta(1, 64, 16, 16, 3, 72, 3)
     with pytest.raises(ops.RcbError):
-        ops.siren_fwd(xf, pe, torch.zeros(2, bad.d_net, device=DEV), bad)          # width 48 exists in 16-bit modes only
+        ops.siren_fwd(xf, pe, torch.zeros(2, bad.d_net, device=DEV), bad)          # fp32 mode: widths up to 64
     bad = SirenMeta(1, 64, 16, 16, 3, 40, 3, precision=1)
     with pytest.raises(ops.RcbError):
         ops.siren_fwd(xf, pe, torch.zeros(2, bad.d_net, device=DEV), bad)          # unsupported width
