@@ -79,6 +79,15 @@ typedef struct {
                           * elements).  The coordinate grid is constant for a whole run and the kernel rounds it to bf16 for
                           * its MFMA operand anyway: given the copy, both input halves are loaded as operand bits (no
                           * unpack / re-round per tile).  Results are bit-identical with and without it.            */
+  int32_t pe_grid_dims;  /* 0: pe / dpe are [G][P][E].  1..3 (16-bit kernels): the rows are the PATCHES of stitched grids, as the
+                          * reference's patched presets build them (utils.py:60-116: the latent grids of a datapoint's patches
+                          * are stitched, upsampled together and cut back into patches): pe / dpe are the upsampling net's own
+                          * channel-last output [S * n_datapoints][G_0]..[G_d-1][E], G_i = pe_patch_nums[i] * pe_patch_size[i];
+                          * row g = n * S + s is patch n % prod(patch_nums) (row-major) of datapoint n / prod(patch_nums) in
+                          * image s * n_datapoints + datapoint, its pixel p the row-major position inside the patch.  Saves
+                          * the cut-back copy of pe and the stitching copy of dpe; results are bit-identical          */
+  int32_t pe_patch_nums[3];  /* patches per axis (first pe_grid_dims entries)                                          */
+  int32_t pe_patch_size[3];  /* pixels per axis of one patch; their product is n_pix                                   */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */

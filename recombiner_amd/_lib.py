@@ -29,7 +29,8 @@ class SirenDesc(C.Structure):
                 ("pe_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
                 ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
                 ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_split", C.c_void_p), ("pixel_chunks", C.c_int32),
-                ("xf_bf16", C.c_void_p)]
+                ("xf_bf16", C.c_void_p), ("pe_grid_dims", C.c_int32), ("pe_patch_nums", C.c_int32 * 3),
+                ("pe_patch_size", C.c_int32 * 3)]
 
 
 class Level(C.Structure):

@@ -32,7 +32,35 @@ struct SirenArgs {
   void* dw_split;     // nullable: split-bf16 copy of the wide layers' weight gradients (see rcb_siren_desc)
   int chunks;         // >= 1: workgroups per row of wvec (pixel tiles split; dwvec / sse hold per-chunk partials)
   const void* xf16;   // nullable: bf16 copy of xf, same shape and strides (rcb_siren_desc.xf_bf16)
+  // pe / dpe layout (rcb_siren_desc.pe_grid_dims): 0 = [G][P][E]; else the rows are the patches of stitched grids
+  // [images][G0][G1][G2][E], G_i = pe_pn[i] * pe_ps[i] (unused leading axes are 1), image = sample * pe_ndc + datapoint
+  int pe_nd, pe_ndc;
+  int pe_pn[3], pe_ps[3];
+  unsigned pe_m1, pe_m2;   // ceil(2^32 / pe_ps[1]), ceil(2^32 / pe_ps[2]): exact quotients for p * ps < 2^32
 };
+
+// pixel index (to be multiplied by E) of pixel 0 of row g in the pe / dpe array, and of pixel p relative to it
+__device__ __forceinline__ long long pe_row_base(const SirenArgs& a, int g) {
+  if (a.pe_nd == 0) return (long long)g * a.P;
+  const int n = g / a.S, s = g - n * a.S;
+  const int np = a.pe_pn[0] * a.pe_pn[1] * a.pe_pn[2];
+  const int d = n / np;
+  int pl = n - d * np;
+  const int c2 = pl % a.pe_pn[2];
+  pl /= a.pe_pn[2];
+  const int c1 = pl % a.pe_pn[1], c0 = pl / a.pe_pn[1];
+  const long long img = (long long)s * a.pe_ndc + d;
+  const int G0 = a.pe_pn[0] * a.pe_ps[0], G1 = a.pe_pn[1] * a.pe_ps[1], G2 = a.pe_pn[2] * a.pe_ps[2];
+  return ((img * G0 + c0 * a.pe_ps[0]) * G1 + c1 * a.pe_ps[1]) * G2 + c2 * a.pe_ps[2];
+}
+__device__ __forceinline__ int pe_pix_off(const SirenArgs& a, int p) {
+  if (a.pe_nd == 0) return p;
+  // (an axis of one pixel has no 32-bit reciprocal: its quotient is the dividend)
+  const unsigned t = a.pe_ps[2] == 1 ? (unsigned)p : __umulhi((unsigned)p, a.pe_m2), y2 = (unsigned)p - t * (unsigned)a.pe_ps[2];
+  const unsigned y0 = a.pe_ps[1] == 1 ? t : __umulhi(t, a.pe_m1), y1 = t - y0 * (unsigned)a.pe_ps[1];
+  const int G1 = a.pe_pn[1] * a.pe_ps[1], G2 = a.pe_pn[2] * a.pe_ps[2];
+  return (int)((y0 * G1 + y1) * G2 + y2);
+}
 
 // row of accumulator register r for lane half h (32x32 MFMA C/D layout)
 __device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -405,6 +405,29 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
               "siren: pixel_chunks=%d needs a 16-bit precision mode, at most one chunk per 32-pixel tile and dw_split == NULL "
               "(rcb_siren_reduce_chunks emits it)", d->pixel_chunks);
   memset(&a, 0, sizeof(a));
+  if (d->pe_grid_dims != 0) {
+    const int nd = d->pe_grid_dims;
+    RCB_REQUIRE(nd >= 1 && nd <= 3 && d->precision >= 1 && d->pe_dim > 0, RCB_ERR_UNSUPPORTED,
+                "siren: pe_grid_dims=%d (1..3, 16-bit kernels, pe_dim > 0)", nd);
+    long long np = 1, pp = 1;
+    for (int i = 0; i < 3; ++i) a.pe_pn[i] = a.pe_ps[i] = 1;
+    for (int i = 0; i < nd; ++i) {                                  // right-aligned: unused leading axes are 1
+      RCB_REQUIRE(d->pe_patch_nums[i] >= 1 && d->pe_patch_size[i] >= 1, RCB_ERR_SHAPE, "siren: stitched pe axis %d: %d x %d", i,
+                  d->pe_patch_nums[i], d->pe_patch_size[i]);
+      a.pe_pn[3 - nd + i] = d->pe_patch_nums[i];
+      a.pe_ps[3 - nd + i] = d->pe_patch_size[i];
+      np *= d->pe_patch_nums[i];
+      pp *= d->pe_patch_size[i];
+    }
+    RCB_REQUIRE(pp == d->n_pix && (d->n_rows / d->samples) % np == 0 && pp * 4096 < (1ll << 32) && a.pe_ps[1] <= 4096 &&
+                    a.pe_ps[2] <= 4096,
+                RCB_ERR_SHAPE, "siren: stitched pe layout: patch of %lld pixels for n_pix=%d, %lld patches per datapoint for %d INRs",
+                pp, d->n_pix, np, d->n_rows / d->samples);
+    a.pe_nd = nd;
+    a.pe_ndc = (int)((d->n_rows / d->samples) / np);
+    a.pe_m1 = (unsigned)(((1ull << 32) + a.pe_ps[1] - 1) / a.pe_ps[1]);
+    a.pe_m2 = (unsigned)(((1ull << 32) + a.pe_ps[2] - 1) / a.pe_ps[2]);
+  }
   a.chunks = chunks;
   a.pe_bf16 = d->pe_bf16;
   a.dw_split = d->dw_split;

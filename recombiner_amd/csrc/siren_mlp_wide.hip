@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
   const int g = blockIdx.x % a.G, chunk = blockIdx.x / a.G;     // chunk-major: partial buffers are [chunk][g]
   const int n = g / a.S;
   const int P = a.P;
+  const long long pe_row = pe_row_base(a, g);      // pixel 0 of this row in pe / dpe (contiguous rows or patches of a stitched grid)
 
   uint4* frags = reinterpret_cast<uint4*>(smem_raw + G::FR_OFF);
   uint4* fragsx = reinterpret_cast<uint4*>(smem_raw + G::FX_OFF);
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
     const int pcl = pp < P ? pp : P - 1;
     if constexpr (IN16) {
       const __bf16* s16 = (h == 0) ? (reinterpret_cast<const __bf16*>(a.xf16) + (long long)n * a.xf_stride + (long long)pcl * F)
-                                   : (reinterpret_cast<const __bf16*>(a.pe) + ((long long)g * P + pcl) * E);
+                                   : (reinterpret_cast<const __bf16*>(a.pe) + (pe_row + pe_pix_off(a, pcl)) * E);
       const int kh16 = (h == 0) ? KH0 : KH1;
 #pragma unroll
       for (int s = 0; s < K0S; ++s) {
@@ -313,10 +314,10 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
       }
     } else {
     const float* src = (h == 0) ? (a.xf + (long long)n * a.xf_stride + (long long)pcl * F)
-                                : (a.pe + ((long long)g * P + pcl) * E);
+                                : (a.pe + (pe_row + pe_pix_off(a, pcl)) * E);
     const int kh = (h == 0) ? KH0 : KH1;
     if (E % 8 == 0 && a.pe_bf16 && h == 1) {   // bf16-stored pe: 16 B per 8 features, widened exactly
-      const uint4* s16 = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.pe) + ((long long)g * P + pcl) * E);
+      const uint4* s16 = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.pe) + (pe_row + pe_pix_off(a, pcl)) * E);
 #pragma unroll
       for (int s = 0; s < K0S; ++s) {
         uint4 u = make_uint4(0, 0, 0, 0);
@@ -691,9 +692,9 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
 #pragma unroll
           for (int ks = 0; ks < KSH; ++ks) dx = Op16<T>::mfma(fb[0][ks], dzb[ks], dx);
           if (valid) {
-            float* dst = a.dpe + ((long long)g * P + p) * E;
+            float* dst = a.dpe + (pe_row + pe_pix_off(a, p)) * E;
             if (E % 8 == 0 && a.pe_bf16) {
-              __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + ((long long)g * P + p) * E;
+              __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + (pe_row + pe_pix_off(a, p)) * E;
 #pragma unroll
               for (int g4 = 0; g4 < E / 8; ++g4) {
                 typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),

@@ -107,7 +107,21 @@ def _xf_bf16(xf):
     return copy
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1):
+class PeLayout:
+    """pe / dpe given as the upsampling net's own channel-last output on the STITCHED grids of the patched presets
+    (rcb_siren_desc.pe_grid_dims): [S * n_datapoints, *(patch_nums[i] * patch_size[i]), E] instead of [G, P, E]."""
+
+    def __init__(self, patch_nums, patch_size):
+        self.patch_nums, self.patch_size = [int(v) for v in patch_nums], [int(v) for v in patch_size]
+        assert 1 <= len(self.patch_nums) == len(self.patch_size) <= 3
+
+    def shape(self, G, meta):
+        n_inr = G // meta.samples
+        per = int(np.prod(self.patch_nums))
+        return (meta.samples * (n_inr // per),) + tuple(a * b for a, b in zip(self.patch_nums, self.patch_size)) + (meta.pe_dim,)
+
+
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1, pe_layout=None):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -118,6 +132,12 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1):
     d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
                   meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split), int(chunks), None)
+    if pe_layout is not None:
+        nd = len(pe_layout.patch_nums)
+        d.pe_grid_dims = nd
+        for i in range(nd):
+            d.pe_patch_nums[i] = pe_layout.patch_nums[i]
+            d.pe_patch_size[i] = pe_layout.patch_size[i]
     if meta.precision == 1 and pe is not None and pe.dtype == bf16 and not _os.environ.get("RCB_SIREN_NO_XF16"):   # (A/B switch)
         x16 = _xf_bf16(xf)
         if x16 is not None:
@@ -132,19 +152,20 @@ def _dev_ptr_strided(t):
     return C.c_void_p(t.data_ptr())
 
 
-def _check_pe(pe, G, meta):
+def _check_pe(pe, G, meta, pe_layout=None):
     if meta.pe_dim == 0:
         return
-    if pe is None or tuple(pe.shape) != (G, meta.n_pix, meta.pe_dim):
-        raise RcbError(f"pe must be [{G},{meta.n_pix},{meta.pe_dim}]")
+    want = (G, meta.n_pix, meta.pe_dim) if pe_layout is None else pe_layout.shape(G, meta)
+    if pe is None or tuple(pe.shape) != tuple(want) or not pe.is_contiguous():
+        raise RcbError(f"pe must be contiguous {list(want)}")
     if pe.dtype not in (f32, bf16) or (pe.dtype == bf16 and meta.precision == 0):
         raise RcbError("pe must be fp32 (any precision mode) or bf16 (16-bit modes only)")
 
 
-def siren_fwd(xf, pe, wvec, meta: SirenMeta, pixel_chunks=None):
+def siren_fwd(xf, pe, wvec, meta: SirenMeta, pixel_chunks=None, pe_layout=None):
     lib = _lib.load()
-    d, G = _siren_desc(meta, wvec, xf, pe, None, pixel_chunks or siren_pixel_chunks(wvec.shape[0], meta))
-    _check_pe(pe, G, meta)
+    d, G = _siren_desc(meta, wvec, xf, pe, None, pixel_chunks or siren_pixel_chunks(wvec.shape[0], meta), pe_layout)
+    _check_pe(pe, G, meta, pe_layout)
     y = torch.empty(G, meta.n_pix, meta.out_dim, device=wvec.device, dtype=f32)
     check(lib.rcb_siren_fwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
                             ptr(y), stream_ptr()), "rcb_siren_fwd")
@@ -178,7 +199,7 @@ def siren_wide_layers(meta: SirenMeta):
 
 
 def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_split=False,
-                   pixel_chunks=None):
+                   pixel_chunks=None, pe_layout=None):
     """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_split (16-bit modes) also
     the split-bf16 left operands [n_wide, G, 3 W] of the wide layers' gradients (ops._Stacked, as split_bf16 returns)."""
     lib = _lib.load()
@@ -191,8 +212,8 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
         stacked = torch.empty(n_wide, G, 3 * w, device=wvec.device, dtype=bf16)
         split = _Stacked(list(stacked.unbind(0)), stacked)
     chunks = pixel_chunks or siren_pixel_chunks(G, meta)
-    d, G = _siren_desc(meta, wvec, xf, pe, None if (split is None or chunks > 1) else split.stacked, chunks)
-    _check_pe(pe, G, meta)
+    d, G = _siren_desc(meta, wvec, xf, pe, None if (split is None or chunks > 1) else split.stacked, chunks, pe_layout)
+    _check_pe(pe, G, meta, pe_layout)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
         raise RcbError(f"target must be [{N},{meta.n_pix},{meta.out_dim}], got {tuple(target.shape)}")

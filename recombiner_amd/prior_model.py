@@ -114,6 +114,7 @@ class PriorBNNmodel(nn.Module):
         self.lowp_gemm = False       # 16-bit mode only: bf16-operand hipBLASLt GEMMs for the A transform
         self.stage1_bf16 = True      # 16-bit mode only: bf16-operand GEMMs for stage 1 of the upsampling net
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
+        self.stitched_pe = True      # 16-bit mode, patched presets: the SIREN kernel reads pe / writes dpe inside the stitched grids
         self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
         self.split_terms = 2         # with split_gemm: 3 = both operands split; 2 = the mappings enter as bf16 (ops.SplitATransform)
         self.split_dgrad_terms = None  # with split_gemm: terms of the data-gradient GEMM (None = split_terms)
@@ -140,9 +141,16 @@ class PriorBNNmodel(nn.Module):
                         self._d_lpe, self.train_size)
         return c["net"], lpe
 
-    def _pe(self, upsample_net, lpe):
+    def _pe_layout(self):
+        """the patched presets in the 16-bit modes hand the SIREN kernel the upsampling net's output on the stitched grids
+        as it is (ops.PeLayout); None: pe is cut back into [N, S, P, 16]"""
+        if self.precision != 0 and self.patch and self.stitched_pe:
+            return ops.PeLayout(self.patch_nums[:self.data_dim], self.pixel_sizes[:self.data_dim])
+        return None
+
+    def _pe(self, upsample_net, lpe, stitched=False):
         """lpe [S, N, *lat, C] -> pe [N, S, P, 16]: hand-written phase-conv kernels in the 16-bit modes
-        where the geometry is instantiated, the nn.Module (MIOpen) otherwise."""
+        where the geometry is instantiated, the nn.Module (MIOpen) otherwise.  `stitched`: see _pe_layout."""
         if self.precision != 0 and hip_path_supported(upsample_net, self.pixel_sizes, self.upsample_factors, self.patch,
                                                       self.data_dim):
             return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
@@ -152,7 +160,7 @@ class PriorBNNmodel(nn.Module):
         elif self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
             net = phase_module(upsample_net) or upsample_net       # torch-level phase form: same function, fewer flops
         return map_lpe_to_inr_inputs(net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
-                                     self.patch, self.patch_nums, self.data_dim)
+                                     self.patch, self.patch_nums, self.data_dim, stitched=stitched)
 
     def _noise(self, shape):
         if self.noise_source is not None:
@@ -327,6 +335,8 @@ class PriorBNNmodel(nn.Module):
                    and ops.rng_eligible(lpe_lv))
         rng_seed = ws["seed"]
 
+        pe_lay = self._pe_layout()
+
         def seg1a():
             ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
@@ -337,9 +347,12 @@ class PriorBNNmodel(nn.Module):
                 lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
             lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
             with torch.enable_grad():
-                pe = self._pe(upsample_net, lpe_t)                       # [N, 1, P, E]
-                pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
-                #                                                               materialises zeros + a copy)
+                if pe_lay is not None:                                   # stitched grids, addressed in place by the kernel
+                    pe_c = self._pe(upsample_net, lpe_t, stitched=True)
+                else:
+                    pe = self._pe(upsample_net, lpe_t)                   # [N, 1, P, E]
+                    pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
+                    #                                                               materialises zeros + a copy)
             if use_rng:
                 h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
                 eps, h_w = [e0], h_w.view(N, D)
@@ -368,9 +381,10 @@ class PriorBNNmodel(nn.Module):
             meta = self._meta(x, pe_c.shape[-1])
             dw_split = None
             if split is not None and split.matches_siren(meta):      # the kernel's epilogue also emits the split form
-                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_split=True)
+                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_split=True,
+                                                            pe_layout=pe_lay)
             else:
-                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta)
+                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, pe_layout=pe_lay)
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
             if lowp:

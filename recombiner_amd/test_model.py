@@ -244,7 +244,13 @@ class TestBNNmodel(nn.Module):
         cum = self.cum_param_sizes
         return [(0 if i == 0 else int(cum[i - 1]), int(cum[i])) for i in range(self.n_layers)]
 
-    def _pe(self, lpe):
+    def _pe_layout(self):
+        """as PriorBNNmodel._pe_layout: the patched presets in the 16-bit modes keep pe / dpe on the stitched grids"""
+        if self.precision != 0 and self.patch and getattr(self, "stitched_pe", True):
+            return ops.PeLayout(self.patch_nums[:self.data_dim], self.pixel_sizes[:self.data_dim])
+        return None
+
+    def _pe(self, lpe, stitched=False):
         if self.precision != 0 and hip_path_supported(self.upsample_net, self.pixel_sizes, self.upsample_factors,
                                                       self.patch, self.data_dim):
             if not hasattr(self, "_weff_cache"):
@@ -256,7 +262,7 @@ class TestBNNmodel(nn.Module):
         elif self.precision != 0 and phase_form_preferred(self.data_dim, self.patch):
             net = phase_module(self.upsample_net) or self.upsample_net
         return map_lpe_to_inr_inputs(net, lpe, self.latent_dim, self.pixel_sizes, self.upsample_factors,
-                                     self.patch, self.patch_nums, self.data_dim)
+                                     self.patch, self.patch_nums, self.data_dim, stitched=stitched)
 
     def _pe_from_sample(self, sample, S):
         N, D = self._n, self._d_net
@@ -504,14 +510,19 @@ class TestBNNmodel(nn.Module):
                 ws["split"] = split
             split = split or None
 
+        pe_lay = self._pe_layout()
+
         def body(adjust):
             ops.step_begin(tab, step_t, dyn)
             eps = self._draw_all(S)
             sample = ops.reparam_fwd(specs, eps, S)                                   # [N,S,Dtot]
             lpe_t = self._pe_from_sample(sample, S).contiguous().requires_grad_(True)
             with torch.enable_grad():
-                pe = self._pe(lpe_t)
-                pe_c = pe.reshape(N * S, P, pe.shape[-1]).contiguous()
+                if pe_lay is not None:
+                    pe_c = self._pe(lpe_t, stitched=True)
+                else:
+                    pe = self._pe(lpe_t)
+                    pe_c = pe.reshape(N * S, P, pe.shape[-1]).contiguous()
             h_w = sample[..., :D].reshape(N * S, D)
             wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)
             if split is not None:
@@ -521,9 +532,10 @@ class TestBNNmodel(nn.Module):
                     torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
             dw_split = None
             if split is not None and split.matches_siren(meta):
-                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, want_split=True)
+                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, want_split=True,
+                                                            pe_layout=pe_lay)
             else:
-                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta)
+                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, pe_layout=pe_lay)
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
             Dt = self._l1.D
             if self.patch:        # levels 2 and 3 need the contiguous [N, S, D] gradient as well

@@ -40,10 +40,13 @@ def hierarchy_row_maps(n_inr, patch_nums, hierarchical_patch_nums, data_dim):
 # latent positional encodings -> per-pixel inputs (utils.py:4-120)
 # ---------------------------------------------------------------------------------------------
 def map_lpe_to_inr_inputs(upsample_net, latent_pe, latent_dim, pixel_sizes, upsample_factors, patch, patch_nums,
-                          data_dim):
+                          data_dim, stitched=False):
     """latent_pe [S, N, ...] -> pe [N, S, P, C_out] (channel-last, P row-major over the pixel grid).
     Patched presets: the latent grids of all patches of a datapoint are stitched into one grid,
-    upsampled together, and cut back into patches."""
+    upsampled together, and cut back into patches.
+    `stitched` (patched presets only): skip the cut-back and return the upsampling net's channel-last output on the stitched
+    grids, [S * n_datapoints, *(patch_nums[i] * pixel_sizes[i]), C_out], for kernels that address the patches inside it
+    (rcb_siren_desc.pe_grid_dims, ops.PeLayout(patch_nums, pixel_sizes))."""
     S, N = latent_pe.shape[:2]
     lat = [pixel_sizes[i] // upsample_factors[i] for i in range(data_dim)]
     z = latent_pe.reshape(S, N, *lat, -1)
@@ -59,6 +62,8 @@ def map_lpe_to_inr_inputs(upsample_net, latent_pe, latent_dim, pixel_sizes, upsa
         z = z.permute([0, 1] + inter + [2 + 2 * data_dim])
         z = z.reshape(S * nd, *[pn[i] * lat[i] for i in range(data_dim)], latent_dim)
         o = upsample_net(z.movedim(-1, 1)).movedim(1, -1)
+        if stitched:
+            return o.contiguous()
         ch = o.shape[-1]
         split = [v for i in range(data_dim) for v in (pn[i], pixel_sizes[i])]
         o = o.reshape(S, nd, *split, ch)

@@ -395,6 +395,48 @@ def test_siren_per_inr_coordinates_and_strided_rows():
     assert rel_err(y_hip, ref) < 2e-5
 
 
+def _stitch(t, S, pn, ps):
+    """[N * S rows (row = n * S + s), P, E] -> the stitched channel-last grids [S * nd, *(pn_i * ps_i), E] of utils.map_lpe_to_inr_inputs"""
+    G, P, E = t.shape
+    dd, N = len(pn), G // S
+    nd = N // int(np.prod(pn))
+    v = t.view(nd, *pn, S, *ps, E)                                   # [nd, pn.., S, ps.., E]
+    perm = [1 + dd, 0] + [x for i in range(dd) for x in (1 + i, 2 + dd + i)] + [2 + 2 * dd]
+    return v.permute(perm).reshape(S * nd, *[a * b for a, b in zip(pn, ps)], E).contiguous()
+
+
+def _unstitch(t, S, pn, ps):
+    dd, E = len(pn), t.shape[-1]
+    nd = t.shape[0] // S
+    v = t.view(S, nd, *[x for i in range(dd) for x in (pn[i], ps[i])], E)
+    perm = [1] + [2 + 2 * i for i in range(dd)] + [0] + [3 + 2 * i for i in range(dd)] + [2 + 2 * dd]
+    return v.permute(perm).reshape(nd * int(np.prod(pn)) * S, int(np.prod(ps)), E).contiguous()
+
+
+@pytest.mark.parametrize("pn,ps,S,width,prec", [((2, 3), (8, 16), 2, 32, 1), ((3,), (200,), 1, 32, 1), ((2, 1, 2), (4, 6, 10), 1, 64, 2),
+                                                ((2, 2), (16, 16), 1, 48, 1), ((2, 2, 2), (2, 8, 8), 3, 32, 2)])
+def test_siren_stitched_pe_layout_is_bit_identical(pn, ps, S, width, prec):
+    """rcb_siren_desc.pe_grid_dims: pe / dpe addressed inside the upsampling net's stitched output grids (the patched presets,
+    reference utils.py:60-116) == the same launch on patch-major copies, bit for bit (forward, loss + backward)."""
+    P, per = int(np.prod(ps)), int(np.prod(pn))
+    N = 2 * per
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=P, N=N, S=S, hidden=width)
+    dims, D, xf, pe, wv, y = _siren_case(seed=41, **case)
+    meta = SirenMeta(S, P, 16, 16, 3, width, 3, precision=prec)
+    pe16 = g(pe).bfloat16()                                        # [N * S, P, E]
+    lay = ops.PeLayout(pn, ps)
+    st = _stitch(pe16, S, list(pn), list(ps))
+    assert torch.equal(_unstitch(st, S, list(pn), list(ps)), pe16)
+    assert torch.equal(ops.siren_fwd(g(xf), st, g(wv), meta, pe_layout=lay), ops.siren_fwd(g(xf), pe16, g(wv), meta))
+    scale = 1.0 / (S * P * 3)
+    s1, w1, d1 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta)
+    s2, w2, d2 = ops.siren_loss_bwd(g(xf), st, g(wv), g(y), scale, meta, pe_layout=lay)
+    assert d2.shape == st.shape and torch.equal(s1, s2) and torch.equal(w1, w2)
+    assert torch.equal(_unstitch(d2, S, list(pn), list(ps)), d1)
+    with pytest.raises(ops.RcbError):
+        ops.siren_loss_bwd(g(xf), st.float(), g(wv), g(y), scale, SirenMeta(S, P, 16, 16, 3, 32, 3, precision=0), pe_layout=lay)
+
+
 def test_siren_rejects_bad_arguments():
     meta = SirenMeta(1, 64, 16, 16, 3, 32, 3)
     xf = torch.zeros(64, 16, device=DEV)

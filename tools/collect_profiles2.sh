@@ -18,5 +18,9 @@ run video python3 tools/prof_preset.py video 4 32 1
 run protein python3 tools/prof_preset.py protein 4096 32 1
 run kodak_w48 python3 tools/prof_preset.py kodak 2 48 1
 run video_w64_f16 python3 tools/prof_preset.py video 4 64 2
+run cifar_w64 python3 tools/prof_preset.py cifar 4096 64 1
+run siren_wide_w64 python3 tools/run_siren.py bf16 4096 10 pe16 64
+run siren_wide_w48 python3 tools/run_siren.py bf16 4096 10 pe16 48
+run siren_wide_w64_f16 python3 tools/run_siren.py f16 4096 10 pe16 64
 python3 tools/bench_presets.py > $OUT/presets.log 2>&1
 cat $OUT/presets.log | grep "ms/step"
