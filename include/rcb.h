@@ -446,6 +446,18 @@ int rcb_window_gather(const void* x, void* cols, int32_t B, int32_t g0, int32_t 
 int rcb_window_fold(const void* dcols, void* dx, int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t C, int32_t nd,
                     rcb_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The window-GEMM weight of a  nearest-upsample(f) -> conv(k, pad)  stage (reference prior_model.py:23-59: up1 + conv1 of the
+ * upsampling net, evaluated on the 1-D / 3-D and stitched 2-D grids as one GEMM over 3^d-pixel windows, all phases at once):
+ *   Wbig[(n_0..n_d-1, ci), (a_0..a_d-1, co)] = sum of W[co][ci][kk] over the taps kk with floor((a_i + kk_i - pad) / f_i) + 1 == n_i
+ * rcb_phase_bigweight: `wt` = the conv weight in channel-last order [k^nd][cin][cout] (fp32) -> big [3^nd * cin][prod(f) * cout],
+ * bf16 (out_bf16 = 1) or fp32.  rcb_phase_bigweight_grad: its adjoint, dbig (bf16 or fp32) -> dwt [k^nd][cin][cout] fp32.
+ * `f` holds nd upsampling factors (<= 8); k <= 8; every phase must stay inside the 3-pixel window (all reference stages do). */
+int rcb_phase_bigweight(const float* wt, void* big, int32_t out_bf16, int32_t nd, const int32_t* f, int32_t k, int32_t pad,
+                        int32_t cin, int32_t cout, rcb_stream_t stream);
+int rcb_phase_bigweight_grad(const void* dbig, int32_t in_bf16, float* dwt, int32_t nd, const int32_t* f, int32_t k, int32_t pad,
+                             int32_t cin, int32_t cout, rcb_stream_t stream);
+
 /* sigma = softplus(log_scale)/6 elementwise (prior_model.py:88).                                */
 int rcb_softplus_scale(const float* log_scale, float* scale, int64_t n, rcb_stream_t stream);
 

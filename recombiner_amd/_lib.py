@@ -17,7 +17,8 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_upconv_dgrad_partial_rows", "rcb_split_bf16", "rcb_debug_generic_kernels_only", "rcb_philox_normal",
            "rcb_reparam_rng_fwd", "rcb_upconv_bwd_fused", "rcb_tile_gather", "rcb_tile_crop", "rcb_tile_fold",
            "rcb_window_gather", "rcb_window_fold", "rcb_siren_reduce_chunks", "rcb_phaseconv_pack", "rcb_phaseconv_pack_uint4",
-           "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace"]
+           "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace",
+           "rcb_phase_bigweight", "rcb_phase_bigweight_grad"]
 
 
 class RcbError(RuntimeError):

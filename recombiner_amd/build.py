@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librcb_hip.so")
-SOURCES = ["phaseconv.hip", "posterior.hip", "rec_score.hip", "siren_mlp.hip", "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_mlp_generic.hip", "tiles.hip", "upconv.hip", "upconv_weff.hip"]
+SOURCES = ["phase_weight.hip", "phaseconv.hip", "posterior.hip", "rec_score.hip", "siren_mlp.hip", "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_mlp_generic.hip", "tiles.hip", "upconv.hip", "upconv_weff.hip"]
 
 
 def hipcc():

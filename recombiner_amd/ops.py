@@ -855,6 +855,33 @@ def window_fold(dcols, shape):
     return dx
 
 
+def phase_bigweight(W, factors, k, pad, dtype=bf16):
+    """conv weight W [Cout, Cin, *k] (fp32) -> the window-GEMM weight [3^d * Cin, prod(f) * Cout] of the stage
+    nearest-upsample(f) -> conv(k, pad) (rcb_phase_bigweight), in `dtype` (bf16 / fp32)"""
+    if W.dtype != f32 or not W.is_cuda or dtype not in (bf16, f32):
+        raise RcbError("phase_bigweight: fp32 GPU weight, bf16 or fp32 result")
+    nd, cout, cin = W.dim() - 2, W.shape[0], W.shape[1]
+    wt = W.permute(*range(2, 2 + nd), 1, 0).contiguous()                       # [k^d, Cin, Cout]
+    f = (C.c_int32 * 3)(*[int(v) for v in factors], *([0] * (3 - nd)))
+    big = torch.empty(3 ** nd * cin, int(np.prod(factors)) * cout, device=W.device, dtype=dtype)
+    check(_lib.load().rcb_phase_bigweight(ptr(wt), ptr(big, None, True), int(dtype == bf16), nd, f, int(k), int(pad), cin, cout,
+                                          stream_ptr()), "rcb_phase_bigweight")
+    return big
+
+
+def phase_bigweight_grad(dbig, w_shape, factors, k, pad):
+    """the adjoint of phase_bigweight: dbig (bf16 / fp32) -> dW of shape `w_shape` = [Cout, Cin, *k] (fp32)"""
+    nd, cout, cin = len(w_shape) - 2, w_shape[0], w_shape[1]
+    if dbig.dtype not in (bf16, f32) or not dbig.is_cuda or not dbig.is_contiguous() or \
+            tuple(dbig.shape) != (3 ** nd * cin, int(np.prod(factors)) * cout):
+        raise RcbError("phase_bigweight_grad: contiguous [3^d * Cin, prod(f) * Cout] GPU matrix expected")
+    f = (C.c_int32 * 3)(*[int(v) for v in factors], *([0] * (3 - nd)))
+    dwt = torch.empty(*([int(k)] * nd), cin, cout, device=dbig.device, dtype=f32)
+    check(_lib.load().rcb_phase_bigweight_grad(ptr(dbig, None, True), int(dbig.dtype == bf16), ptr(dwt), nd, f, int(k), int(pad),
+                                               cin, cout, stream_ptr()), "rcb_phase_bigweight_grad")
+    return dwt.permute(nd + 1, nd, *range(nd)).contiguous()
+
+
 # ---------------------------------------------------------------------------------------------------
 # direct sub-pixel convolutions for grids of any dimension (rcb_phaseconv_*)
 # ---------------------------------------------------------------------------------------------------

@@ -45,6 +45,7 @@ class PhaseStage:
         self.f = [int(v) for v in (factors if isinstance(factors, (tuple, list)) else [factors] * dd)]
         self.plans = [_axis_plan(f, k, pad) for f in self.f]
         self.k, self.pad = k, pad
+        self.hip_weight = True       # GPU: build the window-GEMM weight with rcb_phase_bigweight (False: einsums, for A/B and tests)
 
     def eff_weight(self, W):
         """W [Cout, Cin, *k] -> Weff [*taps, Cin, *phases, Cout]."""
@@ -87,7 +88,11 @@ class PhaseStage:
         dd, g = self.dd, list(x.shape[1:-1])
         dt = x.dtype if dtype is None else dtype
         nph = int(np.prod(self.f))
-        y = _WindowGemmFn.apply(x.to(dt), self.big_weight(W).to(dt), b.to(dt).repeat(nph))
+        if x.is_cuda and W.dtype == torch.float32 and dt in (torch.bfloat16, torch.float32) and self.window3() and self.hip_weight:
+            Wbig = _BigWeightFn.apply(W, self, dt)               # rcb_phase_bigweight: one gather-sum kernel each way
+        else:
+            Wbig = self.big_weight(W).to(dt)
+        y = _WindowGemmFn.apply(x.to(dt), Wbig, b.to(dt).repeat(nph))
         y = y.view([x.shape[0]] + g + self.f + [W.shape[0]])
         perm = [0] + [v for d in range(dd) for v in (1 + d, 1 + dd + d)] + [1 + 2 * dd]
         return y.permute(perm).reshape([x.shape[0]] + [g[d] * self.f[d] for d in range(dd)] + [W.shape[0]])
@@ -134,6 +139,22 @@ class PhaseStage:
             index.append(slice(None))
             ov[tuple(index)] = Yp
         return out
+
+
+class _BigWeightFn(torch.autograd.Function):
+    """PhaseStage.big_weight(W).to(dtype) through rcb_phase_bigweight / _grad (the same 0 / 1 linear map, fp32 sums)"""
+
+    @staticmethod
+    def forward(ctx, W, stage, dtype):
+        from . import ops
+        ctx.stage, ctx.w_shape = stage, tuple(W.shape)
+        return ops.phase_bigweight(W.detach(), stage.f, stage.k, stage.pad, dtype)
+
+    @staticmethod
+    def backward(ctx, dbig):
+        from . import ops
+        st = ctx.stage
+        return ops.phase_bigweight_grad(dbig.contiguous(), ctx.w_shape, st.f, st.k, st.pad), None, None
 
 
 class _WindowGemmFn(torch.autograd.Function):

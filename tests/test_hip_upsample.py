@@ -461,3 +461,28 @@ def test_phaseconv_forward_and_data_gradient(shape, cout, leaky):
     dW2, db2 = ops.phaseconv_wgrad(x, dy)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)      # no atomics: bitwise reproducible
     print("phaseconv %s cout %d: fwd %.1e dgrad %.1e wgrad %.1e dbias %.1e" % (shape, cout, e_fwd, e_bwd, e_w, e_b))
+
+
+@pytest.mark.parametrize("dd,f,k,pad,cin,cout", [(1, 4, 5, 2, 16, 8), (2, 4, 5, 2, 24, 16), (3, 4, 5, 2, 8, 8), (1, 6, 5, 2, 16, 8),
+                                                 (3, 2, 3, 1, 8, 16), (2, 2, 3, 1, 64, 64)])
+def test_phase_bigweight_kernels_match_the_einsum_form(dd, f, k, pad, cin, cout):
+    """rcb_phase_bigweight / _grad == PhaseStage.big_weight (einsums with 0 / 1 tensors) and its autograd gradient: the window-
+    GEMM weight of a nearest-upsample(f) -> conv(k, pad) stage for every stage geometry of the reference nets; and the bf16
+    result is the rounded fp32 one."""
+    from recombiner_amd import ops
+    from recombiner_amd.upsample_fast import PhaseStage
+    torch.manual_seed(3)
+    st = PhaseStage(f, k, pad, dd)
+    W = torch.randn(cout, cin, *([k] * dd), device=DEV)
+    Wr = W.clone().requires_grad_(True)
+    ref = st.big_weight(Wr)
+    got = ops.phase_bigweight(W, st.f, k, pad, torch.float32)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref.detach(), rtol=1e-5, atol=1e-5)      # (sums of up to 2^d taps in another order)
+    assert torch.equal(ops.phase_bigweight(W, st.f, k, pad, torch.bfloat16), got.bfloat16())
+    dbig = torch.randn_like(ref)
+    (gref,) = torch.autograd.grad(ref, [Wr], dbig)
+    gw = ops.phase_bigweight_grad(dbig, tuple(W.shape), st.f, k, pad)
+    torch.testing.assert_close(gw, gref, rtol=2e-5, atol=2e-5)
+    gw16 = ops.phase_bigweight_grad(dbig.bfloat16(), tuple(W.shape), st.f, k, pad)
+    torch.testing.assert_close(gw16, ops.phase_bigweight_grad(dbig.bfloat16().float(), tuple(W.shape), st.f, k, pad), rtol=0, atol=0)
