@@ -1,5 +1,5 @@
 """One-off: tune the library GEMMs of a workload on this GPU and write a TunableOp result file.
-   python tools/tune_gemms.py <out.csv> [bench|compress]        then        python tools/tune_gemms.py --merge out.csv a.csv b.csv ..."""
+   python tools/tune_gemms.py <out.csv> [bench|compress|presets [label ...]]   then   python tools/tune_gemms.py --merge out.csv a.csv b.csv ..."""
 import os, runpy, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -36,6 +36,9 @@ if __name__ == "__main__":
         sys.path.insert(0, os.path.dirname(here))
         import bench
         bench.main()
+    elif what == "presets":            # the patched presets' small-row GEMMs (tools/bench_presets.py: kodak, audio, video, ...)
+        sys.argv = ["bench_presets.py"] + sys.argv[3:]
+        runpy.run_path(os.path.join(here, "bench_presets.py"), run_name="__main__")
     else:
         sys.argv = ["bench_compress.py", "bf16"]
         runpy.run_path(os.path.join(here, "bench_compress.py"), run_name="__main__")
