@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
   constexpr float WS = Op16<T>::W_SCALE;
   constexpr int NL = G::NL, IN0 = G::IN0, K0S = G::K0S, NB0 = G::NB0, HB = G::HB, KSH = G::KSH, DNET = G::DNET;
   constexpr int BST = G::BIAS_STRIDE;
+  constexpr bool FB_EARLY_C = IN16 && NB0 == 1;             // instances whose register budget allows reads far ahead of their use
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* bias = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x;
@@ -480,6 +481,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
       // ---- forward: software-pipelined by hand -- the bias / fragment reads of a layer are issued before the sine / cosine
       // work of the layer before it (scheduling barriers keep them there), and the two row blocks' MFMA chains alternate
       constexpr int KMAX = cmax(K0S, KSH);
+      constexpr bool EARLY_READS = FB_EARLY_C;              // (register budget: 16-bit inputs and one input block)
       bf16x8 fr[HB][KMAX];
       f32x16 acc2[HB];
       auto issue = [&](int l) {
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
         for (int mb = 0; mb < HB; ++mb) cur[mb] = acc2[mb];
         __builtin_amdgcn_sched_barrier(0);
         if (l + 1 < NH) {
-          issue(l + 1);
+          if (EARLY_READS) issue(l + 1);
         } else {
           const float* Bl = bias + (NL - 1) * BST;
 #pragma unroll
@@ -541,6 +543,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
             }
           }
         }
+        if (!EARLY_READS && l + 1 < NH) issue(l + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       {
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
           }
       };
       // (with 16-bit inputs and one input block the register budget allows it; the other instances read after the barrier)
-      constexpr bool FB_EARLY = IN16 && NB0 == 1;
+      constexpr bool FB_EARLY = FB_EARLY_C;
       if (FB_EARLY && active) load_fb();
       RCB_WBARRIER();
       // (1) data gradient of this wave's pixel tile
