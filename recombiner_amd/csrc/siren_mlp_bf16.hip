@@ -33,6 +33,9 @@ extern "C" int rcb_debug_read_stamps(unsigned long long* dst, int n_entries) {
 #else
 #define RCB_STAMP(k) do { } while (0)
 #endif
+#ifndef RCB_W32_DIRECT_FRAGS
+#define RCB_W32_DIRECT_FRAGS 1      // 0: stage the row of wvec in LDS and gather the fragments from there (A/B builds)
+#endif
 
 namespace {
 using namespace rcb::op16;
@@ -110,6 +113,22 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   // ---- stage weights, build MFMA A-fragments, clear the zero padding of bufB ---------------------
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
+#if RCB_W32_DIRECT_FRAGS
+    // The fragments are gathered straight from the row of wvec in global memory: every wave issues the 8 x (3 or 4) loads of
+    // its slots back to back -- ONE memory round trip -- instead of staging the row in LDS (a round trip and a barrier) and
+    // gathering from there (another 32 dependent LDS reads per lane).  The lines of the 13 KB row are fetched from L2 once and
+    // hit in L1 afterwards.  Only the biases live in LDS (wl keeps the layout of the parameter vector; nothing else of it
+    // is read).  The sine layers work in revolutions: w0 / 2 pi is folded into their forward fragments and biases.
+    const float* wsrc = src;
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+      if (tid < G::lout(l)) wl[G::off(l) + tid] = src[G::off(l) + tid] * (l < NH ? a.k_hi : 1.0f);
+    if (32 * NB0 > IN0) {
+      for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
+    }
+    RCB_STAMP(1);
+#else
+    const float* wsrc = wl;
     {
       // all loads first, then the LDS stores: written as `wl[i] = src[i]` in a loop the compiler waits for every load before
       // its store -- 13 serialized HBM round trips, 17 % of the whole kernel by the in-kernel stamps (tools/siren_stamps.py)
@@ -137,6 +156,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #pragma unroll
       for (int l = 0; l < NH; ++l) wl[G::off(l) + tid] *= a.k_hi;
     }
+#endif
     // one fragment slot per wave and pass; `slot` is a compile-time constant inside the unrolled loop, so the layer
     // offsets and shapes below fold away and only the lane-dependent part of the gather address remains
 #pragma unroll
@@ -150,26 +170,26 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         if (slot < K0S) {
           int kk = 8 * slot + j;
           int row = (fh == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
-          if (row >= 0) w = wl[G::off(0) + HID + row * HID + fq];
+          if (row >= 0) w = wsrc[G::off(0) + HID + row * HID + fq];
         } else if (slot < NFA) {
           int l = 1 + (slot - K0S) / 2, st = (slot - K0S) & 1;
           int no = (l == NL - 1) ? C : HID;
           int o = 0;
           for (int i = 0; i < l; ++i) o += G::lout(i) * (G::lin(i) + 1);
-          if (fq < no) w = wl[o + no + fk(st, fh, j) * no + fq];
+          if (fq < no) w = wsrc[o + no + fk(st, fh, j) * no + fq];
         } else {
           int b = slot - NFA;
           if (b == 0) {
             int oo = fk(0, fh, j);
-            if (oo < C) w = wl[G::off(NL - 1) + C + fq * C + oo];
+            if (oo < C) w = wsrc[G::off(NL - 1) + C + fq * C + oo];
           } else if (b < 1 + 2 * (NH - 1)) {
             int l = (NH - 1) - (b - 1) / 2, st = (b - 1) & 1;
             int o = 0;
             for (int i = 0; i < l; ++i) o += G::lout(i) * (G::lin(i) + 1);
-            w = wl[o + HID + fq * HID + fk(st, fh, j)];
+            w = wsrc[o + HID + fq * HID + fk(st, fh, j)];
           } else {
             int st = (b - 1 - 2 * (NH - 1));
-            if (fq < E) w = wl[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
+            if (fq < E) w = wsrc[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
           }
         }
         // forward fragments of the sine layers carry w0 / 2 pi; the transposed fragments that produce a hidden layer's
