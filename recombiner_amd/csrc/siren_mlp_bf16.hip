@@ -34,7 +34,7 @@ extern "C" int rcb_debug_read_stamps(unsigned long long* dst, int n_entries) {
 #define RCB_STAMP(k) do { } while (0)
 #endif
 #ifndef RCB_W32_DIRECT_FRAGS
-#define RCB_W32_DIRECT_FRAGS 1      // 0: stage the row of wvec in LDS and gather the fragments from there (A/B builds)
+#define RCB_W32_DIRECT_FRAGS 0      // 1: gather the fragments straight from global memory (measured slower: 0.265 vs 0.254 ms; A/B builds)
 #endif
 
 namespace {
