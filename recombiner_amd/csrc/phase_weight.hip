@@ -41,9 +41,18 @@ __global__ void __launch_bounds__(256) phase_bigweight_kernel(const float* __res
   const int n2 = r % g.wd[2]; r /= g.wd[2];
   const int n1 = r % g.wd[1];
   const int n0 = r / g.wd[1];
-  for (int e = threadIdx.x; e < ktot * g.cout; e += 256) {
-    const int t = e / g.cout, co = e - t * g.cout;
-    wl[e] = wt[((long long)t * g.cin + ci) * g.cout + co];
+  // loads in batches of eight before their LDS stores (a load-store loop pays one L2 round trip per iteration)
+  for (int e0 = threadIdx.x; e0 < ktot * g.cout; e0 += 8 * 256) {
+    float stage[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u < ktot * g.cout ? e0 + 256 * u : ktot * g.cout - 1;
+      const int t = e / g.cout, co = e - t * g.cout;
+      stage[u] = wt[((long long)t * g.cin + ci) * g.cout + co];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 256 * u < ktot * g.cout) wl[e0 + 256 * u] = stage[u];
   }
   __syncthreads();
   const unsigned long long t0 = pick3(g.tapmask[0], n0), t1 = pick3(g.tapmask[1], n1), t2 = pick3(g.tapmask[2], n2);
@@ -68,6 +77,80 @@ __global__ void __launch_bounds__(256) phase_bigweight_kernel(const float* __res
         }
       }
       out[a * g.cout + co] = (TO)s;
+    }
+  }
+}
+
+// The same forward map evaluated SEPARABLY for the stage geometries of the reference nets (trailing factors (1, 4) and (4, 4)):
+// the direct sum above takes prod_i |taps_i(a_i, n_i)| terms per output -- 43 on average in the centre window cell of the
+// video stage ((6,4,4) x 5^3: 4100 dependent LDS reads per lane and workgroup, 128 such workgroups set the kernel's time) --
+// whereas q[a2] = sum_{k2} w[k0][k1][k2], acc[a1][a2] += q[a2] over k1, over k0 needs ~30 operations per (k0, k1) pair and
+// reads every staged weight once.  The waves split the phases of the leading axis.
+template <typename TO, int F1, int F2>
+__global__ void __launch_bounds__(256) phase_bigweight_sep_kernel(const float* __restrict__ wt, TO* __restrict__ big, PhaseWGeo g) {
+  extern __shared__ float wl[];                                         // [k^d][cout]
+  const int K1 = g.kd[1], K2 = g.kd[2], ktot = g.kd[0] * K1 * K2, nph = g.f[0] * F1 * F2;
+  int r = blockIdx.x;                                                   // (n0, n1, n2, ci), ci fastest
+  const int ci = r % g.cin; r /= g.cin;
+  const int n2 = r % g.wd[2]; r /= g.wd[2];
+  const int n1 = r % g.wd[1];
+  const int n0 = r / g.wd[1];
+  for (int e0 = threadIdx.x; e0 < ktot * g.cout; e0 += 8 * 256) {
+    float stage[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u < ktot * g.cout ? e0 + 256 * u : ktot * g.cout - 1;
+      const int t = e / g.cout, co = e - t * g.cout;
+      stage[u] = wt[((long long)t * g.cin + ci) * g.cout + co];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 256 * u < ktot * g.cout) wl[e0 + 256 * u] = stage[u];
+  }
+  __syncthreads();
+  const unsigned long long t0 = pick3(g.tapmask[0], n0), t1 = pick3(g.tapmask[1], n1), t2 = pick3(g.tapmask[2], n2);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  TO* out = big + (long long)blockIdx.x * nph * g.cout;                 // row (n, ci), columns (a0, a1, a2, co)
+  for (int a0 = wave; a0 < g.f[0]; a0 += 4) {
+    const unsigned m0 = (unsigned)(t0 >> (8 * a0)) & 0xffu;
+    for (int co = lane; co < g.cout; co += 64) {
+      float acc[F1][F2];
+#pragma unroll
+      for (int a1 = 0; a1 < F1; ++a1)
+#pragma unroll
+        for (int a2 = 0; a2 < F2; ++a2) acc[a1][a2] = 0.f;
+      for (unsigned b0 = m0; b0; b0 &= b0 - 1) {
+        const int k0 = __builtin_ctz(b0);
+        for (int k1 = 0; k1 < K1; ++k1) {
+          unsigned s1 = 0;                                               // the phases a1 whose window cell n1 takes tap k1
+#pragma unroll
+          for (int a1 = 0; a1 < F1; ++a1) s1 |= ((unsigned)(t1 >> (8 * a1 + k1)) & 1u) << a1;
+          if (!s1) continue;
+          float w2[8];
+#pragma unroll
+          for (int k2 = 0; k2 < 8; ++k2) w2[k2] = k2 < K2 ? wl[((k0 * K1 + k1) * K2 + k2) * g.cout + co] : 0.f;
+          float q[F2];
+#pragma unroll
+          for (int a2 = 0; a2 < F2; ++a2) {
+            const unsigned m2 = (unsigned)(t2 >> (8 * a2)) & 0xffu;
+            float v = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2)
+              if ((m2 >> k2) & 1u) v += w2[k2];
+            q[a2] = v;
+          }
+#pragma unroll
+          for (int a1 = 0; a1 < F1; ++a1)
+            if ((s1 >> a1) & 1u) {
+#pragma unroll
+              for (int a2 = 0; a2 < F2; ++a2) acc[a1][a2] += q[a2];
+            }
+        }
+      }
+#pragma unroll
+      for (int a1 = 0; a1 < F1; ++a1)
+#pragma unroll
+        for (int a2 = 0; a2 < F2; ++a2) out[((a0 * F1 + a1) * F2 + a2) * g.cout + co] = (TO)acc[a1][a2];
     }
   }
 }
@@ -103,6 +186,45 @@ __global__ void __launch_bounds__(256) phase_bigweight_grad_kernel(const TI* __r
             s += (float)dbig[row * cols + col];
           }
         }
+      }
+      dwt[it * g.cout + co] = s;
+    }
+  }
+}
+
+// the adjoint with the trailing factors known at compile time: the F1 * F2 loads of a leading-axis phase are issued together
+template <typename TI, int F1, int F2>
+__global__ void __launch_bounds__(256) phase_bigweight_grad_fixed_kernel(const TI* __restrict__ dbig, float* __restrict__ dwt, PhaseWGeo g) {
+  const int nph = g.f[0] * F1 * F2;
+  const long long cols = (long long)nph * g.cout;
+  const long long n_items = (long long)g.kd[0] * g.kd[1] * g.kd[2] * g.cin;
+  const int lane = threadIdx.x & 63;
+  for (long long it = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long long)gridDim.x * 4) {
+    int r = __builtin_amdgcn_readfirstlane((int)it);
+    const int ci = r % g.cin; r /= g.cin;
+    const int k2 = r % g.kd[2]; r /= g.kd[2];
+    const int k1 = r % g.kd[1];
+    const int k0 = r / g.kd[1];
+    const unsigned c0 = (unsigned)(((k0 >> 2) ? g.cellcode[0][1] : g.cellcode[0][0]) >> (16 * (k0 & 3))) & 0xffffu;
+    const unsigned c1 = (unsigned)(((k1 >> 2) ? g.cellcode[1][1] : g.cellcode[1][0]) >> (16 * (k1 & 3))) & 0xffffu;
+    const unsigned c2 = (unsigned)(((k2 >> 2) ? g.cellcode[2][1] : g.cellcode[2][0]) >> (16 * (k2 & 3))) & 0xffffu;
+    for (int co = lane; co < g.cout; co += 64) {
+      float s = 0.f;
+      for (int a0 = 0; a0 < g.f[0]; ++a0) {
+        const int n0 = (c0 >> (2 * a0)) & 3;
+        TI v[F1][F2];
+#pragma unroll
+        for (int a1 = 0; a1 < F1; ++a1)
+#pragma unroll
+          for (int a2 = 0; a2 < F2; ++a2) {
+            const int n1 = (c1 >> (2 * a1)) & 3, n2 = (c2 >> (2 * a2)) & 3;
+            const long long row = (((long long)n0 * g.wd[1] + n1) * g.wd[2] + n2) * g.cin + ci;
+            v[a1][a2] = dbig[row * cols + (long long)((a0 * F1 + a1) * F2 + a2) * g.cout + co];
+          }
+#pragma unroll
+        for (int a1 = 0; a1 < F1; ++a1)
+#pragma unroll
+          for (int a2 = 0; a2 < F2; ++a2) s += (float)v[a1][a2];
       }
       dwt[it * g.cout + co] = s;
     }
@@ -155,10 +277,28 @@ extern "C" int rcb_phase_bigweight(const float* wt, void* big, int32_t out_bf16,
   const size_t lds = (size_t)g.kd[0] * g.kd[1] * g.kd[2] * cout * sizeof(float);
   RCB_REQUIRE(blocks < (1ll << 31) && lds <= 64 * 1024, RCB_ERR_UNSUPPORTED, "phase_bigweight: %lld rows, %zu B of LDS per input channel",
               blocks, lds);
-  if (out_bf16)
-    phase_bigweight_kernel<__bf16><<<(int)blocks, 256, lds, (hipStream_t)stream>>>(wt, static_cast<__bf16*>(big), g);
-  else
-    phase_bigweight_kernel<float><<<(int)blocks, 256, lds, (hipStream_t)stream>>>(wt, static_cast<float*>(big), g);
+  hipStream_t st = (hipStream_t)stream;
+#define RCB_BW_LAUNCH(KERNEL)                                                                  \
+  do {                                                                                         \
+    if (out_bf16)                                                                              \
+      KERNEL<__bf16><<<(int)blocks, 256, lds, st>>>(wt, static_cast<__bf16*>(big), g);         \
+    else                                                                                       \
+      KERNEL<float><<<(int)blocks, 256, lds, st>>>(wt, static_cast<float*>(big), g);           \
+  } while (0)
+  if (g.f[1] == 4 && g.f[2] == 4) {
+    if (out_bf16)
+      phase_bigweight_sep_kernel<__bf16, 4, 4><<<(int)blocks, 256, lds, st>>>(wt, static_cast<__bf16*>(big), g);
+    else
+      phase_bigweight_sep_kernel<float, 4, 4><<<(int)blocks, 256, lds, st>>>(wt, static_cast<float*>(big), g);
+  } else if (g.f[1] == 1 && g.f[2] == 4) {
+    if (out_bf16)
+      phase_bigweight_sep_kernel<__bf16, 1, 4><<<(int)blocks, 256, lds, st>>>(wt, static_cast<__bf16*>(big), g);
+    else
+      phase_bigweight_sep_kernel<float, 1, 4><<<(int)blocks, 256, lds, st>>>(wt, static_cast<float*>(big), g);
+  } else {
+    RCB_BW_LAUNCH(phase_bigweight_kernel);
+  }
+#undef RCB_BW_LAUNCH
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -172,10 +312,22 @@ extern "C" int rcb_phase_bigweight_grad(const void* dbig, int32_t in_bf16, float
   const long long items = (long long)g.kd[0] * g.kd[1] * g.kd[2] * cin;                                   // one wave each
   RCB_REQUIRE(items < (1ll << 31), RCB_ERR_UNSUPPORTED, "phase_bigweight_grad: %lld taps x channels", items);
   const int grid = (int)((items + 3) / 4 > 65536 ? 65536 : (items + 3) / 4);
-  if (in_bf16)
-    phase_bigweight_grad_kernel<__bf16><<<grid, 256, 0, (hipStream_t)stream>>>(static_cast<const __bf16*>(dbig), dwt, g);
-  else
-    phase_bigweight_grad_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(static_cast<const float*>(dbig), dwt, g);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.f[1] == 4 && g.f[2] == 4) {
+    if (in_bf16)
+      phase_bigweight_grad_fixed_kernel<__bf16, 4, 4><<<grid, 256, 0, st>>>(static_cast<const __bf16*>(dbig), dwt, g);
+    else
+      phase_bigweight_grad_fixed_kernel<float, 4, 4><<<grid, 256, 0, st>>>(static_cast<const float*>(dbig), dwt, g);
+  } else if (g.f[1] == 1 && g.f[2] == 4) {
+    if (in_bf16)
+      phase_bigweight_grad_fixed_kernel<__bf16, 1, 4><<<grid, 256, 0, st>>>(static_cast<const __bf16*>(dbig), dwt, g);
+    else
+      phase_bigweight_grad_fixed_kernel<float, 1, 4><<<grid, 256, 0, st>>>(static_cast<const float*>(dbig), dwt, g);
+  } else if (in_bf16) {
+    phase_bigweight_grad_kernel<__bf16><<<grid, 256, 0, st>>>(static_cast<const __bf16*>(dbig), dwt, g);
+  } else {
+    phase_bigweight_grad_kernel<float><<<grid, 256, 0, st>>>(static_cast<const float*>(dbig), dwt, g);
+  }
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
