@@ -731,13 +731,17 @@ extern "C" int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, cons
   return RCB_OK;
 }
 
-constexpr int kWgSlots = 128;      // workgroups per (mb, nb) block of the weight gradient = slabs to add
+// workgroups per (mb, nb) block of the weight gradient = slabs to add.  The 16-channel stage needs the 128 for its parallelism
+// (64: 95 -> 157 us on the video grid); the 64-channel stage has four times the (mb, nb) blocks and a 1 MB slab, whose sum
+// over the slabs is what costs (128 slabs = 134 MB: 30 us): 64 there (wgrad 47 -> 39 us, sum 30 -> 15 us)
+constexpr int kWgSlotsMax = 128;
+__host__ constexpr int wg_slots(int cout) { return cout == 64 ? 64 : 128; }
 
 extern "C" int64_t rcb_phaseconv_wgrad_workspace(int32_t nd, int32_t cout) {
   if (nd < 1 || nd > 3 || (cout != 16 && cout != 64)) return -1;
   const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
   const int64_t slab = (int64_t)ny * np * np * 1024;
-  return (int64_t)kWgSlots * (slab + cout) + slab;
+  return (int64_t)kWgSlotsMax * (slab + cout) + slab;
 }
 
 extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW, float* dbias, float* workspace,
@@ -751,6 +755,7 @@ extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW,
   RCB_REQUIRE(workspace_floats >= rcb_phaseconv_wgrad_workspace(nd, cout), RCB_ERR_SHAPE, "phaseconv_wgrad: workspace too small");
   const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
   const long long slab = (long long)ny * np * np * 1024;
+  const int kWgSlots = wg_slots(cout);
   const int gx = pc.n_tiles < kWgSlots ? pc.n_tiles : kWgSlots;
   WgArgs w;
   w.x = static_cast<const __bf16*>(x_act);
