@@ -254,6 +254,33 @@ typedef struct {
 int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, int64_t cols, int64_t ld_x,
                    int64_t out_row_stride, int64_t out_block_stride, int32_t lo_mask, rcb_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K2, hand-written: the A transform of all layer vectors in one launch per direction (atrans.hip).
+ *   forward        wvec[:, lo_l:hi_l] = h_w[:, lo_l:hi_l] @ A[l]      prior_model.py:173-174, test_model.py:348-349
+ *   data gradient  dh  [:, lo_l:hi_l] = dw [:, lo_l:hi_l] @ A[l]^T    (autograd of the line above)
+ *   weight gradient dA[l] = h_w[:, lo_l:hi_l]^T @ dw[:, lo_l:hi_l]    (autograd; summed over the rows = INRs x samples)
+ * Layer l is the square map A[l] [sizes[l], sizes[l]] (fp32, row-major); the layer vectors sit side by side in rows of
+ * x / out (column offset of layer l = sizes[0] + ... + sizes[l-1], row strides ld_x / ld_out in elements, 4-byte
+ * aligned rows suffice).  bf16 matrix cores with fp32 accumulation; the per-row operand is split x = hi + lo inside
+ * the kernel, the mapping enters as bf16 (terms 2) or as hi + lo (terms 3: (hi + lo) A_hi + hi A_lo, ~2^-17 relative);
+ * terms 1 = plain bf16 operands.  No atomics anywhere: results are bitwise reproducible.
+ *
+ * rcb_atrans_pack_elems : bf16 elements of the packed images of the mappings (4 planes: forward hi, gradient hi,
+ *                         forward lo, gradient lo; each layer padded to a multiple of 32 both ways), < 0 on bad arguments
+ * rcb_atrans_pack       : fp32 mappings -> packed images (once per step when they are trained); the lo planes only if want_lo
+ * rcb_atrans_plan       : HOST: work decomposition for `rows` rows on n_cu compute units into plan[0 .. return value) (int32;
+ *                         plan[0] = workgroups); the caller keeps a 16-byte aligned device copy of it for rcb_atrans_apply
+ * rcb_atrans_apply      : transpose = 0: out = x @ A (forward), 1: out = x @ A^T (data gradient)
+ * ------------------------------------------------------------------------------------------- */
+#define RCB_ATRANS_MAX_LAYERS 8
+int64_t rcb_atrans_pack_elems(int32_t n_layers, const int32_t* sizes);
+int rcb_atrans_pack(const float* const* A, int32_t n_layers, const int32_t* sizes, void* packed, int32_t want_lo,
+                    rcb_stream_t stream);
+int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* sizes, int32_t n_cu, int32_t* plan, int32_t max_ints);
+int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_t ld_out, int64_t rows, int32_t n_layers,
+                     const int32_t* sizes, const void* packed, int32_t transpose, int32_t terms, const int32_t* plan_dev,
+                     int32_t n_wg, rcb_stream_t stream);
+
 /* Bookkeeping of one optimisation step whose counter lives on the device, so that the whole step can be captured
  * once as a HIP graph and replayed (prior_model.py train() / test_model.py train() loop bodies):
  *   begin: dyn[0..1] = adam_table[step] ({lr / (1 - beta1^t), sqrt(1 - beta2^t)}, row clamped to the table);

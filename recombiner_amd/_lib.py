@@ -18,7 +18,8 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_reparam_rng_fwd", "rcb_upconv_bwd_fused", "rcb_tile_gather", "rcb_tile_crop", "rcb_tile_fold",
            "rcb_window_gather", "rcb_window_fold", "rcb_siren_reduce_chunks", "rcb_phaseconv_pack", "rcb_phaseconv_pack_uint4",
            "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace",
-           "rcb_phase_bigweight", "rcb_phase_bigweight_grad"]
+           "rcb_phase_bigweight", "rcb_phase_bigweight_grad", "rcb_atrans_pack_elems", "rcb_atrans_pack", "rcb_atrans_plan",
+           "rcb_atrans_apply"]
 
 
 class RcbError(RuntimeError):
@@ -88,6 +89,7 @@ def load():
         lib.rcb_rec_workspace_bytes.restype = C.c_int64
         lib.rcb_phaseconv_pack_uint4.restype = C.c_int64
         lib.rcb_phaseconv_wgrad_workspace.restype = C.c_int64
+        lib.rcb_atrans_pack_elems.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RcbError(f"{LIB_PATH} does not export {name}")

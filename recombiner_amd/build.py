@@ -1,13 +1,21 @@
-"""Builds librcb_hip.so (gfx950) in-tree with hipcc.  Usage: python -m recombiner_amd.build"""
+"""Builds librcb_hip.so (gfx950) in-tree with hipcc.  Usage: python -m recombiner_amd.build [--force]
+
+Every .hip file is compiled to its own object (in parallel, cached under recombiner_amd/lib/obj by the modification
+times of the source and the shared headers), then linked: a change to one kernel file costs one compile, not eleven."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librcb_hip.so")
-SOURCES = ["phase_weight.hip", "phaseconv.hip", "posterior.hip", "rec_score.hip", "siren_mlp.hip", "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_mlp_generic.hip", "tiles.hip", "upconv.hip", "upconv_weff.hip"]
+SOURCES = ["atrans.hip", "phase_weight.hip", "phaseconv.hip", "posterior.hip", "rec_score.hip", "siren_mlp.hip",
+           "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_mlp_generic.hip", "tiles.hip", "upconv.hip",
+           "upconv_weff.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def hipcc():
@@ -17,23 +25,44 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(HERE, "..", "include", "rcb.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "rcb.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def needs_build():
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
+    return _stale(LIB, deps)
+
+
+def build(force=False, verbose=True, jobs=None):
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc, hdrs = hipcc(), _headers()
+    todo = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            todo.append([cc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    jobs = jobs or min(len(todo), os.cpu_count() or 4, 8) or 1
+    with ThreadPoolExecutor(jobs) as ex:
+        list(ex.map(run, todo))
+    run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] +
+        [os.path.join(OBJDIR, s[:-4] + ".o") for s in SOURCES] + ["-o", LIB])
     return LIB
 
 

@@ -1125,3 +1125,78 @@ class SplitATransform:
         """True if the wide layers of this transform are exactly those rcb_siren_desc.dw_split covers"""
         n_wide, w = siren_wide_layers(meta)
         return len(self.fast) == n_wide and all(self.slices[i][1] - self.slices[i][0] == w for i in self.fast)
+
+
+class ATransform:
+    """The A transform `wvec[:, lo:hi] = h_w[:, lo:hi] @ A[l]` (prior_model.py:173-174, test_model.py:348-349), its data
+    gradient `dh[:, lo:hi] = dw[:, lo:hi] @ A[l]^T` and its weight gradient on the hand-written kernels of atrans.hip:
+    all layers in one launch per direction, the per-row operand split hi + lo inside the kernel, the mappings as bf16
+    (terms = 2) or hi + lo (terms = 3).  prepare(A) converts the mappings (once per step when they are trained)."""
+
+    def __init__(self, slices, device, terms=2, dgrad_terms=None):
+        if terms not in (1, 2, 3):
+            raise RcbError("ATransform: terms must be 1, 2 or 3")
+        self.terms = terms
+        self.dgrad_terms = terms if dgrad_terms is None else dgrad_terms
+        if self.dgrad_terms not in (1, 2, 3) or self.dgrad_terms > terms:
+            raise RcbError("ATransform: dgrad_terms must be 1 .. terms")
+        self.slices = list(slices)
+        if self.slices[0][0] != 0 or any(a[1] != b[0] for a, b in zip(self.slices, self.slices[1:])):
+            raise RcbError("ATransform: the layer vectors must tile the row without gaps")
+        self.sizes = [hi - lo for lo, hi in self.slices]
+        self.cols = self.slices[-1][1]
+        self.device = torch.device(device)
+        self._sizes_c = (C.c_int32 * len(self.sizes))(*self.sizes)
+        n = _lib.load().rcb_atrans_pack_elems(len(self.sizes), self._sizes_c)
+        if n <= 0:
+            raise RcbError("ATransform: bad layer sizes")
+        self.packed = torch.zeros(int(n), device=self.device, dtype=bf16)
+        self._plans = {}
+        self.n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+
+    def prepare(self, A):
+        mats = [a.detach() for a in A]
+        for a, n in zip(mats, self.sizes):
+            if tuple(a.shape) != (n, n) or a.dtype != f32 or not a.is_cuda or not a.is_contiguous():
+                raise RcbError("ATransform.prepare: contiguous fp32 GPU matrices [L_l, L_l] expected")
+        arr = (C.c_void_p * len(mats))(*[a.data_ptr() for a in mats])
+        check(_lib.load().rcb_atrans_pack(arr, len(mats), self._sizes_c, ptr(self.packed), int(self.terms == 3), stream_ptr()),
+              "rcb_atrans_pack")
+
+    def _plan(self, rows):
+        pl = self._plans.get(rows)
+        if pl is None:
+            lib = _lib.load()
+            cap = 1 << 16
+            while True:
+                buf = (C.c_int32 * cap)()
+                n = lib.rcb_atrans_plan(C.c_int64(rows), len(self.sizes), self._sizes_c, int(self.n_cu), buf, cap)
+                if n > 0:
+                    break
+                if cap >= 1 << 26:
+                    check(n, "rcb_atrans_plan")
+                cap *= 8
+            host = torch.frombuffer(buf, dtype=torch.int32, count=n).clone()
+            pl = (host.to(self.device), int(host[0]))
+            self._plans[rows] = pl
+        return pl
+
+    def _apply(self, x, out, transpose, terms):
+        rows = x.shape[0]
+        for t_ in (x, out):
+            if t_.dtype != f32 or not t_.is_cuda or t_.dim() != 2 or t_.stride(1) != 1 or t_.shape[1] != self.cols:
+                raise RcbError(f"ATransform: fp32 GPU rows of {self.cols} columns expected")
+        if out.shape[0] != rows:
+            raise RcbError("ATransform: row counts differ")
+        plan, n_wg = self._plan(rows)
+        check(_lib.load().rcb_atrans_apply(C.c_void_p(x.data_ptr()), C.c_int64(x.stride(0)), C.c_void_p(out.data_ptr()),
+                                          C.c_int64(out.stride(0)), C.c_int64(rows), len(self.sizes), self._sizes_c,
+                                          ptr(self.packed), int(transpose), int(terms), ptr(plan), n_wg, stream_ptr()),
+              "rcb_atrans_apply")
+        return out
+
+    def forward(self, h_w, out):
+        return self._apply(h_w, out, 0, self.terms)
+
+    def dgrad(self, dw, out):
+        return self._apply(dw, out, 1, self.dgrad_terms)

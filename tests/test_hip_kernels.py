@@ -564,6 +564,50 @@ def test_split_bf16_operands_and_a_transform():
         ops.SplitATransform(slices, terms=4)
 
 
+@pytest.mark.parametrize("rows,sizes", [(37, [1056, 1056, 1056, 99]), (300, [1056, 1056, 1056, 99]), (4096, [1056, 1056, 1056, 99]),
+                                        (192, [1584, 2352, 2352, 147]), (130, [420, 441, 63]), (5, [33]), (129, [64, 8, 40])])
+def test_atrans_kernels_forward_and_data_gradient(rows, sizes):
+    """atrans.hip (K2, prior_model.py:173-174): out[:, lo:hi] = x[:, lo:hi] @ A[l] and x @ A[l]^T for all layers in one launch.
+    Asymmetric random mappings (a transposed or mis-indexed operand cannot pass); held to the fp64 product with the operands
+    each number of terms keeps: 3 -> both to ~16 bits, 2 -> the mapping rounded to bf16, 1 -> both rounded to bf16."""
+    gen = torch.Generator().manual_seed(rows * 7 + len(sizes))
+    D = sum(sizes)
+    cum = np.cumsum([0] + sizes)
+    slices = [(int(cum[i]), int(cum[i + 1])) for i in range(len(sizes))]
+    big = torch.randn(rows + 3, D + 5, generator=gen) * 0.03          # rows with a stride that is not a multiple of 4 floats
+    x = g(big)[1:rows + 1, 2:D + 2]
+    A = [g(torch.randn(n, n, generator=gen) / n ** 0.5) for n in sizes]
+    for terms in (3, 2, 1):
+        tr = ops.ATransform(slices, DEV, terms=terms)
+        tr.prepare(A)
+        w = tr.forward(x, torch.full((rows, D), float("nan"), device=DEV))
+        outbuf = torch.full((rows + 2, D + 3), 7.0, device=DEV)        # strided output: nothing outside the view is touched
+        dh = tr.dgrad(x, outbuf[1:rows + 1, 1:D + 1])
+        assert torch.isfinite(w).all() and torch.isfinite(dh).all()
+        assert float(outbuf[0].min()) == 7.0 and float(outbuf[-1].min()) == 7.0 and float(outbuf[:, 0].min()) == 7.0 \
+            and float(outbuf[:, D + 1:].min()) == 7.0
+        for (a, b), m in zip(slices, A):
+            xs = x[:, a:b].double() if terms >= 2 else x[:, a:b].bfloat16().double()
+            md = m.double() if terms == 3 else m.bfloat16().double()
+            tol = 2e-5 if terms >= 2 else 1e-5
+            assert rel_err(w[:, a:b], xs @ md) < tol, (terms, a, b)
+            assert rel_err(dh[:, a:b], xs @ md.t()) < tol, (terms, a, b)
+            if terms == 3 and b - a >= 64:
+                assert rel_err(x[:, a:b].bfloat16().float() @ m.bfloat16().float(), x[:, a:b].double() @ m.double()) > 3e-4
+    # bitwise reproducible (no atomics, fixed decomposition)
+    tr = ops.ATransform(slices, DEV, terms=2)
+    tr.prepare(A)
+    w1 = tr.forward(x, torch.empty(rows, D, device=DEV))
+    w2 = tr.forward(x, torch.empty(rows, D, device=DEV))
+    assert torch.equal(w1, w2)
+    # identity mappings with an asymmetric probe: the forward returns bf16-exact inputs untouched, column for column
+    eye = [g(torch.eye(n)) for n in sizes]
+    tr.prepare(eye)
+    xi = g(torch.arange(rows * D, dtype=torch.float32).reshape(rows, D) % 251 - 125.0)
+    assert torch.equal(tr.forward(xi, torch.empty(rows, D, device=DEV)), xi)
+    assert torch.equal(tr.dgrad(xi, torch.empty(rows, D, device=DEV)), xi)
+
+
 def test_philox_noise_stream_and_fused_reparam():
     """in-kernel noise: N(0,1) statistics, a pure function of (seed, stream, step, index), and the fused kernel equals
     the explicit-noise reparam on the materialised stream bit for bit (including a tail that is not a multiple of 4)."""

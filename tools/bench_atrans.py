@@ -1,0 +1,50 @@
+"""Times the hand-written A-transform kernels (atrans.hip) against the split-bf16 library GEMMs they replace.
+usage: python tools/bench_atrans.py [rows] [terms]"""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recombiner_amd import ops
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+terms = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+sizes = [1056, 1056, 1056, 99]
+cum = [0]
+for n in sizes:
+    cum.append(cum[-1] + n)
+slices = list(zip(cum[:-1], cum[1:]))
+D = cum[-1]
+dev = "cuda"
+torch.manual_seed(0)
+x = torch.randn(rows, D, device=dev) * 0.03
+dw = torch.randn(rows, D, device=dev) * 1e-3
+A = [torch.randn(n, n, device=dev) / n ** 0.5 for n in sizes]
+out = torch.empty(rows, D, device=dev)
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+tr = ops.ATransform(slices, dev, terms=terms)
+t_pack = timeit(lambda: tr.prepare(A))
+t_fwd = timeit(lambda: tr.forward(x, out))
+t_dg = timeit(lambda: tr.dgrad(dw, out))
+flops = 2.0 * rows * sum(n * n for n in sizes) * terms
+print(f"atrans rows={rows} terms={terms}: pack {t_pack:.1f} us, forward {t_fwd:.1f} us ({flops / t_fwd / 1e6:.0f} TFLOP/s), "
+      f"dgrad {t_dg:.1f} us ({flops / t_dg / 1e6:.0f} TFLOP/s)")
+old = ops.SplitATransform(slices, terms, terms)
+t_prep = timeit(lambda: old.prepare(A))
+t_f = timeit(lambda: old.forward(x, out))
+t_d = timeit(lambda: old.dgrad(dw, out))
+t_w = timeit(lambda: old.wgrad(x, dw, True))
+print(f"library split-bf16: prepare {t_prep:.1f} us, forward (incl. split) {t_f:.1f} us, dgrad (incl. split) {t_d:.1f} us, wgrad {t_w:.1f} us")
