@@ -42,16 +42,23 @@ def needs_build():
     return _stale(LIB, deps)
 
 
-def build(force=False, verbose=True, jobs=None):
-    if not force and not needs_build():
+def build(force=False, verbose=True, jobs=None, variant=None, extra_flags=(), only=()):
+    """variant: a diagnostic build of the same ABI -- the sources named in `only` recompiled with `extra_flags` (-D
+    switches), the other objects shared with the main build -- written to lib/librcb_<variant>.so and selected at run
+    time with RCB_LIB (same-box A/B timing of kernel changes)."""
+    if not variant and not force and not needs_build():
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     cc, hdrs = hipcc(), _headers()
-    todo = []
+    todo, objs = [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s[:-4] + ".o")
         if force or _stale(obj, [src] + hdrs):
             todo.append([cc] + FLAGS + ["-c", src, "-o", obj])
+        if variant and s in only:
+            obj = os.path.join(OBJDIR, f"{s[:-4]}.{variant}.o")
+            todo.append([cc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])
+        objs.append(obj)
 
     def run(cmd):
         if verbose:
@@ -61,11 +68,16 @@ def build(force=False, verbose=True, jobs=None):
     jobs = jobs or min(len(todo), os.cpu_count() or 4, 8) or 1
     with ThreadPoolExecutor(jobs) as ex:
         list(ex.map(run, todo))
-    run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] +
-        [os.path.join(OBJDIR, s[:-4] + ".o") for s in SOURCES] + ["-o", LIB])
-    return LIB
+    lib = os.path.join(LIBDIR, f"librcb_{variant}.so") if variant else LIB
+    run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    if variant and needs_build():        # (the main library is kept current as well)
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJDIR, s[:-4] + ".o") for s in SOURCES] + ["-o", LIB])
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    # python -m recombiner_amd.build [--force] [--variant NAME --only a.hip,b.hip -DX=1 ...]
+    argv = sys.argv[1:]
+    var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
+    only = argv[argv.index("--only") + 1].split(",") if "--only" in argv else ()
+    print(build(force="--force" in argv, variant=var, extra_flags=[f for f in argv if f.startswith("-D")], only=only))

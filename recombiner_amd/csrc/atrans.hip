@@ -9,19 +9,23 @@
 // rcb_atrans_pack converts the fp32 mappings once per step into the two bf16 images the two directions read with the
 // contraction index contiguous (forward: A^T, data gradient: A), zero-padded to multiples of 32.
 //
-// Decomposition (forward / data gradient).  The output of layer l is [rows, L_l]; rows are cut into 128-row tiles, the
+// Decomposition (forward / data gradient).  The output of layer l is [rows, L_l]; rows are cut into 256-row tiles, the
 // columns of all layers, flattened into 32-column blocks, into R contiguous runs per row tile of (nearly) equal cost, so
-// that rows/128 * R workgroups fill the chip once (4096 rows: 32 * 8 = 256 workgroups, 12-13 blocks each) -- the 33
-// blocks of a 1056-wide layer divide by nothing useful, and a tile grid per layer leaves 1/8 of a wave of tiles over.
-// A run is cut at layer boundaries into segments of <= 13 blocks (host side: rcb_atrans_plan); per segment a 512-thread
-// workgroup walks the contraction in 32-deep chunks: x rows fp32 -> registers -> hi / lo -> LDS, mapping rows bf16 ->
-// registers -> LDS (64-byte rows, 16-byte chunk index XOR (row >> 2) & 3: conflict-free ds_read_b128 fragments), two LDS
-// stages, one barrier per chunk, next chunk's global loads in flight during the MFMAs.  Wave (r, h) = row block r of the
-// tile x column half h: two waves per SIMD (w and w + 4 share one) cover each other's LDS latency; <= 7 accumulator
-// tiles per wave.  Workgroups sharing a row tile are mapped to one XCD (they re-read the same x rows through its L2).
+// that rows/256 * R workgroups fill the chip once (4096 rows: 16 * 16 = 256 workgroups of 6-7 blocks) -- the 33 blocks
+// of a 1056-wide layer divide by nothing useful, and a tile grid per layer leaves 1/8 of a wave of tiles over.  A run is
+// cut at layer boundaries into segments of <= 7 blocks (host side: rcb_atrans_plan).  Per segment a 512-thread workgroup
+// walks the contraction in 32-deep chunks through a ring of three LDS stages filled by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no ds_write): the x rows as they are (fp32, 128-byte rows; every wave fetches the 32 rows it
+// multiplies), the mapping rows as bf16 (64-byte rows); the 16-byte chunk index is XORed with row bits ON THE SOURCE
+// ADDRESS (the DMA writes LDS linearly) so that the fragment reads (ds_read_b128) are conflict-free.  One barrier per
+// chunk, counted vmcnt: the DMAs of the next two chunks stay in flight across it.  A wave owns one 32-row block and all
+// <= 7 column blocks: it reads its x fragment as fp32, forms hi / lo in registers (each row is converted once per
+// workgroup) and issues <= 28 MFMAs per chunk on <= 7 accumulator tiles; two waves per SIMD cover each other's LDS latency.
+// Workgroups sharing a row tile are mapped to one XCD (they re-read the same x rows through its L2).
 #include "rcb_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 using namespace rcb;
@@ -29,16 +33,57 @@ using namespace rcb;
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BK = 32, NT = 512, MAXL = RCB_ATRANS_MAX_LAYERS;
-constexpr int XT_BYTES = BM * BK * 2;              // one bf16 image of the x tile (8 KB)
+// diagnostic builds only (python -m recombiner_amd.build --variant ... -DATRANS_DIAG=n): 1 = no output stores, 2 = every
+// chunk re-reads chunk 0 (cache-hot sources), 3 = no compute at all, 4 = fragment reads + conversion but no MFMAs, 6 = no DMAs
+// in the chunk loop; never defined in the library
+#ifndef ATRANS_DIAG
+#define ATRANS_DIAG 0
+#endif
+#ifndef ATRANS_STAMPS
+#define ATRANS_STAMPS 0      // diagnostic build: s_memtime stamps of workgroup 0 (rcb_debug_atrans_stamps)
+#endif
+#ifndef ATRANS_SPREAD_PIN
+#define ATRANS_SPREAD_PIN 1
+#endif
+constexpr int BM = 256, BK = 32, NT = 512, MAXL = RCB_ATRANS_MAX_LAYERS, MAXSEG = 7;
+constexpr int XT_BYTES = BM * BK * 4;              // fp32 image of the x tile (32 KB)
 
 __device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-// byte offset of 16-byte chunk c (k = 8 c .. 8 c + 7) of row `row` in a [rows][32] bf16 image
-__device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// x image: [256 rows][32 fp32] = 128-byte rows of eight 16-byte chunks; chunk c of row `row` at
+__device__ __forceinline__ int xswz(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+// mapping image: [rows][32 bf16] = 64-byte rows of four chunks
+__device__ __forceinline__ int bswz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(const void* g, char* l) {          // 64 lanes x 16 B -> l + 16 lane (l wave-uniform)
+  __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)l, 16, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
+#if ATRANS_DIAG == 4
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#if ATRANS_STAMPS
+__device__ unsigned long long g_stamps[8][40][6];
+#define STAMP(it, pt)                                                                 \
+  do {                                                                               \
+    if (blockIdx.x == 0 && (it) < 40) {                                              \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+      if (lane == 0) g_stamps[wave][it][pt] = t_;                                    \
+    }                                                                                \
+  } while (0)
+#else
+#define STAMP(it, pt)
+#endif
 
 struct AtArgs {
   const float* x;
@@ -55,176 +100,269 @@ struct AtArgs {
 
 template <int NCB, int TERMS>
 struct Geo {
-  static constexpr int NH0 = (NCB + 1) / 2, NH1 = NCB / 2;
-  static constexpr int NBI = (NCB * 128 + NT - 1) / NT;        // mapping chunks (16 B) per thread and stage
-  static constexpr int XL_OFF = XT_BYTES;
-  static constexpr int BH_OFF = (TERMS >= 2 ? 2 : 1) * XT_BYTES;
+  static constexpr int NBW = (2 * NCB + 7) / 8;              // mapping DMAs per wave and stage (one DMA = 16 rows x 64 B)
+  static constexpr int NDMA = 4 + NBW * (TERMS == 3 ? 2 : 1);  // all DMAs per wave and stage
+  static constexpr int BH_OFF = XT_BYTES;
   static constexpr int BT_BYTES = NCB * 32 * BK * 2;
   static constexpr int BL_OFF = BH_OFF + BT_BYTES;
   static constexpr int STAGE = BH_OFF + (TERMS == 3 ? 2 : 1) * BT_BYTES;
+  static constexpr int NSTAGE = TERMS == 3 ? 2 : 3;
 };
+constexpr int LDS_MAX_BYTES = 3 * (XT_BYTES + MAXSEG * 32 * BK * 2);        // = 2 stages of the three-term form (138 KB)
 
-template <int NCB, int TERMS>
-struct StageRegs {
-  float xv[8];
-  uint4 bh[Geo<NCB, TERMS>::NBI];
-  uint4 bl[TERMS == 3 ? Geo<NCB, TERMS>::NBI : 1];
-};
-
-// RAGGED: the layer size is not a multiple of 8 (the output layer: 99 = 3 * 33): element-wise guarded loads; otherwise a
-// group of 8 contraction indices lies inside the layer or outside it as a whole and the loads are two 16-byte vectors
-// from a clamped (always readable) address, zeroed by selects -- no branch in the chunk loop.
-template <int NCB, int TERMS, bool RAGGED>
-__device__ __forceinline__ void stage_load(StageRegs<NCB, TERMS>& s, const float* __restrict__ xrow, bool row_ok, int K,
-                                           const __bf16* __restrict__ bh, const __bf16* __restrict__ bl, int Lp, int brow0,
-                                           int kc, int t) {
-  typedef Geo<NCB, TERMS> G;
-  const int c = t & 3;
-  const int k0 = kc * BK + 8 * c;
-  if (RAGGED) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s.xv[i] = (row_ok && k0 + i < K) ? xrow[k0 + i] : 0.f;
-  } else {
-    const bool in = row_ok && k0 < K;
-    const float* __restrict__ p = xrow + min(k0, K - 8);
-    const f32x4u v0 = *reinterpret_cast<const f32x4u*>(p);
-    const f32x4u v1 = *reinterpret_cast<const f32x4u*>(p + 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s.xv[i] = in ? v0[i] : 0.f;
-      s.xv[4 + i] = in ? v1[i] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < G::NBI; ++j) {
-    // (threads past the end of the image repeat its last chunk: one broadcast load and a same-value store instead of a branch)
-    const int item = (G::NBI * NT == NCB * 128) ? t + NT * j : min(t + NT * j, NCB * 128 - 1);
-    const int grow = min(brow0 + (item >> 2), Lp - 1);          // (blocks past the end of a layer are computed, never stored)
-    const long long o = (long long)grow * Lp + kc * BK + 8 * (item & 3);
-    s.bh[j] = *reinterpret_cast<const uint4*>(bh + o);
-    if (TERMS == 3) s.bl[j] = *reinterpret_cast<const uint4*>(bl + o);
-  }
-}
-
-template <int NCB, int TERMS>
-__device__ __forceinline__ void stage_write(const StageRegs<NCB, TERMS>& s, char* __restrict__ st, int t) {
-  typedef Geo<NCB, TERMS> G;
-  union {
-    bf16x8 v;
-    uint4 u;
-  } hi, lo;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)s.xv[i];
-    hi.v[i] = h;
-    lo.v[i] = (__bf16)(s.xv[i] - (float)h);
-  }
-  const int xo = swz(t >> 2, t & 3);
-  *reinterpret_cast<uint4*>(st + xo) = hi.u;
-  if (TERMS >= 2) *reinterpret_cast<uint4*>(st + G::XL_OFF + xo) = lo.u;
-#pragma unroll
-  for (int j = 0; j < G::NBI; ++j) {
-    const int item = (G::NBI * NT == NCB * 128) ? t + NT * j : min(t + NT * j, NCB * 128 - 1);
-    const int bo = swz(item >> 2, item & 3);
-    *reinterpret_cast<uint4*>(st + G::BH_OFF + bo) = s.bh[j];
-    if (TERMS == 3) *reinterpret_cast<uint4*>(st + G::BL_OFF + bo) = s.bl[j];
-  }
-}
-
-// one segment: out[row0 .. row0 + 127, off_l + 32 cb0 .. + 32 ncb) of layer l
+// one segment: out[row0 .. row0 + 255, off_l + 32 cb0 .. + 32 ncb) of layer l
 template <int NCB, int TERMS, bool RAGGED>
 __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char* __restrict__ lds) {
   typedef Geo<NCB, TERMS> G;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int r = wave & 3, h = wave >> 2;
   const int l = sg.x, row0 = sg.y, cb0 = sg.z, ncb = sg.w;
   const int K = a.L[l], Lp = a.Lp[l];
   const int nk = Lp / BK;
   const __bf16* __restrict__ bh = a.bh[l];
   const __bf16* __restrict__ bl = a.bl[l];
-  const long long xr_i = (long long)row0 + (t >> 2);
-  const bool row_ok = xr_i < a.rows;
-  const float* __restrict__ xrow = a.x + (row_ok ? xr_i : 0) * a.ld_x + a.off[l];
+  const float* __restrict__ xl0 = a.x + a.off[l];
 
-  f32x16 acc[G::NH0];
+  f32x16 acc[NCB];
 #pragma unroll
-  for (int i = 0; i < G::NH0; ++i)
+  for (int i = 0; i < NCB; ++i)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 
-  StageRegs<NCB, TERMS> sr;
-  stage_load<NCB, TERMS, RAGGED>(sr, xrow, row_ok, K, bh, bl, Lp, cb0 * 32, 0, t);
-  stage_write<NCB, TERMS>(sr, lds, t);
-  if (nk > 1) stage_load<NCB, TERMS, RAGGED>(sr, xrow, row_ok, K, bh, bl, Lp, cb0 * 32, 1, t);
-  __syncthreads();
-
-  const int frow = lane & 31, fh = lane >> 5;
-  const int cbase = h ? G::NH0 : 0;
-  // one 32-deep chunk: both k-steps of the wave's x fragments, then column block by column block (four dependent MFMAs
-  // per accumulator: back-to-back issue on one accumulation chain runs at the full rate); the block only the first
-  // column half owns comes last, behind the one wave-uniform branch of the chunk
-  auto compute = [&](const char* __restrict__ cur) {
-    const int xo0 = swz(32 * r + frow, fh), xo1 = swz(32 * r + frow, 2 + fh);
-    const bf16x8 xh0 = *reinterpret_cast<const bf16x8*>(cur + xo0);
-    const bf16x8 xh1 = *reinterpret_cast<const bf16x8*>(cur + xo1);
-    bf16x8 xl0, xl1;
-    if (TERMS >= 2) {
-      xl0 = *reinterpret_cast<const bf16x8*>(cur + G::XL_OFF + xo0);
-      xl1 = *reinterpret_cast<const bf16x8*>(cur + G::XL_OFF + xo1);
-    }
+  // ---- DMA sources of this lane (fixed over the chunks but for the contraction offset) ---------------------------------------
+  // x: DMA i of wave w fills rows 32 w + 8 i .. + 7 of the tile (8 lanes per 128-byte row); lane -> (row, physical chunk),
+  //    it fetches the logical chunk that belongs there.  Rows past the end repeat the last row (computed, never stored).
+  const float* xsrc[4];
+  int xk[4];
 #pragma unroll
-    for (int cb = 0; cb < G::NH0; ++cb) {
-      if (G::NH1 == G::NH0 || cb < G::NH1 || h == 0) {
-        const int bo0 = swz((cbase + cb) * 32 + frow, fh), bo1 = swz((cbase + cb) * 32 + frow, 2 + fh);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(cur + G::BH_OFF + bo0);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(cur + G::BH_OFF + bo1);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, b0, acc[cb], 0, 0, 0);
-        if (TERMS >= 2) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, b0, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, b1, acc[cb], 0, 0, 0);
-        if (TERMS >= 2) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, b1, acc[cb], 0, 0, 0);
-        if (TERMS == 3) {
-          const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(cur + G::BL_OFF + bo0);
-          const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(cur + G::BL_OFF + bo1);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, c0, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, c1, acc[cb], 0, 0, 0);
-        }
-      }
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const long long gr = min((long long)row0 + row, a.rows - 1);
+    xsrc[i] = xl0 + gr * a.ld_x;
+    xk[i] = 4 * c;
+  }
+  // mapping: DMA j of wave w fills rows 16 (w + 8 j) .. + 15 of the image (4 lanes per 64-byte row); images shorter than
+  // 8 NBW DMAs: the surplus DMAs repeat the last one (same bytes to the same place)
+  const __bf16* bsrc[G::NBW];
+  const __bf16* bsrc2[G::NBW];
+  int bdst[G::NBW];
+#pragma unroll
+  for (int j = 0; j < G::NBW; ++j) {
+    const int d = min(wave + 8 * j, 2 * NCB - 1);
+    const int row = 16 * d + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int grow = min(cb0 * 32 + row, Lp - 1);                 // (blocks past the end of a layer are computed, never stored)
+    bsrc[j] = bh + (long long)grow * Lp + 8 * c;
+    bsrc2[j] = bl + (long long)grow * Lp + 8 * c;
+    bdst[j] = __builtin_amdgcn_readfirstlane(d * 1024);
+  }
+  // DMA i (0 .. NDMA-1) of chunk kc: the wave's four x pieces, then its mapping pieces
+  auto issue_one = [&](int kc_, int i) {
+    char* __restrict__ st = lds + (kc_ % G::NSTAGE) * G::STAGE;
+    const int kc = ATRANS_DIAG == 2 ? 0 : kc_;
+    if (i < 4) {
+      // chunks past the end of the layer (its padding to a multiple of 32) meet zero rows of the mapping: any finite
+      // values do, so they repeat the layer's last chunk instead of reading past the row
+      const int k = RAGGED ? 0 : min(kc * BK + xk[i], K - 4);
+      dma16(xsrc[i] + k, st + (32 * wave + 8 * i) * 128);
+    } else if (TERMS == 3) {
+      const int j = (i - 4) >> 1;
+      if ((i - 4) & 1) dma16(bsrc2[j] + kc * BK, st + G::BL_OFF + bdst[j]);
+      else dma16(bsrc[j] + kc * BK, st + G::BH_OFF + bdst[j]);
+    } else {
+      dma16(bsrc[i - 4] + kc * BK, st + G::BH_OFF + bdst[i - 4]);
     }
   };
-  // steady state without a branch inside: convert + store the chunk loaded during the previous iteration, request the one
-  // after it, multiply the current one; the last two chunks are peeled
-  int kc = 0;
-  for (; kc + 2 < nk; ++kc) {
-    stage_write<NCB, TERMS>(sr, lds + ((kc + 1) & 1) * G::STAGE, t);
-    stage_load<NCB, TERMS, RAGGED>(sr, xrow, row_ok, K, bh, bl, Lp, cb0 * 32, kc + 2, t);
-    compute(lds + (kc & 1) * G::STAGE);
+  auto issue = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < G::NDMA; ++i) issue_one(kc, i);
+  };
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int xrow = 32 * wave + frow;
+  // the wave's two x fragments (k-steps 0, 1) of a chunk: fp32 from its own rows of the stage, split hi + lo in registers
+  bf16x8 xh[2], xlo[2];
+  f32x4 raw[4];
+  auto x_read = [&](const char* __restrict__ st) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const f32x4*>(st + xswz(xrow, 4 * (q >> 1) + 2 * fh + (q & 1)));
+  };
+  auto x_convert = [&](int q) {                 // quarter q: elements 4 (q & 1) .. + 3 of k-step q >> 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = raw[q][i];
+      const __bf16 hb = (__bf16)v;
+      xh[q >> 1][4 * (q & 1) + i] = hb;
+      if (TERMS >= 2) xlo[q >> 1][4 * (q & 1) + i] = (__bf16)(v - (float)hb);
+    }
+  };
+  // One 32-deep chunk on the fragments in xh / xlo.  ISSUE: the DMAs of chunk kc + AHEAD go out BETWEEN the column
+  // blocks' MFMAs (a DMA costs its wave tens of cycles of issue: in one burst behind the barrier every wave of the
+  // workgroup stalls at once and the matrix pipes run dry).  PREF: the x fragments of chunk kc + 1 are fetched and
+  // converted in the second half of the blocks, so that the next chunk starts on its MFMAs instead of ~60 conversion
+  // instructions with nothing to overlap them; the x rows of a wave are filled by its own DMAs, so its counted vmcnt
+  // alone (no barrier) makes them readable.
+  constexpr int NBT = G::NDMA - 4;                                 // mapping DMAs per wave and stage
+  constexpr int CBR = (NCB - 1) / 2;                               // block behind which the next x fragments are requested
+  auto compute = [&](const char* __restrict__ cur, const char* __restrict__ nxt, int kn, auto issue_c, auto pref_c) {
+    constexpr bool ISSUE = decltype(issue_c)::value, PREF = decltype(pref_c)::value;
+    bf16x8 b0 = *reinterpret_cast<const bf16x8*>(cur + G::BH_OFF + bswz(frow, fh));
+    bf16x8 b1 = *reinterpret_cast<const bf16x8*>(cur + G::BH_OFF + bswz(frow, 2 + fh));
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const bf16x8 c0 = b0, c1 = b1;
+      if (cb + 1 < NCB) {                                           // next block's mapping fragments: one block ahead
+        b0 = *reinterpret_cast<const bf16x8*>(cur + G::BH_OFF + bswz((cb + 1) * 32 + frow, fh));
+        b1 = *reinterpret_cast<const bf16x8*>(cur + G::BH_OFF + bswz((cb + 1) * 32 + frow, 2 + fh));
+      }
+      acc[cb] = mma(xh[0], c0, acc[cb]);
+      if (TERMS >= 2) acc[cb] = mma(xlo[0], c0, acc[cb]);
+      acc[cb] = mma(xh[1], c1, acc[cb]);
+      if (TERMS >= 2) acc[cb] = mma(xlo[1], c1, acc[cb]);
+      if (TERMS == 3) {
+        const int bo0 = bswz(cb * 32 + frow, fh), bo1 = bswz(cb * 32 + frow, 2 + fh);
+        const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(cur + G::BL_OFF + bo0);
+        const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(cur + G::BL_OFF + bo1);
+        acc[cb] = mma(xh[0], d0, acc[cb]);
+        acc[cb] = mma(xh[1], d1, acc[cb]);
+      }
+      if (ISSUE && ATRANS_DIAG != 6) {
+#pragma unroll
+        for (int i = cb * G::NDMA / NCB; i < (cb + 1) * G::NDMA / NCB; ++i) issue_one(kn, i);
+      }
+      if (PREF) {
+        if (cb == CBR) {
+          STAMP(kn - 2, 3);
+          // outstanding, oldest first: the next stage's x pieces, its mapping pieces, this iteration's DMAs so far
+          wait_vm<NBT + (ISSUE ? (CBR + 1) * G::NDMA / NCB : 0)>();
+          x_read(nxt);
+        }
+      }
+#if ATRANS_SPREAD_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    if (PREF) {
+      STAMP(kn - 2, 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x_convert(q);
+    }
+  };
+  auto yes = std::integral_constant<bool, true>{};
+  auto no = std::integral_constant<bool, false>{};
+
+  if (RAGGED) {
+    // layer size not a multiple of 8 (the output layer: 99 = 3 * 33): a 16-byte chunk may straddle the end of the layer
+    // and of the row, so x goes through registers with element-wise guards (zero fill), synchronously; the mapping by DMA.
+    // A few short chunks per step: speed does not matter here.
+    for (int kc = 0; kc < nk; ++kc) {
+      __syncthreads();                                       // every wave is done with the stage
+#pragma unroll
+      for (int j = 0; j < G::NBW; ++j) {
+        dma16(bsrc[j] + kc * BK, lds + G::BH_OFF + bdst[j]);
+        if (TERMS == 3) dma16(bsrc2[j] + kc * BK, lds + G::BL_OFF + bdst[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 32 * wave + 8 * i + (lane >> 3), pc = lane & 7;
+        const int k0 = kc * BK + xk[i];
+        const bool rok = (long long)row0 + row < a.rows;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (rok && k0 + e < K) ? xsrc[i][k0 + e] : 0.f;
+        *reinterpret_cast<f32x4*>(lds + row * 128 + pc * 16) = v;
+      }
+      wait_vm<0>();
+      __syncthreads();
+      x_read(lds);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x_convert(q);
+      compute(lds, lds, -1, no, no);
+    }
     __syncthreads();
+  } else if (G::NSTAGE == 2) {
+    // two stages (three-term form): chunk kc + 1 is requested while chunk kc is multiplied
+    issue(0);
+    for (int kc = 0; kc < nk; ++kc) {
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* cur = lds + (kc & 1) * G::STAGE;
+      x_read(cur);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x_convert(q);
+      if (kc + 1 < nk) compute(cur, cur, kc + 1, yes, no);
+      else compute(cur, cur, -1, no, no);
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    // ring of three stages: chunk kc + 2 is requested during iteration kc, behind its barrier (every wave has then
+    // finished reading the stage it overwrites, chunk kc - 1); a wave waits for ITS DMAs of chunk kc (all but the NDMA
+    // youngest) before that barrier, so behind it the whole stage has landed.
+    issue(0);
+    if (nk > 1) {
+      issue(1);
+      wait_vm<G::NDMA + NBT>();                              // the wave's x pieces of chunk 0
+    } else {
+      wait_vm<NBT>();
+    }
+    x_read(lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x_convert(q);
+    int kc = 0;
+    for (; kc + 2 < nk; ++kc) {
+      STAMP(kc, 0);
+      wait_vm<G::NDMA>();
+      STAMP(kc, 1);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(kc, 2);
+      if (ATRANS_DIAG != 3) compute(lds + (kc % 3) * G::STAGE, lds + ((kc + 1) % 3) * G::STAGE, kc + 2, yes, yes);
+      else issue(kc + 2);
+      STAMP(kc, 5);
+    }
+    if (kc + 1 < nk) {
+      wait_vm<G::NDMA>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (ATRANS_DIAG != 3) compute(lds + (kc % 3) * G::STAGE, lds + ((kc + 1) % 3) * G::STAGE, -1, no, yes);
+      ++kc;
+    }
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ATRANS_DIAG != 3) compute(lds + (kc % 3) * G::STAGE, lds, -1, no, no);
+    __builtin_amdgcn_s_barrier();                            // (the next segment's first DMAs overwrite stages still being read)
   }
-  if (kc + 1 < nk) {
-    stage_write<NCB, TERMS>(sr, lds + ((kc + 1) & 1) * G::STAGE, t);
-    compute(lds + (kc & 1) * G::STAGE);
-    __syncthreads();
-    ++kc;
-  }
-  compute(lds + (kc & 1) * G::STAGE);
-  __syncthreads();
 
   // epilogue: accumulator register q of lane (col, fh) is row rho(q, fh) of the wave's 32-row block
-  const int nmine = h ? G::NH1 : G::NH0;
   float* __restrict__ ob = a.out + a.off[l];
 #pragma unroll
-  for (int cb = 0; cb < G::NH0; ++cb) {
-    if (cb < nmine && cbase + cb < ncb) {
-      const int col = (cb0 + cbase + cb) * 32 + frow;
+  for (int cb = 0; cb < NCB; ++cb) {
+    if (cb < ncb && (ATRANS_DIAG != 1 || a.rows < 0)) {
+      const int col = (cb0 + cb) * 32 + frow;
       if (col < K) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const long long row = (long long)row0 + 32 * r + rho(q, fh);
+          const long long row = (long long)row0 + 32 * wave + rho(q, fh);
           if (row < a.rows) ob[row * a.ld_out + col] = acc[cb][q];
         }
       }
     }
+  }
+}
+
+template <int TERMS, bool RAGGED>
+__device__ __forceinline__ void dispatch_segment(const AtArgs& a, const int4 sg, char* lds) {
+  switch (sg.w) {
+    case 1: run_segment<1, TERMS, RAGGED>(a, sg, lds); break;
+    case 2: run_segment<2, TERMS, RAGGED>(a, sg, lds); break;
+    case 3: run_segment<3, TERMS, RAGGED>(a, sg, lds); break;
+    case 4: run_segment<4, TERMS, RAGGED>(a, sg, lds); break;
+    case 5: run_segment<5, TERMS, RAGGED>(a, sg, lds); break;
+    case 6: run_segment<6, TERMS, RAGGED>(a, sg, lds); break;
+    default: run_segment<7, TERMS, RAGGED>(a, sg, lds); break;
   }
 }
 
@@ -237,17 +375,12 @@ __global__ void __launch_bounds__(NT, 2) atrans_kernel(AtArgs a) {
   const int s0 = a.seg_begin[id], s1 = a.seg_begin[id + 1];
   for (int s = s0; s < s1; ++s) {
     const int4 sg = a.segs[s];
-    const int ncb = sg.w;
-    if (a.L[sg.x] & 7) {           // (the planner cuts such layers into segments of <= 4 blocks)
-      if (ncb > 2) run_segment<4, TERMS, true>(a, sg, lds);
-      else run_segment<2, TERMS, true>(a, sg, lds);
-    } else if (ncb > 12) run_segment<13, TERMS, false>(a, sg, lds);
-    else if (ncb > 10) run_segment<12, TERMS, false>(a, sg, lds);
-    else if (ncb > 8) run_segment<10, TERMS, false>(a, sg, lds);
-    else if (ncb > 6) run_segment<8, TERMS, false>(a, sg, lds);
-    else if (ncb > 4) run_segment<6, TERMS, false>(a, sg, lds);
-    else if (ncb > 2) run_segment<4, TERMS, false>(a, sg, lds);
-    else run_segment<2, TERMS, false>(a, sg, lds);
+    if (a.L[sg.x] & 7) {           // (the planner cuts such layers into segments of <= 2 blocks)
+      if (sg.w > 1) run_segment<2, TERMS, true>(a, sg, lds);
+      else run_segment<1, TERMS, true>(a, sg, lds);
+    } else {
+      dispatch_segment<TERMS, false>(a, sg, lds);
+    }
   }
 }
 
@@ -296,14 +429,12 @@ __global__ void __launch_bounds__(256) atrans_pack_kernel(PackArgs a) {
 
 inline int pad32(int v) { return (v + 31) / 32 * 32; }
 
-// instantiated segment widths: a segment of n column blocks costs as much as the next width >= n
-inline int variant_blocks(int n) { return n > 12 ? 13 : (n > 10 ? 12 : (n > 8 ? 10 : (n > 6 ? 8 : (n > 4 ? 6 : (n > 2 ? 4 : 2))))); }
 
 struct Blk {
   int layer, cb, w, maxseg;      // column block cb of the layer; w = contraction chunks (cost of one block); longest segment
 };
 
-// cost of blocks [b0, b1) as one run: cut at layer boundaries, pieces of more than 13 blocks in near-equal parts
+// cost of blocks [b0, b1) as one run: cut at layer boundaries, pieces of more than maxseg blocks in near-equal parts
 long long run_cost(const std::vector<Blk>& blks, int b0, int b1, std::vector<int4>* segs, int row0) {
   long long cost = 0;
   int i = b0;
@@ -314,7 +445,7 @@ long long run_cost(const std::vector<Blk>& blks, int b0, int b1, std::vector<int
     int done = 0;
     for (int p = 0; p < parts; ++p) {
       const int m = (n - done + (parts - p) - 1) / (parts - p);
-      cost += (long long)variant_blocks(m) * blks[i].w + 8;        // + 8: prologue / epilogue of a segment, in chunk units
+      cost += (long long)m * blks[i].w + 6;        // + 6: prologue / epilogue of a segment, in block-chunk units
       if (segs) segs->push_back(make_int4(blks[i].layer, row0, blks[i + done].cb, m));
       done += m;
     }
@@ -368,7 +499,7 @@ extern "C" int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* si
   for (int l = 0; l < n_layers; ++l) {
     RCB_REQUIRE(sizes[l] >= 1, RCB_ERR_ARG, "atrans_plan: layer %d empty", l);
     const int lp = pad32(sizes[l]);
-    for (int cb = 0; cb < lp / 32; ++cb) blks.push_back(Blk{l, cb, lp / BK, (sizes[l] & 7) ? 4 : 13});
+    for (int cb = 0; cb < lp / 32; ++cb) blks.push_back(Blk{l, cb, lp / BK, (sizes[l] & 7) ? 2 : MAXSEG});
   }
   const int nb = (int)blks.size();
   const long long m_tiles = (rows + BM - 1) / BM;
@@ -450,7 +581,7 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
   a.seg_begin = plan_dev + 2;
   a.segs = reinterpret_cast<const int4*>(plan_dev + head);
   a.n_wg = n_wg;
-  const int lds = 2 * (terms == 1 ? Geo<13, 1>::STAGE : (terms == 2 ? Geo<13, 2>::STAGE : Geo<13, 3>::STAGE));
+  const int lds = LDS_MAX_BYTES;
   hipError_t e;
   if (terms == 1) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(atrans_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -466,3 +597,11 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
+
+#if ATRANS_STAMPS
+extern "C" int rcb_debug_atrans_stamps(unsigned long long* host, int32_t n) {
+  if (n > 8 * 40 * 6) n = 8 * 40 * 6;
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+  return (int)e;
+}
+#endif

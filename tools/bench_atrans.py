@@ -16,8 +16,9 @@ slices = list(zip(cum[:-1], cum[1:]))
 D = cum[-1]
 dev = "cuda"
 torch.manual_seed(0)
-x = torch.randn(rows, D, device=dev) * 0.03
-dw = torch.randn(rows, D, device=dev) * 1e-3
+pad = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # extra floats per row (1: rows of 3268 floats = 16-byte aligned)
+x = (torch.randn(rows, D + pad, device=dev) * 0.03)[:, :D]
+dw = (torch.randn(rows, D + pad, device=dev) * 1e-3)[:, :D]
 A = [torch.randn(n, n, device=dev) / n ** 0.5 for n in sizes]
 out = torch.empty(rows, D, device=dev)
 
@@ -40,8 +41,10 @@ t_pack = timeit(lambda: tr.prepare(A))
 t_fwd = timeit(lambda: tr.forward(x, out))
 t_dg = timeit(lambda: tr.dgrad(dw, out))
 flops = 2.0 * rows * sum(n * n for n in sizes) * terms
-print(f"atrans rows={rows} terms={terms}: pack {t_pack:.1f} us, forward {t_fwd:.1f} us ({flops / t_fwd / 1e6:.0f} TFLOP/s), "
+print(f"atrans rows={rows} terms={terms} pad={pad}: pack {t_pack:.1f} us, forward {t_fwd:.1f} us ({flops / t_fwd / 1e6:.0f} TFLOP/s), "
       f"dgrad {t_dg:.1f} us ({flops / t_dg / 1e6:.0f} TFLOP/s)")
+if pad:
+    sys.exit(0)
 old = ops.SplitATransform(slices, terms, terms)
 t_prep = timeit(lambda: old.prepare(A))
 t_f = timeit(lambda: old.forward(x, out))
