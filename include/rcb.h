@@ -66,15 +66,15 @@ typedef struct {
   int32_t pe_bf16;       /* 1: pe and dpe are bf16 arrays (precision >= 1, pe_dim % 8 == 0): the 16-bit
                           * kernels round pe / dpe to bf16 for their MFMA operands anyway, so storing
                           * them as bf16 gives bit-identical results with half the traffic        */
-  void* dw_split;        /* nullable, 16-bit kernels, rcb_siren_bwd / _loss_bwd only: besides dwvec, the gradient of
-                          * every layer vector of the maximal length W (even) is also written as the split-bf16 LEFT
-                          * operand of rcb_split_bf16: bf16 [n_wide_layers][n_rows][3 * W] = [hi | lo | hi], wide layers
-                          * in layer order -- saves the separate split pass over dwvec                          */
+  void* dw_bf16;         /* nullable, 16-bit kernels, rcb_siren_bwd / _loss_bwd only: besides dwvec, a bf16 copy of it,
+                          * [n_rows][dw_bf16_stride] with dwvec's column layout -- the operand of the batched bf16
+                          * weight-gradient GEMM of the A transform (rcb_atrans_*), written while the values are in
+                          * registers instead of by a cast pass over dwvec                                      */
   int32_t pixel_chunks;  /* 0 / 1: one workgroup per row of wvec.  c > 1 (16-bit kernels): the 32-pixel tiles of every row
                           * are split over c workgroups (launches with few rows -- one Kodak photo is 96 INRs -- would
                           * otherwise leave most of the 256 CUs idle).  y_out / dpe are unaffected; dwvec and sse then
                           * receive PARTIAL results: dwvec [c][n_rows][w_row_stride], sse [c][n_rows], to be summed in
-                          * chunk order by rcb_siren_reduce_chunks; dw_split must be NULL (the reduction emits it)  */
+                          * chunk order by rcb_siren_reduce_chunks; dw_bf16 must be NULL (the reduction emits it)   */
   const void* xf_bf16;   /* nullable, bf16 operand mode with pe_bf16 = 1: a bf16 copy of xf (same shape, same strides in
                           * elements).  The coordinate grid is constant for a whole run and the kernel rounds it to bf16 for
                           * its MFMA operand anyway: given the copy, both input halves are loaded as operand bits (no
@@ -88,6 +88,7 @@ typedef struct {
                           * the cut-back copy of pe and the stitching copy of dpe; results are bit-identical          */
   int32_t pe_patch_nums[3];  /* patches per axis (first pe_grid_dims entries)                                          */
   int32_t pe_patch_size[3];  /* pixels per axis of one patch; their product is n_pix                                   */
+  int64_t dw_bf16_stride;    /* elements between the rows of dw_bf16 (>= the length of a row of layer vectors)         */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */
@@ -101,7 +102,7 @@ int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const void* pe, cons
 
 /* Sum of the per-chunk partials of a pixel_chunks = c launch, in chunk order (deterministic): dwvec[g, :] = sum_k
  * dw_partial[k][g][:], sse[g] = sum_k sse_partial[k][g] (sse_partial / sse may be NULL for rcb_siren_bwd), and, if
- * d->dw_split != NULL, the split-bf16 copy of the summed wide-layer gradients as rcb_siren_desc.dw_split describes.  */
+ * d->dw_bf16 != NULL, the bf16 copy of the sums as rcb_siren_desc.dw_bf16 describes.                              */
 int rcb_siren_reduce_chunks(const rcb_siren_desc* d, const float* dw_partial, const float* sse_partial, float* dwvec,
                             float* sse, rcb_stream_t stream);
 
@@ -140,12 +141,15 @@ int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, in
 /* Noise drawn in the kernel (prior_model.py:140-145 draws torch.randn_like and then forms loc + st(log_scale) * eps):
  * eps[i] ~ N(0,1) from Philox4x32-10 + Box-Muller, a pure function of (seed, rng_stream, step, i), where `step` is read
  * from device memory so that a replayed HIP graph draws fresh noise.  rcb_reparam_rng_fwd: plain case (one level, one
- * sample, no maps), flat over n = rows * cols elements; writes eps_out (for rcb_posterior_bwd) and out.
+ * sample, no maps), flat over n = rows * cols elements; writes eps_out (for rcb_posterior_bwd) and out, and, if out_bf16
+ * != NULL, a bf16 copy of out as [n / cols][ld_bf16] rows (the operand of the A transform's batched bf16 weight-gradient
+ * GEMM, written while the values are in registers).
  * rcb_philox_normal materialises the same stream (step from step_dev if non-NULL, else step_host).              */
 int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev, int64_t step_host,
                       rcb_stream_t stream);
 int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
-                        const int64_t* step_dev, float* eps_out, float* out, rcb_stream_t stream);
+                        const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, int32_t cols, int64_t ld_bf16,
+                        rcb_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -241,19 +245,6 @@ int rcb_adam_multi(const rcb_adam_tensor* tensors, int32_t count, const rcb_adam
  * same operations in the same order, so both settings must give identical bits (tests/test_hip_kernels.py).     */
 int rcb_debug_generic_kernels_only(int32_t on);
 
-/* Split-bf16 GEMM operands (K2: the dense A transform `h_w @ A[l]`, prior_model.py:101-127, and its data gradient, on
- * the bf16 matrix cores at fp32 accuracy): x = hi + lo, hi = bf16(x), lo = bf16(x - hi).  For every item (all of one
- * shape) writes  out[r * out_row_stride + blk * out_block_stride + c] = (lo_mask >> blk) & 1 ? lo[r, c] : hi[r, c]
- * for blk = 0, 1, 2, so that [hi | lo | hi] @ [hi ; hi ; lo] (one bf16 GEMM, fp32 accumulation, K tripled) equals the
- * fp32 product to ~2^-17 relative.  cols must be even.                                                          */
-#define RCB_SPLIT_MAX_ITEMS 8
-typedef struct {
-  const float* x;   /* [rows, cols] with row stride ld_x */
-  void* out;        /* bf16 */
-} rcb_split_item;
-int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, int64_t cols, int64_t ld_x,
-                   int64_t out_row_stride, int64_t out_block_stride, int32_t lo_mask, rcb_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * K2, hand-written: the A transform of all layer vectors in one launch per direction (atrans.hip).
  *   forward        wvec[:, lo_l:hi_l] = h_w[:, lo_l:hi_l] @ A[l]      prior_model.py:173-174, test_model.py:348-349
@@ -271,6 +262,9 @@ int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, i
  * rcb_atrans_plan       : HOST: work decomposition for `rows` rows on n_cu compute units into plan[0 .. return value) (int32;
  *                         plan[0] = workgroups); the caller keeps a 16-byte aligned device copy of it for rcb_atrans_apply
  * rcb_atrans_apply      : transpose = 0: out = x @ A (forward), 1: out = x @ A^T (data gradient)
+ * rcb_atrans_wgrad_narrow : dA = h^T @ d for ONE narrow layer (the 99-wide output layer) in fp32, exact-product arithmetic,
+ *                         fixed summation order; h / d point at the layer's first column; workspace:
+ *                         rcb_atrans_wgrad_narrow_workspace(L, n_slabs) floats
  * ------------------------------------------------------------------------------------------- */
 #define RCB_ATRANS_MAX_LAYERS 8
 int64_t rcb_atrans_pack_elems(int32_t n_layers, const int32_t* sizes);
@@ -280,6 +274,9 @@ int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* sizes, int32_
 int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_t ld_out, int64_t rows, int32_t n_layers,
                      const int32_t* sizes, const void* packed, int32_t transpose, int32_t terms, const int32_t* plan_dev,
                      int32_t n_wg, rcb_stream_t stream);
+int64_t rcb_atrans_wgrad_narrow_workspace(int32_t L, int32_t n_slabs);
+int rcb_atrans_wgrad_narrow(const float* h, int64_t ld_h, const float* d, int64_t ld_d, int64_t rows, int32_t L, float* dA,
+                            float* workspace, int32_t n_slabs, rcb_stream_t stream);
 
 /* Bookkeeping of one optimisation step whose counter lives on the device, so that the whole step can be captured
  * once as a HIP graph and replayed (prior_model.py train() / test_model.py train() loop bodies):

@@ -771,6 +771,109 @@ def gen_checkpoint_and_psnr(out):
     print("checkpoint + PSNR ok: bpp %.3f, PSNR" % tm.bpp, d["psnr"], "(%.0f s)" % (time.time() - t0), flush=True)
 
 
+def gen_rd_trained(out):
+    """The PSNR@bpp half of the metric for a prior the reference TRAINED ITSELF, mappings included -- the path the
+    throughput number times.  For two rate targets: the reference's EM loop (main_prior_training.py:112-172: train with
+    training_mappings=True -> beta rule -> closed-form prior refit) on 64 smooth synthetic images with its own classes,
+    then its grouping and its compression of 16 other images (main_compression.py:47-162).  Stored per rate: the
+    trajectory of the loop (KL bits per INR before the beta rule, beta after it, MSE per INR), the number of groups, bpp
+    and per-image PSNR.  The trained mappings themselves do not travel (13 MB per rate): the GPU test trains its own
+    prior with the product on the same data and schedule and is held to the same rate-distortion points.
+    Noise of the loop: torch.manual_seed(em_seed) before it, then per step randn_like(lpe) and randn_like(level 1)."""
+    import contextlib
+    import io
+    import time
+    P, _ = presets()
+    cfg = P["cifar"]
+    n_train, n_test = 64, 16
+    n_iter, first_epochs, epochs, lr = 30, 100, 50, 2e-3
+    n_opt, n_ft = 300, 4
+    _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
+    Ytr = smooth_images(n_train, cfg["pixel_sizes"], 300)
+    Yte = smooth_images(n_test, cfg["pixel_sizes"], 400)
+    X = x[None].repeat(n_train, 1, 1)
+    Xte = x[None].repeat(n_test, 1, 1)
+    px = np.prod(cfg["pixel_sizes"])
+    d = Bag({"cfg": np.array(jsonable(cfg)), "n_train": np.array(n_train), "n_test": np.array(n_test),
+             "train_seed": np.array(300), "test_seed": np.array(400), "n_iter": np.array(n_iter),
+             "first_epochs": np.array(first_epochs), "epochs": np.array(epochs), "lr": np.array(lr), "n_opt": np.array(n_opt),
+             "n_ft": np.array(n_ft), "Y_train_stats": stats(Ytr), "Y_test_stats": stats(Yte)})
+    rates = [3.0, 1.0]
+    d["max_bitrate"] = np.array(rates)
+    t0 = time.time()
+    for ri, max_bitrate in enumerate(rates):
+        pm = build_prior(cfg, n_train)
+        lt, up = build_maps(cfg, pm.dims)
+        s0 = torch.nn.functional.softplus(torch.tensor(-2.0)) / 6
+        pri = [torch.zeros(pm.loc.shape[1]), torch.ones(pm.loc.shape[1]) * s0,
+               torch.zeros(pm.lpe_loc.shape[1:]), torch.ones(pm.lpe_loc.shape[1:]) * s0, None, None, None, None]
+        budget_max = max_bitrate * px
+        budget_min = max(cfg["lowest_bitrate"], max_bitrate - cfg["bitrate_range"]) * px
+        kl_beta, n_epoch = 1e-8, first_epochs
+        em_seed = 10 + ri
+        torch.manual_seed(em_seed)
+        traj = []
+        with NoiseTap() as tap:
+            for it in range(n_iter):
+                mse, kl, _ = pm.train(n_epoch, lr, X, Ytr, *pri, lt, up, kl_beta, training_mappings=True)
+                n_epoch = epochs
+                kls = kl / np.log(2.)
+                if kls > budget_max:
+                    kl_beta *= 1.5
+                if kls < budget_min:
+                    kl_beta /= 1.5
+                kl_beta = min(max(kl_beta, 1e-20), 1)
+                with torch.no_grad():                                 # main_prior_training.py:157-172
+                    pri[0] = pm.loc.clone().detach().mean(0)
+                    pri[1] = ((pm.st(pm.log_scale.clone().detach()) ** 2).mean(0) + pm.loc.clone().detach().var(0)) ** 0.5
+                    pri[2] = pm.lpe_loc.clone().detach().mean(0)
+                    pri[3] = ((pm.st(pm.lpe_log_scale.clone().detach()) ** 2).mean(0) + pm.lpe_loc.clone().detach().var(0)) ** 0.5
+                traj.append([kls, kl_beta, mse])
+                print("  rate %.1f EM %d: %.1f bits/INR, beta %.3e, mse %.3e (%.0f s)" % (max_bitrate, it, kls, kl_beta, mse,
+                                                                                          time.time() - t0), flush=True)
+            noise_first, noise_last, n_noise = [tap.log[0], tap.log[1]], [tap.log[-2], tap.log[-1]], len(tap.log)
+        d[f"r{ri}_traj"] = np.array(traj)
+        d[f"r{ri}_em_seed"] = np.array(em_seed)
+        d[f"r{ri}_noise_shapes"] = np.array(json.dumps([list(e.shape) for e in noise_first]))
+        d[f"r{ri}_noise_count"] = np.array(n_noise)
+        d[f"r{ri}_noise_first_stats"] = np.stack([stats(e) for e in noise_first])
+        d[f"r{ri}_noise_last_stats"] = np.stack([stats(e) for e in noise_last])
+        d[f"r{ri}_budget"] = np.array([budget_min, budget_max])
+        with torch.no_grad():
+            psnr_train = np.asarray(ref_utils.metric(Ytr.numpy(), pm.forward(X, lt, up).numpy(), "cifar"))
+            avg_ls = torch.cat([pm.log_scale.clone().detach().mean(0), pm.lpe_log_scale.clone().detach().mean([0]).flatten()])
+            q_loc = torch.cat([pm.loc.flatten(start_dim=1), pm.lpe_loc.flatten(start_dim=1)], -1)
+            q_scale = torch.cat([pm.st(pm.log_scale).flatten(start_dim=1), pm.st(pm.lpe_log_scale).flatten(start_dim=1)], -1)
+            p_loc = torch.cat([pri[0].flatten(), pri[2].flatten()])
+            p_scale = torch.cat([pri[1].flatten(), pri[3].flatten()])
+            group_idx, gs, ge, group2param, param2group, n_groups, group_kls, weights = ref_prior.get_grouping(q_loc, q_scale, p_loc, p_scale)
+        d[f"r{ri}_psnr_train"] = psnr_train
+        d[f"r{ri}_n_groups"] = np.array(n_groups)
+        _p_locs = p_loc.clone()[param2group]
+        _p_log_scales = torch.log(torch.exp(p_scale * 6) - 1).clone()[param2group]
+        _avg = avg_ls[param2group].cpu().detach()
+        tm = ref_test.TestBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n_test, cfg["upsample_factors"],
+                                   cfg["latent_dim"], cfg["data_dim"], cfg["pixel_sizes"], False, None, None, "cifar",
+                                   linear_transform=lt, upsample_net=up, p_loc=_p_locs, p_log_scale=_p_log_scales,
+                                   init_log_scale=_avg, param_to_group=param2group, group_to_param=group2param,
+                                   n_groups=n_groups, group_start_index=gs, group_end_index=ge, group_idx=group_idx, w0=30.,
+                                   c=6., random_seed=42, device="cpu", kl_upper_buffer=0., kl_lower_buffer=0.4,
+                                   kl_adjust_gap=10, initial_beta=kl_beta, beta_step_size=0.05)
+        d[f"r{ri}_bpp"] = np.array(tm.bpp)
+        with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+            tm.optimize_posteriors(Xte, Yte, n_epochs=n_opt, lr=lr, verbose=False)
+            with torch.no_grad():
+                d[f"r{ri}_psnr_after_opt"] = np.asarray(ref_utils.metric(Yte.numpy(), tm.predict(Xte).numpy(), "cifar"))
+            dist = tm.compress_posteriors(Xte, Yte, n_epochs_finetune=n_ft, h_n_epochs_finetune=None, hh_n_epochs_finetune=None,
+                                          verbose=False, lr=lr, fine_tune_gap=1)
+        d[f"r{ri}_psnr"] = np.asarray(dist)
+        print("rate %.1f: %d groups, bpp %.3f, train PSNR %.2f, after opt %.2f, compressed %.2f dB (%.0f s)" % (
+            max_bitrate, n_groups, tm.bpp, psnr_train.mean(), d[f"r{ri}_psnr_after_opt"].mean(), np.mean(dist), time.time() - t0),
+            flush=True)
+        np.savez_compressed(os.path.join(out, "rd_trained_cifar.npz"), **d)
+    print("rd ok (%.0f s)" % (time.time() - t0), flush=True)
+
+
 def gen_metrics(out):
     d = {}
     rng = np.random.RandomState(0)
@@ -848,4 +951,7 @@ if __name__ == "__main__":
         gen_long_groups(a.out)
     if "ckpt" in todo:
         gen_checkpoint_and_psnr(a.out)
+    # round-3 addition
+    if "rd" in todo:
+        gen_rd_trained(a.out)
     print("done")

@@ -14,12 +14,12 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_rec_commit", "rcb_rec_workspace_bytes", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
            "rcb_step_end", "rcb_upconv_weff_build", "rcb_upconv_weff_grad",
-           "rcb_upconv_dgrad_partial_rows", "rcb_split_bf16", "rcb_debug_generic_kernels_only", "rcb_philox_normal",
+           "rcb_upconv_dgrad_partial_rows", "rcb_debug_generic_kernels_only", "rcb_philox_normal",
            "rcb_reparam_rng_fwd", "rcb_upconv_bwd_fused", "rcb_tile_gather", "rcb_tile_crop", "rcb_tile_fold",
            "rcb_window_gather", "rcb_window_fold", "rcb_siren_reduce_chunks", "rcb_phaseconv_pack", "rcb_phaseconv_pack_uint4",
            "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace",
            "rcb_phase_bigweight", "rcb_phase_bigweight_grad", "rcb_atrans_pack_elems", "rcb_atrans_pack", "rcb_atrans_plan",
-           "rcb_atrans_apply"]
+           "rcb_atrans_apply", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow"]
 
 
 class RcbError(RuntimeError):
@@ -30,9 +30,9 @@ class SirenDesc(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("samples", C.c_int32), ("n_pix", C.c_int32), ("fourier_dim", C.c_int32),
                 ("pe_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
                 ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
-                ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_split", C.c_void_p), ("pixel_chunks", C.c_int32),
+                ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_bf16", C.c_void_p), ("pixel_chunks", C.c_int32),
                 ("xf_bf16", C.c_void_p), ("pe_grid_dims", C.c_int32), ("pe_patch_nums", C.c_int32 * 3),
-                ("pe_patch_size", C.c_int32 * 3)]
+                ("pe_patch_size", C.c_int32 * 3), ("dw_bf16_stride", C.c_int64)]
 
 
 class Level(C.Structure):
@@ -48,10 +48,6 @@ class RecDesc(C.Structure):
                 ("max_glen", C.c_int32), ("gumbel", C.c_void_p), ("gumbel_absmax", C.c_double),
                 ("n_candidates", C.c_int32), ("job_row", C.c_void_p), ("job_start", C.c_void_p),
                 ("job_glen", C.c_void_p), ("n_jobs", C.c_int32)]
-
-
-class SplitItem(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p)]
 
 
 class AdamTensor(C.Structure):
@@ -90,6 +86,7 @@ def load():
         lib.rcb_phaseconv_pack_uint4.restype = C.c_int64
         lib.rcb_phaseconv_wgrad_workspace.restype = C.c_int64
         lib.rcb_atrans_pack_elems.restype = C.c_int64
+        lib.rcb_atrans_wgrad_narrow_workspace.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RcbError(f"{LIB_PATH} does not export {name}")

@@ -300,6 +300,9 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char
     // ring of three stages: chunk kc + 2 is requested during iteration kc, behind its barrier (every wave has then
     // finished reading the stage it overwrites, chunk kc - 1); a wave waits for ITS DMAs of chunk kc (all but the NDMA
     // youngest) before that barrier, so behind it the whole stage has landed.
+    // ring of three stages: chunk kc + 2 is requested during iteration kc, behind its barrier (every wave has then
+    // finished reading the stage it overwrites, chunk kc - 1); a wave waits for ITS DMAs of chunk kc (all but the NDMA
+    // youngest) before that barrier, so behind it the whole stage has landed.
     issue(0);
     if (nk > 1) {
       issue(1);
@@ -594,6 +597,99 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
     if (e == hipSuccess) atrans_kernel<3><<<n_wg, NT, lds, (hipStream_t)stream>>>(a);
   }
   RCB_REQUIRE(e == hipSuccess, (int)e, "atrans_apply: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+// ---- weight gradient of a narrow layer (the output layer: 99 x 99 from 4096 rows) -------------------------------------------
+// dA[k][n] = sum_m h[m][k] d[m][n] in fp32 on v_mfma_f32_32x32x2_f32 (bit for bit a chain of fmaf in row order: exact
+// products, one rounding per term): 32 x 32 output tiles x row slabs, four waves per workgroup taking the slab's row
+// pairs in turn; both operands are read straight from global memory in the operand layout (lane = column, 128 contiguous
+// bytes per row and lane half), no LDS.  The four waves' tiles are added in wave order, a second kernel adds the slabs
+// in slab order: no atomics, bitwise reproducible.  A few MFLOP per step: the library's heuristics take 29 us for this
+// shape, this takes a few.
+namespace {
+__global__ void __launch_bounds__(256) wgrad_narrow_kernel(const float* __restrict__ h, long long ld_h, const float* __restrict__ d,
+                                                           long long ld_d, long long rows, int L, int n_slabs,
+                                                           float* __restrict__ part) {
+  __shared__ float red[4][16][64];
+  const int nt = (L + 31) / 32;
+  const int tile = blockIdx.x % (nt * nt), slab = blockIdx.x / (nt * nt);
+  const int k0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
+  const long long per = ((rows + n_slabs - 1) / n_slabs + 7) / 8 * 8;
+  const long long m_begin = slab * per, m_end = min(rows, m_begin + per);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, kh = lane >> 5;
+  const bool kin = k0 + i < L, nin = n0 + i < L;
+  const float* __restrict__ hp = h + k0 + (kin ? i : 0);
+  const float* __restrict__ dp = d + n0 + (nin ? i : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  // wave w multiplies the row pairs (m, m + 1), m = m_begin + 2 w, + 8, + 16, ...; eight pairs' loads in flight
+  for (long long m0 = m_begin + 2 * wave; m0 < m_end; m0 += 64) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long m = m0 + 8 * u + kh;
+      const bool ok = m < m_end;
+      const long long mc = ok ? m : m_begin;
+      av[u] = hp[mc * ld_h];
+      bv[u] = dp[mc * ld_d];
+      av[u] = (ok && kin) ? av[u] : 0.f;
+      bv[u] = (ok && nin) ? bv[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[wave][q][lane] = acc[q];
+  __syncthreads();
+  float* o = part + ((long long)slab * nt * nt + tile) * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = t + 256 * j, q = e >> 6, ln = e & 63;
+    const float v = ((red[0][q][ln] + red[1][q][ln]) + red[2][q][ln]) + red[3][q][ln];
+    o[rho(q, ln >> 5) * 32 + (ln & 31)] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) wgrad_narrow_sum_kernel(const float* __restrict__ part, int L, int n_slabs, float* __restrict__ dA) {
+  const int nt = (L + 31) / 32;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * L) return;
+  const int k = i / L, n = i - k * L;
+  const int tile = (k >> 5) * nt + (n >> 5);
+  const float* p = part + (long long)tile * 1024 + (k & 31) * 32 + (n & 31);
+  float s = 0.f;
+  const long long st = (long long)nt * nt * 1024;
+  int sl = 0;
+  for (; sl + 8 <= n_slabs; sl += 8) {           // eight independent loads in flight, added in slab order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(sl + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; sl < n_slabs; ++sl) s += p[sl * st];
+  dA[i] = s;
+}
+}  // namespace
+
+extern "C" int64_t rcb_atrans_wgrad_narrow_workspace(int32_t L, int32_t n_slabs) {
+  if (L < 1 || n_slabs < 1) return -1;
+  const int64_t nt = (L + 31) / 32;
+  return (int64_t)n_slabs * nt * nt * 1024;
+}
+
+extern "C" int rcb_atrans_wgrad_narrow(const float* h, int64_t ld_h, const float* d, int64_t ld_d, int64_t rows, int32_t L,
+                                       float* dA, float* workspace, int32_t n_slabs, rcb_stream_t stream) {
+  RCB_REQUIRE(h && d && dA && workspace && rows >= 1 && L >= 1 && L <= 1024 && n_slabs >= 1 && n_slabs <= 4096, RCB_ERR_ARG,
+              "atrans_wgrad_narrow: bad arguments (L = %d, slabs = %d)", L, n_slabs);
+  RCB_REQUIRE(ld_h >= L && ld_d >= L, RCB_ERR_SHAPE, "atrans_wgrad_narrow: row strides below the layer size");
+  const int nt = (L + 31) / 32;
+  wgrad_narrow_kernel<<<nt * nt * n_slabs, 256, 0, (hipStream_t)stream>>>(h, ld_h, d, ld_d, rows, L, n_slabs, workspace);
+  RCB_LAUNCH_CHECK();
+  wgrad_narrow_sum_kernel<<<(L * L + 255) / 256, 256, 0, (hipStream_t)stream>>>(workspace, L, n_slabs, dA);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

@@ -204,10 +204,13 @@ __global__ void __launch_bounds__(256) philox_normal_kernel(float* __restrict__ 
 // reparameterised sample with the noise drawn in the kernel: out = loc + st(log_scale) * eps, eps written once for the
 // posterior update.  Replaces torch.randn + the flat reparam kernel (the generated values never make a round trip
 // through HBM before their first use); same arithmetic as reparam_flat_kernel on the same eps.
+// out16 (nullable): a bf16 copy of out as [n / cols][ld16] rows -- the operand of the A transform's batched bf16
+// weight-gradient GEMM, written while the values are in registers.
 __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
                                                           float* __restrict__ eps_out, float* __restrict__ out, long long n,
                                                           unsigned long long seed, unsigned stream,
-                                                          const long long* __restrict__ step_dev) {
+                                                          const long long* __restrict__ step_dev, __bf16* __restrict__ out16,
+                                                          int cols, long long ld16) {
   const unsigned long long step = (unsigned long long)*step_dev;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -222,6 +225,16 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
     o.w = add_rn(m.w, mul_rn(st_f32(l.w), e.w));
     reinterpret_cast<float4*>(eps_out)[i] = e;
     reinterpret_cast<float4*>(out)[i] = o;
+    if (out16) {
+      long long r = (4 * i) / cols;
+      int c = (int)(4 * i - r * cols);
+      const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        out16[r * ld16 + c] = (__bf16)ov[k];
+        if (++c == cols) { c = 0; ++r; }
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 3)) {      // tail group
     const float4 e = philox_normal4((unsigned long long)n4, stream, step, seed);
@@ -230,6 +243,7 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
       const long long i = (n4 << 2) + k;
       eps_out[i] = ev[k];
       out[i] = add_rn(loc[i], mul_rn(st_f32(ls[i]), ev[k]));
+      if (out16) out16[(i / cols) * ld16 + i % cols] = (__bf16)out[i];
     }
   }
 }
@@ -247,15 +261,19 @@ extern "C" int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t 
 }
 
 extern "C" int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
-                                   const int64_t* step_dev, float* eps_out, float* out, rcb_stream_t stream) {
+                                   const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, int32_t cols,
+                                   int64_t ld_bf16, rcb_stream_t stream) {
   RCB_REQUIRE(loc && log_scale && step_dev && eps_out && out && n > 0, RCB_ERR_ARG, "reparam_rng_fwd: null pointer / empty");
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   RCB_REQUIRE(al16(loc) && al16(log_scale) && al16(eps_out) && al16(out), RCB_ERR_ARG, "reparam_rng_fwd: 16-byte alignment");
+  RCB_REQUIRE(out_bf16 == nullptr || (cols >= 1 && n % cols == 0 && ld_bf16 >= cols), RCB_ERR_SHAPE,
+              "reparam_rng_fwd: bf16 copy: n = %lld is not rows x %d columns, or row stride %lld < columns", (long long)n, cols, (long long)ld_bf16);
   int blocks = cdiv(n >> 2, 256);
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
   reparam_rng_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(loc, log_scale, eps_out, out, (long long)n, seed, rng_stream,
-                                                              (const long long*)step_dev);
+                                                              (const long long*)step_dev, reinterpret_cast<__bf16*>(out_bf16),
+                                                              out_bf16 ? cols : 1, (long long)ld_bf16);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -774,62 +792,6 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, l
     m[i] = mi;
     v[i] = vi;
   }
-}
-
-// ---- split-bf16 operands for fp32-grade GEMMs on the bf16 matrix cores --------------------------------------
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): hi*hi' + lo*hi' + hi*lo' reproduces the fp32 product to ~2^-17
-// relative.  The three products become ONE bf16 GEMM with fp32 accumulation by concatenating along K: the left
-// operand [hi | lo | hi], the right operand [hi ; hi ; lo].  This kernel writes the three blocks of an operand:
-//   out[item][r * out_row_stride + blk * out_block_stride + c] = (lo_mask >> blk) & 1 ? lo : hi,   blk = 0, 1, 2
-struct SplitArgs {
-  const float* x[RCB_SPLIT_MAX_ITEMS];
-  __bf16* out[RCB_SPLIT_MAX_ITEMS];
-  long long rows, cols, ld_x, out_row_stride, out_block_stride;
-  int lo_mask;
-};
-
-__global__ void __launch_bounds__(256) split_bf16_kernel(SplitArgs a) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  const float* __restrict__ x = a.x[blockIdx.z];
-  __bf16* __restrict__ out = a.out[blockIdx.z];
-  const long long half = a.cols >> 1;                       // pairs of columns (cols is even)
-  const long long total = a.rows * half;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const long long r = i / half, c = (i - r * half) * 2;
-    const float v0 = x[r * a.ld_x + c], v1 = x[r * a.ld_x + c + 1];
-    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-    const bf2 hi = {h0, h1};
-    const bf2 lo = {(__bf16)(v0 - (float)h0), (__bf16)(v1 - (float)h1)};
-    __bf16* o = out + r * a.out_row_stride + c;
-#pragma unroll
-    for (int blk = 0; blk < 3; ++blk)
-      *reinterpret_cast<bf2*>(o + blk * a.out_block_stride) = ((a.lo_mask >> blk) & 1) ? lo : hi;
-  }
-}
-
-extern "C" int rcb_split_bf16(const rcb_split_item* items, int32_t n_items, int64_t rows, int64_t cols, int64_t ld_x,
-                              int64_t out_row_stride, int64_t out_block_stride, int32_t lo_mask, rcb_stream_t stream) {
-  RCB_REQUIRE(items && n_items >= 1 && n_items <= RCB_SPLIT_MAX_ITEMS, RCB_ERR_ARG, "split_bf16: %d items (1..%d)", n_items,
-              RCB_SPLIT_MAX_ITEMS);
-  RCB_REQUIRE(rows > 0 && cols > 0 && (cols & 1) == 0 && ld_x >= cols, RCB_ERR_SHAPE, "split_bf16: rows=%lld cols=%lld ld=%lld",
-              (long long)rows, (long long)cols, (long long)ld_x);
-  RCB_REQUIRE((out_row_stride & 1) == 0 && (out_block_stride & 1) == 0, RCB_ERR_SHAPE, "split_bf16: odd output strides");
-  SplitArgs a;
-  memset(&a, 0, sizeof(a));
-  for (int i = 0; i < n_items; ++i) {
-    RCB_REQUIRE(items[i].x && items[i].out && (reinterpret_cast<uintptr_t>(items[i].out) & 3) == 0, RCB_ERR_ARG,
-                "split_bf16: item %d null / misaligned", i);
-    a.x[i] = items[i].x;
-    a.out[i] = reinterpret_cast<__bf16*>(items[i].out);
-  }
-  a.rows = rows; a.cols = cols; a.ld_x = ld_x;
-  a.out_row_stride = out_row_stride; a.out_block_stride = out_block_stride; a.lo_mask = lo_mask;
-  long long blocks = (rows * (cols >> 1) + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  split_bf16_kernel<<<dim3((unsigned)blocks, 1, (unsigned)n_items), 256, 0, (hipStream_t)stream>>>(a);
-  RCB_LAUNCH_CHECK();
-  return RCB_OK;
 }
 
 // ---- per-step bookkeeping of a captured training step (device-resident step counter) -------------------------

@@ -29,7 +29,8 @@ struct SirenArgs {
   float k_hi, k_lo;   // w0 / (2 pi) split in two floats
   float w0, dy_scale;
   int pe_bf16;        // pe / dpe hold bf16 elements (16-bit kernels only)
-  void* dw_split;     // nullable: split-bf16 copy of the wide layers' weight gradients (see rcb_siren_desc)
+  __bf16* dw16;       // nullable: bf16 copy of dwvec, rows dw16_stride elements apart (rcb_siren_desc.dw_bf16)
+  long long dw16_stride;
   int chunks;         // >= 1: workgroups per row of wvec (pixel tiles split; dwvec / sse hold per-chunk partials)
   const void* xf16;   // nullable: bf16 copy of xf, same shape and strides (rcb_siren_desc.xf_bf16)
   // pe / dpe layout (rcb_siren_desc.pe_grid_dims): 0 = [G][P][E]; else the rows are the patches of stitched grids

@@ -396,13 +396,13 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d->pe_bf16 == 0 || (d->pe_bf16 == 1 && d->precision >= 1 && d->pe_dim % 8 == 0), RCB_ERR_UNSUPPORTED,
               "siren: bf16 pe storage needs a 16-bit precision mode and pe_dim %% 8 == 0 (precision=%d, E=%d)", d->precision,
               d->pe_dim);
-  RCB_REQUIRE(d->dw_split == nullptr || d->precision >= 1, RCB_ERR_UNSUPPORTED,
-              "siren: the split-bf16 gradient output exists in the 16-bit kernels only");
+  RCB_REQUIRE(d->dw_bf16 == nullptr || d->precision >= 1, RCB_ERR_UNSUPPORTED,
+              "siren: the bf16 copy of the gradient exists in the 16-bit kernels only");
   const int chunks = d->pixel_chunks > 1 ? d->pixel_chunks : 1;
-  RCB_REQUIRE(chunks == 1 || (d->precision >= 1 && chunks <= (d->n_pix + 31) / 32 && d->dw_split == nullptr &&
+  RCB_REQUIRE(chunks == 1 || (d->precision >= 1 && chunks <= (d->n_pix + 31) / 32 && d->dw_bf16 == nullptr &&
                               (long long)d->n_rows * chunks < (1ll << 30)),
               RCB_ERR_UNSUPPORTED,
-              "siren: pixel_chunks=%d needs a 16-bit precision mode, at most one chunk per 32-pixel tile and dw_split == NULL "
+              "siren: pixel_chunks=%d needs a 16-bit precision mode, at most one chunk per 32-pixel tile and dw_bf16 == NULL "
               "(rcb_siren_reduce_chunks emits it)", d->pixel_chunks);
   memset(&a, 0, sizeof(a));
   if (d->pe_grid_dims != 0) {
@@ -430,7 +430,8 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   }
   a.chunks = chunks;
   a.pe_bf16 = d->pe_bf16;
-  a.dw_split = d->dw_split;
+  a.dw16 = reinterpret_cast<__bf16*>(d->dw_bf16);
+  a.dw16_stride = d->dw_bf16_stride;
   a.xf16 = d->xf_bf16;
   a.G = d->n_rows;
   a.S = d->samples;
@@ -453,10 +454,9 @@ struct ReduceArgs {
   const float* sse_part;
   float* dw;
   float* sse;
-  void* split;
-  long long stride;
-  int G, chunks, dnet, nl, wmax;
-  int off[MAXL + 1], wide[MAXL];     // layer offsets; rank of the layer among the layers of length wmax, or -1
+  __bf16* dw16;
+  long long stride, stride16;
+  int G, chunks, dnet;
 };
 
 __global__ void __launch_bounds__(256) siren_reduce_chunks_kernel(ReduceArgs r) {
@@ -466,17 +466,7 @@ __global__ void __launch_bounds__(256) siren_reduce_chunks_kernel(ReduceArgs r) 
     float v = 0.f;
     for (int k = 0; k < r.chunks; ++k) v += r.part[((long long)k * r.G + g) * r.stride + j];
     r.dw[(long long)g * r.stride + j] = v;
-    if (r.split) {
-      int l = 0;
-      while (l + 1 < r.nl && j >= r.off[l + 1]) ++l;
-      if (r.wide[l] >= 0) {
-        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-        __bf16* o = reinterpret_cast<__bf16*>(r.split) + ((long long)r.wide[l] * r.G + g) * (3 * r.wmax) + (j - r.off[l]);
-        o[0] = hi;
-        o[r.wmax] = lo;
-        o[2 * r.wmax] = hi;
-      }
-    }
+    if (r.dw16) r.dw16[(long long)g * r.stride16 + j] = (__bf16)v;
   }
   if (r.sse && blockIdx.x == 0) {
     for (int g = threadIdx.x; g < r.G; g += 256) {
@@ -550,25 +540,19 @@ extern "C" int rcb_siren_reduce_chunks(const rcb_siren_desc* d, const float* dw_
   r.sse_part = sse_partial;
   r.dw = dwvec;
   r.sse = sse;
-  r.split = d->dw_split;
+  r.dw16 = reinterpret_cast<__bf16*>(d->dw_bf16);
+  r.stride16 = d->dw_bf16_stride;
   r.stride = d->w_row_stride;
   r.G = d->n_rows;
   r.chunks = d->pixel_chunks;
-  r.nl = d->n_hidden + 1;
-  int o = 0, wmax = 0;
-  int size[MAXL];
-  for (int l = 0; l < r.nl; ++l) {
-    const int li = l == 0 ? d->fourier_dim + d->pe_dim : d->hidden, lo = l == r.nl - 1 ? d->out_dim : d->hidden;
-    r.off[l] = o;
-    size[l] = lo * (li + 1);
-    o += size[l];
-    wmax = size[l] > wmax ? size[l] : wmax;
+  const int nl = d->n_hidden + 1;
+  int o = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int li = l == 0 ? d->fourier_dim + d->pe_dim : d->hidden, lo = l == nl - 1 ? d->out_dim : d->hidden;
+    o += lo * (li + 1);
   }
-  r.off[r.nl] = o;
   r.dnet = o;
-  r.wmax = wmax;
-  int k = 0;
-  for (int l = 0; l < r.nl; ++l) r.wide[l] = (size[l] == wmax && (wmax & 1) == 0) ? k++ : -1;
+  RCB_REQUIRE(r.dw16 == nullptr || r.stride16 >= r.dnet, RCB_ERR_SHAPE, "siren_reduce_chunks: bf16 row stride %lld < %d", r.stride16, r.dnet);
   RCB_REQUIRE(r.stride >= r.dnet, RCB_ERR_SHAPE, "siren_reduce_chunks: row stride %lld < %d", r.stride, r.dnet);
   const long long total = (long long)r.G * r.dnet;
   long long blocks = (total + 255) / 256;

@@ -571,14 +571,7 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         }
         const float v = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
         dst[ol + e] = v;
-        if (size == G::WMAX && (G::WMAX & 1) == 0 && a.dw_split != nullptr) {
-          // split-bf16 left operand [hi | lo | hi] of the data-gradient GEMM (wide layers only, in layer order)
-          const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-          __bf16* o = reinterpret_cast<__bf16*>(a.dw_split) + ((long long)G::wide_index(l) * a.G + g) * (3 * G::WMAX) + e;
-          o[0] = hi;
-          o[G::WMAX] = lo;
-          o[2 * G::WMAX] = hi;
-        }
+        if (a.dw16 != nullptr) a.dw16[(long long)g * a.dw16_stride + ol + e] = (__bf16)v;   // operand of the weight-gradient GEMM
       }
     }
   }

@@ -829,17 +829,10 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
     auto store_tile = [&](auto l_c, int ob, int ib, const f32x16& acc, float bt, bool with_bias) {
       constexpr int l = decltype(l_c)::value;
       constexpr int no = G::lout(l), ni = G::lin(l), ol = G::off(l);
-      constexpr bool SPLIT = (G::lsize(l) == G::WMAX) && ((G::WMAX & 1) == 0);
-      __bf16* sp = (SPLIT && a.dw_split != nullptr)
-                       ? reinterpret_cast<__bf16*>(a.dw_split) + ((long long)G::wide_index(l) * a.G + g) * (3 * G::WMAX) : nullptr;
+      __bf16* sp = a.dw16 != nullptr ? a.dw16 + (long long)g * a.dw16_stride + ol : nullptr;
       auto emit = [&](int e, float v) {
         dst[ol + e] = v;
-        if (SPLIT && sp != nullptr) {
-          const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-          sp[e] = hi;
-          sp[G::WMAX + e] = lo;
-          sp[2 * G::WMAX + e] = hi;
-        }
+        if (sp != nullptr) sp[e] = (__bf16)v;        // bf16 copy: operand of the weight-gradient GEMM
       };
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll

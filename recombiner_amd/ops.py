@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamCfg, AdamTensor, SplitItem, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
+from ._lib import AdamCfg, AdamTensor, Level, LevelBwd, RcbError, SirenDesc, addr, check, ptr, stream_ptr
 
 f32 = torch.float32
 f64 = torch.float64
@@ -121,7 +121,7 @@ class PeLayout:
         return (meta.samples * (n_inr // per),) + tuple(a * b for a, b in zip(self.patch_nums, self.patch_size)) + (meta.pe_dim,)
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1, pe_layout=None):
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_layout=None):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -131,7 +131,8 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_split=None, chunks=1, pe_
         raise RcbError("rows of wvec must be a multiple of samples")
     d = SirenDesc(G, meta.samples, meta.n_pix, meta.fourier_dim, meta.pe_dim, meta.n_hidden, meta.hidden,
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
-                  meta.precision, int(pe is not None and pe.dtype == bf16), addr(dw_split), int(chunks), None)
+                  meta.precision, int(pe is not None and pe.dtype == bf16), None if dw_bf16 is None else dw_bf16.data_ptr(), int(chunks), None)
+    d.dw_bf16_stride = 0 if dw_bf16 is None else int(dw_bf16.stride(0))
     if pe_layout is not None:
         nd = len(pe_layout.patch_nums)
         d.pe_grid_dims = nd
@@ -192,27 +193,26 @@ def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True, pixel_chunks=Non
 
 
 def siren_wide_layers(meta: SirenMeta):
-    """(number of layer vectors of maximal length, that length): the layers rcb_siren_desc.dw_split covers"""
+    """(number of layer vectors of maximal length, that length)"""
     dims = [meta.fourier_dim + meta.pe_dim] + [meta.hidden] * meta.n_hidden + [meta.out_dim]
     sizes = [dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1)]
     return sizes.count(max(sizes)), max(sizes)
 
 
-def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_split=False,
+def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_bf16=False,
                    pixel_chunks=None, pe_layout=None):
-    """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_split (16-bit modes) also
-    the split-bf16 left operands [n_wide, G, 3 W] of the wide layers' gradients (ops._Stacked, as split_bf16 returns)."""
+    """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_bf16 (16-bit modes) also a
+    bf16 copy of dwvec, [G, d_net] with a row stride that is a multiple of 8 (rcb_siren_desc.dw_bf16: the operand of the
+    A transform's batched weight-gradient GEMM, written by the kernel's epilogue)."""
     lib = _lib.load()
     G = wvec.shape[0]
-    split = None
-    if want_split:
-        n_wide, w = siren_wide_layers(meta)
-        if meta.precision == 0 or w % 2:
-            raise RcbError("the split-bf16 gradient output needs a 16-bit precision mode and an even layer length")
-        stacked = torch.empty(n_wide, G, 3 * w, device=wvec.device, dtype=bf16)
-        split = _Stacked(list(stacked.unbind(0)), stacked)
+    dw16 = None
+    if want_bf16:
+        if meta.precision == 0:
+            raise RcbError("the bf16 copy of the gradient needs a 16-bit precision mode")
+        dw16 = torch.empty(G, (meta.d_net + 7) // 8 * 8, device=wvec.device, dtype=bf16)[:, :meta.d_net]
     chunks = pixel_chunks or siren_pixel_chunks(G, meta)
-    d, G = _siren_desc(meta, wvec, xf, pe, None if (split is None or chunks > 1) else split.stacked, chunks, pe_layout)
+    d, G = _siren_desc(meta, wvec, xf, pe, None if chunks > 1 else dw16, chunks, pe_layout)
     _check_pe(pe, G, meta, pe_layout)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
@@ -229,10 +229,10 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
                                  _dev_ptr_strided(dw if part is None else part), ptr(dpe, None, True), stream_ptr()),
           "rcb_siren_loss_bwd")
     if part is not None:
-        d2, _ = _siren_desc(meta, wvec, xf, pe, None if split is None else split.stacked, chunks)
+        d2, _ = _siren_desc(meta, wvec, xf, pe, dw16, chunks)
         check(lib.rcb_siren_reduce_chunks(C.byref(d2), ptr(part), ptr(sse_part), _dev_ptr_strided(dw), ptr(sse), stream_ptr()),
               "rcb_siren_reduce_chunks")
-    return (sse, dw, dpe, split) if want_split else (sse, dw, dpe)
+    return (sse, dw, dpe, dw16) if want_bf16 else (sse, dw, dpe)
 
 
 class SirenFn(torch.autograd.Function):
@@ -322,19 +322,22 @@ def rng_eligible(lv: LevelSpec):
             and lv.cols_out == lv.cols and lv.n_inr == lv.rows and lv.loc.is_contiguous() and lv.log_scale.is_contiguous())
 
 
-def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step):
+def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False):
     """-> (out [n, 1, cols], eps [n, 1, cols]): reparameterised sample with the noise drawn inside the kernel
-    (rcb_reparam_rng_fwd).  `step` is the device-resident int64 step counter."""
+    (rcb_reparam_rng_fwd).  `step` is the device-resident int64 step counter.  want_bf16: third result, a bf16 copy of
+    out as [n, cols] with a row stride that is a multiple of 8 (operand of the A transform's weight-gradient GEMM)."""
     lib = _lib.load()
     if not rng_eligible(lv):
         raise RcbError("reparam_rng: plain levels only")
     n, cols = lv.rows, lv.cols
     out = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
     eps = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
+    o16 = torch.empty(n, (cols + 7) // 8 * 8, device=lv.loc.device, dtype=bf16) if want_bf16 else None
     check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
                                   C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64), ptr(eps),
-                                  ptr(out), stream_ptr()), "rcb_reparam_rng_fwd")
-    return out, eps
+                                  ptr(out), ptr(o16, bf16, True), int(cols), C.c_int64(0 if o16 is None else o16.stride(0)),
+                                  stream_ptr()), "rcb_reparam_rng_fwd")
+    return (out, eps, o16[:, :cols]) if want_bf16 else (out, eps)
 
 
 def philox_normal(n, seed: int, rng_stream: int, step, device="cuda"):
@@ -989,144 +992,6 @@ def upconv_weff_grad(dweff1, dweff2, dweff3, db1_partial=None):
     return (dW1, dW2, dW3) if db1_partial is None else (dW1, dW2, dW3, db1)
 
 
-def split_bf16(xs, layout, lo_mask):
-    """Split-bf16 GEMM operands (rcb_split_bf16).  xs: fp32 2-D views of one shape and row stride (unit column stride).
-    layout "cols": each result is [rows, 3 * cols] (blocks side by side: a left operand, or a right operand to be used
-    transposed); "rows": [3 * rows, cols] (blocks stacked: a right operand).  lo_mask: bit b set -> block b holds the
-    low part.  Left operands use 0b010 ([hi | lo | hi]), right operands 0b100 ([hi ; hi ; lo])."""
-    lib = _lib.load()
-    rows, cols = xs[0].shape
-    ld = xs[0].stride(0)
-    arr = (SplitItem * len(xs))()
-    shape = (rows, 3 * cols) if layout == "cols" else (3 * rows, cols)
-    stacked = torch.empty((len(xs),) + shape, device=xs[0].device, dtype=bf16)     # one tensor: batched GEMMs can use it
-    outs = list(stacked.unbind(0))
-    for i, x in enumerate(xs):
-        if x.dtype != f32 or not x.is_cuda or tuple(x.shape) != (rows, cols) or x.stride(1) != 1 or x.stride(0) != ld:
-            raise RcbError("split_bf16: fp32 GPU views of one shape and row stride expected")
-        arr[i] = SplitItem(x.data_ptr(), outs[i].data_ptr())
-    if layout == "cols":
-        row_stride, blk_stride = 3 * cols, cols
-    else:
-        row_stride, blk_stride = cols, rows * cols
-    check(lib.rcb_split_bf16(arr, len(xs), C.c_int64(rows), C.c_int64(cols), C.c_int64(ld), C.c_int64(row_stride),
-                             C.c_int64(blk_stride), int(lo_mask), stream_ptr()), "rcb_split_bf16")
-    return _Stacked(outs, stacked)
-
-
-class _Stacked(list):
-    """list of the per-item results that also carries the tensor they are slices of (`.stacked`, [n_items, ...])"""
-
-    def __init__(self, items, stacked):
-        super().__init__(items)
-        self.stacked = stacked
-
-
-class SplitATransform:
-    """The A transform `wvec[:, lo:hi] = h_w[:, lo:hi] @ A[l]` (prior_model.py:101-127) and its data gradient
-    `dh[:, lo:hi] = dw[:, lo:hi] @ A[l]^T` with split-bf16 operands for the layers of one common even width (the three
-    1056-wide layers of the 3x32 SIREN); other layers (the 99-wide output layer) stay plain fp32 GEMMs.
-    prepare(A) splits the mappings once (per step when they are trained, per train() call when they are fixed)."""
-
-    def __init__(self, slices, terms=3, dgrad_terms=None):
-        # terms = 3: x hi * A hi + x lo * A hi + x hi * A lo (both operands to ~16 mantissa bits);
-        # terms = 2: the last product is dropped, i.e. the shared mappings enter as bf16 (their fp32 master copy only
-        #            feeds Adam) while the per-INR left operand keeps its low part: K shrinks from 3 W to 2 W
-        if terms not in (2, 3):
-            raise RcbError("SplitATransform: terms must be 2 or 3")
-        self.terms = terms
-        # the data gradient dh = dw @ A^T may use fewer terms than the forward product (1 = bf16 high parts only: a
-        # gradient, consumed by Adam's normalisation)
-        self.dgrad_terms = terms if dgrad_terms is None else dgrad_terms
-        if self.dgrad_terms not in (1, 2, 3) or self.dgrad_terms > terms:
-            raise RcbError("SplitATransform: dgrad_terms must be 1 .. terms")
-        self.slices = list(slices)
-        widths = [hi - lo for lo, hi in self.slices]
-        big = max(widths)
-        self.fast = [i for i, w in enumerate(widths) if w == big and w % 2 == 0 and w >= 256]
-        self.rest = [i for i in range(len(widths)) if i not in self.fast]
-        # wide layers adjacent and in order (true for the SIREN layer vectors): their outputs form one [rows, k * W] block
-        self._contiguous_fast = all(self.slices[a][1] == self.slices[b][0] for a, b in zip(self.fast, self.fast[1:])) and \
-            all(b == a + 1 for a, b in zip(self.fast, self.fast[1:]))
-        self.a_rows = self.a_cols = None
-        self._last = {False: None, True: None}      # split left operands of the last forward / dgrad call
-
-    def wgrad(self, h_w, dw, bf16_hi=True):
-        """dA[l] = h_w[:, lo:hi]^T @ dw[:, lo:hi], summed over the rows (INRs x samples).  With bf16_hi the wide layers
-        use the bf16 high parts both split calls already produced (fp32 accumulation and result): the sum over thousands
-        of rows averages the unbiased operand rounding down, unlike the per-row products above."""
-        out = [None] * len(self.slices)
-        hs, ds = self._last[False], self._last[True]
-        if bf16_hi and hs is not None and ds is not None and len(self.fast) > 1:
-            lo, hi = self.slices[self.fast[0]]
-            w = hi - lo
-            # one batched GEMM over the wide layers: a single layer's 1056 x 1056 result has too few tiles for 256 CUs
-            g = torch.bmm(hs.stacked[:, :, :w].transpose(1, 2), ds.stacked[:, :, :w], out_dtype=f32)
-            for k, i in enumerate(self.fast):
-                out[i] = g[k]
-            for i in self.rest:
-                lo, hi = self.slices[i]
-                out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
-            return out
-        for k, i in enumerate(self.fast):
-            lo, hi = self.slices[i]
-            w = hi - lo
-            if bf16_hi and hs is not None and ds is not None:
-                out[i] = torch.mm(hs[k][:, :w].t(), ds[k][:, :w], out_dtype=f32)
-            else:
-                out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
-        for i in self.rest:
-            lo, hi = self.slices[i]
-            out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
-        return out
-
-    def prepare(self, A):
-        mats = [A[i].detach() for i in self.fast]
-        self.a_rows = split_bf16(mats, "rows", 0b100)      # [hi ; hi ; lo]          right operand of the forward
-        self.a_cols = split_bf16(mats, "cols", 0b100)      # [hi | hi | lo] (^T)     right operand of the data gradient
-        self.A = A
-
-    def _apply(self, x, out, right, transpose, lefts=None):
-        if lefts is None:        # (the producer of x may already have written its split form: siren dw_split, reparam)
-            lefts = split_bf16([x[:, lo:hi] for lo, hi in (self.slices[i] for i in self.fast)], "cols", 0b010)
-        self._last[transpose] = lefts
-        batched = False
-        if self._contiguous_fast and hasattr(lefts, "stacked") and hasattr(right, "stacked") and len(self.fast) > 1:
-            # one batched GEMM over the wide layers, written straight into their column slices of `out`
-            # ([k, rows, W] view with strides (W, ld, 1)): better CU fill than one layer at a time
-            lo0 = self.slices[self.fast[0]][0]
-            k, w = len(self.fast), self.slices[self.fast[0]][1] - lo0
-            kk = (self.dgrad_terms if transpose else self.terms) * w        # leading blocks of [hi | lo | hi] x [hi ; hi ; lo]
-            try:
-                view = out[:, lo0:lo0 + k * w].view(out.shape[0], k, w).permute(1, 0, 2)
-                rs = right.stacked[:, :, :kk].transpose(1, 2) if transpose else right.stacked[:, :kk]
-                torch.bmm(lefts.stacked[:, :, :kk], rs, out_dtype=f32, out=view)
-                batched = True
-            except RuntimeError:
-                batched = False
-        if not batched:
-            for k, i in enumerate(self.fast):
-                lo, hi = self.slices[i]
-                kk = (self.dgrad_terms if transpose else self.terms) * (hi - lo)
-                torch.mm(lefts[k][:, :kk], right[k][:, :kk].t() if transpose else right[k][:kk], out_dtype=f32, out=out[:, lo:hi])
-        for i in self.rest:
-            lo, hi = self.slices[i]
-            a = self.A[i].detach()
-            torch.mm(x[:, lo:hi], a.t() if transpose else a, out=out[:, lo:hi])
-        return out
-
-    def forward(self, h_w, out, lefts=None):
-        return self._apply(h_w, out, self.a_rows, False, lefts)
-
-    def dgrad(self, dw, out, lefts=None):
-        return self._apply(dw, out, self.a_cols, True, lefts)
-
-    def matches_siren(self, meta):
-        """True if the wide layers of this transform are exactly those rcb_siren_desc.dw_split covers"""
-        n_wide, w = siren_wide_layers(meta)
-        return len(self.fast) == n_wide and all(self.slices[i][1] - self.slices[i][0] == w for i in self.fast)
-
-
 class ATransform:
     """The A transform `wvec[:, lo:hi] = h_w[:, lo:hi] @ A[l]` (prior_model.py:173-174, test_model.py:348-349), its data
     gradient `dh[:, lo:hi] = dw[:, lo:hi] @ A[l]^T` and its weight gradient on the hand-written kernels of atrans.hip:
@@ -1196,7 +1061,56 @@ class ATransform:
         return out
 
     def forward(self, h_w, out):
+        """out[:, lo:hi] = h_w[:, lo:hi] @ A[l]"""
         return self._apply(h_w, out, 0, self.terms)
 
     def dgrad(self, dw, out):
+        """out[:, lo:hi] = dw[:, lo:hi] @ A[l]^T"""
         return self._apply(dw, out, 1, self.dgrad_terms)
+
+    def new_rows(self, rows):
+        """fp32 [rows, cols] view whose rows start on 128-byte lines (row stride a multiple of 32 floats): the layout the
+        kernels stream fastest.  The SIREN kernels take the stride (rcb_siren_desc.w_row_stride) and give it to dwvec."""
+        ld = (self.cols + 31) // 32 * 32
+        return torch.empty(rows, ld, device=self.device, dtype=f32)[:, :self.cols]
+
+    def wgrad(self, h_w, dw, h16=None, dw16=None, bf16_hi=True):
+        """dA[l] = h_w[:, lo:hi]^T @ dw[:, lo:hi], summed over the rows (INRs x samples).  With bf16_hi the widest layers
+        (adjacent, one size, a multiple of 8) take bf16 operands in one batched GEMM with fp32 accumulation: the sum over
+        thousands of rows averages the unbiased operand rounding down, unlike the per-row products of forward / dgrad.
+        h16 / dw16: bf16 copies of h_w / dw ([rows, cols], row stride a multiple of 8) written by their producers
+        (reparam_rng(want_bf16), siren_loss_bwd(want_bf16)); cast here when absent.  Narrow layers (the output layer):
+        rcb_atrans_wgrad_narrow, exact fp32 products in a fixed order; anything else: fp32 GEMMs."""
+        out = [None] * len(self.sizes)
+        big = max(self.sizes)
+        wide = [i for i, n in enumerate(self.sizes) if n == big]
+        adjacent = all(b == a + 1 for a, b in zip(wide, wide[1:]))
+        rows = h_w.shape[0]
+        if bf16_hi and big >= 256 and big % 8 == 0 and adjacent and self.slices[wide[0]][0] % 8 == 0:
+            k, lo0 = len(wide), self.slices[wide[0]][0]
+
+            def view(t16, t32):
+                if t16 is None or t16.stride(1) != 1 or t16.stride(0) % 8:
+                    t16 = torch.empty(rows, (self.cols + 7) // 8 * 8, device=self.device, dtype=bf16)[:, :self.cols]
+                    t16.copy_(t32)
+                return t16.as_strided((k, rows, big), (big, t16.stride(0), 1), t16.storage_offset() + lo0)
+
+            g = torch.bmm(view(h16, h_w).transpose(1, 2), view(dw16, dw), out_dtype=f32)
+            for j, i in enumerate(wide):
+                out[i] = g[j]
+        lib = _lib.load()
+        for i, (lo, hi) in enumerate(self.slices):
+            if out[i] is not None:
+                continue
+            n = hi - lo
+            if n <= 256:
+                slabs = max(1, min(64, (rows + 63) // 64))
+                ws = torch.empty(int(lib.rcb_atrans_wgrad_narrow_workspace(n, slabs)), device=self.device, dtype=f32)
+                g = torch.empty(n, n, device=self.device, dtype=f32)
+                check(lib.rcb_atrans_wgrad_narrow(C.c_void_p(h_w[:, lo:hi].data_ptr()), C.c_int64(h_w.stride(0)),
+                                                  C.c_void_p(dw[:, lo:hi].data_ptr()), C.c_int64(dw.stride(0)), C.c_int64(rows),
+                                                  n, ptr(g), ptr(ws), slabs, stream_ptr()), "rcb_atrans_wgrad_narrow")
+                out[i] = g
+            else:
+                out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
+        return out

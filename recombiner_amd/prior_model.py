@@ -116,7 +116,7 @@ class PriorBNNmodel(nn.Module):
         self.pe_bf16 = True          # 16-bit mode only: pe / dpe stored as bf16 (bit-identical, half the traffic)
         self.stitched_pe = True      # 16-bit mode, patched presets: the SIREN kernel reads pe / writes dpe inside the stitched grids
         self.split_gemm = True       # 16-bit mode only: split-bf16 (hi/lo) operands for the A-transform fwd / dgrad GEMMs
-        self.split_terms = 2         # with split_gemm: 3 = both operands split; 2 = the mappings enter as bf16 (ops.SplitATransform)
+        self.split_terms = 2         # with split_gemm: 3 = both operands split; 2 = the mappings enter as bf16 (ops.ATransform)
         self.split_dgrad_terms = None  # with split_gemm: terms of the data-gradient GEMM (None = split_terms)
         self.wgrad_bf16 = True       # with split_gemm: bf16 high parts for the A weight-gradient GEMMs (sum over INRs)
         self.fused_noise = True      # draw eps inside the reparam kernel (Philox) when no noise_source is injected
@@ -295,8 +295,9 @@ class PriorBNNmodel(nn.Module):
                             + self._train_calls * 0x94D049BB133111EB + rank_id * 0xD6E8FEB86659FD93) & (2 ** 64 - 1),
                       flat=(torch.empty(sum(q.numel() for q in A + conv), device=dev, dtype=torch.float32)
                             if (training_mappings and world > 1) else None))
-            split = ops.SplitATransform(slices, self.split_terms, self.split_dgrad_terms) if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None
-            ws["split"] = split if (split is not None and split.fast) else None
+            # 16-bit modes: the A transform on the hand-written kernels of atrans.hip (every geometry)
+            ws["split"] = (ops.ATransform(slices, dev, self.split_terms, self.split_dgrad_terms)
+                           if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None)
             if graphable:
                 self._ws = ws
         else:
@@ -336,6 +337,8 @@ class PriorBNNmodel(nn.Module):
         rng_seed = ws["seed"]
 
         pe_lay = self._pe_layout()
+        if split is not None and not training_mappings:
+            split.prepare(A)                          # fixed mappings: packed once per call, outside the captured step
 
         def seg1a():
             ops.step_begin(tab, step_t, dyn, kl_slots)
@@ -353,8 +356,13 @@ class PriorBNNmodel(nn.Module):
                     pe = self._pe(upsample_net, lpe_t)                   # [N, 1, P, E]
                     pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
                     #                                                               materialises zeros + a copy)
+            h16 = None
+            want16 = split is not None and training_mappings and self.wgrad_bf16     # bf16 operands of the weight gradient
             if use_rng:
-                h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
+                if want16:
+                    h_w, e0, h16 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=True)
+                else:
+                    h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
                 eps, h_w = [e0], h_w.view(N, D)
             else:
                 eps = [self._noise((N, 1, D)) for _ in net]
@@ -371,18 +379,19 @@ class PriorBNNmodel(nn.Module):
                 h16 = h_w.to(torch.bfloat16)
                 A16 = [a.detach().to(torch.bfloat16) for a in A]
             elif split is not None:
-                split.prepare(A)                      # the mappings change every step when they are trained
-                wvec = split.forward(h_w, torch.empty(N, D, device=dev, dtype=torch.float32))
+                if training_mappings:
+                    split.prepare(A)                  # the mappings change every step when they are trained
+                wvec = split.forward(h_w, split.new_rows(N))
             else:
                 wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
-            dw_split = None
-            if split is not None and split.matches_siren(meta):      # the kernel's epilogue also emits the split form
-                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_split=True,
-                                                            pe_layout=pe_lay)
+            dw16 = None
+            if want16:        # the kernel's epilogue also writes the bf16 copy of the gradient
+                sse, dw, dpe, dw16 = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_bf16=True,
+                                                        pe_layout=pe_lay)
             else:
                 sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, pe_layout=pe_lay)
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
@@ -393,9 +402,9 @@ class PriorBNNmodel(nn.Module):
                 if training_mappings:
                     gA = [torch.mm(h16[:, lo:hi].t(), dw16[:, lo:hi]).float() for (lo, hi) in slices]
             elif split is not None:
-                dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32), dw_split)
+                dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
                 if training_mappings:
-                    gA = split.wgrad(h_w, dw, self.wgrad_bf16)
+                    gA = split.wgrad(h_w, dw, h16, dw16, self.wgrad_bf16)
             else:
                 dh = torch.empty(N, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):

@@ -501,14 +501,10 @@ class TestBNNmodel(nn.Module):
         split = None
         if self.split_gemm and self.precision != 0:
             split = ws.get("split")
-            if split is None:                       # the mappings are fixed at test time: split them once per workspace
-                split = ops.SplitATransform(slices, self.split_terms)
-                if split.fast:
-                    split.prepare(A)
-                else:
-                    split = False
+            if split is None:                       # the mappings are fixed at test time: packed once per workspace
+                split = ops.ATransform(slices, dev, self.split_terms)
+                split.prepare(A)
                 ws["split"] = split
-            split = split or None
 
         pe_lay = self._pe_layout()
 
@@ -524,18 +520,13 @@ class TestBNNmodel(nn.Module):
                     pe = self._pe(lpe_t)
                     pe_c = pe.reshape(N * S, P, pe.shape[-1]).contiguous()
             h_w = sample[..., :D].reshape(N * S, D)
-            wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)
             if split is not None:
-                split.forward(h_w, wvec)
+                wvec = split.forward(h_w, split.new_rows(N * S))
             else:
+                wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
-            dw_split = None
-            if split is not None and split.matches_siren(meta):
-                sse, dw, dpe, dw_split = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, want_split=True,
-                                                            pe_layout=pe_lay)
-            else:
-                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, pe_layout=pe_lay)
+            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, pe_layout=pe_lay)
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
             Dt = self._l1.D
             if self.patch:        # levels 2 and 3 need the contiguous [N, S, D] gradient as well
@@ -545,7 +536,7 @@ class TestBNNmodel(nn.Module):
                 d_full = torch.empty(N, S, Dt, device=dev, dtype=torch.float32)
                 dh = d_full.view(N * S, Dt)[:, :D]
             if split is not None:
-                split.dgrad(dw, dh, dw_split)
+                split.dgrad(dw, dh)
             else:
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(dw[:, lo:hi], a.t(), out=dh[:, lo:hi])

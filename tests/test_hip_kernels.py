@@ -320,8 +320,8 @@ def test_siren_wide_model_scale_weights_f16(W):
 
 
 def test_siren_wide_bf16_pe_storage_and_split_output():
-    """width 64: bf16-stored pe / dpe reproduce fp32 storage exactly, and the split-bf16 gradient copy of the two
-    4160-long layer vectors equals split_bf16 of the fp32 gradient (as for width 32)"""
+    """width 64: bf16-stored pe / dpe reproduce fp32 storage exactly, and the bf16 copy of the gradient the epilogue
+    writes (rcb_siren_desc.dw_bf16) is the rounded fp32 gradient (as for width 32)"""
     case = dict(F=16, E=16, n_hidden=3, C=3, P=200, N=3, S=1, hidden=64)
     dims, D, xf, pe, wv, y = _siren_case(seed=13, **case)
     meta = SirenMeta(1, 200, 16, 16, 3, 64, 3, precision=1)
@@ -330,15 +330,11 @@ def test_siren_wide_bf16_pe_storage_and_split_output():
     scale = 1.0 / (200 * 3)
     assert torch.equal(ops.siren_fwd(g(xf), pe32, g(wv), meta), ops.siren_fwd(g(xf), pe16, g(wv), meta))
     s32, w32, d32 = ops.siren_loss_bwd(g(xf), pe32, g(wv), g(y), scale, meta)
-    s16, w16, d16, split = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_split=True)
+    s16, w16, d16, wcopy = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_bf16=True)
     assert d16.dtype == torch.bfloat16
     assert torch.equal(s32, s16) and torch.equal(w32, w16) and torch.equal(d32.bfloat16(), d16)
-    n_wide, wlen = ops.siren_wide_layers(meta)
-    assert (n_wide, wlen) == (2, 64 * 65)
-    lo0 = 64 * 33
-    want = ops.split_bf16([w32[:, lo0 + k * wlen:lo0 + (k + 1) * wlen] for k in range(n_wide)], "cols", 0b010)
-    for k in range(n_wide):
-        assert torch.equal(split[k], want[k])
+    assert ops.siren_wide_layers(meta) == (2, 64 * 65)
+    assert wcopy.shape == w32.shape and wcopy.stride(0) % 8 == 0 and torch.equal(wcopy, w32.bfloat16())
 
 
 @pytest.mark.parametrize("width,prec", [(32, 1), (32, 2), (48, 1), (64, 2)])
@@ -361,15 +357,13 @@ def test_siren_pixel_chunks_equal_whole_row_launch(width, prec):
     y1 = ops.siren_fwd(g(xf), pe16, g(wv), meta, pixel_chunks=1)
     for c in (2, 4, 32):
         assert torch.equal(ops.siren_fwd(g(xf), pe16, g(wv), meta, pixel_chunks=c), y1)
-    s1, w1, d1, sp1 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_split=True, pixel_chunks=1)
+    s1, w1, d1, sp1 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_bf16=True, pixel_chunks=1)
+    assert torch.equal(sp1, w1.bfloat16())
     for c in (2, 5):
-        sc, wc, dc, spc = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_split=True, pixel_chunks=c)
+        sc, wc, dc, spc = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_bf16=True, pixel_chunks=c)
         assert torch.equal(dc, d1)
         assert rel_err(sc, s1) < 1e-6 and rel_err(wc, w1) < 2e-6
-        n_wide, wlen = ops.siren_wide_layers(meta)
-        lo0 = dims[1] * (dims[0] + 1) if width != 32 else 0
-        want = ops.split_bf16([wc[:, lo0 + k * wlen:lo0 + (k + 1) * wlen] for k in range(n_wide)], "cols", 0b010)
-        assert torch.equal(spc.stacked, want.stacked)
+        assert torch.equal(spc, wc.bfloat16())                                   # (written by the chunk reduction)
         s2, w2, d2 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, pixel_chunks=c)
         assert torch.equal(w2, wc) and torch.equal(s2, sc)                       # deterministic
     dy = 1e-3 * torch.randn(6, 1000, 3, device=DEV)
@@ -505,63 +499,18 @@ def test_reparam_flat_fast_path_equals_generic(N, D):
     assert rel_err(fast[:, 0], ref) < 1e-6
 
 
-def test_siren_split_gradient_output_equals_split_of_dw():
-    """rcb_siren_desc.dw_split: the epilogue's split-bf16 copy of the wide layers' gradients == rcb_split_bf16(dwvec)"""
+def test_siren_bf16_gradient_copy_equals_rounded_dw():
+    """rcb_siren_desc.dw_bf16: the epilogue's bf16 copy of the gradient == dwvec rounded to bf16, the fp32 results untouched"""
     case = dict(F=16, E=16, n_hidden=3, C=3, P=256, N=5, S=1)
     dims, D, xf, pe, wv, y = _siren_case(seed=13, **case)
     meta = SirenMeta(1, 256, 16, 16, 3, 32, 3, precision=1)
     assert ops.siren_wide_layers(meta) == (3, 1056)
-    sse, dw, dpe, sp = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, meta, want_split=True)
+    sse, dw, dpe, d16 = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, meta, want_bf16=True)
     sse2, dw2, dpe2 = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, meta)
     assert torch.equal(dw, dw2) and torch.equal(dpe, dpe2) and torch.equal(sse, sse2)
-    ref = ops.split_bf16([dw[:, a:b] for a, b in ((0, 1056), (1056, 2112), (2112, 3168))], "cols", 0b010)
-    assert sp.stacked.shape == (3, 5, 3168) and torch.equal(sp.stacked, ref.stacked)
+    assert d16.shape == (5, 3267) and d16.stride(0) == 3272 and torch.equal(d16, dw.bfloat16())
     with pytest.raises(ops.RcbError):
-        ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, SirenMeta(1, 256, 16, 16, 3, 32, 3), want_split=True)
-
-
-def test_split_bf16_operands_and_a_transform():
-    """rcb_split_bf16: exact hi / lo parts in both layouts; the split-bf16 A transform and its data gradient agree with
-    the fp32 product at fp32-rounding level (not at bf16 level)."""
-    gen = torch.Generator().manual_seed(21)
-    N, D = 37, 3267
-    slices = [(0, 1056), (1056, 2112), (2112, 3168), (3168, 3267)]
-    x = g(torch.randn(N, D, generator=gen) * 0.03)
-    hi = x.bfloat16()
-    lo = (x - hi.float()).bfloat16()
-    left = ops.split_bf16([x[:, a:b] for a, b in slices[:3]], "cols", 0b010)
-    for (a, b), o in zip(slices[:3], left):
-        assert o.shape == (N, 3 * 1056)
-        assert torch.equal(o[:, :1056], hi[:, a:b]) and torch.equal(o[:, 1056:2112], lo[:, a:b]) and torch.equal(o[:, 2112:], hi[:, a:b])
-    A = [g(torch.randn(b - a, b - a, generator=gen) / (b - a) ** 0.5) for a, b in slices]
-    ah = [m.bfloat16() for m in A]
-    al = [(m - h.float()).bfloat16() for m, h in zip(A, ah)]
-    rows = ops.split_bf16(A[:3], "rows", 0b100)
-    cols = ops.split_bf16(A[:3], "cols", 0b100)
-    for k in range(3):
-        assert torch.equal(rows[k], torch.cat([ah[k], ah[k], al[k]], 0))
-        assert torch.equal(cols[k], torch.cat([ah[k], ah[k], al[k]], 1))
-    tr = ops.SplitATransform(slices, terms=3)
-    assert tr.fast == [0, 1, 2] and tr.rest == [3]
-    tr.prepare(A)
-    w = tr.forward(x, torch.empty(N, D, device=DEV))
-    dh = tr.dgrad(x, torch.empty(N, D, device=DEV))
-    for (a, b), m in zip(slices, A):
-        ref = x[:, a:b].double() @ m.double()
-        refT = x[:, a:b].double() @ m.double().t()
-        assert rel_err(w[:, a:b], ref) < 2e-5 and rel_err(dh[:, a:b], refT) < 2e-5
-        assert rel_err(x[:, a:b].bfloat16().float() @ m.bfloat16().float(), ref) > 5e-4      # what plain bf16 would give
-    # terms = 2 (the models' default): the mappings enter as bf16, the per-INR operand keeps hi + lo -> the product with
-    # the ROUNDED mappings at fp32-rounding level
-    tr2 = ops.SplitATransform(slices, terms=2)
-    tr2.prepare(A)
-    w2 = tr2.forward(x, torch.empty(N, D, device=DEV))
-    dh2 = tr2.dgrad(x, torch.empty(N, D, device=DEV))
-    for k, ((a, b), m) in enumerate(zip(slices, A)):
-        mr = m.bfloat16().double() if k < 3 else m.double()
-        assert rel_err(w2[:, a:b], x[:, a:b].double() @ mr) < 2e-5 and rel_err(dh2[:, a:b], x[:, a:b].double() @ mr.t()) < 2e-5
-    with pytest.raises(ops.RcbError):
-        ops.SplitATransform(slices, terms=4)
+        ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / 768, SirenMeta(1, 256, 16, 16, 3, 32, 3), want_bf16=True)
 
 
 @pytest.mark.parametrize("rows,sizes", [(37, [1056, 1056, 1056, 99]), (300, [1056, 1056, 1056, 99]), (4096, [1056, 1056, 1056, 99]),
@@ -608,6 +557,43 @@ def test_atrans_kernels_forward_and_data_gradient(rows, sizes):
     assert torch.equal(tr.dgrad(xi, torch.empty(rows, D, device=DEV)), xi)
 
 
+@pytest.mark.parametrize("rows,sizes", [(300, [1056, 1056, 1056, 99]), (4096, [1056, 1056, 1056, 99]), (192, [1584, 2352, 2352, 147]),
+                                        (70, [64, 8, 40]), (1000, [33])])
+def test_atrans_weight_gradient(rows, sizes):
+    """dA[l] = h_w[:, lo:hi]^T @ dw[:, lo:hi]: the batched GEMM on bf16 operands (the producers' copies, or cast on the
+    spot) agrees with the fp64 product of the rounded operands; the narrow layers' kernel (fp32 MFMA: exact products,
+    fixed order) with the fp64 product of the fp32 ones."""
+    gen = torch.Generator().manual_seed(rows + 11)
+    D = sum(sizes)
+    cum = np.cumsum([0] + sizes)
+    slices = [(int(cum[i]), int(cum[i + 1])) for i in range(len(sizes))]
+    h = g(torch.randn(rows, D, generator=gen) * 0.03)
+    dw = g(torch.randn(rows, D, generator=gen) * 1e-3)
+    tr = ops.ATransform(slices, DEV, terms=2)
+    ld = (D + 7) // 8 * 8
+    h16 = torch.zeros(rows, ld, device=DEV, dtype=torch.bfloat16)[:, :D]
+    h16.copy_(h)
+    gA = tr.wgrad(h, dw, h16, None, True)               # one operand handed over, the other cast inside
+    gA32 = tr.wgrad(h, dw, None, None, False)
+    big = max(sizes)
+    for (a, b), g16, g32 in zip(slices, gA, gA32):
+        ref = h[:, a:b].double().t() @ dw[:, a:b].double()
+        assert rel_err(g32, ref) < 1e-5
+        if b - a == big and big >= 256:
+            ref16 = h[:, a:b].bfloat16().double().t() @ dw[:, a:b].bfloat16().double()
+            assert rel_err(g16, ref16) < 1e-5
+        else:
+            assert torch.equal(g16, g32)
+    g2 = tr.wgrad(h, dw, h16, None, True)
+    assert all(torch.equal(x1, x2) for x1, x2 in zip(gA, g2))            # reproducible
+    # narrow kernel = a chain of fmaf in row order per (wave, slab): bit-exact restatement for one small case
+    if rows <= 300:
+        n = sizes[-1]
+        if n <= 256:
+            hh, dd = h[:, slices[-1][0]:].double(), dw[:, slices[-1][0]:].double()
+            assert rel_err(gA[-1], hh.t() @ dd) < 2e-6
+
+
 def test_philox_noise_stream_and_fused_reparam():
     """in-kernel noise: N(0,1) statistics, a pure function of (seed, stream, step, index), and the fused kernel equals
     the explicit-noise reparam on the materialised stream bit for bit (including a tail that is not a multiple of 4)."""
@@ -623,6 +609,10 @@ def test_philox_noise_stream_and_fused_reparam():
         assert float((o == e[:4096].float()).float().mean()) < 0.01 and abs(float((o.double() * e[:4096]).mean())) < 0.08
     step = torch.tensor([7], device=DEV, dtype=torch.int64)
     assert torch.equal(ops.philox_normal(4096, 1234, 0, step), e[:4096].float())                     # device-side step
+    lvb = LevelSpec(g(torch.randn(5, 3267) * 0.05), g(torch.full((5, 3267), -4.0)), 3267, 5)
+    ob, eb, o16 = ops.reparam_rng(lvb, 99, 0, step, want_bf16=True)                                  # bf16 copy on the side
+    o2, e2 = ops.reparam_rng(lvb, 99, 0, step)
+    assert torch.equal(ob, o2) and torch.equal(eb, e2) and o16.stride(0) == 3272 and torch.equal(o16, ob.view(5, 3267).bfloat16())
     gen = torch.Generator().manual_seed(31)
     for N, D in ((5, 3267), (4, 512), (3, 7)):
         loc = g(torch.randn(N, D, generator=gen))

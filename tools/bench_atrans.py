@@ -1,5 +1,5 @@
-"""Times the hand-written A-transform kernels (atrans.hip) against the split-bf16 library GEMMs they replace.
-usage: python tools/bench_atrans.py [rows] [terms]"""
+"""Times the hand-written A-transform kernels (atrans.hip).
+usage: python tools/bench_atrans.py [rows] [terms] [pad floats per row]"""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,11 +43,7 @@ t_dg = timeit(lambda: tr.dgrad(dw, out))
 flops = 2.0 * rows * sum(n * n for n in sizes) * terms
 print(f"atrans rows={rows} terms={terms} pad={pad}: pack {t_pack:.1f} us, forward {t_fwd:.1f} us ({flops / t_fwd / 1e6:.0f} TFLOP/s), "
       f"dgrad {t_dg:.1f} us ({flops / t_dg / 1e6:.0f} TFLOP/s)")
-if pad:
-    sys.exit(0)
-old = ops.SplitATransform(slices, terms, terms)
-t_prep = timeit(lambda: old.prepare(A))
-t_f = timeit(lambda: old.forward(x, out))
-t_d = timeit(lambda: old.dgrad(dw, out))
-t_w = timeit(lambda: old.wgrad(x, dw, True))
-print(f"library split-bf16: prepare {t_prep:.1f} us, forward (incl. split) {t_f:.1f} us, dgrad (incl. split) {t_d:.1f} us, wgrad {t_w:.1f} us")
+h16 = x.bfloat16()
+d16 = dw.bfloat16()
+t_wg = timeit(lambda: tr.wgrad(x, dw, h16, d16, True))
+print(f"wgrad (batched bf16 library GEMM on the producers' copies + narrow-layer kernel) {t_wg:.1f} us")

@@ -21,7 +21,7 @@ y = torch.rand(G, P, 3, device=dev)
 for c in (1, 2, 3, 4, 6, 8, 16):
     if c > (P + 31) // 32:
         continue
-    f = lambda: ops.siren_loss_bwd(xf, pe, wv, y, 1.0 / (3 * P), meta, want_split=True, pixel_chunks=c)
+    f = lambda: ops.siren_loss_bwd(xf, pe, wv, y, 1.0 / (3 * P), meta, want_bf16=True, pixel_chunks=c)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
