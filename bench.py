@@ -27,8 +27,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # PMC traffic of the SIREN training kernel per launch (4096 INRs), by pe/dpe storage type (True: bf16)
-PMC_FILE = {True: "r02_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
+PMC_FILE = {True: "r03_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
 STEPS_PER_INR = 200 + 549 * 100   # reference schedule
+
+
+def siren_source_sha16():
+    """hash of the sources of the width-32 16-bit SIREN kernel: stamps the committed PMC traffic summary (see roofline)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("siren_mlp_bf16.hip", "siren_common.h", "siren_op16.h"):
+        with open(os.path.join(ROOT, "recombiner_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -41,7 +51,7 @@ def parse():
                     help="bf16 = bf16 MFMA operands / fp32 accumulate / fp32 master weights (BASELINE config[1]); "
                          "fp32 = exact-parity mode (fp32 MFMA, MIOpen upsample net)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (per-kernel table, REC roofline, PSNR@bpp run)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (per-kernel table, REC roofline, PSNR@bpp run, presets table)")
     ap.add_argument("--frozen-mappings", action="store_true", help="training_mappings=False")
     ap.add_argument("--lowp-gemm", action="store_true", help="bf16-operand A-transform GEMMs (experimental)")
     ap.add_argument("--no-split-gemm", action="store_true", help="plain fp32 A-transform GEMMs instead of split-bf16 fwd/dgrad")
@@ -138,6 +148,8 @@ def kernel_table(run, steps, n, D):
         "upconv_wgrad_kernel": ("hbm", 64 * 64 * 2 + 256 * 64 * 2),
         "adam_multi_kernel": ("hbm", 0),
     }
+    dims_l = [1056, 1056, 1056, 99]
+    atrans_flops = 2 * 2 * 2.0 * sum(v * v for v in dims_l) * n          # forward + data gradient, two terms each
     out, gemm_us, gemm_calls = [], 0.0, 0.0
     for name, (us, calls) in rows.items():
         if name.startswith("Cijk_"):
@@ -145,11 +157,10 @@ def kernel_table(run, steps, n, D):
             gemm_calls += calls
     merged = [(k, v) for k, v in rows.items() if not k.startswith("Cijk_")]
     if gemm_us:
-        merged.append(("library GEMMs (hipBLASLt: A transform fwd/dgrad/wgrad, stage-1 upsample fwd/dgrad/wgrad, 99-wide layer)",
+        merged.append(("library GEMMs (hipBLASLt: A-transform weight gradient of the wide layers, stage-1 upsample fwd/dgrad/wgrad)",
                        (gemm_us, gemm_calls)))
     merged.sort(key=lambda kv: -kv[1][0])
-    dims_l = [1056, 1056, 1056, 99]
-    gemm_flops = (6.0 * sum(v * v for v in dims_l) + 3 * 2.0 * 512 * 4096) * n
+    gemm_flops = (2.0 * sum(v * v for v in dims_l[:3]) + 3 * 2.0 * 512 * 4096) * n
     for name, (us, calls) in merged[:8]:
         rec = {"kernel": name[:120], "launches_per_step": round(calls, 2), "us_per_step": round(us, 1), "share_of_kernel_time": round(us / total, 4)}
         key = next((k for k in per_inr if k in name), None)
@@ -157,6 +168,10 @@ def kernel_table(run, steps, n, D):
             ach = gemm_flops / (us * 1e-6) / 1e12
             rec.update(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
                        alg_flops_per_step=gemm_flops)
+        elif "atrans_kernel" in name:
+            ach = atrans_flops / (us * 1e-6) / 1e12
+            rec.update(bound="mfma", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s", frac=round(ach / 2500.0, 4),
+                       alg_flops_per_step=atrans_flops)
         elif key is not None and per_inr[key][1] > 0:
             b = per_inr[key][1] * n
             ach = b / (us * 1e-6) / 1e9
@@ -245,24 +260,171 @@ def psnr_at_bpp(dev, precision):
                     "(optimise, A* encode all groups, fine-tune between rounds), precision mode of this bench line"}
 
 
+def presets_table(dev):
+    """BASELINE configs[2..4] (and the reference presets they vary) plus the test-time path on this box, untimed by the
+    driver's step clock but inside its run: prior-training step of each preset in its 16-bit mode (production path: device
+    noise, graph replay; 50 replayed steps between events) with its dominant kernel from a 10-step profile, the
+    TestBNNmodel.train step (N = 500 images, S = 5) and one A* encode round."""
+    import contextlib
+    import io
+    import warnings
+    import numpy as np
+    from torch.profiler import ProfilerActivity, profile
+    from recombiner_amd import config, utils
+    from recombiner_amd import prior_model as PM
+    runs = [("kodak-w48 (configs[2])", "kodak", 2, 48, 1), ("audio (configs[3], one rank's presets step on 8 clips)", "audio", 8, 32, 1),
+            ("video-w64-f16 (configs[4])", "video", 4, 64, 2), ("kodak", "kodak", 2, 32, 1), ("video", "video", 4, 32, 1)]
+    out = []
+    for label, name, n_data, width, prec in runs:
+        cfg = dict(config.configs[name])
+        cfg["hidden_dims"] = [width] * len(cfg["hidden_dims"])
+        per = int(np.prod(cfg["patch_nums"])) if cfg["patch"] else 1
+        n = n_data * per
+        X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                             cfg["hierarchical_patch_nums"], random_seed=42, device=dev)
+        m.precision = prec
+        torch.manual_seed(1)
+        lt = PM.LinearTransform(m.dims).to(dev)
+        up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(dev)
+        s0, D = 0.0211547, m._d_net
+        lat = list(m.lpe_loc.shape[1:])
+        pri = [torch.zeros(D, device=dev), torch.full((D,), s0, device=dev), torch.zeros(lat, device=dev), torch.full(lat, s0, device=dev)]
+        pri += ([torch.zeros(D, device=dev), torch.full((D,), s0, device=dev)] * 2) if cfg["patch"] else [None] * 4
+        Xd, Yd = X.to(dev)[None].expand(n, -1, -1), Y.to(dev)
+
+        def run(k):
+            return m.train(k, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            run(8)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            _, _, elbo = run(50)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 50
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                run(10)
+                torch.cuda.synchronize()
+        rows = sorted(((float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)) / 10, e.key)
+                       for e in prof.key_averages()), reverse=True)
+        total = sum(r[0] for r in rows) or 1.0
+        top_us, top = rows[0]
+        px, C, E = int(np.prod(cfg["pixel_sizes"])), cfg["output_dim"], 16
+        rec = {"preset": label, "inrs": n, "pixels_per_inr": px, "hidden": width, "operands": "bf16" if prec == 1 else "f16",
+               "ms_per_step": round(ms, 4), "inr_steps_per_sec": round(n / (ms * 1e-3)), "graph_replay": m._ws is not None and m._ws["graphs"] is not None,
+               "finite": bool(np.isfinite(elbo).all()), "dominant_kernel": top[:80], "dominant_kernel_us": round(top_us, 1),
+               "dominant_kernel_share": round(top_us / total, 3)}
+        if "siren" in top:
+            b = (2 * px * E * 2 + px * C * 4 + 2 * D * 4 + 4) * n       # pe + dpe (bf16), target, wvec + dwvec, sse
+            dims = m.dims
+            fl = 6.0 * px * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n
+            rec.update(dominant_alg_bytes=b, dominant_hbm_frac=round(b / (top_us * 1e-6) / 8e12, 4), dominant_alg_flops=fl,
+                       dominant_mfma_frac=round(fl / (top_us * 1e-6) / 2.5e15, 4))
+        out.append(rec)
+        del m, lt, up, Xd, Yd, X, Y, pri
+        torch.cuda.empty_cache()
+    # test-time path (main_compression.py: 500 CIFAR images per batch, S = 5)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_rec as BR
+    with contextlib.redirect_stdout(io.StringIO()):
+        tm = BR.build(500, 4.0, dev)
+    tm.precision = 1
+    cfg = config.configs["cifar"]
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], 500, 3, seed=0)
+    Xd, Yd = X.to(dev)[None].expand(500, -1, -1), Y.to(dev)
+    tm.train(Xd, Yd, 24, torch.optim.Adam(tm.parameters(), lr=2e-4), False, sample_size=5)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    tm.train(Xd, Yd, 100, torch.optim.Adam(tm.parameters(), lr=2e-4), False, sample_size=5)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_tt = e0.elapsed_time(e1) / 100
+    lv = tm._l1
+    for glen in np.unique((lv.end - lv.start)):
+        tm._table(lv, int(glen), 65536)
+    tm._encode_round(lv, True, 0)
+    ms_round = BR.timed(lambda: tm._encode_round(lv, True, 1), 10)
+    return {"prior_training": out,
+            "test_time": {"what": "TestBNNmodel.train, 500 CIFAR INRs, S = 5, bf16 mode, graph replay", "ms_per_step": round(ms_tt, 4),
+                          "inr_sample_steps_per_sec": round(2500 / (ms_tt * 1e-3)),
+                          "encode_round_ms": round(ms_round, 4), "encode_round_what": "500 rows, K = 65536: group choice, A* scoring, commit"}}
+
+
+def comm_report(m, lt, up, dev):
+    """Sharded step (every rank calls this): bytes of the two per-step all-reduces (gradients of the A matrices, of the conv
+    weights), their duration on their own, the duration of each captured segment of the step, and the slack = compute
+    that runs while a bucket travels (A bucket: upsampling-net backward + posterior update; conv bucket: posterior update)
+    minus that bucket's all-reduce.  Also checks that the shared mappings are bit-identical on every rank after training."""
+    import torch.distributed as dist
+    w = m._ws
+    flat = w["flat"] if w is not None else None
+    n_a = sum(q.numel() for q in lt.A)
+    chk = torch.stack([torch.cat([q.detach().double().reshape(-1) for q in list(lt.parameters()) + list(up.parameters())]).sum(),
+                       torch.cat([(q.detach().double() ** 2).reshape(-1) for q in list(lt.parameters()) + list(up.parameters())]).sum()])
+    hi, lo = chk.clone(), chk.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    rep = {"mappings_identical_across_ranks": bool(torch.equal(hi, lo)), "backend": dist.get_backend()}
+    if flat is None or w["graphs"] is None or w["graphs"][0] != "segments":
+        rep["note"] = "the step did not run as captured segments (frozen mappings or eager stepping)"
+        return rep
+
+    def timed(fn, reps=10):
+        evs = []
+        for _ in range(reps):
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        t = torch.tensor([sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    buckets = [flat[:n_a], flat[n_a:]]
+    ar = [timed(lambda b=b: dist.all_reduce(b, group=m.dp_group)) for b in buckets]
+    graphs = w["graphs"][1]
+    seg = []
+    for _ in range(3):                                    # whole steps, segment by segment (no collectives: timing only)
+        row = []
+        for g in graphs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            row.append((e0, e1))
+        torch.cuda.synchronize()
+        seg.append([a.elapsed_time(b) for a, b in row])
+    seg = [sorted(col)[1] for col in zip(*seg)]
+    rep.update({"allreduce_bytes_per_step": int(flat.numel() * 4), "bucket_bytes": [int(b.numel() * 4) for b in buckets],
+                "allreduce_ms_alone": [round(x, 4) for x in ar],
+                "segment_ms": {"1a sample..A-transform backward": round(seg[0], 4), "1b upsampling-net backward": round(seg[1], 4),
+                               "2 posterior update": round(seg[2], 4), "3 Adam on the mappings": round(seg[3], 4)},
+                "overlap_window_ms": [round(seg[1] + seg[2], 4), round(seg[2], 4)],
+                "slack_ms": [round(seg[1] + seg[2] - ar[0], 4), round(seg[2] - ar[1], 4)]})
+    return rep
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a CHILD
     process and exit with its code.  Nothing in this parent has touched the GPU yet (device_count() does not initialise
     it), and the parent is not replaced (no exec)."""
-    import socket
     import subprocess
     ndev = torch.cuda.device_count()
     rehearsal = os.environ.get("RCB_DIST_BACKEND", "nccl") != "nccl"
     if ndev < a.gpus and not rehearsal:
         sys.exit(f"bench.py: --gpus {a.gpus} requested but only {ndev} GPU(s) are visible: one rank per GPU over RCCL "
                  f"needs {a.gpus} devices (RCB_DIST_BACKEND=gloo rehearses the sharded code path on fewer; never for numbers)")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks AND holds the rendezvous port itself (no bind / close / reuse race with other jobs on the box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
@@ -404,23 +566,36 @@ def main():
                     "alg_bytes_per_launch": alg_bytes, "share_of_step": share}
         else:
             # 16-bit operand path: 0.03 ms of matrix work at peak vs 0.09 ms of HBM traffic -> HBM-bound
-            traffic = None
+            # PMC counters cannot be collected inside this run: the figure comes from the committed rocprofv3 passes over THIS
+            # kernel.  It is tied to the kernel's source: the summary records the hash of the SIREN kernel files it was
+            # measured on, and a mismatch (kernel edited since) reports no traffic instead of a stale one.
+            traffic, traffic_note = None, None
             try:
                 with open(os.path.join(ROOT, "profiles", PMC_FILE[pe16])) as f:
-                    traffic = json.load(f)["hbm_bytes_per_launch"] if n == 4096 else None
+                    pmc = json.load(f)
+                if n == 4096:
+                    if pmc.get("kernel_source_sha16") == siren_source_sha16():
+                        traffic = pmc["hbm_bytes_per_launch"]
+                    else:
+                        traffic_note = "stale: the SIREN kernel sources changed since the counters were collected"
             except (OSError, KeyError, ValueError):
                 traffic = None
             ach = alg_bytes / t / 1e9
             roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" % PMC_FILE[pe16],
+                    "traffic_note": traffic_note,
                     "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": alg_bytes, "alg_flops_per_launch": flops,
                     "mfma_tflops": round(flops / t / 1e12, 1), "share_of_step": share}
+    # ---- sharded runs: what the per-step collectives move, and how much compute they have to hide behind -----------------
+    comm = None
+    if ws > 1:
+        comm = comm_report(m, lt, up, dev)
     cpu = None
     extras = {}
     if rank == 0 and ws == 1 and not a.no_extras:
         for key, fn in (("kernels", lambda: kernel_table(run, 10, n, D)), ("rec", lambda: rec_roofline(dev)),
-                        ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision))):
+                        ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision)), ("presets", lambda: presets_table(dev))):
             try:
                 extras[key] = fn()
             except Exception as exc:            # extras never take the bench line down; the failure is visible in it
@@ -438,6 +613,8 @@ def main():
                                       f"S=1, training_mappings={tm}, Adam lr 2e-4", "inrs_per_gpu": n,
                           "parallelism": f"datapoint-sharded x{ws}", "tuned_library_gemms": bool(tuned)},
                "roofline": roof, "cpu_baseline": cpu}
+        if comm is not None:
+            out["comm"] = comm
         out.update(extras)
         print(json.dumps(out))
     if ws > 1:

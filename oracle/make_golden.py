@@ -786,7 +786,7 @@ def gen_rd_trained(out):
     P, _ = presets()
     cfg = P["cifar"]
     n_train, n_test = 64, 16
-    n_iter, first_epochs, epochs, lr = 30, 100, 50, 2e-3
+    n_iter, first_epochs, epochs, lr = 30, 200, 60, 1e-3
     n_opt, n_ft = 300, 4
     _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
     Ytr = smooth_images(n_train, cfg["pixel_sizes"], 300)
@@ -798,7 +798,7 @@ def gen_rd_trained(out):
              "train_seed": np.array(300), "test_seed": np.array(400), "n_iter": np.array(n_iter),
              "first_epochs": np.array(first_epochs), "epochs": np.array(epochs), "lr": np.array(lr), "n_opt": np.array(n_opt),
              "n_ft": np.array(n_ft), "Y_train_stats": stats(Ytr), "Y_test_stats": stats(Yte)})
-    rates = [3.0, 1.0]
+    rates = [3.0, 1.5]
     d["max_bitrate"] = np.array(rates)
     t0 = time.time()
     for ri, max_bitrate in enumerate(rates):

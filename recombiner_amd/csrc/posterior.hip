@@ -338,13 +338,10 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
   }
   if (!g_generic_only && n_levels == 1 && a.lv[0].col_map && !a.lv[0].row_map && !a.lv[0].row_perm && a.lv[0].rows == n_inr &&
       a.lv[0].cols_out == out_cols && (size_t)a.lv[0].cols * 16 <= 150 * 1024) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reparam_staged_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail((int)e, "reparam_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_done = true;
-    }
+    // (per launch: the attribute belongs to the (function, device) pair; a process may drive several devices)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reparam_staged_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail((int)e, "reparam_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     reparam_staged_kernel<<<n_inr, 1024, (size_t)a.lv[0].cols * 16, (hipStream_t)stream>>>(a);
     RCB_LAUNCH_CHECK();
     return RCB_OK;
@@ -756,13 +753,10 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
     const long long n_total = (long long)lv->rows * lv->cols;
     if (!g_generic_only && lv->d_out && lv->col_inv && !lv->member_ptr && !lv->row_perm_inv &&
         (size_t)lv->samples * lv->cols_out * 8 <= 150 * 1024) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(posterior_staged_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   // + 128 B static
-        if (e != hipSuccess) return fail((int)e, "posterior_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-      }
+      // (per launch: the attribute belongs to the (function, device) pair; a process may drive several devices)
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(posterior_staged_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   // + 128 B static
+      if (e != hipSuccess) return fail((int)e, "posterior_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
       posterior_staged_kernel<<<lv->rows, 1024, (size_t)lv->samples * lv->cols_out * 8, (hipStream_t)stream>>>(a);
       RCB_LAUNCH_CHECK();
       return RCB_OK;

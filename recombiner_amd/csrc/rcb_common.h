@@ -51,7 +51,10 @@ __device__ __forceinline__ float exp_fast(float x) {
   return __builtin_fmaf(e, lo * 0.693147182464599609375f, e);                       // e * 2^lo ~ e (1 + lo ln 2)
 }
 
-// ln u for u away from 0 (hardware log2, <= 1 ulp, times ln 2)
+// ln u for u away from 0 (hardware log2, <= 1 ulp, times ln 2).  PRECONDITION shared with div_fast / kl_elem_f32: normal,
+// finite operands.  v_log / v_rcp flush denormal inputs, so a denormal variance ratio or prior scale would give -inf / inf
+// where the library forms stay finite.  Not enforced: the scales here are softplus(log_scale) / 6 with log_scale started at
+// -4 (prior_model.py:103) and moved by Adam steps of ~1e-4, and softplus(x) / 6 stays a normal float down to x ~ -85.
 __device__ __forceinline__ float log_fast(float u) { return __builtin_amdgcn_logf(u) * 0.693147182464599609375f; }
 
 // softplus(x, beta=1, threshold=20) / 6 in fp32  (prior_model.py:88)

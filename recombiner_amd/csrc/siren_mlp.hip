@@ -333,14 +333,11 @@ __global__ void __launch_bounds__(256) siren_kernel(SirenArgs a) {
 
 template <int NH, int KS0, int NB0, int MODE>
 int launch(const SirenArgs& a, size_t smem_bytes, hipStream_t st) {
-  static bool attr_done = false;
-  auto kfn = siren_kernel<NH, KS0, NB0, MODE>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "siren: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+    auto kfn = siren_kernel<NH, KS0, NB0, MODE>;
+  // (per launch: the attribute belongs to the (function, device) pair; a process may drive several devices)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024);
+  if (e != hipSuccess) return fail((int)e, "siren: hipFuncSetAttribute: %s", hipGetErrorString(e));
   kfn<<<a.G, 256, smem_bytes, st>>>(a);
   RCB_LAUNCH_CHECK();
   return RCB_OK;

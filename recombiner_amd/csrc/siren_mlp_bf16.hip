@@ -582,14 +582,11 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 template <typename T, int NH, int F, int E, int C, int MODE, bool IN16>
 int launch_one(const SirenArgs& a, hipStream_t st) {
   using G = Geo<NH, F, E, C>;
-  static bool attr_done = false;
-  auto kfn = siren_bf16_kernel<T, NH, F, E, C, MODE, IN16>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "siren(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+    auto kfn = siren_bf16_kernel<T, NH, F, E, C, MODE, IN16>;
+  // (per launch: the attribute belongs to the (function, device) pair; a process may drive several devices)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024);
+  if (e != hipSuccess) return fail((int)e, "siren(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
   kfn<<<a.G * a.chunks, 256, G::LDS_BYTES, st>>>(a);
   RCB_LAUNCH_CHECK();
   return RCB_OK;

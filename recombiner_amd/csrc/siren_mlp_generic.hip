@@ -206,13 +206,11 @@ __global__ void __launch_bounds__(256) siren_generic_kernel(SirenArgs a, GenGeo 
 
 template <int MODE>
 int launch_generic(const SirenArgs& a, const GenGeo& geo, hipStream_t st) {
-  static bool attr_done = false;
   auto kfn = siren_generic_kernel<MODE>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "siren(generic): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+  // per launch, not once per process: the attribute belongs to the (function, device) pair and a process may drive
+  // several devices or call from several threads; the call is a table write
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return fail((int)e, "siren(generic): hipFuncSetAttribute: %s", hipGetErrorString(e));
   kfn<<<a.G, 256, (size_t)geo.total * sizeof(float), st>>>(a, geo);
   RCB_LAUNCH_CHECK();
   return RCB_OK;

@@ -874,14 +874,11 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
 template <typename T, int NH, int F, int E, int C, int W, int MODE, bool IN16>
 int launch_one(const SirenArgs& a, hipStream_t st) {
   using G = GeoW<NH, F, E, C, W>;
-  static bool attr_done = false;
   auto kfn = siren_wide_kernel<T, NH, F, E, C, W, MODE, IN16>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       G::LDS_BYTES);
-    if (e != hipSuccess) return fail((int)e, "siren(wide): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+  // (per launch: the attribute belongs to the (function, device) pair; a process may drive several devices)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     G::LDS_BYTES);
+  if (e != hipSuccess) return fail((int)e, "siren(wide): hipFuncSetAttribute: %s", hipGetErrorString(e));
   kfn<<<a.G * a.chunks, 256, G::LDS_BYTES, st>>>(a);
   RCB_LAUNCH_CHECK();
   return RCB_OK;

@@ -999,12 +999,10 @@ __global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* _
 }
 
 template <typename K, typename A>
-int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& attr_done) {
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& /*unused: the attribute is set per launch*/) {
+  // (the attribute belongs to the (function, device) pair and a process may drive several devices: set it every time)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
   kfn<<<grid, 512, smem, st>>>(args);
   RCB_LAUNCH_CHECK();
   return RCB_OK;

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all ari
 hot path runs in librcb_hip.so.  Every wrapper raises if the library is missing or a tensor is
 not on the GPU -- there is no CPU fallback.
 """
+import collections
 import ctypes as C
 import os as _os
 from dataclasses import dataclass
@@ -84,26 +85,38 @@ def siren_pixel_chunks(G, meta: SirenMeta):
     return max(1, min(4 if G <= 128 else 2, ntiles // 8))
 
 
-_XF16_CACHE = {}
+_XF16_CACHE = collections.OrderedDict()
 
 
-def _xf_bf16(xf):
-    """bf16 copy of the coordinate features with the same shape / strides in elements (rcb_siren_desc.xf_bf16), cached: the
-    grid is constant for a whole run.  Only for shared grids ([P, F] or a stride-0 expansion of one).  The cache entry keeps
-    a reference to the source tensor: while it is held, the allocator cannot hand the address to other data, so
-    (address, shape, version counter) identifies the contents."""
+def xf_bf16(xf):
+    """bf16 copy of the coordinate features with the same shape / strides in elements (rcb_siren_desc.xf_bf16); None for
+    grids that are not shared ([P, F] or a stride-0 expansion of one).  A caller that records kernel launches (HIP graph)
+    must OWN the copy it passes on (`xf16=` of the siren_* wrappers; the models keep it in their graph workspace): the
+    cache below only serves eager calls and may drop its entries."""
+    if xf.dim() == 3 and xf.stride(0) != 0:
+        return None
+    base = xf if xf.dim() == 2 else xf[0]
+    return base.to(bf16).contiguous()
+
+
+def _xf_bf16_cached(xf):
+    """xf_bf16 through a small LRU cache for eager calls: the grid is constant for a whole run.  An entry keeps a
+    reference to its source tensor (while it is held the allocator cannot hand the address to other data, so (address,
+    shape, version counter) identifies the contents); the least recently used entry is dropped beyond 16 -- a copy is only
+    ever referenced by the call that fetched it (`d._keep`), never by a recorded graph."""
     if xf.dim() == 3 and xf.stride(0) != 0:
         return None
     base = xf if xf.dim() == 2 else xf[0]
     key = (base.data_ptr(), tuple(base.shape), base._version, str(base.device))
     hit = _XF16_CACHE.get(key)
     if hit is not None:
+        _XF16_CACHE.move_to_end(key)
         return hit[1]
     copy = base.to(bf16).contiguous()
     if not torch.cuda.is_current_stream_capturing():      # (a copy made inside a capture lives in that graph's memory pool)
-        if len(_XF16_CACHE) >= 16:
-            _XF16_CACHE.clear()
         _XF16_CACHE[key] = (base, copy)
+        while len(_XF16_CACHE) > 16:
+            _XF16_CACHE.popitem(last=False)
     return copy
 
 
@@ -121,7 +134,7 @@ class PeLayout:
         return (meta.samples * (n_inr // per),) + tuple(a * b for a, b in zip(self.patch_nums, self.patch_size)) + (meta.pe_dim,)
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_layout=None):
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_layout=None, xf16=None):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -140,7 +153,7 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_l
             d.pe_patch_nums[i] = pe_layout.patch_nums[i]
             d.pe_patch_size[i] = pe_layout.patch_size[i]
     if meta.precision == 1 and pe is not None and pe.dtype == bf16 and not _os.environ.get("RCB_SIREN_NO_XF16"):   # (A/B switch)
-        x16 = _xf_bf16(xf)
+        x16 = xf16 if xf16 is not None else _xf_bf16_cached(xf)
         if x16 is not None:
             d.xf_bf16 = x16.data_ptr()
             d._keep = x16
@@ -200,7 +213,7 @@ def siren_wide_layers(meta: SirenMeta):
 
 
 def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_bf16=False,
-                   pixel_chunks=None, pe_layout=None):
+                   pixel_chunks=None, pe_layout=None, xf16=None):
     """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_bf16 (16-bit modes) also a
     bf16 copy of dwvec, [G, d_net] with a row stride that is a multiple of 8 (rcb_siren_desc.dw_bf16: the operand of the
     A transform's batched weight-gradient GEMM, written by the kernel's epilogue)."""
@@ -212,7 +225,7 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
             raise RcbError("the bf16 copy of the gradient needs a 16-bit precision mode")
         dw16 = torch.empty(G, (meta.d_net + 7) // 8 * 8, device=wvec.device, dtype=bf16)[:, :meta.d_net]
     chunks = pixel_chunks or siren_pixel_chunks(G, meta)
-    d, G = _siren_desc(meta, wvec, xf, pe, None if chunks > 1 else dw16, chunks, pe_layout)
+    d, G = _siren_desc(meta, wvec, xf, pe, None if chunks > 1 else dw16, chunks, pe_layout, xf16)
     _check_pe(pe, G, meta, pe_layout)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
@@ -229,7 +242,7 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
                                  _dev_ptr_strided(dw if part is None else part), ptr(dpe, None, True), stream_ptr()),
           "rcb_siren_loss_bwd")
     if part is not None:
-        d2, _ = _siren_desc(meta, wvec, xf, pe, dw16, chunks)
+        d2, _ = _siren_desc(meta, wvec, xf, pe, dw16, chunks, None, xf16)
         check(lib.rcb_siren_reduce_chunks(C.byref(d2), ptr(part), ptr(sse_part), _dev_ptr_strided(dw), ptr(sse), stream_ptr()),
               "rcb_siren_reduce_chunks")
     return (sse, dw, dpe, dw16) if want_bf16 else (sse, dw, dpe)

@@ -3,8 +3,9 @@ ELBO/KL, Adam -- the call surface of the reference's prior_model.py (same class 
 argument order and return values, cited per member) on top of hand-written HIP kernels.
 
 Where the reference chains torch ops through autograd, `train()` here runs one fused pipeline per
-step: sample (K1) -> upsample net (torch/MIOpen for now) -> A-transform GEMMs -> fused SIREN
-fwd+MSE+bwd (K3/K4) -> GEMM backward -> fused reparam-bwd + KL-bwd + Adam (K1'/K5'/K11).
+step: sample (K1, in-kernel noise) -> upsampling net (hand-written phase-conv kernels in the 16-bit modes,
+MIOpen only in the fp32 parity mode) -> A transform (atrans.hip) -> fused SIREN fwd+MSE+bwd (K3/K4) -> A-transform
+backward -> upsampling-net backward -> fused reparam-bwd + KL-bwd + Adam (K1'/K5'/K11), replayed as one HIP graph.
 `forward()` / `calculate_kl()` stay autograd-capable through custom Functions so user code written
 against the reference API keeps working.  There is no CPU fallback.
 """
@@ -294,7 +295,10 @@ class PriorBNNmodel(nn.Module):
                       seed=(int(self.random_seed) * 0x9E3779B97F4A7C15 + int(torch.initial_seed()) * 0xBF58476D1CE4E5B9
                             + self._train_calls * 0x94D049BB133111EB + rank_id * 0xD6E8FEB86659FD93) & (2 ** 64 - 1),
                       flat=(torch.empty(sum(q.numel() for q in A + conv), device=dev, dtype=torch.float32)
-                            if (training_mappings and world > 1) else None))
+                            if (training_mappings and world > 1) else None),
+                      # the bf16 copy of the coordinate grid the captured SIREN launches read: owned by the workspace,
+                      # i.e. alive exactly as long as the graphs that reference its address
+                      xf16=ops.xf_bf16(x) if (self.precision == 1 and dev.type == "cuda") else None)
             # 16-bit modes: the A transform on the hand-written kernels of atrans.hip (every geometry)
             ws["split"] = (ops.ATransform(slices, dev, self.split_terms, self.split_dgrad_terms)
                            if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None)
@@ -391,9 +395,10 @@ class PriorBNNmodel(nn.Module):
             dw16 = None
             if want16:        # the kernel's epilogue also writes the bf16 copy of the gradient
                 sse, dw, dpe, dw16 = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_bf16=True,
-                                                        pe_layout=pe_lay)
+                                                        pe_layout=pe_lay, xf16=ws["xf16"])
             else:
-                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, pe_layout=pe_lay)
+                sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, pe_layout=pe_lay,
+                                                  xf16=ws["xf16"])
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
             if lowp:

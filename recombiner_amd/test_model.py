@@ -244,6 +244,21 @@ class TestBNNmodel(nn.Module):
         cum = self.cum_param_sizes
         return [(0 if i == 0 else int(cum[i - 1]), int(cum[i])) for i in range(self.n_layers)]
 
+    # ---- reference API: helpers (test_model.py:260-281) ------------------------------------------------------------
+    def group_to_layer(self, param, layer_idx):
+        """the slice of a layer-vector row (.. x D_net) that belongs to layer `layer_idx`"""
+        lo, hi = self._layer_slices()[layer_idx]
+        return param[..., lo:hi]
+
+    def layer_to_weight(self, in_dim, out_dim, layer_param):
+        """layer vectors [N, L] or [N, S, L] -> (weights [.., in, out], bias [.., 1, out]): `[bias | W row-major]`"""
+        if layer_param.ndim == 2:
+            return layer_param[:, out_dim:].reshape(-1, in_dim, out_dim), layer_param[:, :out_dim][:, None, :]
+        if layer_param.ndim == 3:
+            return (layer_param[:, :, out_dim:].reshape(layer_param.shape[0], layer_param.shape[1], in_dim, out_dim),
+                    layer_param[:, :, :out_dim][:, :, None, :])
+        raise ValueError("layer_to_weight: [N, L] or [N, S, L] expected")
+
     def _pe_layout(self):
         """as PriorBNNmodel._pe_layout: the patched presets in the 16-bit modes keep pe / dpe on the stitched grids"""
         if self.precision != 0 and self.patch and getattr(self, "stitched_pe", True):
@@ -338,6 +353,7 @@ class TestBNNmodel(nn.Module):
             b = -np.log(-log_u[i] + np.exp(-b))
             out[i] = b
         self.g_samples = torch.from_numpy(out).to(self.loc.device)
+        self._g_absmax = float(np.abs(out).max())       # (the fast scorer's error bound uses it: never stale)
 
     def get_sobol_normal_sample(self, param_size, sample_size):
         """scrambled Sobol -> scipy norm.ppf -> clamp +-100 (test_model.py:493-498), fp64 container."""
@@ -489,7 +505,9 @@ class TestBNNmodel(nn.Module):
             ws = dict(key=key, tab=ops.adam_table(lr, max(n_epochs, 2048)).to(dev),
                       dyn=torch.zeros(2, device=dev), step_t=torch.zeros(1, device=dev, dtype=torch.long),
                       states=[{k: torch.zeros_like(lv.loc.detach()) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
-                              for lv in self._levels], graphs={}, warm=0)
+                              for lv in self._levels], graphs={}, warm=0,
+                      # bf16 copy of the coordinate grid: owned by the workspace that owns the graphs reading its address
+                      xf16=ops.xf_bf16(x) if (self.precision == 1 and dev.type == "cuda") else None)
             self._ws = ws
         else:
             for st in ws["states"]:
@@ -526,7 +544,8 @@ class TestBNNmodel(nn.Module):
                 wvec = torch.empty(N * S, D, device=dev, dtype=torch.float32)
                 for (lo, hi), a in zip(slices, A):
                     torch.mm(h_w[:, lo:hi], a, out=wvec[:, lo:hi])
-            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, pe_layout=pe_lay)
+            sse, dw, dpe = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (S * P * Cc), meta, pe_layout=pe_lay,
+                                              xf16=ws["xf16"])
             (d_lpe,) = torch.autograd.grad(pe_c, [lpe_t], dpe)                        # [S,N,*lat,C]
             Dt = self._l1.D
             if self.patch:        # levels 2 and 3 need the contiguous [N, S, D] gradient as well
@@ -656,6 +675,12 @@ class TestBNNmodel(nn.Module):
                               "KL in uncompressed groups: MAX %.3f" % left.max(), "AVE %.3f. " % left.mean(), flush=True)
             if verbose and lv is not self._l1:
                 print(' ')
+            # the kernels reject a malformed job by returning index -1 and rcb_rec_commit skips it: an encode round must
+            # not be able to leave a group behind silently (checked once per level: one device reduction, one host read)
+            if not bool(lv.d_done.all().item()):
+                left = torch.nonzero(~lv.d_done.bool().reshape(lv.rows, -1))
+                raise ops.RcbError("compress_posteriors: %d (row, group) pairs of a level were not encoded, first at row %d "
+                                   "group %d" % (left.shape[0], int(left[0, 0]), int(left[0, 1])))
         distortion = self._report(x, y)
         if verbose:
             print("Optimization Finished. Average Distortion %.4f" % np.mean(distortion), flush=True)

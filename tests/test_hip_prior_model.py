@@ -358,6 +358,31 @@ def test_bench_gpus_flag_launches_ranks():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["inrs_per_gpu"] == 64 and rec["value"] > 0
+    # the sharded step's communication report: both buckets, every segment, mappings identical on both ranks
+    comm = rec["comm"]
+    assert comm["mappings_identical_across_ranks"] is True and comm["backend"] == "gloo"
+    assert comm["allreduce_bytes_per_step"] == 4 * (3 * 1056 * 1056 + 99 * 99 + 251024) and len(comm["segment_ms"]) == 4
+
+
+def test_bench_two_ranks_over_rccl():
+    """N > 1 readiness: with two GPUs visible, `python bench.py --gpus 2` runs the sharded step over RCCL (backend nccl on
+    ROCm) -- two ranks, one per GPU, mappings bit-identical across the ranks after training.  Skipped on one-GPU boxes (the
+    gloo rehearsal above covers the code path there)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RCB_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--inrs", "512",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=dict(base, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["comm"]["backend"] == "nccl" and rec["comm"]["mappings_identical_across_ranks"] is True
 
 
 @pytest.mark.parametrize("n", [1, 3, 5, 258])
