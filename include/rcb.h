@@ -27,6 +27,7 @@ extern "C" {
 #define RCB_ERR_SHAPE (-2)
 #define RCB_ERR_UNSUPPORTED (-3)
 #define RCB_KL_SLOTS 1024
+#define RCB_KL_FX_SCALE 16777216.0   /* 2^24: the KL slots count 2^-24 nats */
 
 typedef void* rcb_stream_t;
 
@@ -165,10 +166,14 @@ int rcb_gauss_kl(const float* loc, const float* log_scale, const float* p_loc, c
                  const int32_t* group_idx, int32_t n_groups, const int32_t* seg_start,
                  const int32_t* seg_end, double* kl_row, double* kl_group, rcb_stream_t stream);
 
-/* Per-parameter KL summed over rows, out[j] = sum_r kl(r, j) (fp64): the statistic behind
- * get_grouping (prior_model.py:264-271); q_scale holds sigma (or log-scales if q_scale_is_log).  */
+/* Per-parameter KL summed over rows: the statistic behind get_grouping (prior_model.py:264-271); q_scale holds sigma (or
+ * log-scales if q_scale_is_log).  out_fx[j] = sum of the 256-row partial sums (fp64, fixed order) rounded to
+ * RCB_COLSUM_FX_SCALE units per nat, accumulated as 64-bit integers: the result does not depend on the order in which the
+ * workgroups (or, after an integer all-reduce, the ranks) contribute -- bitwise reproducible, and the same sharded or not
+ * when the shards are cut at multiples of 256 rows.                                                                 */
+#define RCB_COLSUM_FX_SCALE 1073741824.0        /* 2^30 */
 int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32_t q_scale_is_log, const float* p_loc,
-                        const float* p_scale, int32_t rows, int32_t cols, double* out, rcb_stream_t stream);
+                        const float* p_scale, int32_t rows, int32_t cols, int64_t* out_fx, rcb_stream_t stream);
 
 /* K8: per-group beta annealing (test_model.py:404-413): groups above 16+upper bits get
  * beta *= (1+step), groups at or below 16-lower bits beta /= (1+step), clamp [0, 1e4]; encoded
@@ -216,7 +221,8 @@ typedef struct {
   float* g_loc;            /* nullable outputs [rows, cols]                         */
   float* g_log_scale;
   float* m_loc; float* v_loc; float* m_ls; float* v_ls;   /* Adam state            */
-  double* kl_accum;        /* nullable [RCB_KL_SLOTS]: partial sums of the unweighted elementwise KL (before the
+  int64_t* kl_accum;       /* nullable [RCB_KL_SLOTS], fixed point (RCB_KL_FX_SCALE units per nat, integer atomics: the sum does
+                            * not depend on the order of the workgroups): partial sums of the unweighted elementwise KL (before the
                               update) are atomically added to the slots; their total is the KL           */
   const float* kl_scalar_dev; /* nullable device scalar: the KL weight becomes kl_scalar * (*kl_scalar_dev), so a
                               captured graph can be replayed with a new beta (main_prior_training.py:144-154) */
@@ -285,19 +291,25 @@ int rcb_atrans_wgrad_narrow(const float* h, int64_t ld_h, const float* d, int64_
  *   end  : mse_log[step] = mse_scale * sum(sse[0..n_sse)),  kl_log[step] = sum(kl_slots)  (each nullable, written
  *          only while step < n_log; fixed-order fp64 sums);  step += 1;  aux_counter (e.g. a noise counter that is not
  *          reset between train() calls) += 1                                                                        */
-int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, double* kl_slots,
+int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, int64_t* kl_slots,
                    rcb_stream_t stream);
-int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const double* kl_slots, double* mse_log,
+int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const int64_t* kl_slots, double* mse_log,
                  double* kl_log, int64_t n_log, int64_t* step, int64_t* aux_counter /* nullable: += 1 */,
                  rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172).
- * For x = loc[rows, cols]: sum[j], m2[j] = sum_r (x - mean_j)^2, and sig2[j] = sum_r sigma(r,j)^2
- * with sigma = softplus(log_scale)/6, all fp64.  Shards are merged on the host (Chan).
+ * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172), as EXACT fixed-point sums:
+ * for x = loc[rows, cols] (|x| < 64) and sigma = softplus(log_scale) / 6 (< 4), up to 2^20 rows over all ranks,
+ *   sum_fx[j] = sum_r rint(x 2^36),   sq_fx[j] = sum_r rint(x^2 2^30),   sig2_fx[j] = sum_r rint(sigma^2 2^44)
+ * as 64-bit integers.  Every element is rounded once to the grid where it enters; integer addition is associative, so
+ * the sums -- and the prior refit from them -- are bitwise independent of the order of the workgroups and, after an
+ * integer all-reduce, of how the rows are sharded over ranks.  mean = sum / n, M2 = sum x^2 - (sum x)^2 / n in fp64.
  * ------------------------------------------------------------------------------------------- */
-int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, double* sum,
-                    double* m2, double* sig2, rcb_stream_t stream);
+#define RCB_MOM_SUM_FX_SCALE 68719476736.0       /* 2^36 */
+#define RCB_MOM_SQ_FX_SCALE 1073741824.0         /* 2^30 */
+#define RCB_MOM_SIG_FX_SCALE 17592186044416.0    /* 2^44 */
+int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* sum_fx,
+                    int64_t* sq_fx, int64_t* sig2_fx, rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9: A* / relative-entropy-coding candidate scoring (test_model.py:501-533 sample_group, :535-584

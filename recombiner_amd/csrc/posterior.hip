@@ -33,6 +33,16 @@ int fail(int code, const char* fmt, ...) {
 
 using namespace rcb;
 
+// ---- order-independent reductions --------------------------------------------------------------------------------------
+// Sums that many workgroups (or ranks) contribute to are accumulated in 64-bit FIXED POINT with integer atomics: integer
+// addition is associative, so the result does not depend on the order in which the contributions arrive -- bitwise
+// reproducible from run to run, and identical whether the rows sit on one GPU or are sharded (the all-reduce over ranks
+// is an integer sum as well).  A contribution is rounded once, to the fixed-point grid, where it enters.
+__device__ __forceinline__ void fx_add(int64_t* dst, double v, double scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double2ll_rn(v * scale));
+}
+constexpr double KL_FX = 16777216.0;          // RCB_KL_FX_SCALE = 2^24 units per nat
+
 extern "C" int rcb_version(void) { return RCB_VERSION; }
 extern "C" const char* rcb_last_error_string(void) { return last_error_buf(); }
 
@@ -576,9 +586,9 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
     double kv = wave_sum(act ? (double)kl_elem_f32(loc, sig, L.p_loc[j], spk) : 0.0);
     if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
     __syncthreads();
-    // one atomic per block, spread over RCB_KL_SLOTS addresses (a single address serialises)
+    // one (integer, fixed-point) atomic per block, spread over RCB_KL_SLOTS addresses (a single address serialises)
     if (threadIdx.x == 0)
-      atomicAdd(L.kl_accum + ((blockIdx.x * 7 + blockIdx.y) & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
+      fx_add(L.kl_accum + ((blockIdx.x * 7 + blockIdx.y) & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]), KL_FX);
   }
   if (w != 0.0f) {
     float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
@@ -674,7 +684,7 @@ __global__ void __launch_bounds__(1024) posterior_staged_kernel(PostBwdArgs a) {
     if (threadIdx.x == 0) {
       double t = 0.0;
       for (int k = 0; k < 16; ++k) t += s_kl[k];
-      atomicAdd(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), t);
+      fx_add(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), t, KL_FX);
     }
   }
 }
@@ -724,7 +734,7 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
     __syncthreads();
     if (threadIdx.x == 0)
-      atomicAdd(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
+      fx_add(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]), KL_FX);
   }
   if (!act) return;
   reinterpret_cast<float4*>(L.loc + b)[0] = loc4;
@@ -791,7 +801,7 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, l
 // ---- per-step bookkeeping of a captured training step (device-resident step counter) -------------------------
 __global__ void __launch_bounds__(1024) step_begin_kernel(const float* __restrict__ table, long long n_steps,
                                                           const long long* __restrict__ step, float* __restrict__ dyn,
-                                                          double* __restrict__ kl_slots) {
+                                                          long long* __restrict__ kl_slots) {
   const int t = threadIdx.x;
   if (t < 2) {
     long long s = *step;
@@ -799,54 +809,57 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(const float* __restric
     if (s >= n_steps) s = n_steps - 1;      // replayed past the table: keep the last row rather than read outside
     dyn[t] = table[2 * s + t];
   }
-  if (kl_slots) kl_slots[t] = 0.0;
+  if (kl_slots) kl_slots[t] = 0;
 }
 
-// fixed-order fp64 sums (thread-strided partials, then a tree over LDS): the same value eagerly and under replay
+// fixed-order fp64 sums (thread-strided partials, then a tree over LDS): the same value eagerly and under replay; the KL
+// slots are fixed-point integers (exact sum)
 __global__ void __launch_bounds__(1024) step_end_kernel(const float* __restrict__ sse, int n_sse, double mse_scale,
-                                                        const double* __restrict__ kl_slots, double* __restrict__ mse_log,
+                                                        const long long* __restrict__ kl_slots, double* __restrict__ mse_log,
                                                         double* __restrict__ kl_log, long long n_log,
                                                         long long* __restrict__ step, long long* __restrict__ aux_counter) {
-  __shared__ double red[2][1024];
+  __shared__ double red[1024];
+  __shared__ long long redk[1024];
   const int t = threadIdx.x;
   double a = 0.0;
   if (sse)
     for (int i = t; i < n_sse; i += 1024) a += (double)sse[i];
-  red[0][t] = a;
-  red[1][t] = kl_slots ? kl_slots[t] : 0.0;
+  red[t] = a;
+  redk[t] = kl_slots ? kl_slots[t] : 0;
   __syncthreads();
   for (int off = 512; off > 0; off >>= 1) {
     if (t < off) {
-      red[0][t] += red[0][t + off];
-      red[1][t] += red[1][t + off];
+      red[t] += red[t + off];
+      redk[t] += redk[t + off];
     }
     __syncthreads();
   }
   if (t == 0) {
     const long long s = *step;
     if (s >= 0 && s < n_log) {
-      if (mse_log && sse) mse_log[s] = red[0][0] * mse_scale;
-      if (kl_log && kl_slots) kl_log[s] = red[1][0];
+      if (mse_log && sse) mse_log[s] = red[0] * mse_scale;
+      if (kl_log && kl_slots) kl_log[s] = (double)redk[0] * (1.0 / KL_FX);
     }
     *step = s + 1;
     if (aux_counter) *aux_counter += 1;      // e.g. the noise counter, which is NOT reset between train() calls
   }
 }
 
-extern "C" int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, double* kl_slots,
+extern "C" int rcb_step_begin(const float* adam_table, int64_t n_steps, const int64_t* step, float* dyn, int64_t* kl_slots,
                               rcb_stream_t stream) {
   RCB_REQUIRE(adam_table && step && dyn && n_steps >= 1, RCB_ERR_ARG, "step_begin: null pointer / empty table");
   static_assert(RCB_KL_SLOTS == 1024, "one slot per thread");
-  step_begin_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(adam_table, (long long)n_steps, (const long long*)step, dyn, kl_slots);
+  step_begin_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(adam_table, (long long)n_steps, (const long long*)step, dyn,
+                                                          (long long*)kl_slots);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
 
-extern "C" int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const double* kl_slots, double* mse_log,
+extern "C" int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const int64_t* kl_slots, double* mse_log,
                             double* kl_log, int64_t n_log, int64_t* step, int64_t* aux_counter, rcb_stream_t stream) {
   RCB_REQUIRE(step, RCB_ERR_ARG, "step_end: null step counter");
   RCB_REQUIRE(n_sse >= 0 && n_log >= 0, RCB_ERR_SHAPE, "step_end: negative size");
-  step_end_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(sse, n_sse, mse_scale, kl_slots, mse_log, kl_log, (long long)n_log,
+  step_end_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(sse, n_sse, mse_scale, (const long long*)kl_slots, mse_log, kl_log, (long long)n_log,
                                                      (long long*)step, (long long*)aux_counter);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
@@ -926,53 +939,45 @@ extern "C" int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64
 }
 
 // ------------------------------------------------------------------------------------------
-// K12 column moments (shifted sums in fp64, fp64 atomics across row chunks)
+// K12 column moments: exact fixed-point sums (order-independent, see fx_add)
+//   sum_fx[j] = sum_r rint(x 2^36),  sq_fx[j] = sum_r rint(x^2 2^30),  sig2_fx[j] = sum_r rint(sigma^2 2^44)
+// (x = loc[r, j] with |x| < 64, sigma = softplus(log_scale) / 6 < 4; up to 2^20 rows over all ranks)
 // ------------------------------------------------------------------------------------------
 constexpr int kMomRowsPerBlock = 256;
+constexpr double SUM_FX = 68719476736.0, SQ_FX = 1073741824.0, SIG_FX = 17592186044416.0;   // 2^36, 2^30, 2^44
 
 __global__ void __launch_bounds__(256) col_moments_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
-                                                          int rows, int cols, double* s1, double* s2, double* sg) {
+                                                          int rows, int cols, long long* s1, long long* s2, long long* sg) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
   int r0 = blockIdx.y * kMomRowsPerBlock;
   int r1 = min(rows, r0 + kMomRowsPerBlock);
-  double shift = (double)loc[j];  // row 0 as the shift
-  double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  long long a1 = 0, a2 = 0, a3 = 0;
   for (int r = r0; r < r1; ++r) {
-    double x = (double)loc[(long long)r * cols + j] - shift;
-    a1 += x;
-    a2 += x * x;
-    float s = st_f32(ls[(long long)r * cols + j]);
-    a3 += (double)mul_rn(s, s);
+    const double x = (double)loc[(long long)r * cols + j];
+    a1 += __double2ll_rn(x * SUM_FX);
+    a2 += __double2ll_rn(x * x * SQ_FX);
+    const float s = st_f32(ls[(long long)r * cols + j]);
+    a3 += __double2ll_rn((double)mul_rn(s, s) * SIG_FX);
   }
-  atomicAdd(&s1[j], a1);
-  atomicAdd(&s2[j], a2);
-  atomicAdd(&sg[j], a3);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&s1[j]), (unsigned long long)a1);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&s2[j]), (unsigned long long)a2);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&sg[j]), (unsigned long long)a3);
 }
 
-__global__ void col_moments_finalize(const float* loc, int rows, int cols, double* s1, double* s2) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cols) return;
-  double a1 = s1[j], a2 = s2[j];
-  s2[j] = a2 - a1 * a1 / (double)rows;          // M2
-  s1[j] = a1 + (double)rows * (double)loc[j];   // sum
-}
-
-extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, double* sum,
-                               double* m2, double* sig2, rcb_stream_t stream) {
-  RCB_REQUIRE(loc && log_scale && sum && m2 && sig2, RCB_ERR_ARG, "col_moments: null pointer");
+extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* sum_fx,
+                               int64_t* sq_fx, int64_t* sig2_fx, rcb_stream_t stream) {
+  RCB_REQUIRE(loc && log_scale && sum_fx && sq_fx && sig2_fx, RCB_ERR_ARG, "col_moments: null pointer");
   RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "col_moments: empty shape");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  if ((e = hipMemsetAsync(sum, 0, sizeof(double) * cols, st)) != hipSuccess) return fail((int)e, "memset");
-  if ((e = hipMemsetAsync(m2, 0, sizeof(double) * cols, st)) != hipSuccess) return fail((int)e, "memset");
-  if ((e = hipMemsetAsync(sig2, 0, sizeof(double) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  if ((e = hipMemsetAsync(sum_fx, 0, sizeof(int64_t) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  if ((e = hipMemsetAsync(sq_fx, 0, sizeof(int64_t) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  if ((e = hipMemsetAsync(sig2_fx, 0, sizeof(int64_t) * cols, st)) != hipSuccess) return fail((int)e, "memset");
   int row_blocks = cdiv(rows, kMomRowsPerBlock);
   RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "col_moments: too many rows");
   dim3 grid(cdiv(cols, 256), row_blocks);
-  col_moments_kernel<<<grid, 256, 0, st>>>(loc, log_scale, rows, cols, sum, m2, sig2);
-  RCB_LAUNCH_CHECK();
-  col_moments_finalize<<<cdiv(cols, 256), 256, 0, st>>>(loc, rows, cols, sum, m2);
+  col_moments_kernel<<<grid, 256, 0, st>>>(loc, log_scale, rows, cols, (long long*)sum_fx, (long long*)sq_fx, (long long*)sig2_fx);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -983,7 +988,7 @@ extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t
 __global__ void __launch_bounds__(256) kl_colsum_kernel(const float* __restrict__ loc, const float* __restrict__ sc,
                                                         int q_is_log, const float* __restrict__ p_loc,
                                                         const float* __restrict__ p_scale, int rows, int cols,
-                                                        double* out) {
+                                                        long long* out) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
   int r0 = blockIdx.y * kMomRowsPerBlock;
@@ -995,21 +1000,21 @@ __global__ void __launch_bounds__(256) kl_colsum_kernel(const float* __restrict_
     if (q_is_log) s = st_f32(s);
     acc += (double)kl_elem_f32(loc[(long long)r * cols + j], s, mp, sp);
   }
-  atomicAdd(&out[j], acc);
+  fx_add(reinterpret_cast<int64_t*>(&out[j]), acc, SQ_FX);            // 2^30 units per nat: exact, order-independent accumulation
 }
 
 extern "C" int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32_t q_scale_is_log, const float* p_loc,
-                                   const float* p_scale, int32_t rows, int32_t cols, double* out,
+                                   const float* p_scale, int32_t rows, int32_t cols, int64_t* out_fx,
                                    rcb_stream_t stream) {
-  RCB_REQUIRE(loc && q_scale && p_loc && p_scale && out, RCB_ERR_ARG, "kl_colsum: null pointer");
+  RCB_REQUIRE(loc && q_scale && p_loc && p_scale && out_fx, RCB_ERR_ARG, "kl_colsum: null pointer");
   RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "kl_colsum: empty shape");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * cols, st);
+  hipError_t e = hipMemsetAsync(out_fx, 0, sizeof(int64_t) * cols, st);
   if (e != hipSuccess) return fail((int)e, "memset");
   int row_blocks = cdiv(rows, kMomRowsPerBlock);
   RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "kl_colsum: too many rows");
   dim3 grid(cdiv(cols, 256), row_blocks);
-  kl_colsum_kernel<<<grid, 256, 0, st>>>(loc, q_scale, q_scale_is_log, p_loc, p_scale, rows, cols, out);
+  kl_colsum_kernel<<<grid, 256, 0, st>>>(loc, q_scale, q_scale_is_log, p_loc, p_scale, rows, cols, (long long*)out_fx);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

@@ -64,12 +64,18 @@ def prior_from_moments(count, total, m2, sig2, out_shape=None):
 
 
 def refit_prior(loc: torch.Tensor, log_scale: torch.Tensor, group=None):
-    """Prior refit over *all* ranks' INRs for one parameter tensor [rows, ...]."""
+    """Prior refit over *all* ranks' INRs for one parameter tensor [rows, ...].  The column sums are exact fixed-point
+    integers (ops.col_moments_fx) and the all-reduce over ranks adds integers: the refit is bitwise the same however the
+    rows are sharded (and from run to run)."""
     from . import ops
-    s, m2, sg = ops.col_moments(loc, log_scale)
-    cnt = torch.tensor(float(loc.shape[0]), dtype=torch.float64, device=loc.device)
-    n, s, m2, sg = merge_moments(cnt, s, m2, sg, group)
-    return prior_from_moments(n, s, m2, sg, loc.shape[1:])
+    fx = ops.col_moments_fx(loc, log_scale)
+    pack = torch.cat([fx.reshape(-1), torch.tensor([loc.shape[0]], dtype=torch.int64, device=loc.device)])
+    rank, ws = world(group)
+    if ws > 1:
+        td.all_reduce(pack, group=group)
+    n = int(pack[-1])
+    s, m2, sg = ops.moments_from_fx(pack[:-1].view(3, -1), n)
+    return prior_from_moments(torch.tensor(float(n), dtype=torch.float64), s, m2, sg, loc.shape[1:])
 
 
 def allreduce_scalar(v: torch.Tensor, group=None) -> torch.Tensor:
@@ -81,8 +87,16 @@ def allreduce_scalar(v: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def grouping_weights(kl_colsum: torch.Tensor, n_rows_local: int, group=None) -> np.ndarray:
-    """mean-over-INRs KL in bits per parameter across ranks -> fp32 numpy weights for get_grouping_by_kl."""
+    """mean-over-INRs KL in bits per parameter across ranks -> fp32 numpy weights for get_grouping_by_kl.  kl_colsum: the
+    exact fixed-point column sums of ops.gauss_kl_colsum_fx (int64: summed over ranks as integers, so the grouping does
+    not depend on the sharding) or plain fp64 sums."""
     rank, ws = world(group)
+    if kl_colsum.dtype == torch.int64:
+        from . import ops
+        pack = torch.cat([kl_colsum, torch.tensor([n_rows_local], dtype=torch.int64, device=kl_colsum.device)])
+        if ws > 1:
+            td.all_reduce(pack, group=group)
+        return (pack[:-1].to(torch.float64) / ops.COLSUM_FX / np.log(2.) / float(pack[-1])).to(torch.float32).cpu().numpy()
     pack = torch.cat([kl_colsum.to(torch.float64), torch.tensor([float(n_rows_local)], dtype=torch.float64,
                                                                 device=kl_colsum.device)])
     if ws > 1:

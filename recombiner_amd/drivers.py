@@ -51,7 +51,7 @@ def adjust_beta(kl_beta, kl_bits, budget_max, budget_min):
 
 def _grouping(q_loc, q_log_scale, p_loc, p_scale, group=None):
     """get_grouping over all ranks' INRs: per-parameter KL summed on the device, all-reduced, packed on the host."""
-    colsum = ops.gauss_kl_colsum(q_loc, q_log_scale, p_loc, p_scale, q_is_log=True)
+    colsum = ops.gauss_kl_colsum_fx(q_loc, q_log_scale, p_loc, p_scale, q_is_log=True)
     return get_grouping_by_kl(dist.grouping_weights(colsum, q_loc.shape[0], group))
 
 

@@ -381,7 +381,7 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  int(n_groups), float(kl_scalar), addr(d_out, f32), addr(eps, f32), addr(lv.member_ptr, i32),
                  addr(lv.member_idx, i32), addr(lv.row_perm_inv, i32), addr(lv.col_inv, i32), lv.rows, lv.cols,
                  lv.cols_out, int(samples), addr(g_loc, f32), addr(g_ls, f32), addr(s.get("m_loc"), f32),
-                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, f64),
+                 addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, torch.int64),
                  addr(kl_scalar_dev, f32))
     if d_out is not None and tuple(d_out.shape) != (lv.n_inr, samples, lv.cols_out):
         raise RcbError(f"d_out must be [{lv.n_inr},{samples},{lv.cols_out}], got {tuple(d_out.shape)}")
@@ -467,17 +467,27 @@ class GaussKLFn(torch.autograd.Function):
         return gl.reshape(shape) * g, gs.reshape(shape) * g, None, None, None, None, None, None, None
 
 
-def gauss_kl_colsum(loc, q_scale, p_loc, p_scale, q_is_log=False):
-    """-> fp64 [cols]: sum over rows of the elementwise KL."""
+COLSUM_FX = 2.0 ** 30          # RCB_COLSUM_FX_SCALE
+MOM_FX = (2.0 ** 36, 2.0 ** 30, 2.0 ** 44)     # RCB_MOM_{SUM,SQ,SIG}_FX_SCALE
+
+
+def gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log=False):
+    """-> int64 [cols]: sum over rows of the elementwise KL in units of 1 / COLSUM_FX nats (exact integer accumulation:
+    bitwise independent of the order of the workgroups; summed over ranks with an integer all-reduce)."""
     lib = _lib.load()
     l2 = loc.detach().reshape(loc.shape[0], -1).contiguous()
     s2 = q_scale.detach().reshape(loc.shape[0], -1).contiguous()
     rows, cols = l2.shape
-    out = torch.empty(cols, device=loc.device, dtype=f64)
+    out = torch.empty(cols, device=loc.device, dtype=torch.int64)
     check(lib.rcb_gauss_kl_colsum(ptr(l2, f32), ptr(s2, f32), int(bool(q_is_log)), ptr(p_loc.reshape(-1).contiguous(), f32),
                                   ptr(p_scale.reshape(-1).contiguous(), f32), rows, cols, ptr(out), stream_ptr()),
           "rcb_gauss_kl_colsum")
     return out
+
+
+def gauss_kl_colsum(loc, q_scale, p_loc, p_scale, q_is_log=False):
+    """-> fp64 [cols]: sum over rows of the elementwise KL."""
+    return gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log).to(f64) / COLSUM_FX
 
 
 def beta_update(kl_group, beta, done_u8, bits=16.0, upper=0.0, lower=0.4, step=0.05):
@@ -516,7 +526,7 @@ def step_begin(table, step, dyn, kl_slots=None):
     if table.dim() != 2 or table.shape[1] != 2 or (kl_slots is not None and kl_slots.numel() != 1024):
         raise RcbError("step_begin: table must be [n_steps, 2], kl_slots [1024]")
     check(lib.rcb_step_begin(ptr(table, f32), C.c_int64(table.shape[0]), ptr(step, torch.int64), ptr(dyn, f32),
-                             ptr(kl_slots, f64, True), stream_ptr()), "rcb_step_begin")
+                             ptr(kl_slots, torch.int64, True), stream_ptr()), "rcb_step_begin")
 
 
 def step_end(step, sse=None, mse_scale=1.0, kl_slots=None, mse_log=None, kl_log=None, aux_counter=None):
@@ -524,7 +534,7 @@ def step_end(step, sse=None, mse_scale=1.0, kl_slots=None, mse_log=None, kl_log=
     lib = _lib.load()
     n_log = min(t.numel() for t in (mse_log, kl_log) if t is not None) if (mse_log is not None or kl_log is not None) else 0
     check(lib.rcb_step_end(ptr(sse, f32, True), 0 if sse is None else sse.numel(), C.c_double(mse_scale),
-                           ptr(kl_slots, f64, True), ptr(mse_log, f64, True), ptr(kl_log, f64, True), C.c_int64(n_log),
+                           ptr(kl_slots, torch.int64, True), ptr(mse_log, f64, True), ptr(kl_log, f64, True), C.c_int64(n_log),
                            ptr(step, torch.int64), ptr(aux_counter, torch.int64, True), stream_ptr()), "rcb_step_end")
 
 
@@ -546,16 +556,29 @@ def adam_multi(params, grads, ms, vs, cfg: AdamCfg):
         check(lib.rcb_adam_multi(arr, len(chunk), C.byref(cfg), stream_ptr()), "rcb_adam_multi")
 
 
-def col_moments(loc, log_scale):
-    """-> (sum, m2, sum sigma^2) fp64 [cols] over the rows of loc (rcb_col_moments)."""
+def col_moments_fx(loc, log_scale):
+    """-> int64 [3, cols]: exact fixed-point sums over the rows of loc (rcb_col_moments): sum x, sum x^2, sum sigma^2 in
+    units of 1 / MOM_FX[k].  Integer sums: add them over ranks with an integer all-reduce, then moments_from_fx."""
     lib = _lib.load()
     l2 = loc.detach().reshape(loc.shape[0], -1)
     s2 = log_scale.detach().reshape(loc.shape[0], -1)
     rows, cols = l2.shape
-    out = torch.empty(3, cols, device=loc.device, dtype=f64)
+    out = torch.empty(3, cols, device=loc.device, dtype=torch.int64)
     check(lib.rcb_col_moments(ptr(l2, f32), ptr(s2, f32), rows, cols, ptr(out[0]), ptr(out[1]), ptr(out[2]),
                               stream_ptr()), "rcb_col_moments")
-    return out[0], out[1], out[2]
+    return out
+
+
+def moments_from_fx(fx, n_rows):
+    """(sum, M2 = sum (x - mean)^2, sum sigma^2) in fp64 from the fixed-point sums of n_rows rows"""
+    s = fx[0].to(f64) / MOM_FX[0]
+    m2 = fx[1].to(f64) / MOM_FX[1] - s * s / float(n_rows)
+    return s, m2, fx[2].to(f64) / MOM_FX[2]
+
+
+def col_moments(loc, log_scale):
+    """-> (sum, m2, sum sigma^2) fp64 [cols] over the rows of loc."""
+    return moments_from_fx(col_moments_fx(loc, log_scale), loc.shape[0])
 
 
 def softplus_scale(log_scale):

@@ -286,7 +286,7 @@ class PriorBNNmodel(nn.Module):
                       map_state=[(_zeros_state(q), _zeros_state(q)) for q in A + conv] if training_mappings else None,
                       tab=ops.adam_table(lr, rows).to(dev), dyn=torch.zeros(2, device=dev, dtype=torch.float32),
                       step_t=torch.zeros(1, device=dev, dtype=torch.long),
-                      kl_slots=torch.zeros(1024, device=dev, dtype=torch.float64),
+                      kl_slots=torch.zeros(1024, device=dev, dtype=torch.int64),       # fixed point, 2^-24 nats
                       mse_buf=torch.zeros(rows, device=dev, dtype=torch.float64),
                       kl_buf=torch.zeros(rows, device=dev, dtype=torch.float64),
                       pri=[None if q is None else torch.empty_like(q) for q in priors],

@@ -807,6 +807,17 @@ def test_col_moments_and_kl_colsum():
     cs = ops.gauss_kl_colsum(g(loc), g(O.st(ls)), g(pl), g(ps))
     ref = O.gauss_kl_elem(loc, O.st(ls), pl, ps).double().sum(0)
     np.testing.assert_allclose(cs.cpu().numpy(), ref.numpy(), rtol=1e-5)
+    # the sums are exact fixed-point integers: bitwise the same from call to call, and the same when the rows are summed in
+    # shards and the integers added (any split for the moments; shards cut at multiples of 256 rows for the KL sums)
+    fx = ops.col_moments_fx(g(loc), g(ls))
+    assert torch.equal(fx, ops.col_moments_fx(g(loc), g(ls)))
+    for cut in (1, 256, 333):
+        parts = ops.col_moments_fx(g(loc[:cut]), g(ls[:cut])) + ops.col_moments_fx(g(loc[cut:]), g(ls[cut:]))
+        assert torch.equal(fx, parts)
+    kfx = ops.gauss_kl_colsum_fx(g(loc), g(ls), g(pl), g(ps), q_is_log=True)
+    assert torch.equal(kfx, ops.gauss_kl_colsum_fx(g(loc), g(ls), g(pl), g(ps), q_is_log=True))
+    assert torch.equal(kfx, ops.gauss_kl_colsum_fx(g(loc[:512]), g(ls[:512]), g(pl), g(ps), q_is_log=True)
+                       + ops.gauss_kl_colsum_fx(g(loc[512:]), g(ls[512:]), g(pl), g(ps), q_is_log=True))
 
 
 # ---------------------------------------------------------------------------------------------------
