@@ -265,21 +265,26 @@ int rcb_debug_generic_kernels_only(int32_t on);
  * rcb_atrans_pack_elems : bf16 elements of the packed images of the mappings (4 planes: forward hi, gradient hi,
  *                         forward lo, gradient lo; each layer padded to a multiple of 32 both ways), < 0 on bad arguments
  * rcb_atrans_pack       : fp32 mappings -> packed images (once per step when they are trained); the lo planes only if want_lo
- * rcb_atrans_plan       : HOST: work decomposition for `rows` rows on n_cu compute units into plan[0 .. return value) (int32;
- *                         plan[0] = workgroups); the caller keeps a 16-byte aligned device copy of it for rcb_atrans_apply
+ * rcb_atrans_plan       : HOST: work decomposition for `rows` rows on n_cu compute units into plan[0 .. return value) (int32);
+ *                         the caller keeps a 16-byte aligned device copy of all of it and the first RCB_ATRANS_PLAN_HEAD
+ *                         entries on the host (plan[0] = workgroups, plan[2] = slices of the contraction: launches of few
+ *                         rows cut it and add the partial sums in a fixed order) for rcb_atrans_apply
+ * rcb_atrans_workspace_floats : fp32 elements of the workspace rcb_atrans_apply needs for that plan (0: none)
  * rcb_atrans_apply      : transpose = 0: out = x @ A (forward), 1: out = x @ A^T (data gradient)
  * rcb_atrans_wgrad_narrow : dA = h^T @ d for ONE narrow layer (the 99-wide output layer) in fp32, exact-product arithmetic,
  *                         fixed summation order; h / d point at the layer's first column; workspace:
  *                         rcb_atrans_wgrad_narrow_workspace(L, n_slabs) floats
  * ------------------------------------------------------------------------------------------- */
 #define RCB_ATRANS_MAX_LAYERS 8
+#define RCB_ATRANS_PLAN_HEAD 12
 int64_t rcb_atrans_pack_elems(int32_t n_layers, const int32_t* sizes);
 int rcb_atrans_pack(const float* const* A, int32_t n_layers, const int32_t* sizes, void* packed, int32_t want_lo,
                     rcb_stream_t stream);
 int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* sizes, int32_t n_cu, int32_t* plan, int32_t max_ints);
 int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_t ld_out, int64_t rows, int32_t n_layers,
                      const int32_t* sizes, const void* packed, int32_t transpose, int32_t terms, const int32_t* plan_dev,
-                     int32_t n_wg, rcb_stream_t stream);
+                     const int32_t* plan_head, float* workspace, rcb_stream_t stream);
+int64_t rcb_atrans_workspace_floats(int64_t rows, int32_t n_layers, const int32_t* sizes, const int32_t* plan_head);
 int64_t rcb_atrans_wgrad_narrow_workspace(int32_t L, int32_t n_slabs);
 int rcb_atrans_wgrad_narrow(const float* h, int64_t ld_h, const float* d, int64_t ld_d, int64_t rows, int32_t L, float* dA,
                             float* workspace, int32_t n_slabs, rcb_stream_t stream);

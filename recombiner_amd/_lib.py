@@ -19,7 +19,7 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_b
            "rcb_window_gather", "rcb_window_fold", "rcb_siren_reduce_chunks", "rcb_phaseconv_pack", "rcb_phaseconv_pack_uint4",
            "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace",
            "rcb_phase_bigweight", "rcb_phase_bigweight_grad", "rcb_atrans_pack_elems", "rcb_atrans_pack", "rcb_atrans_plan",
-           "rcb_atrans_apply", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow"]
+           "rcb_atrans_apply", "rcb_atrans_workspace_floats", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow"]
 
 
 class RcbError(RuntimeError):
@@ -87,6 +87,7 @@ def load():
         lib.rcb_phaseconv_wgrad_workspace.restype = C.c_int64
         lib.rcb_atrans_pack_elems.restype = C.c_int64
         lib.rcb_atrans_wgrad_narrow_workspace.restype = C.c_int64
+        lib.rcb_atrans_workspace_floats.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RcbError(f"{LIB_PATH} does not export {name}")

@@ -93,9 +93,11 @@ struct AtArgs {
   int L[MAXL], Lp[MAXL], off[MAXL];
   const __bf16* bh[MAXL];
   const __bf16* bl[MAXL];
-  const int4* segs;            // {layer, row0, first column block, blocks}
+  const int4* segs;            // two per segment: {layer, row0, first column block, blocks}, {first chunk, end chunk, slab or -1, 0}
   const int* seg_begin;        // [n_wg + 1]
   int n_wg;
+  float* ws;                   // K-split launches (few rows): partial sums [slab][rows][ld_ws], added in slab order afterwards
+  long long ld_ws;
 };
 
 template <int NCB, int TERMS>
@@ -112,13 +114,13 @@ constexpr int LDS_MAX_BYTES = 3 * (XT_BYTES + MAXSEG * 32 * BK * 2);        // =
 
 // one segment: out[row0 .. row0 + 255, off_l + 32 cb0 .. + 32 ncb) of layer l
 template <int NCB, int TERMS, bool RAGGED>
-__device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char* __restrict__ lds) {
+__device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, const int4 sk, char* __restrict__ lds) {
   typedef Geo<NCB, TERMS> G;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l = sg.x, row0 = sg.y, cb0 = sg.z, ncb = sg.w;
   const int K = a.L[l], Lp = a.Lp[l];
-  const int nk = Lp / BK;
+  const int kc0 = sk.x, nk = sk.y - sk.x;          // this segment's slice of the contraction (all of it unless the launch is K-split)
   const __bf16* __restrict__ bh = a.bh[l];
   const __bf16* __restrict__ bl = a.bl[l];
   const float* __restrict__ xl0 = a.x + a.off[l];
@@ -160,7 +162,7 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char
   // DMA i (0 .. NDMA-1) of chunk kc: the wave's four x pieces, then its mapping pieces
   auto issue_one = [&](int kc_, int i) {
     char* __restrict__ st = lds + (kc_ % G::NSTAGE) * G::STAGE;
-    const int kc = ATRANS_DIAG == 2 ? 0 : kc_;
+    const int kc = ATRANS_DIAG == 2 ? 0 : kc0 + kc_;
     if (i < 4) {
       // chunks past the end of the layer (its padding to a multiple of 32) meet zero rows of the mapping: any finite
       // values do, so they repeat the layer's last chunk instead of reading past the row
@@ -256,7 +258,8 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char
     // layer size not a multiple of 8 (the output layer: 99 = 3 * 33): a 16-byte chunk may straddle the end of the layer
     // and of the row, so x goes through registers with element-wise guards (zero fill), synchronously; the mapping by DMA.
     // A few short chunks per step: speed does not matter here.
-    for (int kc = 0; kc < nk; ++kc) {
+    for (int kr = 0; kr < nk; ++kr) {
+      const int kc = kc0 + kr;
       __syncthreads();                                       // every wave is done with the stage
 #pragma unroll
       for (int j = 0; j < G::NBW; ++j) {
@@ -340,7 +343,9 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char
   }
 
   // epilogue: accumulator register q of lane (col, fh) is row rho(q, fh) of the wave's 32-row block
-  float* __restrict__ ob = a.out + a.off[l];
+  const bool direct = sk.z < 0;
+  float* __restrict__ ob = (direct ? a.out : a.ws + (long long)sk.z * a.rows * a.ld_ws) + a.off[l];
+  const long long ldo = direct ? a.ld_out : a.ld_ws;
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     if (cb < ncb && (ATRANS_DIAG != 1 || a.rows < 0)) {
@@ -349,7 +354,7 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const long long row = (long long)row0 + 32 * wave + rho(q, fh);
-          if (row < a.rows) ob[row * a.ld_out + col] = acc[cb][q];
+          if (row < a.rows) ob[row * ldo + col] = acc[cb][q];
         }
       }
     }
@@ -357,15 +362,15 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, char
 }
 
 template <int TERMS, bool RAGGED>
-__device__ __forceinline__ void dispatch_segment(const AtArgs& a, const int4 sg, char* lds) {
+__device__ __forceinline__ void dispatch_segment(const AtArgs& a, const int4 sg, const int4 sk, char* lds) {
   switch (sg.w) {
-    case 1: run_segment<1, TERMS, RAGGED>(a, sg, lds); break;
-    case 2: run_segment<2, TERMS, RAGGED>(a, sg, lds); break;
-    case 3: run_segment<3, TERMS, RAGGED>(a, sg, lds); break;
-    case 4: run_segment<4, TERMS, RAGGED>(a, sg, lds); break;
-    case 5: run_segment<5, TERMS, RAGGED>(a, sg, lds); break;
-    case 6: run_segment<6, TERMS, RAGGED>(a, sg, lds); break;
-    default: run_segment<7, TERMS, RAGGED>(a, sg, lds); break;
+    case 1: run_segment<1, TERMS, RAGGED>(a, sg, sk, lds); break;
+    case 2: run_segment<2, TERMS, RAGGED>(a, sg, sk, lds); break;
+    case 3: run_segment<3, TERMS, RAGGED>(a, sg, sk, lds); break;
+    case 4: run_segment<4, TERMS, RAGGED>(a, sg, sk, lds); break;
+    case 5: run_segment<5, TERMS, RAGGED>(a, sg, sk, lds); break;
+    case 6: run_segment<6, TERMS, RAGGED>(a, sg, sk, lds); break;
+    default: run_segment<7, TERMS, RAGGED>(a, sg, sk, lds); break;
   }
 }
 
@@ -377,13 +382,35 @@ __global__ void __launch_bounds__(NT, 2) atrans_kernel(AtArgs a) {
   if ((a.n_wg & 7) == 0) id = (id & 7) * (a.n_wg >> 3) + (id >> 3);
   const int s0 = a.seg_begin[id], s1 = a.seg_begin[id + 1];
   for (int s = s0; s < s1; ++s) {
-    const int4 sg = a.segs[s];
+    const int4 sg = a.segs[2 * s], sk = a.segs[2 * s + 1];
     if (a.L[sg.x] & 7) {           // (the planner cuts such layers into segments of <= 2 blocks)
-      if (sg.w > 1) run_segment<2, TERMS, true>(a, sg, lds);
-      else run_segment<1, TERMS, true>(a, sg, lds);
+      if (sg.w > 1) run_segment<2, TERMS, true>(a, sg, sk, lds);
+      else run_segment<1, TERMS, true>(a, sg, sk, lds);
     } else {
-      dispatch_segment<TERMS, false>(a, sg, lds);
+      dispatch_segment<TERMS, false>(a, sg, sk, lds);
     }
+  }
+}
+
+// ---- K-split launches: sum of the slabs in slab order (fixed: bitwise reproducible) ---------------------------------------
+struct SlabArgs {
+  const float* ws;
+  float* out;
+  long long rows, ld_ws, ld_out;
+  int n_layers;
+  int off[MAXL + 1], slabs[MAXL];      // column range of every layer, its number of K slices
+};
+
+__global__ void __launch_bounds__(256) atrans_slab_sum_kernel(SlabArgs a) {
+  const long long total = a.rows * a.off[a.n_layers];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / a.off[a.n_layers];
+    const int c = (int)(e - r * a.off[a.n_layers]);
+    int l = 0;
+    while (l + 1 < a.n_layers && c >= a.off[l + 1]) ++l;
+    float v = 0.f;
+    for (int k = 0; k < a.slabs[l]; ++k) v += a.ws[((long long)k * a.rows + r) * a.ld_ws + c];
+    a.out[r * a.ld_out + c] = v;
   }
 }
 
@@ -508,6 +535,15 @@ extern "C" int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* si
   const long long m_tiles = (rows + BM - 1) / BM;
   int R = (int)std::max<long long>(1, n_cu / m_tiles);
   R = std::min(R, (nb + 1) / 2);
+  // Few rows (a Kodak photo is 96 patches, a video clip 64): runs of one or two column blocks would fill the chip but make
+  // every workgroup stream the whole x tile for a handful of MFMAs.  Keep the runs at MAXSEG blocks and cut the CONTRACTION
+  // into S slices instead: a (segment, slice) per workgroup, partial sums to slabs, added in slab order afterwards.
+  const int runs_full = (nb + MAXSEG - 1) / MAXSEG;
+  int S = 1;
+  if (m_tiles * runs_full * 2 <= n_cu) {
+    S = (int)std::min<long long>(8, n_cu / (m_tiles * runs_full));
+    R = runs_full;
+  }
   // contiguous runs minimising the largest cost: binary search on the bound, greedy maximal runs
   long long lo = 0, hi = run_cost(blks, 0, nb, nullptr, 0);
   auto fits = [&](long long bound, std::vector<int>* cuts) {
@@ -529,36 +565,59 @@ extern "C" int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* si
   std::vector<int> cuts;
   fits(hi, &cuts);
   const int runs = (int)cuts.size();
-  const long long n_wg = m_tiles * runs;
-  RCB_REQUIRE(n_wg < (1 << 24), RCB_ERR_SHAPE, "atrans_plan: %lld workgroups", n_wg);
-  std::vector<int4> segs;
+  std::vector<int4> segs;          // two entries per segment
   std::vector<int> begin;
+  int slabs[MAXL];
+  for (int l = 0; l < n_layers; ++l) slabs[l] = std::min(S, pad32(sizes[l]) / BK);
   for (long long mt = 0; mt < m_tiles; ++mt) {
     int b = 0;
     for (int ri = 0; ri < runs; ++ri) {
-      begin.push_back((int)segs.size());
-      run_cost(blks, b, cuts[ri], &segs, (int)(mt * BM));
+      std::vector<int4> run;
+      run_cost(blks, b, cuts[ri], &run, (int)(mt * BM));
       b = cuts[ri];
+      if (S == 1) {                       // one workgroup per run: its segments one after the other, whole contraction
+        begin.push_back((int)segs.size() / 2);
+        for (const int4& sg : run) {
+          segs.push_back(sg);
+          segs.push_back(make_int4(0, pad32(sizes[sg.x]) / BK, -1, 0));
+        }
+      } else {                            // one workgroup per (segment, slice)
+        for (const int4& sg : run) {
+          const int nc = pad32(sizes[sg.x]) / BK, sl = slabs[sg.x];
+          for (int k = 0; k < sl; ++k) {
+            begin.push_back((int)segs.size() / 2);
+            segs.push_back(sg);
+            segs.push_back(make_int4((int)((long long)k * nc / sl), (int)((long long)(k + 1) * nc / sl), k, 0));
+          }
+        }
+      }
     }
   }
-  begin.push_back((int)segs.size());
-  // layout: [n_wg, n_segs, seg_begin (n_wg + 1, padded to a multiple of 4 ints from the start), segs (4 ints each)]
-  const long long head = ((2 + n_wg + 1) + 3) / 4 * 4;
+  begin.push_back((int)segs.size() / 2);
+  const long long n_wg = (long long)begin.size() - 1;
+  RCB_REQUIRE(n_wg < (1 << 24), RCB_ERR_SHAPE, "atrans_plan: %lld workgroups", n_wg);
+  // layout: [n_wg, n_segs, S, 0, slabs[8], seg_begin (n_wg + 1; padded so that the segments start on 16 bytes), segs (2 x 4 ints each)]
+  const long long head = ((RCB_ATRANS_PLAN_HEAD + n_wg + 1) + 3) / 4 * 4;
   const long long need = head + 4 * (long long)segs.size();
   if (need > max_ints) return rcb::fail(RCB_ERR_SHAPE, "atrans_plan: %lld ints needed, %d given", need, max_ints);
   memset(plan, 0, sizeof(int32_t) * head);
   plan[0] = (int32_t)n_wg;
-  plan[1] = (int32_t)segs.size();
-  for (size_t i = 0; i < begin.size(); ++i) plan[2 + i] = begin[i];
+  plan[1] = (int32_t)(segs.size() / 2);
+  plan[2] = S;
+  for (int l = 0; l < n_layers; ++l) plan[4 + l] = S == 1 ? 0 : slabs[l];
+  for (size_t i = 0; i < begin.size(); ++i) plan[RCB_ATRANS_PLAN_HEAD + i] = begin[i];
   memcpy(plan + head, segs.data(), sizeof(int4) * segs.size());
   return (int)need;
 }
 
 extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_t ld_out, int64_t rows, int32_t n_layers,
                                 const int32_t* sizes, const void* packed, int32_t transpose, int32_t terms,
-                                const int32_t* plan_dev, int32_t n_wg, rcb_stream_t stream) {
-  RCB_REQUIRE(x && out && sizes && packed && plan_dev && n_layers >= 1 && n_layers <= MAXL && rows >= 1 && n_wg >= 1, RCB_ERR_ARG,
+                                const int32_t* plan_dev, const int32_t* plan_head, float* workspace, rcb_stream_t stream) {
+  RCB_REQUIRE(x && out && sizes && packed && plan_dev && plan_head && n_layers >= 1 && n_layers <= MAXL && rows >= 1, RCB_ERR_ARG,
               "atrans_apply: bad arguments");
+  const int n_wg = plan_head[0], ksplit = plan_head[2];
+  RCB_REQUIRE(n_wg >= 1 && ksplit >= 1 && ksplit <= 8 && (ksplit == 1 || workspace), RCB_ERR_ARG,
+              "atrans_apply: plan head (workgroups %d, slices %d) / workspace", n_wg, ksplit);
   RCB_REQUIRE(terms >= 1 && terms <= 3, RCB_ERR_ARG, "atrans_apply: terms = %d (1..3)", terms);
   RCB_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(plan_dev) & 15) == 0, RCB_ERR_ARG,
               "atrans_apply: packed images / plan must be 16-byte aligned");
@@ -580,10 +639,12 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
   RCB_REQUIRE(ld_x >= off && ld_out >= off, RCB_ERR_SHAPE, "atrans_apply: row strides %lld / %lld below %lld columns", (long long)ld_x,
               (long long)ld_out, off);
   a.x = x; a.out = out; a.ld_x = ld_x; a.ld_out = ld_out; a.rows = rows; a.n_layers = n_layers;
-  const long long head = ((2 + (long long)n_wg + 1) + 3) / 4 * 4;
-  a.seg_begin = plan_dev + 2;
+  const long long head = ((RCB_ATRANS_PLAN_HEAD + (long long)n_wg + 1) + 3) / 4 * 4;
+  a.seg_begin = plan_dev + RCB_ATRANS_PLAN_HEAD;
   a.segs = reinterpret_cast<const int4*>(plan_dev + head);
   a.n_wg = n_wg;
+  a.ws = workspace;
+  a.ld_ws = (off + 3) / 4 * 4;
   const int lds = LDS_MAX_BYTES;
   hipError_t e;
   if (terms == 1) {
@@ -598,7 +659,30 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
   }
   RCB_REQUIRE(e == hipSuccess, (int)e, "atrans_apply: hipFuncSetAttribute: %s", hipGetErrorString(e));
   RCB_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    SlabArgs r;
+    memset(&r, 0, sizeof(r));
+    r.ws = workspace; r.out = out; r.rows = rows; r.ld_ws = a.ld_ws; r.ld_out = ld_out; r.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+      r.off[l] = a.off[l];
+      r.slabs[l] = plan_head[4 + l];
+      RCB_REQUIRE(r.slabs[l] >= 1 && r.slabs[l] <= ksplit, RCB_ERR_ARG, "atrans_apply: plan head: %d slices for layer %d", r.slabs[l], l);
+    }
+    r.off[n_layers] = (int)off;
+    long long blocks = (rows * off + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    atrans_slab_sum_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r);
+    RCB_LAUNCH_CHECK();
+  }
   return RCB_OK;
+}
+
+extern "C" int64_t rcb_atrans_workspace_floats(int64_t rows, int32_t n_layers, const int32_t* sizes, const int32_t* plan_head) {
+  if (!sizes || !plan_head || n_layers < 1 || n_layers > MAXL || rows < 1) return -1;
+  if (plan_head[2] <= 1) return 0;
+  long long off = 0;
+  for (int l = 0; l < n_layers; ++l) off += sizes[l];
+  return (int64_t)plan_head[2] * rows * ((off + 3) / 4 * 4);
 }
 
 // ---- weight gradient of a narrow layer (the output layer: 99 x 99 from 4096 rows) -------------------------------------------

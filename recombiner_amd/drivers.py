@@ -57,8 +57,10 @@ def _grouping(q_loc, q_log_scale, p_loc, p_scale, group=None):
 
 def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em_iter=550, first_epochs=200,
                 epochs=100, lr=2e-4, kl_beta=1e-8, training_mappings=True, checkpoint_path=None, checkpoint_every=10,
-                precision=0, group=None, log=print):
-    """Coordinate-ascent prior learning.  Returns a dict with the model, mappings, priors, beta and ELBO curve."""
+                precision=0, group=None, log=print, noise_source=None):
+    """Coordinate-ascent prior learning (main_prior_training.py:112-172).  Returns a dict with the model, mappings, priors,
+    beta, the ELBO curve and the trajectory of the loop: per iteration (KL bits per INR before the beta rule, beta after it,
+    MSE per INR).  noise_source: PriorBNNmodel.noise_source (a given epsilon stream instead of the device generator)."""
     tuning.enable_tuned_gemms()
     train_size = Y.shape[0]
     patch = config['patch']
@@ -66,6 +68,7 @@ def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em
                       config['pixel_sizes'], config['upsample_factors'], config['latent_dim'], patch,
                       config['patch_nums'], config['hierarchical_patch_nums'], random_seed=seed, device=device)
     m.precision = precision
+    m.noise_source = noise_source
     lt = LinearTransform(m.dims).to(device)
     up = Upsample(config['data_dim'], config['paddings'], config['layerwise_scale_factors']).to(device)
     if dist.is_dist():
@@ -89,10 +92,10 @@ def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em
         p_hh_loc, p_hh_scale = init_prior(m.hh_loc.shape[-1])
     X, Y = X.to(device), Y.to(device)
     rank, ws = dist.world(group)
-    elbos, n_epoch = [], first_epochs
+    elbos, n_epoch, traj = [], first_epochs, []
     for it in range(n_em_iter):
-        _, _, e = m.train(n_epoch, lr, X, Y, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc,
-                          p_hh_scale, lt, up, kl_beta, training_mappings=training_mappings)
+        mse, _, e = m.train(n_epoch, lr, X, Y, p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc,
+                            p_hh_scale, lt, up, kl_beta, training_mappings=training_mappings)
         elbos += e
         n_epoch = epochs
         # average KL in bits per INR over all ranks -> beta rule
@@ -101,6 +104,7 @@ def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em
         pack = dist.allreduce_scalar(pack, group)
         kls = float(pack[0] / LN2 / pack[1])
         kl_beta = adjust_beta(kl_beta, kls, budget_max, budget_min)
+        traj.append((kls, kl_beta, mse))
         # closed-form prior refit (moment matching over every rank's INRs)
         p_loc, p_scale = dist.refit_prior(m.loc, m.log_scale, group)
         p_lpe_loc, p_lpe_scale = dist.refit_prior(m.lpe_loc, m.lpe_log_scale, group)
@@ -114,7 +118,7 @@ def train_prior(config, dataset, X, Y, max_bitrate, device="cuda", seed=42, n_em
                                       p_hh_scale, kl_beta, group)
                 if rank == 0:
                     save_checkpoint(checkpoint_path, ck)
-    return dict(model=m, linear_transform=lt, upsample_net=up, kl_beta=kl_beta, elbo=elbos,
+    return dict(model=m, linear_transform=lt, upsample_net=up, kl_beta=kl_beta, elbo=elbos, trajectory=traj,
                 priors=(p_loc, p_scale, p_lpe_loc, p_lpe_scale, p_h_loc, p_h_scale, p_hh_loc, p_hh_scale))
 
 

@@ -1078,7 +1078,9 @@ class ATransform:
                     check(n, "rcb_atrans_plan")
                 cap *= 8
             host = torch.frombuffer(buf, dtype=torch.int32, count=n).clone()
-            pl = (host.to(self.device), int(host[0]))
+            head = (C.c_int32 * 12)(*[int(v) for v in host[:12]])
+            nws = int(lib.rcb_atrans_workspace_floats(C.c_int64(rows), len(self.sizes), self._sizes_c, head))
+            pl = (host.to(self.device), head, nws)
             self._plans[rows] = pl
         return pl
 
@@ -1089,11 +1091,12 @@ class ATransform:
                 raise RcbError(f"ATransform: fp32 GPU rows of {self.cols} columns expected")
         if out.shape[0] != rows:
             raise RcbError("ATransform: row counts differ")
-        plan, n_wg = self._plan(rows)
+        plan, head, nws = self._plan(rows)
+        ws = torch.empty(nws, device=self.device, dtype=f32) if nws else None      # (few rows: slabs of the K-split launch)
         check(_lib.load().rcb_atrans_apply(C.c_void_p(x.data_ptr()), C.c_int64(x.stride(0)), C.c_void_p(out.data_ptr()),
                                           C.c_int64(out.stride(0)), C.c_int64(rows), len(self.sizes), self._sizes_c,
-                                          ptr(self.packed), int(transpose), int(terms), ptr(plan), n_wg, stream_ptr()),
-              "rcb_atrans_apply")
+                                          ptr(self.packed), int(transpose), int(terms), ptr(plan), head, ptr(ws, f32, True),
+                                          stream_ptr()), "rcb_atrans_apply")
         return out
 
     def forward(self, h_w, out):

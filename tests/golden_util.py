@@ -168,3 +168,26 @@ def structured_A(dims):
         base = torch.tensor([0.5, -0.25, 0.125, 0.375, -0.5, 0.25, -0.125, -0.375]) / 8
         mats.append(torch.eye(L) + base[(r[:, None] + 3 * r[None, :]) % 8] / L)
     return mats
+
+
+def smooth_images(n, pixel_sizes, seed):
+    """the synthetic images of the R-D fixtures (oracle/make_golden.py::smooth_images, restated: the fixtures store the
+    seeds and moment checksums, not the pixels): per channel three 2-D sinusoids, scaled into [0.1, 0.9]"""
+    rng = np.random.RandomState(seed)
+    h, w = pixel_sizes
+    yy, xx = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    out = np.zeros([n, h * w, 3], dtype=np.float32)
+    for i in range(n):
+        for c in range(3):
+            img = np.zeros([h, w])
+            for _ in range(3):
+                fx, fy = rng.uniform(-2.5, 2.5, size=2)
+                img += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * (fx * xx + fy * yy) + rng.uniform(0, 2 * np.pi))
+            img = 0.5 + 0.4 * img / np.abs(img).max()
+            out[i, :, c] = img.reshape(-1)
+    return torch.from_numpy(out)
+
+
+def moment_stats(t):
+    a = t.detach().double()
+    return np.array([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()])
