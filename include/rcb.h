@@ -303,18 +303,18 @@ int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const int64_
                  rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172), as EXACT fixed-point sums:
- * for x = loc[rows, cols] (|x| < 64) and sigma = softplus(log_scale) / 6 (< 4), up to 2^20 rows over all ranks,
- *   sum_fx[j] = sum_r rint(x 2^36),   sq_fx[j] = sum_r rint(x^2 2^30),   sig2_fx[j] = sum_r rint(sigma^2 2^44)
- * as 64-bit integers.  Every element is rounded once to the grid where it enters; integer addition is associative, so
- * the sums -- and the prior refit from them -- are bitwise independent of the order of the workgroups and, after an
- * integer all-reduce, of how the rows are sharded over ranks.  mean = sum / n, M2 = sum x^2 - (sum x)^2 / n in fp64.
+ * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172), as EXACT fixed-point sums.
+ * For x = loc[rows, cols] and sigma = softplus(log_scale) / 6, every term v in {x, x^2, sigma^2} (|v| < 2^12; up to 2^20
+ * rows over all ranks) is split at 2^-30:  hi = floor(v 2^30), lo = rint((v 2^30 - hi) 2^32), and the parts are summed as
+ * 64-bit integers:  out_fx[q][0][j] = sum_r hi,  out_fx[q][1][j] = sum_r lo  for q = 0: x, 1: x^2, 2: sigma^2
+ * (out_fx is int64 [3][2][cols]; value = (hi + lo 2^-32) 2^-30, resolution 2^-62).  Integer addition is associative,
+ * so the sums -- and the prior refit from them -- are bitwise independent of the order of the workgroups and, after an
+ * integer all-reduce, of how the rows are sharded over ranks.  mean = sum x / n, M2 = sum x^2 - (sum x)^2 / n in fp64.
  * ------------------------------------------------------------------------------------------- */
-#define RCB_MOM_SUM_FX_SCALE 68719476736.0       /* 2^36 */
-#define RCB_MOM_SQ_FX_SCALE 1073741824.0         /* 2^30 */
-#define RCB_MOM_SIG_FX_SCALE 17592186044416.0    /* 2^44 */
-int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* sum_fx,
-                    int64_t* sq_fx, int64_t* sig2_fx, rcb_stream_t stream);
+#define RCB_MOM_FX_SCALE 1073741824.0            /* 2^30 */
+#define RCB_MOM_FX_LO_SCALE 4294967296.0         /* 2^32 */
+int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* out_fx,
+                    rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9: A* / relative-entropy-coding candidate scoring (test_model.py:501-533 sample_group, :535-584

@@ -939,45 +939,50 @@ extern "C" int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64
 }
 
 // ------------------------------------------------------------------------------------------
-// K12 column moments: exact fixed-point sums (order-independent, see fx_add)
-//   sum_fx[j] = sum_r rint(x 2^36),  sq_fx[j] = sum_r rint(x^2 2^30),  sig2_fx[j] = sum_r rint(sigma^2 2^44)
-// (x = loc[r, j] with |x| < 64, sigma = softplus(log_scale) / 6 < 4; up to 2^20 rows over all ranks)
+// K12 column moments: exact fixed-point sums (order-independent, see fx_add).  Every term v (x, x^2, sigma^2; each exact
+// in fp64) is split at 2^-30:  hi = floor(v 2^30),  lo = rint((v 2^30 - hi) 2^32)  and both parts are summed as 64-bit
+// integers: resolution 2^-62, range |v| < 2^12 with up to 2^20 rows over all ranks.
+//   out[q][0][j] = sum_r hi,  out[q][1][j] = sum_r lo   for q = 0: x = loc[r, j], 1: x^2, 2: sigma^2 = (softplus(ls) / 6)^2
 // ------------------------------------------------------------------------------------------
 constexpr int kMomRowsPerBlock = 256;
-constexpr double SUM_FX = 68719476736.0, SQ_FX = 1073741824.0, SIG_FX = 17592186044416.0;   // 2^36, 2^30, 2^44
+constexpr double MOM_FX = 1073741824.0, MOM_FX_LO = 4294967296.0, SQ_FX = 1073741824.0;   // 2^30, 2^32; 2^30 (KL column sums)
+
+__device__ __forceinline__ void fx_split(double v, long long& hi, long long& lo) {
+  const double s = v * MOM_FX;                 // exact (power of two)
+  const double f = floor(s);
+  hi += __double2ll_rn(f);
+  lo += __double2ll_rn((s - f) * MOM_FX_LO);   // s - f in [0, 1) exactly
+}
 
 __global__ void __launch_bounds__(256) col_moments_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
-                                                          int rows, int cols, long long* s1, long long* s2, long long* sg) {
+                                                          int rows, int cols, long long* out) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
   int r0 = blockIdx.y * kMomRowsPerBlock;
   int r1 = min(rows, r0 + kMomRowsPerBlock);
-  long long a1 = 0, a2 = 0, a3 = 0;
+  long long acc[6] = {0, 0, 0, 0, 0, 0};
   for (int r = r0; r < r1; ++r) {
     const double x = (double)loc[(long long)r * cols + j];
-    a1 += __double2ll_rn(x * SUM_FX);
-    a2 += __double2ll_rn(x * x * SQ_FX);
+    fx_split(x, acc[0], acc[1]);
+    fx_split(x * x, acc[2], acc[3]);
     const float s = st_f32(ls[(long long)r * cols + j]);
-    a3 += __double2ll_rn((double)mul_rn(s, s) * SIG_FX);
+    fx_split((double)mul_rn(s, s), acc[4], acc[5]);
   }
-  atomicAdd(reinterpret_cast<unsigned long long*>(&s1[j]), (unsigned long long)a1);
-  atomicAdd(reinterpret_cast<unsigned long long*>(&s2[j]), (unsigned long long)a2);
-  atomicAdd(reinterpret_cast<unsigned long long*>(&sg[j]), (unsigned long long)a3);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(out + (long long)q * cols + j), (unsigned long long)acc[q]);
 }
 
-extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* sum_fx,
-                               int64_t* sq_fx, int64_t* sig2_fx, rcb_stream_t stream) {
-  RCB_REQUIRE(loc && log_scale && sum_fx && sq_fx && sig2_fx, RCB_ERR_ARG, "col_moments: null pointer");
+extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* out_fx,
+                               rcb_stream_t stream) {
+  RCB_REQUIRE(loc && log_scale && out_fx, RCB_ERR_ARG, "col_moments: null pointer");
   RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "col_moments: empty shape");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e;
-  if ((e = hipMemsetAsync(sum_fx, 0, sizeof(int64_t) * cols, st)) != hipSuccess) return fail((int)e, "memset");
-  if ((e = hipMemsetAsync(sq_fx, 0, sizeof(int64_t) * cols, st)) != hipSuccess) return fail((int)e, "memset");
-  if ((e = hipMemsetAsync(sig2_fx, 0, sizeof(int64_t) * cols, st)) != hipSuccess) return fail((int)e, "memset");
+  hipError_t e = hipMemsetAsync(out_fx, 0, sizeof(int64_t) * 6 * cols, st);
+  if (e != hipSuccess) return fail((int)e, "memset");
   int row_blocks = cdiv(rows, kMomRowsPerBlock);
   RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "col_moments: too many rows");
   dim3 grid(cdiv(cols, 256), row_blocks);
-  col_moments_kernel<<<grid, 256, 0, st>>>(loc, log_scale, rows, cols, (long long*)sum_fx, (long long*)sq_fx, (long long*)sig2_fx);
+  col_moments_kernel<<<grid, 256, 0, st>>>(loc, log_scale, rows, cols, (long long*)out_fx);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

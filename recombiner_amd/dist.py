@@ -74,7 +74,7 @@ def refit_prior(loc: torch.Tensor, log_scale: torch.Tensor, group=None):
     if ws > 1:
         td.all_reduce(pack, group=group)
     n = int(pack[-1])
-    s, m2, sg = ops.moments_from_fx(pack[:-1].view(3, -1), n)
+    s, m2, sg = ops.moments_from_fx(pack[:-1].view(3, 2, -1), n)
     return prior_from_moments(torch.tensor(float(n), dtype=torch.float64), s, m2, sg, loc.shape[1:])
 
 

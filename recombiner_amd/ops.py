@@ -468,7 +468,8 @@ class GaussKLFn(torch.autograd.Function):
 
 
 COLSUM_FX = 2.0 ** 30          # RCB_COLSUM_FX_SCALE
-MOM_FX = (2.0 ** 36, 2.0 ** 30, 2.0 ** 44)     # RCB_MOM_{SUM,SQ,SIG}_FX_SCALE
+KL_FX = 2.0 ** 24              # RCB_KL_FX_SCALE: the KL slots of rcb_posterior_bwd / rcb_step_* count 2^-24 nats
+MOM_FX, MOM_FX_LO = 2.0 ** 30, 2.0 ** 32      # RCB_MOM_FX_SCALE, RCB_MOM_FX_LO_SCALE
 
 
 def gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log=False):
@@ -557,23 +558,21 @@ def adam_multi(params, grads, ms, vs, cfg: AdamCfg):
 
 
 def col_moments_fx(loc, log_scale):
-    """-> int64 [3, cols]: exact fixed-point sums over the rows of loc (rcb_col_moments): sum x, sum x^2, sum sigma^2 in
-    units of 1 / MOM_FX[k].  Integer sums: add them over ranks with an integer all-reduce, then moments_from_fx."""
+    """-> int64 [3, 2, cols]: exact fixed-point sums over the rows of loc (rcb_col_moments): (hi, lo) parts of sum x,
+    sum x^2, sum sigma^2.  Integer sums: add them over ranks with an integer all-reduce, then moments_from_fx."""
     lib = _lib.load()
     l2 = loc.detach().reshape(loc.shape[0], -1)
     s2 = log_scale.detach().reshape(loc.shape[0], -1)
     rows, cols = l2.shape
-    out = torch.empty(3, cols, device=loc.device, dtype=torch.int64)
-    check(lib.rcb_col_moments(ptr(l2, f32), ptr(s2, f32), rows, cols, ptr(out[0]), ptr(out[1]), ptr(out[2]),
-                              stream_ptr()), "rcb_col_moments")
+    out = torch.empty(3, 2, cols, device=loc.device, dtype=torch.int64)
+    check(lib.rcb_col_moments(ptr(l2, f32), ptr(s2, f32), rows, cols, ptr(out), stream_ptr()), "rcb_col_moments")
     return out
 
 
 def moments_from_fx(fx, n_rows):
     """(sum, M2 = sum (x - mean)^2, sum sigma^2) in fp64 from the fixed-point sums of n_rows rows"""
-    s = fx[0].to(f64) / MOM_FX[0]
-    m2 = fx[1].to(f64) / MOM_FX[1] - s * s / float(n_rows)
-    return s, m2, fx[2].to(f64) / MOM_FX[2]
+    v = (fx[:, 0].to(f64) + fx[:, 1].to(f64) / MOM_FX_LO) / MOM_FX
+    return v[0], v[1] - v[0] * v[0] / float(n_rows), v[2]
 
 
 def col_moments(loc, log_scale):

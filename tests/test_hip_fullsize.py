@@ -70,10 +70,10 @@ def test_posterior_update_is_row_local():
         l, s = l.clone(), s.clone()
         lv = ops.LevelSpec(l, s, D, l.shape[0])
         st = {k: torch.zeros_like(l) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
-        kl = torch.zeros(1024, device=DEV, dtype=torch.float64)
+        kl = torch.zeros(1024, device=DEV, dtype=torch.int64)             # fixed point, ops.KL_FX units per nat
         for t in (1, 2):
             ops.posterior_bwd(lv, pl, ps, False, 1e-4, d, e, S, adam=ops.adam_cfg(2e-4, t), state=st, kl_accum=kl)
-        return l, s, kl.sum()
+        return l, s, kl.sum().double() / ops.KL_FX
     la, sa, kla = step(loc, ls, eps, dout)
     sl = slice(2048, 2056)
     lb, sb, _ = step(loc[sl].contiguous(), ls[sl].contiguous(), eps[sl].contiguous(), dout[sl].contiguous())

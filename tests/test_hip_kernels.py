@@ -712,15 +712,15 @@ def test_posterior_flat_fast_path_equals_generic_kernel():
         dl, ds = g(loc.clone()), g(ls.clone())
         lv = LevelSpec(dl, ds, D, n, col_map=col_map)
         state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
-        slots = torch.zeros(1024, device=DEV, dtype=torch.float64)
+        slots = torch.zeros(1024, device=DEV, dtype=torch.int64)          # fixed point, ops.KL_FX units per nat
         for step in (1, 2, 3):
             ops.posterior_bwd(lv, g(pl), g(ps), False, 1e-3, Gm, eps, 1, adam=ops.adam_cfg(2e-4, step), state=state,
                               kl_accum=slots)
-        res.append((dl, ds, state, float(slots.sum())))
+        res.append((dl, ds, state, float(slots.sum()) / ops.KL_FX))
     (l0, s0, st0, k0), (l1, s1, st1, k1) = res
     assert torch.equal(l0, l1) and torch.equal(s0, s1)
     assert all(torch.equal(st0[k], st1[k]) for k in st0)
-    assert k0 == pytest.approx(k1, rel=1e-12) and k0 > 0
+    assert k0 == pytest.approx(k1, rel=1e-9) and k0 > 0       # (each workgroup's partial sum is rounded to 2^-24 nats once)
 
 
 def test_lds_staged_gather_kernels_equal_generic_kernels():
@@ -749,17 +749,17 @@ def test_lds_staged_gather_kernels_equal_generic_kernels():
             lv = LevelSpec(dl, ds, D, n, col_map=perm, enc_sample=g(samp), enc_mask=g(mask))
             h = ops.reparam_fwd([lv], [eps], S)
             state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
-            slots = torch.zeros(1024, device=DEV, dtype=torch.float64)
+            slots = torch.zeros(1024, device=DEV, dtype=torch.int64)
             for step in (1, 2):
                 ops.posterior_bwd(lv, g(pl), g(pls), True, 1.0, Gm, eps, S, beta=g(beta), group_idx=g(gidx), n_groups=G,
                                   adam=ops.adam_cfg(2e-4, step), state=state, kl_accum=slots)
-            outs.append((h, dl, ds, state, float(slots.sum())))
+            outs.append((h, dl, ds, state, float(slots.sum()) / ops.KL_FX))
         finally:
             lib.rcb_debug_generic_kernels_only(0)
     (h0, l0, s0, st0, k0), (h1, l1, s1, st1, k1) = outs
     assert torch.equal(h0, h1)
     assert torch.equal(l0, l1) and torch.equal(s0, s1) and all(torch.equal(st0[k], st1[k]) for k in st0)
-    assert k0 == pytest.approx(k1, rel=1e-12) and k0 > 0
+    assert k0 == pytest.approx(k1, rel=1e-9) and k0 > 0
     assert float((l0 - g(loc)).abs().max()) > 0          # the update did something
 
 
