@@ -149,12 +149,13 @@ class PriorBNNmodel(nn.Module):
             return ops.PeLayout(self.patch_nums[:self.data_dim], self.pixel_sizes[:self.data_dim])
         return None
 
-    def _pe(self, upsample_net, lpe, stitched=False):
+    def _pe(self, upsample_net, lpe, stitched=False, lpe16=None):
         """lpe [S, N, *lat, C] -> pe [N, S, P, 16]: hand-written phase-conv kernels in the 16-bit modes
-        where the geometry is instantiated, the nn.Module (MIOpen) otherwise.  `stitched`: see _pe_layout."""
+        where the geometry is instantiated, the nn.Module (MIOpen) otherwise.  `stitched`: see _pe_layout.
+        lpe16: the producer's bf16 copy of lpe [N, Dlpe] (stage-1 operand; saves the cast pass)."""
         if self.precision != 0 and hip_path_supported(upsample_net, self.pixel_sizes, self.upsample_factors, self.patch,
                                                       self.data_dim):
-            return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16, self.pe_bf16)
+            return upsample_cifar_hip(upsample_net, lpe, self.stage1_bf16, self.pe_bf16, lpe16=lpe16)
         net = upsample_net
         if self.precision != 0 and tiled_2d_preferred(upsample_net, self.patch, self.data_dim):
             net = stitched2d_module(upsample_net)                  # stitched 2-D grid: phase-conv kernels on overlapping tiles
@@ -347,7 +348,10 @@ class PriorBNNmodel(nn.Module):
         def seg1a():
             ops.step_begin(tab, step_t, dyn, kl_slots)
             # ---- sample ---------------------------------------------------------------------------------
-            if use_rng:
+            lpe16 = None
+            if use_rng and self.stage1_bf16 and self.precision != 0 and not self.patch:
+                lpe, e_lpe, lpe16 = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=True)   # bf16 copy: stage-1 operand
+            elif use_rng:
                 lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr)
             else:
                 e_lpe = self._noise((N, 1, self._d_lpe))
@@ -357,7 +361,7 @@ class PriorBNNmodel(nn.Module):
                 if pe_lay is not None:                                   # stitched grids, addressed in place by the kernel
                     pe_c = self._pe(upsample_net, lpe_t, stitched=True)
                 else:
-                    pe = self._pe(upsample_net, lpe_t)                   # [N, 1, P, E]
+                    pe = self._pe(upsample_net, lpe_t, lpe16=lpe16)      # [N, 1, P, E]
                     pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
                     #                                                               materialises zeros + a copy)
             h16 = None

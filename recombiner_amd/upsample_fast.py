@@ -386,7 +386,7 @@ class _UpsampleCifarFn(torch.autograd.Function):
     pre-summed 512 x 4096 weight (hipBLASLt); stages 2 and 3 are the rcb_upconv_* kernels."""
 
     @staticmethod
-    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3, stage1_bf16, pe_bf16, cache=None):
+    def forward(ctx, lpe, W1, b1, W2, b2, W3, b3, stage1_bf16, pe_bf16, cache=None, lpe16=None):
         from . import ops
         B = lpe.shape[0]
         # effective (phase-form) weights of all three stages in one launch; bf16 stage 1 = bf16 operands and a bf16 z1
@@ -400,7 +400,8 @@ class _UpsampleCifarFn(torch.autograd.Function):
             if cache is not None:
                 cache[key] = (Weff1, b1rep, Weff2, Weff3, pack)
         if stage1_bf16:
-            lpe = lpe.to(torch.bfloat16)
+            # the stage-1 GEMM operand: the producer's bf16 copy (reparam kernel) when there is one, else a cast pass
+            lpe = lpe16 if (lpe16 is not None and tuple(lpe16.shape) == tuple(lpe.shape)) else lpe.to(torch.bfloat16)
         z1 = torch.addmm(b1rep, lpe, Weff1).view(B, 8, 8, 64)
         h2 = ops.upconv_fwd(z1, Weff2, b2.contiguous(), 8, 64, out_f32=False, preact=True, pack=pack)
         pe = ops.upconv_fwd(h2, Weff3, b3.contiguous(), 16, 16, out_f32=not pe_bf16, linear_bf16=pe_bf16, pack=pack)
@@ -421,18 +422,20 @@ class _UpsampleCifarFn(torch.autograd.Function):
             dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16, pack=pack)      # bf16 [B,16,16,64]
         dz1, db1_part = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, want_dbias=True, pack=pack)   # [B,8,8,64]
         dz1f = dz1.view(B, 4096)
-        dlpe = (dz1f @ Weff1.t()).float() if ctx.needs_input_grad[0] else None
+        dlpe = None
+        if ctx.needs_input_grad[0]:      # fp32 result straight from the GEMM (no cast pass)
+            dlpe = torch.mm(dz1f, Weff1.t(), out_dtype=torch.float32) if dz1f.dtype == torch.bfloat16 else dz1f @ Weff1.t()
         if not need_w:
-            return dlpe, None, None, None, None, None, None, None, None, None
+            return dlpe, None, None, None, None, None, None, None, None, None, None
         if not fused3:
             dWeff3, db3 = ops.upconv_wgrad(h2, dpe, 16, 16)
         dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64, preact=True)
         dWeff1 = lpe.t() @ dz1f                                            # [512, 4096], dtype of the stage-1 operands
         dW1, dW2, dW3, db1 = ops.upconv_weff_grad(dWeff1, dWeff2, dWeff3, db1_part)
-        return dlpe, dW1, db1, dW2, db2, dW3, db3, None, None, None
+        return dlpe, dW1, db1, dW2, db2, dW3, db3, None, None, None, None
 
 
-def upsample_cifar_hip(net, lpe, stage1_bf16=True, pe_bf16=True, frozen_cache=None):
+def upsample_cifar_hip(net, lpe, stage1_bf16=True, pe_bf16=True, frozen_cache=None, lpe16=None):
     """lpe [S, N, 2, 2, 128] -> pe [N, S, 1024, 16] (contiguous) through the HIP phase-conv kernels.
     `stage1_bf16` runs the stage-1 library GEMMs (fwd, dgrad, wgrad) with bf16 operands / fp32 accumulation and keeps
     z1 in bf16.  `pe_bf16` stores pe (and hence its gradient) as bf16: the 16-bit SIREN kernels and the stage-3
@@ -441,7 +444,7 @@ def upsample_cifar_hip(net, lpe, stage1_bf16=True, pe_bf16=True, frozen_cache=No
     S, N = lpe.shape[:2]
     pe = _UpsampleCifarFn.apply(lpe.permute(1, 0, 2, 3, 4).reshape(N * S, 512), net.conv1.weight, net.conv1.bias,
                                 net.conv2.weight, net.conv2.bias, net.conv3.weight, net.conv3.bias, bool(stage1_bf16),
-                                bool(pe_bf16), frozen_cache)
+                                bool(pe_bf16), frozen_cache, lpe16 if S == 1 else None)
     return pe.view(N, S, 1024, 16)
 
 
