@@ -90,6 +90,9 @@ typedef struct {
   int32_t pe_patch_nums[3];  /* patches per axis (first pe_grid_dims entries)                                          */
   int32_t pe_patch_size[3];  /* pixels per axis of one patch; their product is n_pix                                   */
   int64_t dw_bf16_stride;    /* elements between the rows of dw_bf16 (>= the length of a row of layer vectors)         */
+  int32_t hidden_dims[4];    /* all zero: every hidden layer is `hidden` wide.  Otherwise the widths of the n_hidden hidden
+                              * layers one by one (the reference builds its INR from any list, prior_model.py:84-85): fp32
+                              * mode only (1 .. 64 each; the plain-FMA parity kernel), `hidden` = their maximum            */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */

@@ -32,7 +32,7 @@ class SirenDesc(C.Structure):
                 ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
                 ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_bf16", C.c_void_p), ("pixel_chunks", C.c_int32),
                 ("xf_bf16", C.c_void_p), ("pe_grid_dims", C.c_int32), ("pe_patch_nums", C.c_int32 * 3),
-                ("pe_patch_size", C.c_int32 * 3), ("dw_bf16_stride", C.c_int64)]
+                ("pe_patch_size", C.c_int32 * 3), ("dw_bf16_stride", C.c_int64), ("hidden_dims", C.c_int32 * 4)]
 
 
 class Level(C.Structure):

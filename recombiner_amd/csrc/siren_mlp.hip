@@ -345,7 +345,7 @@ int launch(const SirenArgs& a, size_t smem_bytes, hipStream_t st) {
 
 template <int MODE>
 int dispatch(const rcb_siren_desc* d, SirenArgs& a, hipStream_t st) {
-  if (d->hidden != HID) return siren_generic_dispatch(MODE, d, a, st);   // fp32 at other widths: siren_mlp_generic.hip
+  if (d->hidden != HID || d->hidden_dims[0] != 0) return siren_generic_dispatch(MODE, d, a, st);   // fp32 at other widths / per-layer widths: siren_mlp_generic.hip
   const int in0 = d->fourier_dim + d->pe_dim;
   const int ks = d->fourier_dim > d->pe_dim ? d->fourier_dim : d->pe_dim;
   const int nb0 = (in0 + 31) / 32;
@@ -383,6 +383,8 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
                   (d->precision == 0 && d->hidden >= 1 && d->hidden <= 64),
               RCB_ERR_UNSUPPORTED, "siren: hidden width %d (fp32 mode: up to 64; 16-bit modes: 32, 48, 64)", d->hidden);
   RCB_REQUIRE(d->n_hidden >= 1 && d->n_hidden <= 4, RCB_ERR_UNSUPPORTED, "siren: n_hidden=%d", d->n_hidden);
+  RCB_REQUIRE(d->hidden_dims[0] == 0 || d->precision == 0, RCB_ERR_UNSUPPORTED,
+              "siren: per-layer hidden widths exist in the fp32 mode only (the 16-bit kernels take one width: 32, 48 or 64)");
   RCB_REQUIRE(d->out_dim >= 1 && d->out_dim <= 32, RCB_ERR_UNSUPPORTED, "siren: out_dim=%d", d->out_dim);
   RCB_REQUIRE(d->fourier_dim >= 1 && d->pe_dim >= 0 && d->fourier_dim + d->pe_dim <= 64, RCB_ERR_UNSUPPORTED,
               "siren: F=%d E=%d", d->fourier_dim, d->pe_dim);

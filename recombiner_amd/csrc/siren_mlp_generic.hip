@@ -28,7 +28,8 @@ constexpr int GEN_MAXW = 64;                                      // hidden widt
 constexpr int GEN_J = (GEN_MAXW * (GEN_MAXW + 1) + 255) / 256;    // gradient entries per thread and layer
 
 struct GenGeo {
-  int W, NH, in0, dnet;
+  int W, NH, in0, dnet;        // W = the widest hidden layer
+  int wid[MAXL];               // output width of every layer (hidden widths, then C)
   int off[MAXL + 1];
   // LDS map (floats)
   int x0, x0s;                 // inputs [32][x0s]
@@ -52,8 +53,8 @@ __global__ void __launch_bounds__(256) siren_generic_kernel(SirenArgs a, GenGeo 
   float* dz_nxt = smem + geo.dzb;
   float* red = smem + geo.red;
   const int ws = geo.ws, x0s = geo.x0s;
-  auto lin = [&](int l) { return l == 0 ? in0 : W; };
-  auto lout = [&](int l) { return l == NL - 1 ? C : W; };
+  auto lin = [&](int l) { return l == 0 ? in0 : geo.wid[l - 1]; };
+  auto lout = [&](int l) { return geo.wid[l]; };
 
   {
     const float* src = a.wvec + (long long)g * a.w_stride;
@@ -82,21 +83,21 @@ __global__ void __launch_bounds__(256) siren_generic_kernel(SirenArgs a, GenGeo 
       if (l >= NH) continue;
       const float* prev = l == 0 ? X0 + p * x0s : Sb + ((l - 1) * 32 + p) * ws;
       const float* Bl = wl + geo.off[l];
-      const float* Wl = Bl + W;
-      const int ni = lin(l);
+      const int ni = lin(l), no = lout(l);
+      const float* Wl = Bl + no;
       float acc[GEN_MAXW / 8];
 #pragma unroll
-      for (int k = 0; k < GEN_MAXW / 8; ++k) acc[k] = (og + 8 * k < W) ? Bl[og + 8 * k] : 0.f;
+      for (int k = 0; k < GEN_MAXW / 8; ++k) acc[k] = (og + 8 * k < no) ? Bl[og + 8 * k] : 0.f;
       for (int i = 0; i < ni; ++i) {
         const float s = prev[i];
 #pragma unroll
         for (int k = 0; k < GEN_MAXW / 8; ++k)
-          if (og + 8 * k < W) acc[k] = __builtin_fmaf(Wl[i * W + og + 8 * k], s, acc[k]);
+          if (og + 8 * k < no) acc[k] = __builtin_fmaf(Wl[i * no + og + 8 * k], s, acc[k]);
       }
 #pragma unroll
       for (int k = 0; k < GEN_MAXW / 8; ++k) {
         const int o = og + 8 * k;
-        if (o < W) {
+        if (o < no) {
           float s, c;
           sincos_w0_exact(acc[k], a.k_hi, a.k_lo, s, c);
           Sb[(l * 32 + p) * ws + o] = s;
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(256) siren_generic_kernel(SirenArgs a, GenGeo 
         const int o = og + 8 * k;
         if (o < C) {
           float y = Bl[o];
-          for (int i = 0; i < W; ++i) y = __builtin_fmaf(Wl[i * C + o], prev[i], y);
+          for (int i = 0; i < lin(NH); ++i) y = __builtin_fmaf(Wl[i * C + o], prev[i], y);
           if (MODE == MODE_FWD) {
             if (valid) a.yout[((long long)g * P + pix) * C + o] = y;
           } else if (MODE == MODE_LOSS) {
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(256) siren_generic_kernel(SirenArgs a, GenGeo 
 #pragma unroll
         for (int k = 0; k < GEN_MAXW / 8; ++k) {
           const int i = og + 8 * k;
-          if (i < W) {
+          if (i < ni) {
             float dh = 0.f;
             for (int o = 0; o < no; ++o) dh = __builtin_fmaf(Wl[i * no + o], dz_cur[p * ws + o], dh);
             dz_nxt[p * ws + i] = dh * Cb[((l - 1) * 32 + p) * ws + i] * a.w0;
@@ -225,13 +226,21 @@ int siren_generic_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipS
               RCB_ERR_UNSUPPORTED, "siren(generic fp32): hidden=%d n_hidden=%d out_dim=%d pixel_chunks=%d", d->hidden, d->n_hidden,
               d->out_dim, d->pixel_chunks);
   GenGeo geo;
-  geo.W = d->hidden;
   geo.NH = d->n_hidden;
   geo.in0 = d->fourier_dim + d->pe_dim;
+  const bool listed = d->hidden_dims[0] != 0;
+  geo.W = 0;
+  for (int l = 0; l < geo.NH; ++l) {
+    geo.wid[l] = listed ? d->hidden_dims[l] : d->hidden;
+    RCB_REQUIRE(geo.wid[l] >= 1 && geo.wid[l] <= GEN_MAXW, RCB_ERR_UNSUPPORTED, "siren(generic fp32): hidden layer %d is %d wide (1..%d)", l,
+                geo.wid[l], GEN_MAXW);
+    geo.W = geo.wid[l] > geo.W ? geo.wid[l] : geo.W;
+  }
+  geo.wid[geo.NH] = d->out_dim;
   int o = 0;
   for (int l = 0; l <= geo.NH; ++l) {
     geo.off[l] = o;
-    const int li = l == 0 ? geo.in0 : geo.W, lo = l == geo.NH ? d->out_dim : geo.W;
+    const int li = l == 0 ? geo.in0 : geo.wid[l - 1], lo = geo.wid[l];
     o += lo * (li + 1);
   }
   geo.dnet = o;

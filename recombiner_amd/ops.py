@@ -36,10 +36,16 @@ class SirenMeta:
     out_dim: int
     w0: float = 30.0
     precision: int = 0
+    hidden_dims: Optional[tuple] = None      # per-layer hidden widths when they differ (fp32 mode only); hidden = their maximum
+
+    @property
+    def dims(self):
+        hid = list(self.hidden_dims) if self.hidden_dims else [self.hidden] * self.n_hidden
+        return [self.fourier_dim + self.pe_dim] + hid + [self.out_dim]
 
     @property
     def d_net(self):
-        dims = [self.fourier_dim + self.pe_dim] + [self.hidden] * self.n_hidden + [self.out_dim]
+        dims = self.dims
         return sum(dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1))
 
 
@@ -146,6 +152,11 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_l
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
                   meta.precision, int(pe is not None and pe.dtype == bf16), None if dw_bf16 is None else dw_bf16.data_ptr(), int(chunks), None)
     d.dw_bf16_stride = 0 if dw_bf16 is None else int(dw_bf16.stride(0))
+    if meta.hidden_dims and len(set(meta.hidden_dims)) > 1:
+        if meta.precision != 0 or len(meta.hidden_dims) != meta.n_hidden:
+            raise RcbError("per-layer hidden widths: fp32 mode only, one width per hidden layer")
+        for i, w_ in enumerate(meta.hidden_dims):
+            d.hidden_dims[i] = int(w_)
     if pe_layout is not None:
         nd = len(pe_layout.patch_nums)
         d.pe_grid_dims = nd
@@ -207,7 +218,7 @@ def siren_bwd(xf, pe, wvec, dy, meta: SirenMeta, want_dpe=True, pixel_chunks=Non
 
 def siren_wide_layers(meta: SirenMeta):
     """(number of layer vectors of maximal length, that length)"""
-    dims = [meta.fourier_dim + meta.pe_dim] + [meta.hidden] * meta.n_hidden + [meta.out_dim]
+    dims = meta.dims
     sizes = [dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1)]
     return sizes.count(max(sizes)), max(sizes)
 

@@ -84,8 +84,8 @@ class PriorBNNmodel(nn.Module):
         self.patch_nums, self.hierarchical_patch_nums = patch_nums, hierarchical_patch_nums
         self.net_params_list, self.cum_param_sizes = count_net_params(in_dim, hidden_dims, out_dim)
         D = int(self.cum_param_sizes[-1])
-        if len(set(hidden_dims)) != 1:
-            raise ValueError("hidden layers must share one width")
+        # (any list of hidden widths, as in the reference, prior_model.py:84-85: widths that differ run in the fp32 parity
+        # mode on the plain-FMA kernel; the 16-bit modes take one width -- 32, 48 or 64 -- and say so when asked otherwise)
 
         # A1: same CPU-generator draw order as the reference (loc, h_loc, hh_loc, lpe_loc), then moved
         torch.manual_seed(random_seed)
@@ -172,8 +172,9 @@ class PriorBNNmodel(nn.Module):
 
     def _meta(self, x, pe_dim, samples=1):
         return SirenMeta(samples=samples, n_pix=x.shape[-2], fourier_dim=x.shape[-1], pe_dim=pe_dim,
-                         n_hidden=self.n_layers - 1, hidden=self.dims[1], out_dim=self.dims[-1], w0=self.w0,
-                         precision=self.precision)
+                         n_hidden=self.n_layers - 1, hidden=max(self.dims[1:-1]), out_dim=self.dims[-1], w0=self.w0,
+                         precision=self.precision,
+                         hidden_dims=tuple(self.dims[1:-1]) if len(set(self.dims[1:-1])) > 1 else None)
 
     def _layer_slices(self):
         cum = self.cum_param_sizes

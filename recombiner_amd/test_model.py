@@ -237,8 +237,9 @@ class TestBNNmodel(nn.Module):
 
     def _meta(self, x, S):
         return SirenMeta(samples=S, n_pix=x.shape[-2], fourier_dim=x.shape[-1], pe_dim=16,
-                         n_hidden=self.n_layers - 1, hidden=self.dims[1], out_dim=self.dims[-1], w0=self.w0,
-                         precision=self.precision)
+                         n_hidden=self.n_layers - 1, hidden=max(self.dims[1:-1]), out_dim=self.dims[-1], w0=self.w0,
+                         precision=self.precision,
+                         hidden_dims=tuple(self.dims[1:-1]) if len(set(self.dims[1:-1])) > 1 else None)
 
     def _layer_slices(self):
         cum = self.cum_param_sizes

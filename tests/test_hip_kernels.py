@@ -319,6 +319,33 @@ def test_siren_wide_model_scale_weights_f16(W):
         lo += n
 
 
+def test_siren_fp32_with_different_hidden_widths():
+    """the reference builds its INR from any hidden_dims list (prior_model.py:84-85): widths that differ from layer to layer
+    run on the plain-FMA fp32 kernel (rcb_siren_desc.hidden_dims) and match the fp32 restatement and its autograd"""
+    gen = torch.Generator().manual_seed(3)
+    F, E, C, P, N = 16, 16, 3, 70, 3
+    hid = (24, 40, 16)
+    dims = [F + E] + list(hid) + [C]
+    D = sum(dims[i + 1] * (dims[i] + 1) for i in range(len(dims) - 1))
+    xf = torch.rand(P, F, generator=gen) * 2 - 1
+    pe = torch.randn(N, P, E, generator=gen) * 0.5
+    wv = (torch.rand(N, D, generator=gen) * 2 - 1) * 0.05
+    y = torch.rand(N, P, C, generator=gen)
+    meta = SirenMeta(1, P, F, E, 3, max(hid), C, hidden_dims=hid)
+    assert meta.d_net == D
+    out = ops.siren_fwd(g(xf), g(pe), g(wv), meta)
+    wv_r, pe_r = wv.clone().requires_grad_(True), pe.clone().requires_grad_(True)
+    ref = _oracle_mlp(dims, xf, pe_r, wv_r, 1)
+    assert rel_err(out, ref) < 1e-5             # (fp32 on both sides; sin(30 z) amplifies the last-bit differences of z)
+    loss = ((ref - y) ** 2).sum() / (P * C)
+    loss.backward()
+    sse, dw, dpe = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / (P * C), meta)
+    assert rel_err(sse.sum() / (P * C), loss.detach()) < 1e-5
+    assert rel_err(dw, wv_r.grad) < 2e-5 and rel_err(dpe, pe_r.grad) < 2e-5
+    with pytest.raises(ops.RcbError):                                     # the 16-bit kernels take one width
+        ops.siren_fwd(g(xf), g(pe), g(wv), SirenMeta(1, P, F, E, 3, max(hid), C, precision=1, hidden_dims=hid))
+
+
 def test_siren_wide_bf16_pe_storage_and_split_output():
     """width 64: bf16-stored pe / dpe reproduce fp32 storage exactly, and the bf16 copy of the gradient the epilogue
     writes (rcb_siren_desc.dw_bf16) is the rounded fp32 gradient (as for width 32)"""

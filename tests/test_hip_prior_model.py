@@ -338,6 +338,42 @@ def test_sharded_training_rehearsal_two_ranks_one_gpu():
     assert "SHARDED == UNSHARDED OK ws=2" in out.stdout
 
 
+def test_hidden_layers_of_different_widths_fp32():
+    """PriorBNNmodel with hidden_dims = [24, 40, 16] (the reference accepts any list, prior_model.py:84-85): two training steps
+    in the fp32 parity mode, mappings trained, against the CPU oracle on the same injected noise"""
+    from recombiner_amd import config, utils
+    cfg = dict(config.configs["cifar"])
+    cfg["hidden_dims"] = [24, 40, 16]
+    n = 3
+    geo = O.Geometry.from_config(cfg)
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                         cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                         cfg["hierarchical_patch_nums"], random_seed=42, device=DEV)
+    assert m._d_net == geo.d_net == 24 * 33 + 40 * 25 + 16 * 41 + 3 * 17
+    torch.manual_seed(123)
+    lt = PM.LinearTransform(m.dims).to(DEV)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    torch.manual_seed(7)
+    eps = [torch.randn(n, 1, 512), torch.randn(n, 1, geo.d_net), torch.randn(n, 1, 512), torch.randn(n, 1, geo.d_net)]
+    q = [e.clone() for e in eps]
+    m.noise_source = lambda shape: q.pop(0)
+    s0 = 0.0211547
+    pri = [torch.zeros(geo.d_net), torch.full((geo.d_net,), s0), torch.zeros(2, 2, 128), torch.full((2, 2, 128), s0)]
+    prg = [p.to(DEV) for p in pri] + [None] * 4
+    mse, kl, elbo = m.train(2, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *prg, lt, up, 1e-8, training_mappings=True)
+    p = O.init_prior_params(geo, n, seed=42)
+    A = O.make_linear_transform(geo.dims, seed=123)
+    upo = O.UpsampleNet(geo.data_dim, geo.paddings, geo.layerwise_scale_factors, seed=124)
+    replay = [eps[0].reshape(n, 2, 2, 128), eps[1], eps[2].reshape(n, 2, 2, 128), eps[3]]
+    mse_o, kl_o, elbo_o = O.prior_train(geo, p, X[None].repeat(n, 1, 1), Y, pri + [None] * 4, A, upo, 2, 2e-4, 1e-8, True,
+                                        O.Noise(replay))
+    np.testing.assert_allclose(elbo, elbo_o, rtol=2e-4)
+    np.testing.assert_allclose(m.loc.detach().cpu().numpy(), p["loc"].numpy(), rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(lt.A[1].detach().cpu().numpy(), A[1].numpy(), rtol=1e-3, atol=3e-5)
+
+
 def test_bench_gpus_flag_launches_ranks():
     """`python bench.py --gpus 2` (no launcher) must start two ranks itself and report n_gpus = 2 -- here over gloo with
     both ranks on the one GPU of the box (the rehearsal switch) -- and must refuse the RCCL form on a one-GPU box."""
