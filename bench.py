@@ -257,7 +257,48 @@ def psnr_at_bpp(dev, precision):
             "delta_db": round(float(np.mean(dist) - ref.mean()), 3), "seconds": round(el, 2),
             "adam_steps": int(d["n_opt"]) + int(d["n_groups"]) * int(d["n_ft"]), "groups": int(d["n_groups"]),
             "what": "32 smooth synthetic 32x32 images, prior checkpoint written by the reference (tests/golden), full compression "
-                    "(optimise, A* encode all groups, fine-tune between rounds), precision mode of this bench line"}
+                    "(optimise, A* encode all groups, fine-tune between rounds), precision mode of this bench line",
+            "product_trained_prior": rd_trained(dev, precision)}
+
+
+def rd_trained(dev, precision, runs_per_rate=3):
+    """The other half of PSNR@bpp: the prior (and the mappings) TRAINED BY THE PRODUCT in this bench's precision mode -- the
+    path the throughput number times -- carried through to rate-distortion points: tests/golden/rd_trained_cifar.npz holds, for
+    two rate targets, the reference's own EM loop (training_mappings=True) on 64 smooth images and its compression of 16
+    others, four repetitions each; here the product does the same from scratch (drivers.rd_point) a few times per rate.
+    Single runs scatter by ~0.6 dB / ~3 % bpp on either side (every A* index is a random draw): means are compared, the
+    PSNR difference at matched rate through the slope between the reference's two points."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import smooth_images
+    from recombiner_amd import drivers, utils
+    d = np.load(os.path.join(ROOT, "tests", "golden", "rd_trained_cifar.npz"), allow_pickle=False)
+    cfg = json.loads(str(d["cfg"]))
+    Ytr = smooth_images(int(d["n_train"]), cfg["pixel_sizes"], int(d["train_seed"]))
+    Yte = smooth_images(int(d["n_test"]), cfg["pixel_sizes"], int(d["test_seed"]))
+    X, _ = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], 1, 3, seed=0)
+    sched = dict(n_em_iter=int(d["n_iter"]), first_epochs=int(d["first_epochs"]), epochs=int(d["epochs"]), lr=float(d["lr"]),
+                 n_opt=int(d["n_opt"]), finetune_epochs=int(d["n_ft"]))
+    ref = [(float(np.mean(d[f"r{ri}_bpp"])), float(np.mean(d[f"r{ri}_psnr"]))) for ri in range(len(d["max_bitrate"]))]
+    slope = (ref[0][1] - ref[1][1]) / (ref[0][0] - ref[1][0])
+    out = []
+    t0 = time.perf_counter()
+    for ri, rate in enumerate(d["max_bitrate"]):
+        runs = [drivers.rd_point(cfg, "cifar", X, Ytr, Yte, float(rate), device=dev, seed=42 + s, precision=precision, **sched)
+                for s in range(runs_per_rate)]
+        bpp = float(np.mean([r["bpp"] for r in runs]))
+        psnr = float(np.mean([r["psnr"].mean() for r in runs]))
+        out.append({"max_bitrate": float(rate), "bpp": round(bpp, 4), "psnr_db_mean": round(psnr, 3), "runs": runs_per_rate,
+                    "reference_bpp": round(ref[ri][0], 4), "reference_psnr_db_mean": round(ref[ri][1], 3),
+                    "reference_runs": int(np.asarray(d[f"r{ri}_bpp"]).size),
+                    "delta_db_at_matched_rate": round(psnr - ref[ri][1] - slope * (bpp - ref[ri][0]), 3),
+                    "final_kl_bits_per_inr": round(float(np.mean([r["trajectory"][-1, 0] for r in runs])), 1),
+                    "bit_budget": [float(v) for v in d[f"r{ri}_budget"]]})
+    return {"points": out, "reference_slope_db_per_bpp": round(slope, 3), "seconds": round(time.perf_counter() - t0, 1),
+            "what": "64 smooth synthetic training images, 16 test images; EM loop %d iterations (%d + %d x %d Adam steps, lr %g, "
+                    "training_mappings=True), then optimise %d epochs + A* encode every group with %d fine-tune epochs per round"
+                    % (sched["n_em_iter"], sched["first_epochs"], sched["n_em_iter"] - 1, sched["epochs"], sched["lr"], sched["n_opt"],
+                       sched["finetune_epochs"])}
 
 
 def presets_table(dev):

@@ -276,8 +276,12 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
   // One row block (width 32): wave l owns layer l, i.e. one tile, or two for layer 0 with two input blocks (gT).
   constexpr int NHID = NH - 1;
   constexpr int NGH = (HB == 2 && NHID > 0) ? NHID : 1;
-  f32x16 gH[NGH], g0, gO_own, gT[NB0];
-  f32x16& gO = (NB0 == 1) ? g0 : gO_own;                          // one input block: layer-0 tiles on waves 0 / 1 only
+  f32x16 gH[NGH], g0, gT[NB0];
+  // output-layer tiles (waves 2 / 3).  One input block: layer 0's tiles live on waves 0 / 1 only and the output layer takes g0.
+  // Two input blocks: every wave owns a layer-0 tile already, and a fourth full tile per wave is what the register file cannot
+  // hold -- but only the C rows below the padding matter: each pass contracts into a scratch tile and adds those rows to gOk.
+  constexpr bool SLIM_O = (HB == 2 && NB0 == 2);
+  float gOk[16];
   float bH[NGH], b0 = 0.f, bO = 0.f, bT = 0.f;
   float sse_local = 0.f;
   if (MODE != MODE_FWD) {
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
 #pragma unroll
       for (int i = 0; i < NGH; ++i) gH[i][r] = 0.f;
       g0[r] = 0.f;
-      gO_own[r] = 0.f;
+      gOk[r] = 0.f;
 #pragma unroll
       for (int i = 0; i < NB0; ++i) gT[i][r] = 0.f;
     }
@@ -749,7 +753,12 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
           own = true; ob = wave >> 1; ib = wave & 1;
         }
         if (own) {
-          f32x16& acc = (l == NL - 1) ? gO : (l == 0) ? g0 : gH[l > 0 && l < NL - 1 ? l - 1 : 0];
+          f32x16 scratch_o;
+          if (SLIM_O && l == NL - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scratch_o[r] = 0.f;
+          }
+          f32x16& acc = (l == NL - 1) ? (SLIM_O ? scratch_o : g0) : (l == 0) ? g0 : gH[l > 0 && l < NL - 1 ? l - 1 : 0];
           float& bsum = (l == NL - 1) ? bO : (l == 0) ? b0 : bH[l > 0 && l < NL - 1 ? l - 1 : 0];
           // bias gradient = row sums of dZ^T: the two owners of a row block (ib = 0 / 1) sum one k-step each; layer 0 with a
           // single input block has one owner per row block, which sums both
@@ -774,6 +783,11 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) acc = Op16<T>::mfma(av[s2], bv[s2], acc);
+          }
+          if (SLIM_O && l == NL - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (rho(r, 0) < C || rho(r, 1) < C) gOk[r] += scratch_o[r];
           }
         }
       }
@@ -856,7 +870,16 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
       } else {
         store_tile(std::integral_constant<int, 0>{}, wave >> 1, wave & 1, g0, bsum0, (wave & 1) == 0);
       }
-      if (wave >= 2) store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, gO, bsumO, wave == 2);
+      if (wave >= 2) {
+        if (SLIM_O) {
+          f32x16 go;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) go[r] = (rho(r, 0) < C || rho(r, 1) < C) ? gOk[r] : 0.f;
+          store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, go, bsumO, wave == 2);
+        } else {
+          store_tile(std::integral_constant<int, NL - 1>{}, 0, wave - 2, g0, bsumO, wave == 2);
+        }
+      }
     } else {
       if (wave == 0) {
 #pragma unroll

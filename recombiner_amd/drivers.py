@@ -13,6 +13,7 @@ Under torch.distributed the INRs of `train_prior` are the local shard; the prior
 beta and the grouping statistics are all-reduced (recombiner_amd.dist).
 """
 import contextlib
+import io
 import copy
 import gzip
 import pickle
@@ -265,3 +266,23 @@ def compress(config, dataset, checkpoint, x, y, device="cuda", seed=42, n_epochs
         with open(bitstream_path, "wb") as f:
             f.write(bitstream.encode(model))
     return distortion, model
+
+
+def rd_point(config, dataset, X, Y_train, Y_test, max_bitrate, device="cuda", seed=42, n_em_iter=550, first_epochs=200, epochs=100,
+             lr=2e-4, n_opt=30000, finetune_epochs=None, precision=0, noise_source=None):
+    """One rate-distortion point from scratch with the product alone: learn the prior (and the mappings) on Y_train
+    (train_prior), build the checkpoint in memory, compress Y_test from it (compress) -> dict(bpp, psnr (per datapoint),
+    n_groups, trajectory).  The composition main_prior_training.py -> main_compression.py performs through a file."""
+    from . import bitstream
+    nt, ne = Y_train.shape[0], Y_test.shape[0]
+    Xd = X.to(device)
+    out = train_prior(config, dataset, Xd[None].expand(nt, -1, -1), Y_train, float(max_bitrate), device=device, seed=seed,
+                      n_em_iter=n_em_iter, first_epochs=first_epochs, epochs=epochs, lr=lr, precision=precision,
+                      log=lambda *_: None, noise_source=noise_source)
+    ck = build_checkpoint(out["model"], out["linear_transform"], out["upsample_net"], *out["priors"], out["kl_beta"])
+    with contextlib.redirect_stdout(io.StringIO()):           # (the test-time model prints its expected bpp, like the reference's)
+        dist_, model = compress(config, dataset, ck, Xd[None].expand(ne, -1, -1), Y_test.to(device), device=device, seed=seed,
+                                n_epochs=n_opt, lr=lr, precision=precision, finetune_epochs=finetune_epochs)
+    bits = bitstream.payload_bits(bitstream.encode(model))
+    return dict(bpp=bits / (ne * int(np.prod(config["pixel_sizes"]))), psnr=np.asarray(dist_, dtype=np.float64),
+                n_groups=int(ck[0][5]), trajectory=np.array(out["trajectory"]))
