@@ -1,4 +1,5 @@
-"""Launches the fused SIREN kernel alone (for rocprofv3): python tools/run_siren.py [bf16|f16|fp32] [N] [reps] [pe16] [width]"""
+"""Launches the fused SIREN kernel alone (for rocprofv3): python tools/run_siren.py [bf16|f16|fp32] [N] [reps] [pe16] [width] [step]
+`step`: as the training step launches it (rows on 128-byte lines, bf16 copy of the gradient written by the epilogue)."""
 import os
 import sys
 
@@ -18,6 +19,13 @@ meta = SirenMeta(1, 1024, 16, 16, 3, width, 3, precision=prec)
 Xd, Yd = X.to(dev), Y.to(dev)
 pe = torch.randn(n, 1024, 16, device=dev) * 0.1
 wv = (torch.rand(n, meta.d_net, device=dev) * 2 - 1) * 0.02
+as_step = len(sys.argv) > 6 and sys.argv[6] == "step" and prec != 0
+kw = {}
+if as_step:
+    wv_p = torch.empty(n, (meta.d_net + 31) // 32 * 32, device=dev)[:, :meta.d_net]
+    wv_p.copy_(wv)
+    wv = wv_p
+    kw = dict(want_bf16=True, xf16=ops.xf_bf16(Xd) if prec == 1 else None)
 if len(sys.argv) > 4 and sys.argv[4] == "pe16":
     pe = pe.bfloat16()
 
@@ -35,7 +43,7 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps, out
 
 
-t, out = timed(lambda: ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta))
+t, out = timed(lambda: ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta, **kw))
 print("loss_bwd (pe %s): avg ms %.4f  sse %.6f" % (pe.dtype, t, float(out[0].sum())))
 t, _ = timed(lambda: ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta, want_dpe=False))
 print("loss_bwd without dpe: avg ms %.4f" % t)
