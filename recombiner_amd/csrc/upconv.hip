@@ -26,6 +26,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int CIN = 64;
+constexpr int XRS = 72;   // row stride (elements) of a staged 64-channel image: 144-byte rows spread 128-byte-strided
+                          // gathers (consecutive positions, one channel chunk) over all LDS banks
 constexpr float SLOPE = 0.01f;
 
 __device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -185,10 +187,15 @@ __device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2
   }
 }
 
-template <int COUT, int OUT_BF16>
-__global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
+// NW waves per workgroup: 8 (one workgroup per CU), or 4 with two workgroups per CU -- each on its own INR, so one stages its
+// image and waits for its loads while the other computes (a single workgroup runs stage -> barrier -> compute in lockstep and
+// leaves the matrix cores idle during the first and HBM idle during most of the second); a wave then owns two tile pairs.
+template <int COUT, int OUT_BF16, int NW>
+__global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArgs a) {
   static_assert(COUT == 16, "epilogue lane swap is written for 16 output channels");
+  static_assert(NW == 8 || NW == 4, "8 or 4 waves");
   constexpr int G = 16, HG = 18, RS = 72;   // image row stride in elements (64 channels + 8 pad = 144 B)
+  constexpr int NT = 64 * NW, NPRE = 2048 / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* img = reinterpret_cast<__bf16*>(smem_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
@@ -217,16 +224,16 @@ __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
   float bia[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) bia[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * h];
-  for (int e = tid; e < HG * HG * RS / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
-  // each thread stages 4 x 16 B of the 32 KB image (element e -> pixel e / 8, chunk e % 8); the next INR's image is
+  for (int e = tid; e < HG * HG * RS / 8; e += NT) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  // each thread stages NPRE x 16 B of the 32 KB image (element e -> pixel e / 8, chunk e % 8); the next INR's image is
   // in flight while the current one is consumed
-  uint4 pre[4];
+  uint4 pre[NPRE];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) pre[k] = make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < NPRE; ++k) pre[k] = make_uint4(0, 0, 0, 0);
 #define RCB_FETCH3(bb)                                                                                          \
   {                                                                                                            \
     const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + (long long)(bb) * G * G * CIN); \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) pre[k] = src_[tid + 512 * k];                                \
+    _Pragma("unroll") for (int k = 0; k < NPRE; ++k) pre[k] = src_[tid + NT * k];                               \
   }
   const int gs = gridDim.x;
   int b = blockIdx.x;
@@ -234,13 +241,14 @@ __global__ void __launch_bounds__(512) upconv_fwd3_lds_kernel(FwdArgs a) {
   for (; b < a.batch; b += gs) {
     __syncthreads();          // everyone is done with the previous image (and with the halo setup)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e_ = tid + 512 * k, pix_ = e_ >> 3, c8_ = e_ & 7;
+    for (int k = 0; k < NPRE; ++k) {
+      const int e_ = tid + NT * k, pix_ = e_ >> 3, c8_ = e_ & 7;
       *reinterpret_cast<uint4*>(img + (((pix_ >> 4) + 1) * HG + ((pix_ & 15) + 1)) * RS + 8 * c8_) = pre[k];
     }
     __syncthreads();
     if (b + gs < a.batch) RCB_FETCH3(b + gs)
-    fwd3_body<COUT, OUT_BF16>(img, fr, a, b, pa, tp, q, h, bia);
+#pragma unroll 1
+    for (int t2 = 0; t2 < 8 / NW; ++t2) fwd3_body<COUT, OUT_BF16>(img, fr, a, b, pa, tp + (NW / 2) * t2, q, h, bia);
   }
 #undef RCB_FETCH3
 }
@@ -491,7 +499,10 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
 // for 32-byte stores and accumulates the per-channel sums of dx (the bias gradient of the stage before) per workgroup.
 template <int X_F32>   // sign source / dx type: 1 fp32, 0 bf16
 __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, float* __restrict__ dbias_partial) {
-  constexpr int G = 8, OG = 16, HO = 18, RS = 72, COUT = 64, IMG = HO * HO * RS;
+  // dy image [18][18][64] in LDS: 128-byte pixels, rows padded by 64 B, and the 16-byte chunk c of pixel column x stored at
+  // c ^ ((x >> 1) & 7): every gather below (lane = output position, pixels two apart, one chunk per instruction) then covers
+  // all 64 banks once per ds_read_b128 lane group (tools/lds_banks.py; the plain padded image cost 4 cycles per group)
+  constexpr int G = 8, OG = 16, HO = 18, RS = 64, ROWS = HO * RS + 32, COUT = 64, IMG = HO * ROWS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                               // [IMG]
   float* red = reinterpret_cast<float*>(smem_raw + ((IMG * 2 + 15) / 16) * 16);   // [4 waves][16][64]
@@ -539,8 +550,8 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int e_ = tid + 512 * k, pix = e_ >> 3, c8 = e_ & 7;
-      *reinterpret_cast<uint4*>(img + (((pix >> 4) + 1) * HO + ((pix & 15) + 1)) * RS + 8 * c8) = pre[k];
+      const int e_ = tid + 512 * k, pix = e_ >> 3, c8 = e_ & 7, xx = (pix & 15) + 1;
+      *reinterpret_cast<uint4*>(img + ((pix >> 4) + 1) * ROWS + xx * RS + 8 * (c8 ^ ((xx >> 1) & 7))) = pre[k];
     }
     __syncthreads();
     if (b + gs < a.batch) RCB_FETCHD2(b + gs)
@@ -568,10 +579,11 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int n = 8 * kh + c, ry = (n >> 2) - 1, rx = (n & 3) - 1;
-      const __bf16* px = img + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h;
+      const int xx = 2 * v + rx + 1, sw = (xx >> 1) & 7;
+      const __bf16* px = img + (2 * u + ry + 1) * ROWS + xx * RS;
       uint4 cur[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) cur[kb] = *reinterpret_cast<const uint4*>(px + 16 * kb);
+      for (int kb = 0; kb < 4; ++kb) cur[kb] = *reinterpret_cast<const uint4*>(px + 8 * ((2 * kb + h) ^ sw));
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         Frag bf, fa;
@@ -671,11 +683,12 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   static_assert(NX * 512 == G * G * (CIN / 8) && ND * 512 == OG * OG * (COUT / 8) && 512 % (COUT / 8) == 0, "tiling");
   constexpr int WSZ = 1024 * COUT, ROW = WSZ + COUT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* ximg = reinterpret_cast<__bf16*>(smem_raw);               // [HG*HG][64]
-  __bf16* dimg = ximg + HG * HG * CIN;                              // [OG*OG][COUT]
+  __bf16* ximg = reinterpret_cast<__bf16*>(smem_raw);               // [HG*HG][XRS]
+  constexpr int DRS = COUT == 64 ? XRS : COUT;                      // dy image row stride: 128-byte rows are padded like x's
+  __bf16* dimg = ximg + HG * HG * XRS;                              // [OG*OG][DRS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = lane >> 5, fb = (lane >> 4) & 1, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
-  for (int e = tid; e < HG * HG * CIN / 8; e += 512) reinterpret_cast<uint4*>(ximg)[e] = make_uint4(0, 0, 0, 0);
+  for (int e = tid; e < HG * HG * XRS / 8; e += 512) reinterpret_cast<uint4*>(ximg)[e] = make_uint4(0, 0, 0, 0);
   f32x16 acc[2][2][NT];   // [combo slot][mt][nt]
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -707,43 +720,47 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
       const int i = pix / G, j = pix - i * G;
       Frag f;
       f.v = raw_frag<X_MODE>(px[k], true);
-      *reinterpret_cast<uint4*>(ximg + ((i + 1) * HG + (j + 1)) * CIN + 8 * c8) = f.u;
+      *reinterpret_cast<uint4*>(ximg + ((i + 1) * HG + (j + 1)) * XRS + 8 * c8) = f.u;
     }
     // 512 % (COUT / 8) == 0: a thread always handles the same 8 channels -> private bias-gradient partials
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
       Frag f;
       f.v = raw_frag<DM>(pd[k], true);
-      reinterpret_cast<uint4*>(dimg)[tid + 512 * k] = f.u;
+      const int e = tid + 512 * k;
+      *reinterpret_cast<uint4*>(dimg + (e / (COUT / 8)) * DRS + 8 * (e % (COUT / 8))) = f.u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
     }
     __syncthreads();
     if (b + (int)gridDim.x < a.batch) RCB_WG_FETCH(b + gridDim.x)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int combo = 2 * wave + c;                 // 16 combos over 8 waves
-      const int p = combo >> 2, t = combo & 3;
-      const int pa = p >> 1, pb = p & 1, ty = t >> 1, tx = t & 1;
+    {
+      // 16 combos (phase p, tap t) over 8 waves: wave w takes t = 2 (w & 1) + c, c = 0 / 1, of phase p = w >> 1.  The dy
+      // operand depends on the phase only: one set of transposed reads feeds both combos
+      const int p = wave >> 1, pa = p >> 1, pb = p & 1, ty = wave & 1;
       for (int pt = 0; pt < G * G / 32; ++pt) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          union { s16x4 s[2]; bf16x8 v; } av[2], bv[NT];
+          union { s16x4 s[2]; bf16x8 v; } av[2][2], bv[NT];
 #pragma unroll
           for (int w2 = 0; w2 < 2; ++w2) {
             const int pos = 32 * pt + 16 * ks + 8 * h + 4 * w2 + q4;
             const int i = pos / G, j = pos - i * G;
-            const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb + tx)) * CIN + 16 * fb + 4 * p4;
+            const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb)) * XRS + 16 * fb + 4 * p4;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) av[mt].s[w2] = tr_read(xr + 32 * mt);
-            const __bf16* dr = dimg + ((2 * i + pa) * OG + (2 * j + pb)) * COUT + 4 * p4;
+            for (int c = 0; c < 2; ++c)               // tx = c: the neighbouring column
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) av[c][mt].s[w2] = tr_read(xr + c * XRS + 32 * mt);
+            const __bf16* dr = dimg + ((2 * i + pa) * OG + (2 * j + pb)) * DRS + 4 * p4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt].s[w2] = tr_read(dr + ((COUT >= 32) ? (32 * nt + 16 * fb) : 0));
           }
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = mfma16(av[mt].v, bv[nt].v, acc[c][mt][nt]);
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = mfma16(av[c][mt].v, bv[nt].v, acc[c][mt][nt]);
         }
       }
     }
@@ -795,6 +812,27 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
 //                    (row stride 24 elements instead of 16) and the x operand from the staged zero-halo x image
 // bf16 dy / x / dx, COUT = 16.  Sums go to per-workgroup slabs (upconv_wgrad_reduce_kernel finishes them).
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build only (-DRCB_B3_STAMPS=1, tools/b3_stamps.py): cycles each wave of workgroup 0 spends per phase, summed
+// over its INRs: 0 first barrier, 1 staging, 2 second barrier, 3 data gradient (incl. prefetch issue), 4 weight gradient
+#ifndef RCB_B3_STAMPS
+#define RCB_B3_STAMPS 0
+#endif
+#ifndef RCB_B3_DIAG
+#define RCB_B3_DIAG 0      // ablations (wrong results): 1 no dx stores, 2 one fragment read per tap pair, 3 one dy read for all taps,
+                           // 4 dx stores land in the workgroup's first INR (L2-resident target)
+#endif
+#if RCB_B3_STAMPS
+__device__ unsigned long long g_b3_stamps[8 * 8];
+#define B3_T(k)                                                     \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    ph_[k] += now_ - last_;                                         \
+    last_ = now_;                                                   \
+  } while (0)
+#else
+#define B3_T(k) do { } while (0)
+#endif
+
 struct Bwd3Args {
   const void* dy;
   const float* weff;
@@ -811,7 +849,9 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* frags = reinterpret_cast<uint4*>(smem_raw);                              // [16 combos][2 mt][64 lanes]
   __bf16* dyimg = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);                // [34][34][24]
-  __bf16* ximg = dyimg + HO * HO * RS;                                            // [18][18][64]
+  __bf16* ximg = dyimg + HO * HO * RS;                                            // [18][18][XRS]
+  constexpr int SCR_RS = 40;                                                      // dx transposition tile: 80-byte rows
+  __bf16* dxscr = ximg + HG * HG * XRS;                                           // [8 waves][32][SCR_RS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
   const int fb = (lane >> 4) & 1, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
   for (int e = tid; e < NF * 64; e += 512) {
@@ -830,7 +870,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, ci, pa, pb, 8 * fh + j, COUT)];
     frags[e] = f.u;
   }
-  for (int e = tid; e < (HO * HO * RS + HG * HG * CIN) / 8; e += 512) reinterpret_cast<uint4*>(dyimg)[e] = make_uint4(0, 0, 0, 0);
+  for (int e = tid; e < (HO * HO * RS + HG * HG * XRS) / 8; e += 512) reinterpret_cast<uint4*>(dyimg)[e] = make_uint4(0, 0, 0, 0);
   f32x16 wacc[2][2];   // weight gradient: [combo slot][mt]
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -856,8 +896,12 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   __syncthreads();
   if (b < a.batch) RCB_FETCH_B3(b)
   const int u = (wave * 32 + q) >> 4, v = (wave * 32 + q) & 15;      // data gradient: this lane's output position
+#if RCB_B3_STAMPS
+  unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (; b < a.batch; b += gs) {
     __syncthreads();
+    B3_T(0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int e = tid + 512 * k;
@@ -871,10 +915,12 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
       }
       {   // x: pixel e >> 3, chunk e & 7
         const int pix = e >> 3, c8 = e & 7;
-        *reinterpret_cast<uint4*>(ximg + (((pix >> 4) + 1) * HG + ((pix & 15) + 1)) * CIN + 8 * c8) = px[k];
+        *reinterpret_cast<uint4*>(ximg + (((pix >> 4) + 1) * HG + ((pix & 15) + 1)) * XRS + 8 * c8) = px[k];
       }
     }
+    B3_T(1);
     __syncthreads();
+    B3_T(2);
     if (b + gs < a.batch) RCB_FETCH_B3(b + gs)
     // ---- data gradient --------------------------------------------------------------------------------------
     {
@@ -887,16 +933,21 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
       for (int n = 0; n < 16; ++n) {
         const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
         Frag bf;
-        bf.u = *reinterpret_cast<const uint4*>(dyimg + ((2 * u + ry + 1) * HO + (2 * v + rx + 1)) * RS + 8 * h);
+        bf.u = *reinterpret_cast<const uint4*>(dyimg + ((2 * u + ((RCB_B3_DIAG == 3) ? 0 : ry) + 1) * HO + (2 * v + ((RCB_B3_DIAG == 3) ? 0 : rx) + 1)) * RS + 8 * h);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           Frag fa;
-          fa.u = frags[(n * 2 + mt) * 64 + lane];
+          fa.u = frags[((RCB_B3_DIAG == 2 ? 0 : n) * 2 + mt) * 64 + lane];
           acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
         }
       }
-      const long long xpix = ((long long)b * G * G + wave * 32 + q) * CIN;
-      const __bf16* xs = ximg + ((u + 1) * HG + (v + 1)) * CIN;
+      // dx rows are 128 B per position; a lane holds 4 x 4 channels of each 32-channel half: stored from the registers that
+      // is eight 8-byte pieces per lane at 128-byte stride (measured: a quarter of the kernel's time).  Instead each half goes
+      // through a per-wave LDS tile [32 positions][32 channels] and leaves as 16-byte pieces, four consecutive lanes per
+      // position: 64 contiguous bytes per position and instruction.
+      const __bf16* xs = ximg + ((u + 1) * HG + (v + 1)) * XRS;
+      __bf16* scr = dxscr + wave * (32 * SCR_RS);
+      __bf16* dxw = reinterpret_cast<__bf16*>(a.dx) + ((long long)(RCB_B3_DIAG == 4 ? (int)blockIdx.x : b) * G * G + wave * 32) * CIN;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -906,37 +957,54 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
           bf16x4 ob;
 #pragma unroll
           for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)t[k] > 0.f ? 1.0f : SLOPE));
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
+          *reinterpret_cast<bf16x4*>(scr + q * SCR_RS + 8 * g4 + 4 * h) = ob;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int pl = 16 * ps + (lane >> 2), ch = lane & 3;
+          const uint4 o = *reinterpret_cast<const uint4*>(scr + pl * SCR_RS + 8 * ch);
+          if (RCB_B3_DIAG != 1 || a.batch < 0) *reinterpret_cast<uint4*>(dxw + pl * CIN + 32 * mt + 8 * ch) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
     // ---- weight gradient --------------------------------------------------------------------------------------
+    // 16 combos (phase p, tap t) over 8 waves: wave w takes t = 2 (w & 1) + c, c = 0 / 1, of phase p = w >> 1.  The dy operand
+    // depends on the phase only: one transposed read feeds both combos (10 reads per 4 MFMAs instead of 12)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int combo = 2 * wave + c;                 // 16 combos over 8 waves
-      const int p = combo >> 2, t = combo & 3;
-      const int pa = p >> 1, pb = p & 1, ty = t >> 1, tx = t & 1;
+    B3_T(3);
+    {
+      const int p = wave >> 1, pa = p >> 1, pb = p & 1, ty = wave & 1;
 #pragma unroll 2
       for (int pt = 0; pt < G * G / 32; ++pt) {       // partly unrolled: the prefetch registers must stay in registers
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          union { s16x4 s[2]; bf16x8 v; } av[2], bv;
+          union { s16x4 s[2]; bf16x8 v; } av[2][2], bv;
 #pragma unroll
           for (int w2 = 0; w2 < 2; ++w2) {
             const int pos = 32 * pt + 16 * ks + 8 * h + 4 * w2 + q4;
             const int i = pos >> 4, j = pos & 15;
-            const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb + tx)) * CIN + 16 * fb + 4 * p4;
+            const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb)) * XRS + 16 * fb + 4 * p4;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) av[mt].s[w2] = tr_read(xr + 32 * mt);
+            for (int c = 0; c < 2; ++c)               // tx = c: the neighbouring column
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) av[c][mt].s[w2] = tr_read(xr + c * XRS + 32 * mt);
             bv.s[w2] = tr_read(dyimg + ((2 * i + pa + 1) * HO + (2 * j + pb + 1)) * RS + 4 * p4);
           }
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) wacc[c][mt] = mfma16(av[mt].v, bv.v, wacc[c][mt]);
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) wacc[c][mt] = mfma16(av[c][mt].v, bv.v, wacc[c][mt]);
         }
       }
     }
+    B3_T(4);
   }
+#if RCB_B3_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_b3_stamps[wave * 8 + k] = ph_[k];
+#endif
 #undef RCB_FETCH_B3
   float* slab = a.partial + (long long)blockIdx.x * ROW;
   {   // bias gradient: per-thread channel partials through LDS (fixed order: deterministic)
@@ -970,6 +1038,14 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   }
 }
 
+#if RCB_B3_STAMPS
+}  // namespace
+extern "C" int rcb_debug_b3_stamps(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_b3_stamps), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
+
 // fixed-order sum of the workgroup slabs: out[j] = sum_w partial[w][j]
 __global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int row,
                                                                   int wsz, float* __restrict__ dweff,
@@ -999,13 +1075,20 @@ __global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* _
 }
 
 template <typename K, typename A>
-int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& /*unused: the attribute is set per launch*/) {
+int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& /*unused: the attribute is set per launch*/,
+           int threads = 512) {
   // (the attribute belongs to the (function, device) pair and a process may drive several devices: set it every time)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  kfn<<<grid, 512, smem, st>>>(args);
+  kfn<<<grid, threads, smem, st>>>(args);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
+}
+
+// two half-size workgroups per CU where the kernel has the variant and the batch fills them (RCB_UPCONV_HALF_WG=0: never)
+static bool half_wg(int batch) {
+  static const bool on = [] { const char* e = getenv("RCB_UPCONV_HALF_WG"); return !(e && e[0] == '0'); }();
+  return on && batch >= 512;
 }
 
 
@@ -1027,11 +1110,13 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 1) {
     static bool done = false;
-    return launch(upconv_fwd3_lds_kernel<16, 0>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
+    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 0, 4>, a, 512, 18 * 18 * 72 * 2, st, done, 256);
+    return launch(upconv_fwd3_lds_kernel<16, 0, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 2) {   // bf16 output, no activation
     static bool done = false;
-    return launch(upconv_fwd3_lds_kernel<16, 1>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
+    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 1, 4>, a, 512, 18 * 18 * 72 * 2, st, done, 256);
+    return launch(upconv_fwd3_lds_kernel<16, 1, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input
     static bool done = false;
@@ -1047,7 +1132,7 @@ extern "C" int32_t rcb_upconv_dgrad_partial_rows(int32_t batch) { return batch >
 
 template <int X_F32>
 static int launch_dgrad2(const DgradArgs& a, float* dbias_partial, hipStream_t st) {
-  constexpr int kSmem = ((18 * 18 * 72 * 2 + 15) / 16) * 16 + 4 * 16 * 64 * 4;
+  constexpr int kSmem = ((18 * (18 * 64 + 32) * 2 + 15) / 16) * 16 + 4 * 16 * 64 * 4;
   static bool done = false;
   auto kfn = upconv_dgrad2_reg_kernel<X_F32>;
   if (!done) {
@@ -1108,10 +1193,10 @@ extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const vo
     hit = true;                                                                              \
     rc = launch(upconv_wgrad_kernel<COUTv, Gv, XM, DF>, a, g, SMEM, st, done);               \
   }
-  RCB_WGRAD_CASE(grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32, 16, 16, 0, 1, (18 * 18 * 64 + 32 * 32 * 16) * 2)
-  RCB_WGRAD_CASE(grid == 16 && cout == 16 && !x_is_f32_preact && !dy_is_f32, 16, 16, 0, 0, (18 * 18 * 64 + 32 * 32 * 16) * 2)
-  RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 1 && !dy_is_f32, 64, 8, 1, 0, (10 * 10 * 64 + 16 * 16 * 64) * 2)
-  RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 2 && !dy_is_f32, 64, 8, 3, 0, (10 * 10 * 64 + 16 * 16 * 64) * 2)
+  RCB_WGRAD_CASE(grid == 16 && cout == 16 && !x_is_f32_preact && dy_is_f32, 16, 16, 0, 1, (18 * 18 * XRS + 32 * 32 * 16) * 2)
+  RCB_WGRAD_CASE(grid == 16 && cout == 16 && !x_is_f32_preact && !dy_is_f32, 16, 16, 0, 0, (18 * 18 * XRS + 32 * 32 * 16) * 2)
+  RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 1 && !dy_is_f32, 64, 8, 1, 0, (10 * 10 * XRS + 16 * 16 * XRS) * 2)
+  RCB_WGRAD_CASE(grid == 8 && cout == 64 && x_is_f32_preact == 2 && !dy_is_f32, 64, 8, 3, 0, (10 * 10 * XRS + 16 * 16 * XRS) * 2)
 #undef RCB_WGRAD_CASE
   if (!hit) return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
   if (rc) return rc;
@@ -1136,7 +1221,7 @@ extern "C" int rcb_upconv_bwd_fused(const void* dy, const float* weff, const voi
   hipStream_t st = (hipStream_t)stream;
   const int g = wgrad_blocks(batch);
   static bool done = false;
-  int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * 64) * 2, st, done);
+  int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * XRS) * 2 + 8 * 32 * 40 * 2, st, done);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
   upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
