@@ -26,6 +26,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int CIN = 64;
+#ifndef RCB_UP_NOSTORE
+#define RCB_UP_NOSTORE 0   // ablation builds (wrong results): 1 stage-2 forward, 2 stage-2 data gradient, 3 stage-3 forward without their stores
+#endif
 constexpr int XRS = 72;   // row stride (elements) of a staged 64-channel image: 144-byte rows spread 128-byte-strided
                           // gathers (consecutive positions, one channel chunk) over all LDS banks
 constexpr float SLOPE = 0.01f;
@@ -127,7 +130,7 @@ struct DgradArgs {
 template <int COUT, int OUT_BF16>
 __device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2][2][2][4], const FwdArgs& a, int b,
                                           int pa, int tp, int q, int h, const float (&bia)[8]) {
-  constexpr int G = 16, HG = 18, RS = 72;
+  constexpr int G = 16, HG = 18, RS = 64;
 #pragma unroll 1
   for (int tt = 0; tt < 2; ++tt) {     // tiles one after the other: two accumulator chains live, no spills
     const int pos = (2 * tp + tt) * 32 + q, i = pos >> 4, j = pos & 15;
@@ -136,15 +139,16 @@ __device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2
     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
-    const __bf16* base = img + ((i + pa) * HG + j) * RS + 8 * h;
+    const __bf16* base = img + ((i + pa) * HG + j) * RS;
 #pragma unroll
     for (int ty = 0; ty < 2; ++ty) {
 #pragma unroll
       for (int dxi = 0; dxi < 3; ++dxi) {
+        const int sw = ((j + dxi) >> 1) & 7;       // chunk swizzle of the image (see the kernel)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           Frag bf;
-          bf.u = *reinterpret_cast<const uint4*>(base + (ty * HG + dxi) * RS + 16 * kb);
+          bf.u = *reinterpret_cast<const uint4*>(base + (ty * HG + dxi) * RS + 8 * ((2 * kb + h) ^ sw));
           Frag fa;
           if (dxi <= 1) {
             fa.u = fr[0][ty][dxi][kb];
@@ -175,8 +179,10 @@ __device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2
         o1.v[k] = (__bf16)va[4 + k]; o1.v[4 + k] = (__bf16)vb[4 + k];
       }
       uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT);
-      dst[0] = o0.u;
-      dst[1] = o1.u;
+      if (RCB_UP_NOSTORE != 3 || a.batch < 0) {
+        dst[0] = o0.u;
+        dst[1] = o1.u;
+      }
     } else {
       float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT);
       dst[0] = make_float4(va[0], va[1], va[2], va[3]);
@@ -194,7 +200,13 @@ template <int COUT, int OUT_BF16, int NW>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArgs a) {
   static_assert(COUT == 16, "epilogue lane swap is written for 16 output channels");
   static_assert(NW == 8 || NW == 4, "8 or 4 waves");
-  constexpr int G = 16, HG = 18, RS = 72;   // image row stride in elements (64 channels + 8 pad = 144 B)
+  // image [18][18][64] in LDS, the 16-byte chunk c of pixel column x stored at c ^ ((x >> 1) & 7): the gathers of fwd3_body
+  // (lane = source position, consecutive pixels, one chunk per instruction) cover all 64 banks once per ds_read_b128 lane
+  // group (tools/lds_banks.py; 144-byte pixel rows without the swizzle cost 2 cycles per group).  Same-box A/B: 66.3 -> 63.7 us.
+  // The same treatment of the other kernels' images removed their conflicts too (SQ_LDS_BANK_CONFLICT 40-55 % -> 0-1 % of the
+  // LDS cycles) but not their time -- stage-2 forward 46.9 -> 48.0 us, stage-2 weight gradient 44.6 -> 47.8, stage-3 backward
+  // 117.0 -> 121.5: the XOR per read address costs them more than the conflicts did -- and was not kept there.
+  constexpr int G = 16, HG = 18, RS = 64;
   constexpr int NT = 64 * NW, NPRE = 2048 / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* img = reinterpret_cast<__bf16*>(smem_raw);
@@ -242,8 +254,8 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArg
     __syncthreads();          // everyone is done with the previous image (and with the halo setup)
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int e_ = tid + NT * k, pix_ = e_ >> 3, c8_ = e_ & 7;
-      *reinterpret_cast<uint4*>(img + (((pix_ >> 4) + 1) * HG + ((pix_ & 15) + 1)) * RS + 8 * c8_) = pre[k];
+      const int e_ = tid + NT * k, pix_ = e_ >> 3, c8_ = e_ & 7, x_ = (pix_ & 15) + 1;
+      *reinterpret_cast<uint4*>(img + (((pix_ >> 4) + 1) * HG + x_) * RS + 8 * (c8_ ^ ((x_ >> 1) & 7))) = pre[k];
     }
     __syncthreads();
     if (b + gs < a.batch) RCB_FETCH3(b + gs)
@@ -484,8 +496,10 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
             o1.v[k] = (__bf16)xa[4 + k]; o1.v[4 + k] = (__bf16)ya[4 + k];
           }
           uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + 32 * mt + 16 * h);
-          dst[0] = o0.u;
-          dst[1] = o1.u;
+          if (RCB_UP_NOSTORE != 1 || a.batch < 0) {
+            dst[0] = o0.u;
+            dst[1] = o1.u;
+          }
         }
       }
     }
@@ -631,7 +645,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
             oo.v[k] = (__bf16)(o[k] * ((float)xb[hf].v[k] > 0.f ? 1.0f : SLOPE));
             dbsum[8 * hf + k] += (float)oo.v[k];     // sums of the values as stored
           }
-          reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.dx) + xoff)[hf] = oo.u;
+          if (RCB_UP_NOSTORE != 2 || a.batch < 0) reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.dx) + xoff)[hf] = oo.u;
         }
       }
     }
@@ -1110,13 +1124,13 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 1) {
     static bool done = false;
-    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 0, 4>, a, 512, 18 * 18 * 72 * 2, st, done, 256);
-    return launch(upconv_fwd3_lds_kernel<16, 0, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
+    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 0, 4>, a, 512, 18 * 18 * 64 * 2, st, done, 256);
+    return launch(upconv_fwd3_lds_kernel<16, 0, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 64 * 2, st, done);
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 2) {   // bf16 output, no activation
     static bool done = false;
-    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 1, 4>, a, 512, 18 * 18 * 72 * 2, st, done, 256);
-    return launch(upconv_fwd3_lds_kernel<16, 1, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 72 * 2, st, done);
+    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 1, 4>, a, 512, 18 * 18 * 64 * 2, st, done, 256);
+    return launch(upconv_fwd3_lds_kernel<16, 1, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 64 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input
     static bool done = false;
