@@ -1147,13 +1147,10 @@ extern "C" int32_t rcb_upconv_dgrad_partial_rows(int32_t batch) { return batch >
 template <int X_F32>
 static int launch_dgrad2(const DgradArgs& a, float* dbias_partial, hipStream_t st) {
   constexpr int kSmem = ((18 * (18 * 64 + 32) * 2 + 15) / 16) * 16 + 4 * 16 * 64 * 4;
-  static bool done = false;
   auto kfn = upconv_dgrad2_reg_kernel<X_F32>;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    done = true;
-  }
+  // (per launch: the attribute belongs to the (function, device) pair)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return fail((int)e, "upconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
   kfn<<<dgrad_blocks(a.batch), 512, kSmem, st>>>(a, dbias_partial);
   RCB_LAUNCH_CHECK();
   return RCB_OK;

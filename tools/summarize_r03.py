@@ -24,7 +24,8 @@ DST = os.path.join(ROOT, "profiles")
 def counters(label, match):
     """per-dispatch counter values of the kernels whose name contains `match`, in dispatch order: {counter: [values]}"""
     out = collections.defaultdict(dict)
-    for f in glob.glob(os.path.join(SRC, label, "*", "*counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(SRC, label, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:           # gpurun merges into an existing directory: only the newest run of a label counts
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
                 d = out[r["Counter_Name"]]
