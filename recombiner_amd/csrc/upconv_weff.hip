@@ -150,6 +150,36 @@ __device__ __forceinline__ void grad_stage(const float* __restrict__ dweff, floa
 __global__ void __launch_bounds__(256) weff_grad_kernel(WeffGradArgs a) {
   const int blk = blockIdx.x, tid = threadIdx.x;
   if (blk < 800) {
+    if (a.bf16_in) {
+      // bf16 dWeff1: a thread takes EIGHT consecutive output channels of one (i, k, l): 16-byte loads, up to 64 in flight
+      // (blocks [0, 100) do the work of all 800; the others return).  Same terms in the same order as the scalar form.
+      if (blk >= 100) return;
+      const int e = blk * 256 + tid;                // < 128 * 25 * 8
+      const int o8 = e & 7, kl = (e >> 3) % 25, i = (e >> 3) / 25, k = kl / 5, l = kl % 5;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll 2
+      for (int y = 0; y < 8; ++y) {             // 16 loads of 16 bytes in flight per thread
+        const int u = y + k - 2;
+        const bool oky = u >= 0 && u < 8;
+        const int s = oky ? (u >> 2) : 0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const int v = x + l - 2;
+          const bool ok = oky && v >= 0 && v < 8;
+          const int t = ok ? (v >> 2) : 0;
+          const long long idx = ((long long)(s * 2 + t) * 128 + i) * 4096 + y * 512 + x * 64 + 8 * o8;
+          union { uint4 u4; __bf16 h[8]; } val;
+          val.u4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.dweff1) + idx);
+          if (!ok) val.u4 = zero;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)val.h[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a.dW1[((8 * o8 + j) * 128 + i) * 25 + kl] = acc[j];
+      return;
+    }
     const int e = blk * 256 + tid;                  // < 128 * 25 * 64
     const int o = e & 63, kl = (e >> 6) % 25, i = (e >> 6) / 25, k = kl / 5, l = kl % 5;
     // fixed-trip, branch-free: all (up to 64) loads of a thread are in flight together
@@ -165,8 +195,7 @@ __global__ void __launch_bounds__(256) weff_grad_kernel(WeffGradArgs a) {
         const bool ok = oky && v >= 0 && v < 8;
         const int t = ok ? (v >> 2) : 0;
         const long long idx = ((long long)(s * 2 + t) * 128 + i) * 4096 + y * 512 + x * 64 + o;
-        const float val = a.bf16_in ? (float)reinterpret_cast<const __bf16*>(a.dweff1)[idx]
-                                    : reinterpret_cast<const float*>(a.dweff1)[idx];
+        const float val = reinterpret_cast<const float*>(a.dweff1)[idx];
         acc += ok ? val : 0.f;
       }
     }
@@ -175,17 +204,24 @@ __global__ void __launch_bounds__(256) weff_grad_kernel(WeffGradArgs a) {
     grad_stage<64>(a.dweff2, a.dW2, blk - 800, tid);
   } else if (blk < 928) {
     grad_stage<16>(a.dweff3, a.dW3, blk - 864, tid);
-  } else {   // stage-1 bias gradient: fixed-order sum of the per-workgroup partials (4 row groups x 4 accumulators)
+  } else {   // stage-1 bias gradient: fixed-order sum of the per-workgroup partials (4 row groups x 16 accumulators:
+    //          this single block is the kernel's critical path, so its loads go out sixteen at a time)
     __shared__ float red[4][64];
     const int ch = tid & 63, part = tid >> 6;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int w = part;
-    for (; w + 12 < a.n_partial; w += 16) {
+    float acc[16];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += a.db1_partial[(w + 4 * k) * 64 + ch];
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    int w = part;
+    for (; w + 60 < a.n_partial; w += 64) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += a.db1_partial[(w + 4 * k) * 64 + ch];
     }
     for (; w < a.n_partial; w += 4) acc[0] += a.db1_partial[w * 64 + ch];
-    red[part][ch] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int st = 8; st > 0; st >>= 1)
+#pragma unroll
+      for (int k = 0; k < st; ++k) acc[k] += acc[k + st];
+    red[part][ch] = acc[0];
     __syncthreads();
     if (tid < 64) a.db1[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
