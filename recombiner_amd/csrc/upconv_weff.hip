@@ -66,17 +66,25 @@ __global__ void __launch_bounds__(256) weff_build_kernel(WeffArgs a) {
     const int i = blk >> 2, st = blk & 3, s = st >> 1, t = st & 1;
     for (int e = tid; e < 64 * 25; e += 256) w[e] = a.W1[((e / 25) * 128 + i) * 25 + e % 25];
     __syncthreads();
-    for (int rem = tid; rem < 4096; rem += 256) {
+    for (int rem = 2 * tid; rem < 4096; rem += 512) {         // two neighbouring output channels per thread: 4-byte bf16 stores
       const int y = rem >> 9, x = (rem >> 6) & 7, o = rem & 63;
       // taps whose source row y + k - 2 lies in rows [4s, 4s + 3] of the up-sampled grid (and likewise for columns)
       const int k0 = max(0, 4 * s + 2 - y), k1 = min(4, 4 * s + 5 - y);
       const int l0 = max(0, 4 * t + 2 - x), l1 = min(4, 4 * t + 5 - x);
-      float acc = 0.f;
+      float acc0 = 0.f, acc1 = 0.f;
       for (int k = k0; k <= k1; ++k)
-        for (int l = l0; l <= l1; ++l) acc += w[o * 25 + k * 5 + l];
+        for (int l = l0; l <= l1; ++l) {
+          acc0 += w[o * 25 + k * 5 + l];
+          acc1 += w[(o + 1) * 25 + k * 5 + l];
+        }
       const long long idx = ((long long)st * 128 + i) * 4096 + rem;
-      if (a.bf16_out) reinterpret_cast<__bf16*>(a.weff1)[idx] = (__bf16)acc;
-      else reinterpret_cast<float*>(a.weff1)[idx] = acc;
+      if (a.bf16_out) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 pr = {(__bf16)acc0, (__bf16)acc1};
+        *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(a.weff1) + idx) = pr;
+      } else {
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(a.weff1) + idx) = make_float2(acc0, acc1);
+      }
     }
   } else if (blk < 576) {
     build_stage<64>(a.W2, a.weff2, blk - 512, w, tid);
