@@ -239,10 +239,24 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
       long long r = (4 * i) / cols;
       int c = (int)(4 * i - r * cols);
       const float ov[4] = {o.x, o.y, o.z, o.w};
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      if (c + 3 < cols && (ld16 & 1) == 0) {                 // the four values stay in one row: 4-byte stores where aligned
+        __bf16* d = out16 + r * ld16 + c;
+        const bf16x2 p01 = {(__bf16)ov[0], (__bf16)ov[1]}, p12 = {(__bf16)ov[1], (__bf16)ov[2]}, p23 = {(__bf16)ov[2], (__bf16)ov[3]};
+        if ((c & 1) == 0) {
+          *reinterpret_cast<bf16x2*>(d) = p01;
+          *reinterpret_cast<bf16x2*>(d + 2) = p23;
+        } else {
+          d[0] = (__bf16)ov[0];
+          *reinterpret_cast<bf16x2*>(d + 1) = p12;
+          d[3] = (__bf16)ov[3];
+        }
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        out16[r * ld16 + c] = (__bf16)ov[k];
-        if (++c == cols) { c = 0; ++r; }
+        for (int k = 0; k < 4; ++k) {
+          out16[r * ld16 + c] = (__bf16)ov[k];
+          if (++c == cols) { c = 0; ++r; }
+        }
       }
     }
   }
