@@ -229,6 +229,19 @@ typedef struct {
                               update) are atomically added to the slots; their total is the KL           */
   const float* kl_scalar_dev; /* nullable device scalar: the KL weight becomes kl_scalar * (*kl_scalar_dev), so a
                               captured graph can be replayed with a new beta (main_prior_training.py:144-154) */
+  /* Optional (plain levels on the flat path only; next_out == NULL: off): the NEXT step's reparameterised sample drawn in
+   * the same pass from the parameters just updated -- what rcb_reparam_rng_fwd would compute at step counter
+   * *rng_step_dev + rng_step_add, bit for bit -- so that the sampling kernel of the next step (a second read of loc and
+   * log_scale) disappears.  next_eps may alias eps: every element is read before it is written. */
+  float* next_out;         /* [rows * cols] fp32 sample                                                          */
+  float* next_eps;         /* [rows * cols] the noise of that sample (read by the next step's call as `eps`)     */
+  void* next_out_bf16;     /* nullable: bf16 copy of next_out as [rows][next_ld_bf16]                            */
+  int64_t next_ld_bf16;
+  uint64_t rng_seed;
+  const int64_t* rng_step_dev;
+  int64_t rng_step_add;
+  uint32_t rng_stream;
+  uint32_t reserved0;
 } rcb_level_bwd;
 
 int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream);

@@ -67,7 +67,10 @@ class LevelBwd(C.Structure):
                 ("member_idx", C.c_void_p), ("row_perm_inv", C.c_void_p), ("col_inv", C.c_void_p),
                 ("rows", C.c_int32), ("cols", C.c_int32), ("cols_out", C.c_int32), ("samples", C.c_int32),
                 ("g_loc", C.c_void_p), ("g_log_scale", C.c_void_p), ("m_loc", C.c_void_p), ("v_loc", C.c_void_p),
-                ("m_ls", C.c_void_p), ("v_ls", C.c_void_p), ("kl_accum", C.c_void_p), ("kl_scalar_dev", C.c_void_p)]
+                ("m_ls", C.c_void_p), ("v_ls", C.c_void_p), ("kl_accum", C.c_void_p), ("kl_scalar_dev", C.c_void_p),
+                ("next_out", C.c_void_p), ("next_eps", C.c_void_p), ("next_out_bf16", C.c_void_p),
+                ("next_ld_bf16", C.c_int64), ("rng_seed", C.c_uint64), ("rng_step_dev", C.c_void_p),
+                ("rng_step_add", C.c_int64), ("rng_stream", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 _lib = None

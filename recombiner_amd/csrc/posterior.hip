@@ -211,6 +211,33 @@ __global__ void __launch_bounds__(256) philox_normal_kernel(float* __restrict__ 
   }
 }
 
+// four consecutive flat elements `first .. first + 3` of a [rows][cols] array as bf16 into [rows][ld16]: 4-byte stores where
+// the four stay in one row and are aligned
+__device__ __forceinline__ void store_bf16_row4(__bf16* __restrict__ out16, long long first, int cols, long long ld16, float4 o) {
+  long long r = first / cols;
+  int c = (int)(first - r * cols);
+  const float ov[4] = {o.x, o.y, o.z, o.w};
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  if (c + 3 < cols && (ld16 & 1) == 0) {
+    __bf16* d = out16 + r * ld16 + c;
+    const bf16x2 p01 = {(__bf16)ov[0], (__bf16)ov[1]}, p12 = {(__bf16)ov[1], (__bf16)ov[2]}, p23 = {(__bf16)ov[2], (__bf16)ov[3]};
+    if ((c & 1) == 0) {
+      *reinterpret_cast<bf16x2*>(d) = p01;
+      *reinterpret_cast<bf16x2*>(d + 2) = p23;
+    } else {
+      d[0] = (__bf16)ov[0];
+      *reinterpret_cast<bf16x2*>(d + 1) = p12;
+      d[3] = (__bf16)ov[3];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      out16[r * ld16 + c] = (__bf16)ov[k];
+      if (++c == cols) { c = 0; ++r; }
+    }
+  }
+}
+
 // reparameterised sample with the noise drawn in the kernel: out = loc + st(log_scale) * eps, eps written once for the
 // posterior update.  Replaces torch.randn + the flat reparam kernel (the generated values never make a round trip
 // through HBM before their first use); same arithmetic as reparam_flat_kernel on the same eps.
@@ -235,30 +262,7 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
     o.w = add_rn(m.w, mul_rn(st_f32(l.w), e.w));
     reinterpret_cast<float4*>(eps_out)[i] = e;
     reinterpret_cast<float4*>(out)[i] = o;
-    if (out16) {
-      long long r = (4 * i) / cols;
-      int c = (int)(4 * i - r * cols);
-      const float ov[4] = {o.x, o.y, o.z, o.w};
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      if (c + 3 < cols && (ld16 & 1) == 0) {                 // the four values stay in one row: 4-byte stores where aligned
-        __bf16* d = out16 + r * ld16 + c;
-        const bf16x2 p01 = {(__bf16)ov[0], (__bf16)ov[1]}, p12 = {(__bf16)ov[1], (__bf16)ov[2]}, p23 = {(__bf16)ov[2], (__bf16)ov[3]};
-        if ((c & 1) == 0) {
-          *reinterpret_cast<bf16x2*>(d) = p01;
-          *reinterpret_cast<bf16x2*>(d + 2) = p23;
-        } else {
-          d[0] = (__bf16)ov[0];
-          *reinterpret_cast<bf16x2*>(d + 1) = p12;
-          d[3] = (__bf16)ov[3];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          out16[r * ld16 + c] = (__bf16)ov[k];
-          if (++c == cols) { c = 0; ++r; }
-        }
-      }
-    }
+    if (out16) store_bf16_row4(out16, 4 * i, cols, ld16, o);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 3)) {      // tail group
     const float4 e = philox_normal4((unsigned long long)n4, stream, step, seed);
@@ -757,6 +761,20 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   reinterpret_cast<float4*>(L.v_loc + b)[0] = v14;
   reinterpret_cast<float4*>(L.m_ls + b)[0] = m24;
   reinterpret_cast<float4*>(L.v_ls + b)[0] = v24;
+  if (L.next_out) {
+    // the next step's sample from the updated parameters: the arithmetic of reparam_rng_kernel on Philox group i4 at the
+    // step counter the next step will see
+    const unsigned long long step = (unsigned long long)(*L.rng_step_dev + L.rng_step_add);
+    const float4 e = philox_normal4((unsigned long long)i4, L.rng_stream, step, L.rng_seed);
+    float4 o;
+    o.x = add_rn(loc4.x, mul_rn(st_f32(ls4.x), e.x));
+    o.y = add_rn(loc4.y, mul_rn(st_f32(ls4.y), e.y));
+    o.z = add_rn(loc4.z, mul_rn(st_f32(ls4.z), e.z));
+    o.w = add_rn(loc4.w, mul_rn(st_f32(ls4.w), e.w));
+    reinterpret_cast<float4*>(L.next_eps + b)[0] = e;
+    reinterpret_cast<float4*>(L.next_out + b)[0] = o;
+    if (L.next_out_bf16) store_bf16_row4(reinterpret_cast<__bf16*>(L.next_out_bf16), b, L.cols, L.next_ld_bf16, o);
+  }
 }
 
 extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream) {
@@ -769,6 +787,8 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
   RCB_REQUIRE(adam || (lv->g_loc && lv->g_log_scale), RCB_ERR_ARG, "posterior_bwd: neither adam nor grad outputs");
   RCB_REQUIRE(!adam || (lv->m_loc && lv->v_loc && lv->m_ls && lv->v_ls && adam->step >= 1), RCB_ERR_ARG,
               "posterior_bwd: adam state missing");
+  RCB_REQUIRE(!lv->next_out || (!lv->col_inv && adam), RCB_ERR_UNSUPPORTED,
+              "posterior_bwd: the fused next sample needs the plain (flat) case with Adam");
   PostBwdArgs a;
   a.L = *lv;
   a.adam = make_adam(adam);
@@ -789,11 +809,15 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
         !lv->row_perm_inv && !lv->col_inv && !lv->g_loc && !lv->g_log_scale && (n_total & 3) == 0 && al16(lv->loc) &&
         al16(lv->log_scale) && al16(lv->d_out) && al16(lv->eps) && al16(lv->m_loc) && al16(lv->v_loc) && al16(lv->m_ls) &&
         al16(lv->v_ls)) {
+      RCB_REQUIRE(!lv->next_out || (lv->next_eps && lv->rng_step_dev && al16(lv->next_out) && al16(lv->next_eps) &&
+                                    (!lv->next_out_bf16 || lv->next_ld_bf16 >= lv->cols)),
+                  RCB_ERR_ARG, "posterior_bwd: next sample: null pointer, alignment or bf16 row stride");
       posterior_flat_kernel<<<cdiv(n_total >> 2, 256), 256, 0, (hipStream_t)stream>>>(a, n_total);
       RCB_LAUNCH_CHECK();
       return RCB_OK;
     }
   }
+  RCB_REQUIRE(!lv->next_out, RCB_ERR_UNSUPPORTED, "posterior_bwd: the fused next sample needs the plain (flat) case");
   dim3 grid(lv->rows, cdiv(lv->cols, 256));
   posterior_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   RCB_LAUNCH_CHECK();

@@ -346,17 +346,39 @@ def rng_eligible(lv: LevelSpec):
             and lv.cols_out == lv.cols and lv.n_inr == lv.rows and lv.loc.is_contiguous() and lv.log_scale.is_contiguous())
 
 
-def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False):
-    """-> (out [n, 1, cols], eps [n, 1, cols]): reparameterised sample with the noise drawn inside the kernel
-    (rcb_reparam_rng_fwd).  `step` is the device-resident int64 step counter.  want_bf16: third result, a bf16 copy of
-    out as [n, cols] with a row stride that is a multiple of 8 (operand of the A transform's weight-gradient GEMM)."""
-    lib = _lib.load()
-    if not rng_eligible(lv):
-        raise RcbError("reparam_rng: plain levels only")
+def sample_buffers(lv: LevelSpec, want_bf16=False):
+    """(out [n, 1, cols], eps [n, 1, cols], bf16 copy [n, ld16] or None): the buffers of one level's sample, for callers
+    that keep them across steps (PriorBNNmodel.train: the posterior update of step t writes the sample of step t + 1)"""
     n, cols = lv.rows, lv.cols
     out = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
     eps = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
     o16 = torch.empty(n, (cols + 7) // 8 * 8, device=lv.loc.device, dtype=bf16) if want_bf16 else None
+    return out, eps, o16
+
+
+class NextSample:
+    """argument of posterior_bwd(next_sample=): draw the next step's sample in the same pass (rcb_level_bwd.next_*) into
+    the buffers of sample_buffers(); step = the device step counter, the sample is that of counter + step_add"""
+
+    def __init__(self, buffers, seed: int, rng_stream: int, step, step_add=1):
+        self.out, self.eps, self.o16 = buffers
+        self.seed, self.rng_stream, self.step, self.step_add = seed, rng_stream, step, step_add
+
+
+def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False, buffers=None):
+    """-> (out [n, 1, cols], eps [n, 1, cols]): reparameterised sample with the noise drawn inside the kernel
+    (rcb_reparam_rng_fwd).  `step` is the device-resident int64 step counter.  want_bf16: third result, a bf16 copy of
+    out as [n, cols] with a row stride that is a multiple of 8 (operand of the A transform's weight-gradient GEMM).
+    buffers: write into the tensors of sample_buffers() instead of new ones."""
+    lib = _lib.load()
+    if not rng_eligible(lv):
+        raise RcbError("reparam_rng: plain levels only")
+    n, cols = lv.rows, lv.cols
+    out, eps, o16 = buffers if buffers is not None else sample_buffers(lv, want_bf16)
+    if want_bf16 and o16 is None:
+        raise RcbError("reparam_rng: the buffers have no bf16 copy")
+    if not want_bf16:
+        o16 = None
     check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
                                   C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64), ptr(eps),
                                   ptr(out), ptr(o16, bf16, True), int(cols), C.c_int64(0 if o16 is None else o16.stride(0)),
@@ -377,8 +399,9 @@ def philox_normal(n, seed: int, rng_stream: int, step, device="cuda"):
 
 def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: float, d_out, eps, samples: int,
                   beta=None, group_idx=None, n_groups=0, adam: Optional[AdamCfg] = None, state=None,
-                  want_grads=False, kl_accum=None, kl_scalar_dev=None):
-    """Fused gradient gather + KL gradient (+ Adam).  Returns (g_loc, g_log_scale) when requested."""
+                  want_grads=False, kl_accum=None, kl_scalar_dev=None, next_sample: Optional["NextSample"] = None):
+    """Fused gradient gather + KL gradient (+ Adam).  Returns (g_loc, g_log_scale) when requested.
+    next_sample (plain levels with Adam): also draw the next step's sample from the updated parameters."""
     lib = _lib.load()
     g_loc = g_ls = None
     if want_grads:
@@ -394,6 +417,17 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  lv.cols_out, int(samples), addr(g_loc, f32), addr(g_ls, f32), addr(s.get("m_loc"), f32),
                  addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, torch.int64),
                  addr(kl_scalar_dev, f32))
+    if next_sample is not None:
+        ns = next_sample
+        if tuple(ns.out.shape) != (lv.rows, 1, lv.cols) or tuple(ns.eps.shape) != (lv.rows, 1, lv.cols):
+            raise RcbError("posterior_bwd: next-sample buffers do not match the level")
+        b.next_out, b.next_eps = addr(ns.out, f32), addr(ns.eps, f32)
+        b.next_out_bf16 = addr(ns.o16, bf16)
+        b.next_ld_bf16 = 0 if ns.o16 is None else int(ns.o16.stride(0))
+        b.rng_seed = ns.seed & (2 ** 64 - 1)
+        b.rng_step_dev = addr(ns.step, torch.int64)
+        b.rng_step_add = int(ns.step_add)
+        b.rng_stream = int(ns.rng_stream)
     if d_out is not None and tuple(d_out.shape) != (lv.n_inr, samples, lv.cols_out):
         raise RcbError(f"d_out must be [{lv.n_inr},{samples},{lv.cols_out}], got {tuple(d_out.shape)}")
     check(lib.rcb_posterior_bwd(C.byref(b), C.byref(adam) if adam is not None else None, stream_ptr()),

@@ -9,6 +9,8 @@ backward -> upsampling-net backward -> fused reparam-bwd + KL-bwd + Adam (K1'/K5
 `forward()` / `calculate_kl()` stay autograd-capable through custom Functions so user code written
 against the reference API keeps working.  There is no CPU fallback.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -121,6 +123,9 @@ class PriorBNNmodel(nn.Module):
         self.split_dgrad_terms = None  # with split_gemm: terms of the data-gradient GEMM (None = split_terms)
         self.wgrad_bf16 = True       # with split_gemm: bf16 high parts for the A weight-gradient GEMMs (sum over INRs)
         self.fused_noise = True      # draw eps inside the reparam kernel (Philox) when no noise_source is injected
+        # with fused_noise: the posterior update of step t also draws the sample of step t + 1 (rcb_level_bwd.next_*), so
+        # the sampling kernels -- a second read of every loc / log_scale -- run once per train() call instead of once per step
+        self.fuse_next_sample = os.environ.get("RCB_FUSE_NEXT", "1") != "0"      # (the switch is for same-box A/B runs)
         self._train_calls = 0
         self._ws = None              # persistent training workspace (captured graphs + everything they reference)
         self._rng_ctr_init = 0       # first value of the noise counter of a new workspace (tests build exact twins)
@@ -271,7 +276,7 @@ class PriorBNNmodel(nn.Module):
         graphable = bool(self.use_graph and self.noise_source is None and dev.type == "cuda" and not verbose)
         key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
-               self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.patch,
+               self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
                # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
@@ -342,59 +347,95 @@ class PriorBNNmodel(nn.Module):
                    and ops.rng_eligible(lpe_lv))
         rng_seed = ws["seed"]
 
+        want16 = split is not None and training_mappings and self.wgrad_bf16     # bf16 operands of the weight gradient
+        lpe16_want = bool(use_rng and self.stage1_bf16 and self.precision != 0 and not self.patch)
+        # (the fused form lives on the posterior update's flat path: element counts divisible by 4)
+        fuse_next = bool(use_rng and self.fuse_next_sample and (N * D) % 4 == 0 and (N * self._d_lpe) % 4 == 0)
+        smp_net = smp_lpe = None
+        if fuse_next:
+            if "smp_net" not in ws:
+                ws["smp_net"] = ops.sample_buffers(net[0], True)
+                ws["smp_lpe"] = ops.sample_buffers(lpe_lv, True)
+            smp_net, smp_lpe = ws["smp_net"], ws["smp_lpe"]
+
+        def prime():
+            """the sample of the call's first step (every later one comes out of the previous step's posterior update)"""
+            ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=want16, buffers=smp_net)
+            ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe)
+
         pe_lay = self._pe_layout()
         if split is not None and not training_mappings:
             split.prepare(A)                          # fixed mappings: packed once per call, outside the captured step
 
         def seg1a():
             ops.step_begin(tab, step_t, dyn, kl_slots)
-            # ---- sample ---------------------------------------------------------------------------------
-            lpe16 = None
-            if use_rng and self.stage1_bf16 and self.precision != 0 and not self.patch:
-                lpe, e_lpe, lpe16 = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=True)   # bf16 copy: stage-1 operand
-            elif use_rng:
-                lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr)
-            else:
-                e_lpe = self._noise((N, 1, self._d_lpe))
-                lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
-            lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
-            with torch.enable_grad():
-                if pe_lay is not None:                                   # stitched grids, addressed in place by the kernel
-                    pe_c = self._pe(upsample_net, lpe_t, stitched=True)
+            # ---- sample + the two forward maps.  With the fused next sample h_w was written by the previous step's posterior
+            # update (the step's LAST big kernel, see body()): its A transform goes first, while h_w is still in the Infinity Cache
+            # (measured: read cold, half a step later, the forward A transform takes 10 us longer)
+            def pe_forward():
+                # ---- sample ---------------------------------------------------------------------------------
+                lpe16 = None
+                if fuse_next:                # written by the previous step's posterior update (or by prime() before the first)
+                    lpe, e_lpe, lpe16 = smp_lpe[0], smp_lpe[1], (smp_lpe[2][:, :lpe_lv.cols] if lpe16_want else None)
+                elif use_rng and lpe16_want:
+                    lpe, e_lpe, lpe16 = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=True)   # bf16 copy: stage-1 operand
+                elif use_rng:
+                    lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr)
                 else:
-                    pe = self._pe(upsample_net, lpe_t, lpe16=lpe16)      # [N, 1, P, E]
-                    pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
-                    #                                                               materialises zeros + a copy)
-            h16 = None
-            want16 = split is not None and training_mappings and self.wgrad_bf16     # bf16 operands of the weight gradient
-            if use_rng:
-                if want16:
-                    h_w, e0, h16 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=True)
+                    e_lpe = self._noise((N, 1, self._d_lpe))
+                    lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
+                lpe_t = lpe.view(1, N, *self._lat, self.latent_dim).requires_grad_(True)
+                with torch.enable_grad():
+                    if pe_lay is not None:                                   # stitched grids, addressed in place by the kernel
+                        pe_c = self._pe(upsample_net, lpe_t, stitched=True)
+                    else:
+                        pe = self._pe(upsample_net, lpe_t, lpe16=lpe16)      # [N, 1, P, E]
+                        pe_c = pe.reshape(N, pe.shape[2], pe.shape[3]).contiguous()   # (not pe[:, 0]: select's backward
+                        #                                                               materialises zeros + a copy)
+                return lpe_t, e_lpe, pe_c
+
+            def net_forward():
+                h16 = None
+                if fuse_next:
+                    h_w, e0, h16 = smp_net[0], smp_net[1], (smp_net[2][:, :D] if want16 else None)
+                    eps, h_w = [e0], h_w.view(N, D)
+                elif use_rng:
+                    if want16:
+                        h_w, e0, h16 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=True)
+                    else:
+                        h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
+                    eps, h_w = [e0], h_w.view(N, D)
                 else:
-                    h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
-                eps, h_w = [e0], h_w.view(N, D)
+                    eps = [self._noise((N, 1, D)) for _ in net]
+                    h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
+                # ---- A transform (dense GEMMs) --------------------------------------------------------------
+                lowp = self.lowp_gemm and self.precision != 0
+                if lowp:
+                    # forward: f16 operands (11-bit mantissa; A pre-scaled by 2^10 so that the ~1e-4 products of
+                    # h_w @ A stay in f16's normal range) -- finer than the bf16 rounding the MLP kernel applies to
+                    # its weights anyway; backward GEMMs: bf16 operands (range-safe, gradients only)
+                    hf = h_w.to(torch.float16)
+                    wvec = torch.cat([torch.mm(hf[:, lo:hi], (a.detach() * 1024.0).to(torch.float16))
+                                      for (lo, hi), a in zip(slices, A)], 1).float() * (1.0 / 1024.0)
+                    h16 = h_w.to(torch.bfloat16)
+                    A16 = [a.detach().to(torch.bfloat16) for a in A]
+                elif split is not None:
+                    if training_mappings:
+                        split.prepare(A)                  # the mappings change every step when they are trained
+                    wvec = split.forward(h_w, split.new_rows(N))
+                else:
+                    wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
+                    for (lo, hi), a in zip(slices, A):
+                        torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
+                return h_w, h16, eps, wvec, (A16 if lowp else None)
+
+            if fuse_next:
+                h_w, h16, eps, wvec, A16 = net_forward()
+                lpe_t, e_lpe, pe_c = pe_forward()
             else:
-                eps = [self._noise((N, 1, D)) for _ in net]
-                h_w = ops.reparam_fwd(net, eps, 1).view(N, D)
-            # ---- A transform (dense GEMMs) --------------------------------------------------------------
+                lpe_t, e_lpe, pe_c = pe_forward()
+                h_w, h16, eps, wvec, A16 = net_forward()
             lowp = self.lowp_gemm and self.precision != 0
-            if lowp:
-                # forward: f16 operands (11-bit mantissa; A pre-scaled by 2^10 so that the ~1e-4 products of
-                # h_w @ A stay in f16's normal range) -- finer than the bf16 rounding the MLP kernel applies to
-                # its weights anyway; backward GEMMs: bf16 operands (range-safe, gradients only)
-                hf = h_w.to(torch.float16)
-                wvec = torch.cat([torch.mm(hf[:, lo:hi], (a.detach() * 1024.0).to(torch.float16))
-                                  for (lo, hi), a in zip(slices, A)], 1).float() * (1.0 / 1024.0)
-                h16 = h_w.to(torch.bfloat16)
-                A16 = [a.detach().to(torch.bfloat16) for a in A]
-            elif split is not None:
-                if training_mappings:
-                    split.prepare(A)                  # the mappings change every step when they are trained
-                wvec = split.forward(h_w, split.new_rows(N))
-            else:
-                wvec = torch.empty(N, D, device=dev, dtype=torch.float32)
-                for (lo, hi), a in zip(slices, A):
-                    torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
             dw16 = None
@@ -460,21 +501,50 @@ class PriorBNNmodel(nn.Module):
             buf = flat[:n_a] if part == 0 else flat[n_a:]
             return torch.distributed.all_reduce(buf, group=self.dp_group, async_op=True)
 
-        def seg2():
+        def seg2_net():
             # fused posterior update (also accumulates the pre-update KL for the ELBO log)
+            nxt_net = None
+            if fuse_next:            # the next step sees the noise counter + 1 (rcb_step_end increments it after this segment)
+                nxt_net = ops.NextSample((smp_net[0], smp_net[1], smp_net[2] if want16 else None), rng_seed, 0, rng_ctr, 1)
             for lv, (pl, ps), e, stt in zip(net, net_priors, st["eps"], net_state):
                 ops.posterior_bwd(lv, pl, ps, False, 1.0, st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots,
-                                  kl_scalar_dev=beta_dev)
-            ops.posterior_bwd(lpe_lv, pri_d[2].reshape(-1), pri_d[3].reshape(-1), False, 1.0, st["d_lpe"],
-                              st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots, kl_scalar_dev=beta_dev)
+                                  kl_scalar_dev=beta_dev, next_sample=nxt_net)
 
-        def seg3():
+        def seg2_lpe():
+            nxt_lpe = None
+            if fuse_next:
+                nxt_lpe = ops.NextSample((smp_lpe[0], smp_lpe[1], smp_lpe[2] if lpe16_want else None), rng_seed, 1, rng_ctr, 1)
+            ops.posterior_bwd(lpe_lv, pri_d[2].reshape(-1), pri_d[3].reshape(-1), False, 1.0, st["d_lpe"],
+                              st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots, kl_scalar_dev=beta_dev,
+                              next_sample=nxt_lpe)
+
+        def seg2():
+            seg2_net()
+            seg2_lpe()
+
+        def seg3_adam():
             if training_mappings:
                 ops.adam_multi([p.data for p in A + conv], [g.contiguous() for g in st["grads"]],
                                [m for m, _ in map_state], [v for _, v in map_state], cfg)
+
+        def seg3_end():
             ops.step_end(step_t, st["sse"], 1.0 / (P * Cc), kl_slots, mse_buf, kl_buf, aux_counter=rng_ctr)
 
+        def seg3():
+            seg3_adam()
+            seg3_end()
+
         def body():
+            if fuse_next and flat is None:
+                # one rank: the network level's update -- which writes the next step's h_w -- is the step's last big kernel, so
+                # that the next step's A transform (its first) finds h_w in the Infinity Cache
+                seg1a()
+                seg1b()
+                seg2_lpe()
+                seg3_adam()
+                seg2_net()
+                seg3_end()
+                return
             seg1a()
             w0 = comm(0)
             seg1b()
@@ -502,6 +572,8 @@ class PriorBNNmodel(nn.Module):
                     w1.wait()
                     gr[3].replay()
 
+        if fuse_next:
+            prime()
         if graphable and (ws["graphs"] is not None or n_epoch > n_warm):
             left = n_epoch
             failure = None

@@ -997,3 +997,42 @@ def test_rec_rejects_bad_jobs_on_the_device_and_refuses_inexact_tables():
     assert int((sample != 0).sum()) == 3 and int((sample[0, :3] != 0).sum()) == 3
     with pytest.raises(ops.RcbError):                                          # host job lists are validated on the host
         ops.rec_score_argmax(g(loc), g(scale), g(pl), g(ps), tabs, gum, [9], [0], [3])
+
+
+def test_posterior_update_draws_the_next_sample_bit_for_bit():
+    """rcb_level_bwd.next_*: the posterior update's fused sample of the next step equals rcb_reparam_rng_fwd run afterwards
+    at step counter + 1 on the updated parameters (sample, noise and bf16 copy), and the update itself is unchanged."""
+    torch.manual_seed(5)
+    rows, cols = 8, 3267
+    def level():
+        loc = (torch.randn(rows, cols) * 0.05).to(DEV)
+        ls = (torch.randn(rows, cols) * 0.3 - 4).to(DEV)
+        return ops.LevelSpec(loc, ls, cols, rows)
+    torch.manual_seed(6)
+    lv_a = level()
+    lv_b = ops.LevelSpec(lv_a.loc.clone(), lv_a.log_scale.clone(), cols, rows)
+    p_loc, p_scale = torch.zeros(cols, device=DEV), torch.full((cols,), 0.02, device=DEV)
+    d = (torch.randn(rows, 1, cols) * 1e-3).to(DEV)
+    step = torch.tensor([41], device=DEV, dtype=torch.int64)
+    seed = 0x1234567890ABCDEF
+    cfg = ops.adam_cfg(2e-4, 3)
+    def state(lv):
+        return {k: torch.zeros_like(lv.loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+    # a: update, then the stand-alone sampling kernel at step 42
+    _, eps_a = ops.reparam_rng(lv_a, seed, 0, step)[:2]
+    ops.posterior_bwd(lv_a, p_loc, p_scale, False, 1.0, d, eps_a, 1, adam=cfg, state=state(lv_a))
+    step42 = step + 1
+    out_a, eps_a2, o16_a = ops.reparam_rng(lv_a, seed, 0, step42, want_bf16=True)
+    # b: update with the fused next sample
+    buf = ops.sample_buffers(lv_b, True)
+    ops.reparam_rng(lv_b, seed, 0, step, want_bf16=True, buffers=buf)
+    ops.posterior_bwd(lv_b, p_loc, p_scale, False, 1.0, d, buf[1], 1, adam=cfg, state=state(lv_b),
+                      next_sample=ops.NextSample(buf, seed, 0, step, 1))
+    assert torch.equal(lv_a.loc, lv_b.loc) and torch.equal(lv_a.log_scale, lv_b.log_scale)
+    assert torch.equal(out_a, buf[0]) and torch.equal(eps_a2, buf[1]) and torch.equal(o16_a, buf[2][:, :cols])
+    # levels that do not take the flat path refuse
+    lv_c = ops.LevelSpec(lv_a.loc[:3].contiguous(), lv_a.log_scale[:3].contiguous(), cols, 3)     # 3 * 3267 is odd
+    bc = ops.sample_buffers(lv_c, False)
+    with pytest.raises(ops.RcbError):
+        ops.posterior_bwd(lv_c, p_loc, p_scale, False, 1.0, d[:3].contiguous(), bc[1], 1, adam=cfg, state=state(lv_c),
+                          next_sample=ops.NextSample(bc, seed, 0, step, 1))

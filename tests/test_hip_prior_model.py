@@ -451,3 +451,34 @@ def test_odd_batch_sizes_in_the_throughput_mode(n):
     m.noise_source = None
     _, _, e2 = m.train(8, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *pri, lt, up, 1e-8, training_mappings=True)
     assert np.isfinite(e2).all()
+
+
+def test_fused_next_sample_equals_separate_sampling_kernels():
+    """PriorBNNmodel.fuse_next_sample: drawing step t + 1's sample inside step t's posterior update gives bitwise the same
+    training as the per-step sampling kernels (same Philox counters, same arithmetic), eager and replayed."""
+    from recombiner_amd import config, utils
+    cfg = config.configs["cifar"]
+    n = 8
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3, seed=2)
+    Xd, Yd = X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV)      # kept alive: the workspace (noise counter, seed) is keyed on them
+    outs = []
+    for fuse in (True, False):
+        torch.manual_seed(77)                      # (the in-kernel noise seed takes torch.initial_seed() in)
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device=DEV)
+        m.precision = 1
+        m.fuse_next_sample = fuse
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(m.dims).to(DEV)
+        torch.manual_seed(124)
+        up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+        D, s0 = m._d_net, 0.0211547
+        pri = [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV), torch.zeros(2, 2, 128, device=DEV),
+               torch.full((2, 2, 128), s0, device=DEV)] + [None] * 4
+        elbos = []
+        for n_steps in (2, 7):                     # an eager call, then a call long enough to capture and replay
+            elbos += m.train(n_steps, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)[2]
+        outs.append([torch.tensor(elbos), m.loc.detach().clone(), m.lpe_loc.detach().clone(), m.log_scale.detach().clone()] +
+                    [p.detach().clone() for p in lt.parameters()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
