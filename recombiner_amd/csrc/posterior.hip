@@ -717,12 +717,29 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   const long long base = i4 * 4;
   const bool act = base < n_total;                                             // n_total % 4 == 0 on this path
   const long long b = act ? base : 0;
-  float4 loc4 = reinterpret_cast<const float4*>(L.loc + b)[0];
-  float4 ls4 = reinterpret_cast<const float4*>(L.log_scale + b)[0];
-  const float4 go4 = reinterpret_cast<const float4*>(L.d_out + b)[0];
-  const float4 ep4 = reinterpret_cast<const float4*>(L.eps + b)[0];
-  float4 m14 = reinterpret_cast<const float4*>(L.m_loc + b)[0], v14 = reinterpret_cast<const float4*>(L.v_loc + b)[0];
-  float4 m24 = reinterpret_cast<const float4*>(L.m_ls + b)[0], v24 = reinterpret_cast<const float4*>(L.v_ls + b)[0];
+  // streaming accesses: everything here is read once and written once per step (900 MB against 256 MB of Infinity Cache).
+  // Non-temporal loads / stores took the kernel from 93.6 to 86.3 us per launch (same box) and leave the sample written at
+  // the end -- the next step's first operand -- a better chance to stay cached (with loc / log_scale non-temporal as well the
+  // next step's A transform took 85.4 instead of 89.4 us).
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  auto nt_ld = [](const float* p) {
+    const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
+  auto nt_st = [](float* p, float4 v) {
+    const nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+  };
+#define RCB_LD4(p) nt_ld(p)
+#define RCB_ST4(p, v) nt_st(p, v)
+#define RCB_LD4P(p) nt_ld(p)
+#define RCB_ST4P(p, v) nt_st(p, v)
+  float4 loc4 = RCB_LD4P(L.loc + b);
+  float4 ls4 = RCB_LD4P(L.log_scale + b);
+  const float4 go4 = RCB_LD4(L.d_out + b);
+  const float4 ep4 = RCB_LD4(L.eps + b);
+  float4 m14 = RCB_LD4(L.m_loc + b), v14 = RCB_LD4(L.v_loc + b);
+  float4 m24 = RCB_LD4(L.m_ls + b), v24 = RCB_LD4(L.v_ls + b);
   float* locv = &loc4.x; float* lsv = &ls4.x;
   const float* gov = &go4.x; const float* epv = &ep4.x;
   float* m1v = &m14.x; float* v1v = &v14.x; float* m2v = &m24.x; float* v2v = &v24.x;
@@ -755,12 +772,12 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
       fx_add(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]), KL_FX);
   }
   if (!act) return;
-  reinterpret_cast<float4*>(L.loc + b)[0] = loc4;
-  reinterpret_cast<float4*>(L.log_scale + b)[0] = ls4;
-  reinterpret_cast<float4*>(L.m_loc + b)[0] = m14;
-  reinterpret_cast<float4*>(L.v_loc + b)[0] = v14;
-  reinterpret_cast<float4*>(L.m_ls + b)[0] = m24;
-  reinterpret_cast<float4*>(L.v_ls + b)[0] = v24;
+  RCB_ST4P(L.loc + b, loc4);
+  RCB_ST4P(L.log_scale + b, ls4);
+  RCB_ST4(L.m_loc + b, m14);
+  RCB_ST4(L.v_loc + b, v14);
+  RCB_ST4(L.m_ls + b, m24);
+  RCB_ST4(L.v_ls + b, v24);
   if (L.next_out) {
     // the next step's sample from the updated parameters: the arithmetic of reparam_rng_kernel on Philox group i4 at the
     // step counter the next step will see
@@ -771,7 +788,7 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     o.y = add_rn(loc4.y, mul_rn(st_f32(ls4.y), e.y));
     o.z = add_rn(loc4.z, mul_rn(st_f32(ls4.z), e.z));
     o.w = add_rn(loc4.w, mul_rn(st_f32(ls4.w), e.w));
-    reinterpret_cast<float4*>(L.next_eps + b)[0] = e;
+    nt_st(L.next_eps + b, e);            // (read again by the NEXT step's update only: non-temporal, as above)
     reinterpret_cast<float4*>(L.next_out + b)[0] = o;
     if (L.next_out_bf16) store_bf16_row4(reinterpret_cast<__bf16*>(L.next_out_bf16), b, L.cols, L.next_ld_bf16, o);
   }
@@ -929,11 +946,12 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(AdamMultiArgs a) {
   for (int k = 0; k < 4; ++k) {
     const long long i = base + k * 256 + threadIdx.x;
     if (i < n) {
-      float pi = p[i], mi = m[i], vi = v[i];
-      adam_apply(pi, g[i], mi, vi, a.s);
+      // (moments and gradient: streamed once per step, non-temporal; the parameter itself is read by the next kernel)
+      float pi = p[i], mi = __builtin_nontemporal_load(m + i), vi = __builtin_nontemporal_load(v + i);
+      adam_apply(pi, __builtin_nontemporal_load(g + i), mi, vi, a.s);
       p[i] = pi;
-      m[i] = mi;
-      v[i] = vi;
+      __builtin_nontemporal_store(mi, m + i);
+      __builtin_nontemporal_store(vi, v + i);
     }
   }
 }
