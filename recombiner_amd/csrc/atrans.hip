@@ -96,6 +96,7 @@ struct AtArgs {
   const int4* segs;            // two per segment: {layer, row0, first column block, blocks}, {first chunk, end chunk, slab or -1, 0}
   const int* seg_begin;        // [n_wg + 1]
   int n_wg;
+  int nt_out;                  // the result is not read again soon (data gradient: consumed by the step's last kernel)
   float* ws;                   // K-split launches (few rows): partial sums [slab][rows][ld_ws], added in slab order afterwards
   long long ld_ws;
 };
@@ -354,7 +355,10 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const long long row = (long long)row0 + 32 * wave + rho(q, fh);
-          if (row < a.rows) ob[row * ldo + col] = acc[cb][q];
+          if (row < a.rows) {
+            if (a.nt_out) __builtin_nontemporal_store(acc[cb][q], ob + row * ldo + col);
+            else ob[row * ldo + col] = acc[cb][q];
+          }
         }
       }
     }
@@ -657,6 +661,7 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
   RCB_REQUIRE(ld_x >= off && ld_out >= off, RCB_ERR_SHAPE, "atrans_apply: row strides %lld / %lld below %lld columns", (long long)ld_x,
               (long long)ld_out, off);
   a.x = x; a.out = out; a.ld_x = ld_x; a.ld_out = ld_out; a.rows = rows; a.n_layers = n_layers;
+  a.nt_out = transpose ? 1 : 0;
   const long long head = ((RCB_ATRANS_PLAN_HEAD + (long long)n_wg + 1) + 3) / 4 * 4;
   a.seg_begin = plan_dev + RCB_ATRANS_PLAN_HEAD;
   a.segs = reinterpret_cast<const int4*>(plan_dev + head);
