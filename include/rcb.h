@@ -433,7 +433,8 @@ int rcb_upconv_bwd_fused(const void* dy, const float* weff, const void* x, void*
  * instead of hundreds of strided scalar ones.  16-byte entries (8 bf16), lane = entry & 63, q = lane & 31, h = lane >> 5:
  *   [    0,  8192) stage-2 forward   [ph][mt][ty][tx][kb][lane]: weff2[ty][tx][16kb+8h+j][ph>>1][ph&1][32mt+q]
  *   [ 8192, 16384) stage-2 dgrad     [kh][mt][c][kb][lane], window combo n = 8kh+c: weff2[ty][tx][32mt+q][pa][pb][16kb+8h+j]
- *   [16384, 20480) stage-3 forward   [pa][pb][ty][tx][kb][lane]: weff3[ty][tx][16kb+8h+j][pa][pb][q] (0 for q >= 16)
+ *   [16384, 18432) stage-3 forward   [pa][pb][ty][tx][kb2][lane], A operands of v_mfma_f32_16x16x32_bf16:
+ *                                    weff3[ty][tx][32kb2+8(lane>>4)+j][pa][pb][lane&15]; [18432, 20480) unused
  *   [20480, 22528) stage-3 dgrad     [n][mt][lane]: weff3[ty][tx][32mt+q][pa][pb][8h+j]
  * (ry = (n>>2)-1, rx = (n&3)-1, pa = ry&1, ty = ry<=0, pb = rx&1, tx = rx<=0.)  rcb_upconv_fwd / _dgrad take the pack
  * through their `frag_pack` argument; with NULL they build the fragments from `weff` themselves.                 */

@@ -29,6 +29,9 @@ constexpr int CIN = 64;
 #ifndef RCB_UP_NOSTORE
 #define RCB_UP_NOSTORE 0   // ablation builds (wrong results): 1 stage-2 forward, 2 stage-2 data gradient, 3 stage-3 forward without their stores
 #endif
+#ifndef RCB_UP_PF
+#define RCB_UP_PF 3          // image gathers in flight ahead of their MFMAs in the register-fragment kernels
+#endif
 constexpr int XRS = 72;   // row stride (elements) of a staged 64-channel image: 144-byte rows spread 128-byte-strided
                           // gathers (consecutive positions, one channel chunk) over all LDS banks
 constexpr float SLOPE = 0.01f;
@@ -127,68 +130,89 @@ struct DgradArgs {
 // column phases.  Its 32 weight fragments ([pb][ty][tx][kb]) stay in registers for the whole kernel, so LDS only
 // serves the image: 24 fragment reads feed 32 MFMAs per tile.  In the epilogue the two lane halves swap
 // (v_permlane32_swap) so that each lane owns all 16 channels of one output pixel and stores them contiguously.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16x32(bf16x8 a_, bf16x8 b_, f32x4v c_) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0);
+}
+
+// One wave, one output-row phase pa, two 32-position tiles of the INR: 16 output channels are ONE row block of
+// v_mfma_f32_16x16x32_bf16 (the 32 x 32 x 16 form spends half of every MFMA on padding rows), so a tile is two position halves
+// (image rows) x two column phases = four 16 x 16 accumulators, K = 64 input channels = two MFMAs per (phase, tap).
+//   A (weights)  [16 co x 32 ci]: lane l = row co = l & 15, k-group kg = l >> 4: ci = 32 kb2 + 8 kg + j   -> fr[pb][ty][tx][kb2]
+//   B (image)    [32 ci x 16 pos]: lane l = position l & 15 of the image row, the 16-byte chunk 4 kb2 + kg of its pixel
+//   D            [16 co x 16 pos]: lane l = position l & 15, channels 4 kg + r
+// 24 gathers feed 32 MFMAs per tile, issued PF ahead of their use (ring of PF + 1 registers, order pinned by scheduling
+// barriers).  Epilogue: v_permlane16_swap between neighbouring k-groups turns (4 channels of pixel 2j, 4 of pixel 2j + 1) into
+// 8 consecutive channels of ONE pixel per lane: 16-byte stores, 1 KB contiguous per instruction.
 template <int COUT, int OUT_BF16>
-__device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2][2][2][4], const FwdArgs& a, int b,
-                                          int pa, int tp, int q, int h, const float (&bia)[8]) {
+__device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2][2][2][2], const FwdArgs& a, int b,
+                                          int pa, int tp, int lane, const float (&bia)[4]) {
   constexpr int G = 16, HG = 18, RS = 64;
+  const int j = lane & 15, kg = lane >> 4;
 #pragma unroll 1
-  for (int tt = 0; tt < 2; ++tt) {     // tiles one after the other: two accumulator chains live, no spills
-    const int pos = (2 * tp + tt) * 32 + q, i = pos >> 4, j = pos & 15;
-    f32x16 acc[2];   // [pb]
+  for (int tt = 0; tt < 2; ++tt) {
+    const int i0 = 2 * (2 * tp + tt);              // the tile's two image rows: i0, i0 + 1
+    f32x4v acc[2][2];   // [position half][pb]
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
-    const __bf16* base = img + ((i + pa) * HG + j) * RS;
+      for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-    for (int ty = 0; ty < 2; ++ty) {
+        for (int r = 0; r < 4; ++r) acc[ph][pb][r] = 0.f;
+    const __bf16* base = img + ((i0 + pa) * HG + j) * RS;
+    constexpr int NG = 24, PF = RCB_UP_PF;
+    uint4 ring[PF + 1];
+    auto gather = [&](int g) {                    // g = ((ty * 3 + dxi) * 2 + kb2) * 2 + ph
+      const int ph = g & 1, kb2 = (g >> 1) & 1, td = g >> 2, ty = td / 3, dxi = td - 3 * ty;
+      const int sw = ((j + dxi) >> 1) & 7;        // chunk swizzle of the image (see the kernel)
+      return *reinterpret_cast<const uint4*>(base + ((ph + ty) * HG + dxi) * RS + 8 * ((4 * kb2 + kg) ^ sw));
+    };
 #pragma unroll
-      for (int dxi = 0; dxi < 3; ++dxi) {
-        const int sw = ((j + dxi) >> 1) & 7;       // chunk swizzle of the image (see the kernel)
+    for (int g = 0; g < PF; ++g) ring[g] = gather(g);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          Frag bf;
-          bf.u = *reinterpret_cast<const uint4*>(base + (ty * HG + dxi) * RS + 8 * ((2 * kb + h) ^ sw));
-          Frag fa;
-          if (dxi <= 1) {
-            fa.u = fr[0][ty][dxi][kb];
-            acc[0] = mfma16(fa.v, bf.v, acc[0]);
-          }
-          if (dxi >= 1) {
-            fa.u = fr[1][ty][dxi - 1][kb];
-            acc[1] = mfma16(fa.v, bf.v, acc[1]);
-          }
+    for (int g = 0; g < NG; ++g) {
+      if (g + PF < NG) ring[(g + PF) % (PF + 1)] = gather(g + PF);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ph = g & 1, kb2 = (g >> 1) & 1, td = g >> 2, ty = td / 3, dxi = td - 3 * ty;
+      Frag bf, fa;
+      bf.u = ring[g % (PF + 1)];
+      if (dxi <= 1) {
+        fa.u = fr[0][ty][dxi][kb2];
+        acc[ph][0] = mfma16x32(fa.v, bf.v, acc[ph][0]);
+      }
+      if (dxi >= 1) {
+        fa.u = fr[1][ty][dxi - 1][kb2];
+        acc[ph][1] = mfma16x32(fa.v, bf.v, acc[ph][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      // lane (j, kg) holds channels 4 kg + r of pixels 2j [pb 0] and 2j + 1 [pb 1]; after the swap: channels 8 (kg >> 1) .. + 7 of
+      // pixel 2j + (kg & 1)
+      float lo[4], hi[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x0 = acc[ph][0][r] + bia[r], x1 = acc[ph][1][r] + bia[r];
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+        lo[r] = __uint_as_float(sw[0]);
+        hi[r] = __uint_as_float(sw[1]);
+      }
+      const long long opix = ((long long)b * (2 * G) + 2 * (i0 + ph) + pa) * (2 * G) + 2 * j + (kg & 1);
+      if (OUT_BF16) {
+        Frag o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o.v[k] = (__bf16)lo[k];
+          o.v[4 + k] = (__bf16)hi[k];
         }
+        if (RCB_UP_NOSTORE != 3 || a.batch < 0)
+          *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT + 8 * (kg >> 1)) = o.u;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT + 8 * (kg >> 1));
+        dst[0] = make_float4(lo[0], lo[1], lo[2], lo[3]);
+        dst[1] = make_float4(hi[0], hi[1], hi[2], hi[3]);
       }
-    }
-    // before: lane (q, h) holds channels {0..3, 8..11} + 4h of pixels (2j) [acc 0] and (2j+1) [acc 1]
-    float va[8], vb[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float x0 = acc[0][r] + bia[r], x1 = acc[1][r] + bia[r];
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
-      va[r] = __uint_as_float(sw[0]);   // channels {0..3, 8..11} of this lane's pixel (2j + h)
-      vb[r] = __uint_as_float(sw[1]);   // channels {4..7, 12..15}
-    }
-    const long long opix = ((long long)b * (2 * G) + 2 * i + pa) * (2 * G) + 2 * j + h;
-    if (OUT_BF16) {
-      Frag o0, o1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        o0.v[k] = (__bf16)va[k];     o0.v[4 + k] = (__bf16)vb[k];
-        o1.v[k] = (__bf16)va[4 + k]; o1.v[4 + k] = (__bf16)vb[4 + k];
-      }
-      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.y) + opix * COUT);
-      if (RCB_UP_NOSTORE != 3 || a.batch < 0) {
-        dst[0] = o0.u;
-        dst[1] = o1.u;
-      }
-    } else {
-      float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * COUT);
-      dst[0] = make_float4(va[0], va[1], va[2], va[3]);
-      dst[1] = make_float4(vb[0], vb[1], vb[2], vb[3]);
-      dst[2] = make_float4(va[4], va[5], va[6], va[7]);
-      dst[3] = make_float4(vb[4], vb[5], vb[6], vb[7]);
     }
   }
 }
@@ -197,7 +221,7 @@ __device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2
 // image and waits for its loads while the other computes (a single workgroup runs stage -> barrier -> compute in lockstep and
 // leaves the matrix cores idle during the first and HBM idle during most of the second); a wave then owns two tile pairs.
 template <int COUT, int OUT_BF16, int NW>
-__global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArgs a) {
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) upconv_fwd3_lds_kernel(FwdArgs a) {
   static_assert(COUT == 16, "epilogue lane swap is written for 16 output channels");
   static_assert(NW == 8 || NW == 4, "8 or 4 waves");
   // image [18][18][64] in LDS, the 16-byte chunk c of pixel column x stored at c ^ ((x >> 1) & 7): the gathers of fwd3_body
@@ -210,10 +234,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArg
   constexpr int NT = 64 * NW, NPRE = 2048 / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* img = reinterpret_cast<__bf16*>(smem_raw);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int pa = wave & 1, tp = wave >> 1;
-  const float wmask = q < COUT ? 1.f : 0.f;
-  uint4 fr[2][2][2][4];
+  uint4 fr[2][2][2][2];   // [pb][ty][tx][kb2]: A operands of v_mfma_f32_16x16x32_bf16 (row = co = lane & 15, ci = 32 kb2 + 8 (lane >> 4) + j)
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -221,21 +244,21 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArg
 #pragma unroll
       for (int tx = 0; tx < 2; ++tx)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
           Frag f;
           if (a.pack) {                     // one coalesced 16-byte load per fragment
-            f.u = a.pack[16384 + ((((pa * 2 + pb) * 2 + ty) * 2 + tx) * 4 + kb) * 64 + lane];
+            f.u = a.pack[16384 + ((((pa * 2 + pb) * 2 + ty) * 2 + tx) * 2 + kb2) * 64 + lane];
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)      // rows >= COUT of the 32-row A tile are zero (clamped load, masked)
-              f.v[j] = (__bf16)(a.weff[weff_index(ty, tx, 16 * kb + 8 * h + j, pa, pb, q < COUT ? q : COUT - 1, COUT)] * wmask);
+            for (int j = 0; j < 8; ++j)
+              f.v[j] = (__bf16)a.weff[weff_index(ty, tx, 32 * kb2 + 8 * (lane >> 4) + j, pa, pb, lane & 15, COUT)];
           }
-          fr[pb][ty][tx][kb] = f.u;
-          pin(fr[pb][ty][tx][kb]);
+          fr[pb][ty][tx][kb2] = f.u;
+          pin(fr[pb][ty][tx][kb2]);
         }
-  float bia[8];
+  float bia[4];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) bia[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+  for (int r = 0; r < 4; ++r) bia[r] = a.bias[4 * (lane >> 4) + r];
   for (int e = tid; e < HG * HG * RS / 8; e += NT) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
   // each thread stages NPRE x 16 B of the 32 KB image (element e -> pixel e / 8, chunk e % 8); the next INR's image is
   // in flight while the current one is consumed
@@ -260,7 +283,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) upconv_fwd3_lds_kernel(FwdArg
     __syncthreads();
     if (b + gs < a.batch) RCB_FETCH3(b + gs)
 #pragma unroll 1
-    for (int t2 = 0; t2 < 8 / NW; ++t2) fwd3_body<COUT, OUT_BF16>(img, fr, a, b, pa, tp + (NW / 2) * t2, q, h, bia);
+    for (int t2 = 0; t2 < 8 / NW; ++t2) fwd3_body<COUT, OUT_BF16>(img, fr, a, b, pa, tp + (NW / 2) * t2, lane, bia);
   }
 #undef RCB_FETCH3
 }
@@ -1103,10 +1126,10 @@ int launch(K kfn, const A& args, int grid, size_t smem, hipStream_t st, bool& /*
   return RCB_OK;
 }
 
-// two half-size workgroups per CU where the kernel has the variant and the batch fills them (RCB_UPCONV_HALF_WG=0: never)
+// two half-size workgroups per CU where the kernel has the variant and the batch fills them (RCB_UPCONV_HALF_WG=1: opt-in)
 static bool half_wg(int batch) {
-  static const bool on = [] { const char* e = getenv("RCB_UPCONV_HALF_WG"); return !(e && e[0] == '0'); }();
-  return on && batch >= 512;
+  static const bool on = [] { const char* e = getenv("RCB_UPCONV_HALF_WG"); return e && e[0] == '1'; }();   // off by default: no gain measured, and the 4-wave instances are at the register limit with the gather ring
+  return on && batch >= 768;
 }
 
 
@@ -1128,12 +1151,12 @@ extern "C" int rcb_upconv_fwd(const void* x, int32_t x_is_f32_preact, const floa
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 1) {
     static bool done = false;
-    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 0, 4>, a, 512, 18 * 18 * 64 * 2, st, done, 256);
+    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 0, 4>, a, 768, 18 * 18 * 64 * 2, st, done, 256);
     return launch(upconv_fwd3_lds_kernel<16, 0, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 64 * 2, st, done);
   }
   if (grid == 16 && cout == 16 && !x_is_f32_preact && y_is_f32_linear == 2) {   // bf16 output, no activation
     static bool done = false;
-    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 1, 4>, a, 512, 18 * 18 * 64 * 2, st, done, 256);
+    if (half_wg(batch)) return launch(upconv_fwd3_lds_kernel<16, 1, 4>, a, 768, 18 * 18 * 64 * 2, st, done, 256);
     return launch(upconv_fwd3_lds_kernel<16, 1, 8>, a, batch < 256 ? batch : 256, 18 * 18 * 64 * 2, st, done);
   }
   if (grid == 8 && cout == 64 && x_is_f32_preact == 2 && !y_is_f32_linear) {   // bf16 pre-activation input

@@ -111,10 +111,13 @@ __global__ void __launch_bounds__(256) weff_build_kernel(WeffArgs a) {
       const int pa = ry & 1, ty = (ry <= 0) ? 1 : 0, pb = rx & 1, tx = (rx <= 0) ? 1 : 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)weff_of(a.W2, ty, tx, 32 * mt + q, pa, pb, 16 * kb + 8 * h + j);
-    } else if (e < 20480) {                          // F3: stage-3 forward, [pa][pb][ty][tx][kb][lane]
-      const int s5 = (e - 16384) >> 6, kb = s5 & 3, tx = (s5 >> 2) & 1, ty = (s5 >> 3) & 1, pb = (s5 >> 4) & 1, pa = s5 >> 5;
+    } else if (e < 20480) {                          // F3: stage-3 forward, [pa][pb][ty][tx][kb2][lane]: A operands of
+      //                                                 v_mfma_f32_16x16x32_bf16 (row co = lane & 15, ci = 32 kb2 + 8 (lane >> 4) + j);
+      //                                                 the second half of the region is unused
+      if (e >= 16384 + 2048) return;
+      const int s5 = (e - 16384) >> 6, kb2 = s5 & 1, tx = (s5 >> 1) & 1, ty = (s5 >> 2) & 1, pb = (s5 >> 3) & 1, pa = s5 >> 4;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f.v[j] = (q < 16) ? (__bf16)weff_of(a.W3, ty, tx, 16 * kb + 8 * h + j, pa, pb, q) : (__bf16)0.f;
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)weff_of(a.W3, ty, tx, 32 * kb2 + 8 * (lane >> 4) + j, pa, pb, lane & 15);
     } else {                                         // D3: stage-3 data gradient, [combo][mt][lane]
       const int s5 = (e - 20480) >> 6, mt = s5 & 1, n = s5 >> 1;
       const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
