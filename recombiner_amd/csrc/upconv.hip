@@ -29,6 +29,9 @@ constexpr int CIN = 64;
 #ifndef RCB_UP_NOSTORE
 #define RCB_UP_NOSTORE 0   // ablation builds (wrong results): 1 stage-2 forward, 2 stage-2 data gradient, 3 stage-3 forward without their stores
 #endif
+#ifndef RCB_B3_PF
+#define RCB_B3_PF 2          // taps whose LDS reads are in flight ahead of their MFMAs in the stage-3 backward's data gradient
+#endif
 #ifndef RCB_UP_PF
 #define RCB_UP_PF 3          // image gathers in flight ahead of their MFMAs in the register-fragment kernels
 #endif
@@ -966,17 +969,32 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      // per tap: one dy gather and two weight fragments from LDS feed two MFMAs.  The reads of tap n + B3_PF are issued before
+      // the MFMAs of tap n (register ring, order pinned by scheduling barriers): the compiler's own schedule re-used one
+      // register set and waited for every read in front of its MFMA, and this phase -- a third of the kernel's matrix work --
+      // took 45 % of its time
+      constexpr int B3_PF = RCB_B3_PF;
+      uint4 rg[B3_PF + 1][3];
+      auto tap_reads = [&](int n, uint4 (&dst)[3]) {
+        const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
+        dst[0] = *reinterpret_cast<const uint4*>(dyimg + ((2 * u + ((RCB_B3_DIAG == 3) ? 0 : ry) + 1) * HO + (2 * v + ((RCB_B3_DIAG == 3) ? 0 : rx) + 1)) * RS + 8 * h);
+        dst[1] = frags[((RCB_B3_DIAG == 2 ? 0 : n) * 2 + 0) * 64 + lane];
+        dst[2] = frags[((RCB_B3_DIAG == 2 ? 0 : n) * 2 + 1) * 64 + lane];
+      };
+#pragma unroll
+      for (int n = 0; n < B3_PF; ++n) tap_reads(n, rg[n]);
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
-        const int ry = (n >> 2) - 1, rx = (n & 3) - 1;
-        Frag bf;
-        bf.u = *reinterpret_cast<const uint4*>(dyimg + ((2 * u + ((RCB_B3_DIAG == 3) ? 0 : ry) + 1) * HO + (2 * v + ((RCB_B3_DIAG == 3) ? 0 : rx) + 1)) * RS + 8 * h);
+        if (n + B3_PF < 16) tap_reads(n + B3_PF, rg[(n + B3_PF) % (B3_PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag bf, fa;
+        bf.u = rg[n % (B3_PF + 1)][0];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          Frag fa;
-          fa.u = frags[((RCB_B3_DIAG == 2 ? 0 : n) * 2 + mt) * 64 + lane];
+          fa.u = rg[n % (B3_PF + 1)][1 + mt];
           acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // dx rows are 128 B per position; a lane holds 4 x 4 channels of each 32-channel half: stored from the registers that
       // is eight 8-byte pieces per lane at 128-byte stride (measured: a quarter of the kernel's time).  Instead each half goes
