@@ -537,6 +537,20 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
 // not fit one wave, so wave w = (ci half w & 1, tile (w >> 1) & 1, combo half w >> 2) keeps 32 of them and the two
 // combo halves are added through LDS.  The epilogue (combo-half 0 waves) multiplies by LeakyReLU'(x), swaps lane halves
 // for 32-byte stores and accumulates the per-channel sums of dx (the bias gradient of the stage before) per workgroup.
+#ifndef RCB_D2_STAMPS
+#define RCB_D2_STAMPS 0    // diagnostic build: cycles per phase of workgroup 0's waves (rcb_debug_d2_stamps, tools/d2_stamps.py)
+#endif
+#if RCB_D2_STAMPS
+__device__ unsigned long long g_d2_stamps[8 * 8];
+#define D2_T(k)                                                     \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    ph_[k] += now_ - last_;                                         \
+    last_ = now_;                                                   \
+  } while (0)
+#else
+#define D2_T(k) do { } while (0)
+#endif
 template <int X_F32>   // sign source / dx type: 1 fp32, 0 bf16
 __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, float* __restrict__ dbias_partial) {
   // dy image [18][18][64] in LDS: 128-byte pixels, rows padded by 64 B, and the 16-byte chunk c of pixel column x stored at
@@ -586,14 +600,20 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
   __syncthreads();   // also a scheduling boundary: the prefetch registers must not overlap the prologue's register peak
   if (b < a.batch) RCB_FETCHD2(b)
   const int pos = tile * 32 + q, u = pos >> 3, v = pos & 7;
+#if RCB_D2_STAMPS
+  unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (; b < a.batch; b += gs) {
     __syncthreads();
+    D2_T(0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int e_ = tid + 512 * k, pix = e_ >> 3, c8 = e_ & 7, xx = (pix & 15) + 1;
       *reinterpret_cast<uint4*>(img + ((pix >> 4) + 1) * ROWS + xx * RS + 8 * (c8 ^ ((xx >> 1) & 7))) = pre[k];
     }
+    D2_T(1);
     __syncthreads();
+    D2_T(2);
     if (b + gs < a.batch) RCB_FETCHD2(b + gs)
     // sign source of this lane's 16 output channels, requested before the MFMA loop
     const long long xoff = ((long long)b * G * G + pos) * CIN + 32 * mt + 16 * h;
@@ -633,13 +653,16 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
       }
       __builtin_amdgcn_sched_barrier(0);     // one combo at a time (the other wave of the SIMD covers the LDS latency)
     }
+    D2_T(3);
     // add the two combo halves (register-major layout: conflict-free)
     float* rw = red + (wave & 3) * 16 * 64;
     if (kh == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) rw[r * 64 + lane] = acc[r];
     }
+    D2_T(4);
     __syncthreads();
+    D2_T(5);
     if (kh == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += rw[r * 64 + lane];
@@ -675,7 +698,12 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
         }
       }
     }
+    D2_T(6);
   }
+#if RCB_D2_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_d2_stamps[wave * 8 + k] = ph_[k];
+#endif
 #undef RCB_FETCHD2
   if (dbias_partial) {   // fixed-order reduction over the 32 pixels of a lane half, then over the two tiles
     __syncthreads();
@@ -1095,6 +1123,11 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
 
 #if RCB_B3_STAMPS
 }  // namespace
+#if RCB_D2_STAMPS
+extern "C" int rcb_debug_d2_stamps(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_d2_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 extern "C" int rcb_debug_b3_stamps(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_b3_stamps), sizeof(unsigned long long) * n);
 }
