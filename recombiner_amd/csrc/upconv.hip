@@ -26,6 +26,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int CIN = 64;
+#ifndef RCB_UP_HOT
+#define RCB_UP_HOT 0       // ablation builds (wrong results): the stage-2 forward / data gradient read one cache-resident INR
+#endif
 #ifndef RCB_UP_NOSTORE
 #define RCB_UP_NOSTORE 0   // ablation builds (wrong results): 1 stage-2 forward, 2 stage-2 data gradient, 3 stage-3 forward without their stores
 #endif
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
     const int e_ = tid + 512 * k;                                                          \
     int b_ = NI * (pp) + (e_ >> 9);                                                        \
     if (b_ >= a.batch) b_ = a.batch - 1;                                                   \
-    pre[k] = raw_load<IN_MODE>(a.x, (long long)b_ * G * G * CIN + 8 * (e_ & 511));         \
+    pre[k] = raw_load<IN_MODE>(a.x, (long long)(RCB_UP_HOT ? (int)(blockIdx.x & 1023) : b_) * G * G * CIN + 8 * (e_ & 511));         \
   }
   const int gs = gridDim.x;
   int p = blockIdx.x;
@@ -592,7 +595,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
   for (int k = 0; k < 4; ++k) pre[k] = make_uint4(0, 0, 0, 0);
 #define RCB_FETCHD2(bb)                                                                                           \
   {                                                                                                               \
-    const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)(bb) * OG * OG * COUT); \
+    const uint4* src_ = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.dy) + (long long)(RCB_UP_HOT ? (int)blockIdx.x : (bb)) * OG * OG * COUT); \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) pre[k] = src_[tid + 512 * k];                                   \
   }
   const int gs = gridDim.x;
