@@ -65,10 +65,6 @@ class Upsample(nn.Module):
         return {k: v for k, v in self.__dict__.items() if not k.startswith("_rcb_")}
 
 
-def _zeros_state(t):
-    return torch.zeros_like(t, memory_format=torch.contiguous_format)
-
-
 class PriorBNNmodel(nn.Module):
     """Training-set posteriors + batched INR evaluation (prior_model.py:62-262)."""
 
@@ -285,12 +281,24 @@ class PriorBNNmodel(nn.Module):
         if ws is not None and (ws["key"] != key or ws["rows"] < n_epoch):
             ws = None
         if ws is None:
+            # all Adam moments (per-INR levels and shared mappings) as views of ONE zero-filled buffer: a train() call resets
+            # them with one launch instead of ~30 (the reference creates a fresh optimiser per call: main_prior_training.py)
+            shapes = [lv.loc.shape for lv in net for _ in range(4)] + [lpe_lv.loc.shape] * 4
+            if training_mappings:
+                shapes += [q.shape for q in A + conv for _ in range(2)]
+            offs, tot = [], 0
+            for shp in shapes:
+                offs.append(tot)
+                tot += (int(np.prod(shp)) + 63) // 64 * 64          # every view starts on a 256-byte boundary
+            state_flat = torch.zeros(tot, device=dev, dtype=torch.float32)
+            views = iter([state_flat[o:o + int(np.prod(shp))].view(shp) for o, shp in zip(offs, shapes)])
+
             def st4(lv):
-                return {k: _zeros_state(lv.loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+                return {k: next(views) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
             rows = max(n_epoch, 256) if graphable else n_epoch
             self._train_calls += 1
-            ws = dict(key=key, rows=rows, net_state=[st4(lv) for lv in net], lpe_state=st4(lpe_lv),
-                      map_state=[(_zeros_state(q), _zeros_state(q)) for q in A + conv] if training_mappings else None,
+            ws = dict(key=key, rows=rows, state_flat=state_flat, net_state=[st4(lv) for lv in net], lpe_state=st4(lpe_lv),
+                      map_state=[(next(views), next(views)) for q in A + conv] if training_mappings else None,
                       tab=ops.adam_table(lr, rows).to(dev), dyn=torch.zeros(2, device=dev, dtype=torch.float32),
                       step_t=torch.zeros(1, device=dev, dtype=torch.long),
                       kl_slots=torch.zeros(1024, device=dev, dtype=torch.int64),       # fixed point, 2^-24 nats
@@ -312,13 +320,7 @@ class PriorBNNmodel(nn.Module):
             if graphable:
                 self._ws = ws
         else:
-            for stt in ws["net_state"] + [ws["lpe_state"]]:
-                for t_ in stt.values():
-                    t_.zero_()
-            if ws["map_state"] is not None:
-                for m_, v_ in ws["map_state"]:
-                    m_.zero_()
-                    v_.zero_()
+            ws["state_flat"].zero_()
         n_a = sum(q.numel() for q in A)                     # the A matrices come first in the gradient bucket
         net_state, lpe_state, map_state = ws["net_state"], ws["lpe_state"], ws["map_state"]
         tab, dyn, step_t, kl_slots = ws["tab"], ws["dyn"], ws["step_t"], ws["kl_slots"]
@@ -630,9 +632,9 @@ class PriorBNNmodel(nn.Module):
                 body()
         mse_buf, kl_buf = mse_buf[:n_epoch], kl_buf[:n_epoch]
         kl_final = self._kl_value(priors)
-        mse_h = mse_buf.cpu()
-        elbo_h = (-(mse_buf + kl_buf * float(kl_beta))).cpu().tolist()
-        return float(mse_h[-1]) / N, float(kl_final.item()) / N, elbo_h
+        # one transfer (one synchronisation) for everything the call returns: [elbo per step ..., last MSE, final KL]
+        out_h = torch.cat([-(mse_buf + kl_buf * float(kl_beta)), mse_buf[-1:], kl_final.reshape(1)]).cpu()
+        return float(out_h[-2]) / N, float(out_h[-1]) / N, out_h[:-2].tolist()
 
 
 # ------------------------------------------------------------------------------------------------------
