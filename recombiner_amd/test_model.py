@@ -503,17 +503,24 @@ class TestBNNmodel(nn.Module):
                tuple(q.data_ptr() for q in A), tuple(q.data_ptr() for q in self.upsample_net.parameters()))
         ws = self._ws
         if ws is None or ws["key"] != key or ws["tab"].shape[0] < n_epochs:
-            ws = dict(key=key, tab=ops.adam_table(lr, max(n_epochs, 2048)).to(dev),
+            # the Adam moments of all levels as views of one buffer: a fine-tune call (a few steps each, thousands of them
+            # per compression run) resets them with one launch
+            shapes = [lv.loc.shape for lv in self._levels for _ in range(4)]
+            offs, tot = [], 0
+            for shp in shapes:
+                offs.append(tot)
+                tot += (int(np.prod(shp)) + 63) // 64 * 64
+            state_flat = torch.zeros(tot, device=dev, dtype=torch.float32)
+            views = iter([state_flat[o:o + int(np.prod(shp))].view(shp) for o, shp in zip(offs, shapes)])
+            ws = dict(key=key, tab=ops.adam_table(lr, max(n_epochs, 2048)).to(dev), state_flat=state_flat,
                       dyn=torch.zeros(2, device=dev), step_t=torch.zeros(1, device=dev, dtype=torch.long),
-                      states=[{k: torch.zeros_like(lv.loc.detach()) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
-                              for lv in self._levels], graphs={}, warm=0,
+                      states=[{k: next(views) for k in ("m_loc", "v_loc", "m_ls", "v_ls")} for lv in self._levels],
+                      graphs={}, warm=0,
                       # bf16 copy of the coordinate grid: owned by the workspace that owns the graphs reading its address
                       xf16=ops.xf_bf16(x) if (self.precision == 1 and dev.type == "cuda") else None)
             self._ws = ws
         else:
-            for st in ws["states"]:
-                for v in st.values():
-                    v.zero_()
+            ws["state_flat"].zero_()
         ws["step_t"].zero_()
         tab, dyn, step_t, states = ws["tab"], ws["dyn"], ws["step_t"], ws["states"]
         cfg = ops.adam_cfg(lr, 1, eps=eps_adam, dyn=dyn)
