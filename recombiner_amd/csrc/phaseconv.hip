@@ -81,6 +81,18 @@ __global__ void pc_pack_fwd_kernel(const float* __restrict__ W, int cout, uint4*
   constexpr int NP = 1 << ND;
   const int mbs = (cout + 31) / 32;
   const int total = NP * mbs * NP * 4 * 64;
+  if (cout == 16) {
+    // 16 output channels are ONE row block of v_mfma_f32_16x16x32_bf16: [phase][tap][kb2][64 lanes], lane = (co = lane & 15,
+    // k-group lane >> 4) holds ci = 32 kb2 + 8 (lane >> 4) + j (the first half of the buffer; the rest stays unused)
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < NP * NP * 2 * 64; e += gridDim.x * blockDim.x) {
+      const int lane = e & 63, kb2 = (e >> 6) & 1, t = (e >> 7) % NP, a = (e >> 7) / NP;
+      Frag f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)weff_elem<ND>(W, cout, lane & 15, 32 * kb2 + 8 * (lane >> 4) + j, a, t);
+      out[e] = f.u;
+    }
+    return;
+  }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int lane = e & 63, c16 = (e >> 6) & 3;
     int rest = e >> 8;
@@ -140,19 +152,20 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
   const int a = wave % NP, tsub = wave / NP, mb = blockIdx.y;
   const int role = a * MB + mb;
-  bf16x8 wf[NP][4];
+  constexpr bool C16 = (COUT == 16);            // one row block of the 16 x 16 x 32 MFMA (see pc_pack_fwd_kernel)
+  bf16x8 wf[NP][C16 ? 2 : 4];
 #pragma unroll
   for (int t = 0; t < NP; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < (C16 ? 2 : 4); ++c) {
       Frag f;
-      f.u = p.frags[((role * NP + t) * 4 + c) * 64 + lane];
+      f.u = C16 ? p.frags[((a * NP + t) * 2 + c) * 64 + lane] : p.frags[((role * NP + t) * 4 + c) * 64 + lane];
       wf[t][c] = f.v;
     }
   float bv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int co = 32 * mb + rho(r, h);
+    const int co = C16 ? 4 * (lane >> 4) + (r & 3) : 32 * mb + rho(r, h);
     bv[r] = co < COUT ? p.bias[co] : 0.f;
   }
   const int g[3] = {p.g0, p.g1, p.g2};
@@ -208,6 +221,64 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
     // ---- this wave's phase of its tile -----------------------------------------------------------------------------------
     const int ts = tg * TPB + tsub;
     if (ts >= p.tiles_per_row) continue;           // (no barrier below this point inside the iteration)
+    if constexpr (C16) {
+      // lane = (position j = lane & 15 of a 16-position half, k-group kg = lane >> 4); D = [16 co x 16 positions]: lane holds
+      // channels 4 kg + r.  Two halves per tile; per tap two MFMAs of K = 32 input channels each.
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const int j16 = lane & 15, kg = lane >> 4;
+      f32x4v acc4[2];
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc4[ph][r] = bv[r];
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        int r = 0;
+        if (ND == 3) r = (((a >> 2) & 1) + ((t >> 2) & 1)) * 3 + (((a >> 1) & 1) + ((t >> 1) & 1));
+        if (ND == 2) r = ((a >> 1) & 1) + ((t >> 1) & 1);
+        Frag f[2][2];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          const int pp = 32 * tsub + 16 * ph + j16 + (a & 1) + (t & 1);
+          const uint4* src = img + (r * PW + pp) * 8;
+          const int sw = (pp >> 1) & 7;
+#pragma unroll
+          for (int kb2 = 0; kb2 < 2; ++kb2) f[ph][kb2].u = src[(4 * kb2 + kg) ^ sw];
+        }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int kb2 = 0; kb2 < 2; ++kb2)
+            acc4[ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][kb2], f[ph][kb2].v, acc4[ph], 0, 0, 0);
+      }
+      long long ob = b;
+#pragma unroll
+      for (int ax = 0; ax < ND - 1; ++ax) ob = ob * (2 * g[ax]) + 2 * lead[ax] + ((a >> (ND - 1 - ax)) & 1);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        // neighbouring k-groups exchange: even kg ends with 8 consecutive channels (its own four + its odd neighbour's)
+        float lo[4], hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc4[ph][r];
+          if (ACT) v = v > 0.f ? v : v * SLOPE;
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), 0u, false, false);
+          lo[r] = __uint_as_float(sw[0]);
+          hi[r] = __uint_as_float(sw[1]);
+        }
+        const int il16 = 32 * ts + 16 * ph + j16;
+        if (il16 < gl && (kg & 1) == 0) {
+          Frag o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            o.v[k] = (__bf16)lo[k];
+            o.v[4 + k] = (__bf16)hi[k];
+          }
+          *reinterpret_cast<uint4*>(p.y + (ob * (2 * gl) + 2 * il16 + (a & 1)) * COUT + 4 * kg) = o.u;
+        }
+      }
+      continue;
+    }
     const int il = 32 * ts + q;
     f32x16 acc;
 #pragma unroll
