@@ -792,6 +792,10 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     reinterpret_cast<float4*>(L.next_out + b)[0] = o;
     if (L.next_out_bf16) store_bf16_row4(reinterpret_cast<__bf16*>(L.next_out_bf16), b, L.cols, L.next_ld_bf16, o);
   }
+#undef RCB_LD4
+#undef RCB_ST4
+#undef RCB_LD4P
+#undef RCB_ST4P
 }
 
 extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream) {
