@@ -23,3 +23,14 @@ for S in (2, 4, 8):
     f = lambda: torch.bmm(a, b, out_dtype=torch.float32)
     g = lambda: torch.bmm(a, b, out_dtype=torch.float32).sum(0)
     print("S=%d: bmm %.1f us, bmm + sum %.1f us, max diff %.2e" % (S, t(f), t(g), float((g() - ref).abs().max())))
+
+# ---- the data gradient dlpe = dz1 @ Weff1^T ([4096, 4096] x [4096, 512], fp32 out): K-sliced
+W = torch.randn(512, 4096, device="cuda").bfloat16()
+ref2 = torch.mm(dz, W.t(), out_dtype=torch.float32)
+print("dlpe one GEMM: %.1f us" % t(lambda: torch.mm(dz, W.t(), out_dtype=torch.float32)))
+for S in (2, 4):
+    a = dz.view(4096, S, 4096 // S).transpose(0, 1)                  # [S, 4096, K/S]
+    b = W.view(512, S, 4096 // S).permute(1, 2, 0)                   # [S, K/S, 512]
+    f = lambda: torch.bmm(a, b, out_dtype=torch.float32)
+    g = lambda: torch.bmm(a, b, out_dtype=torch.float32).sum(0)
+    print("dlpe S=%d: bmm %.1f us, + sum %.1f us, max diff %.2e" % (S, t(f), t(g), float((g() - ref2).abs().max())))
