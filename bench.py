@@ -429,7 +429,17 @@ def comm_report(m, lt, up, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     buckets = [flat[:n_a], flat[n_a:]]
-    ar = [timed(lambda b=b: dist.all_reduce(b, group=m.dp_group)) for b in buckets]
+    # the collectives are timed on a scratch copy (the live buckets hold this step's reduced gradients), and everything the
+    # segment replays below advance -- parameters, Adam moments, step / noise counters, the carried-over sample -- is put
+    # back afterwards: the replays apply Adam steps from LOCAL gradients (no collective between them), so without the
+    # restore the ranks' mappings would drift apart right after having been certified identical
+    scratch = flat.clone()
+    ar = [timed(lambda b=b: dist.all_reduce(b, group=m.dp_group)) for b in (scratch[:n_a], scratch[n_a:])]
+    del scratch
+    live = [q.data for q in list(m.parameters()) + list(lt.parameters()) + list(up.parameters())]
+    live += [w[k] for k in ("state_flat", "step_t", "rng_ctr", "mse_buf", "kl_buf", "flat")]
+    live += [t for k in ("smp_net", "smp_lpe") if k in w for t in w[k] if t is not None]
+    saved = [t.clone() for t in live]
     graphs = w["graphs"][1]
     seg = []
     for _ in range(3):                                    # whole steps, segment by segment (no collectives: timing only)
@@ -443,6 +453,9 @@ def comm_report(m, lt, up, dev):
         torch.cuda.synchronize()
         seg.append([a.elapsed_time(b) for a, b in row])
     seg = [sorted(col)[1] for col in zip(*seg)]
+    for t, c in zip(live, saved):
+        t.copy_(c)
+    torch.cuda.synchronize()
     rep.update({"allreduce_bytes_per_step": int(flat.numel() * 4), "bucket_bytes": [int(b.numel() * 4) for b in buckets],
                 "allreduce_ms_alone": [round(x, 4) for x in ar],
                 "segment_ms": {"1a sample..A-transform backward": round(seg[0], 4), "1b upsampling-net backward": round(seg[1], 4),

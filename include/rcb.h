@@ -21,7 +21,10 @@
 extern "C" {
 #endif
 
-#define RCB_VERSION 100
+/* major * 100 + minor; bumped with every change of a signature or of a structure layout (100: rounds 1-3; 400: round 4 --
+ * rcb_level.scale_is_sigma, rcb_struct_bytes, the hi / lo operand planes of the A transform).  A binding compares
+ * rcb_version() with the RCB_VERSION it was written against and rcb_struct_bytes() with the size of each of its mirrors. */
+#define RCB_VERSION 400
 #define RCB_OK 0
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
@@ -33,6 +36,16 @@ typedef void* rcb_stream_t;
 
 int rcb_version(void);
 const char* rcb_last_error_string(void);
+/* sizeof() of the descriptor structures as this library was compiled -- which: 0 rcb_siren_desc, 1 rcb_level,
+ * 2 rcb_level_bwd, 3 rcb_adam_cfg, 4 rcb_adam_tensor, 5 rcb_rec_desc; -1 for any other value.  A hand-written mirror of a
+ * structure (ctypes, cffi ...) that has drifted from this header is caught at load time instead of corrupting a launch. */
+#define RCB_STRUCT_SIREN_DESC 0
+#define RCB_STRUCT_LEVEL 1
+#define RCB_STRUCT_LEVEL_BWD 2
+#define RCB_STRUCT_ADAM_CFG 3
+#define RCB_STRUCT_ADAM_TENSOR 4
+#define RCB_STRUCT_REC_DESC 5
+int64_t rcb_struct_bytes(int32_t which);
 
 /* ---------------------------------------------------------------------------------------------
  * K3 + K4: batched SIREN coordinate-MLP, one workgroup per (INR, sample).
@@ -137,6 +150,9 @@ typedef struct {
   const int32_t* col_map;  /* nullable [cols_out]                                   */
   const float* eps;        /* [N, S, cols_out]                                      */
   int32_t rows, cols, cols_out;
+  int32_t scale_is_sigma;  /* 0: `log_scale` holds log-scales, sigma = softplus(.)/6 (the models' parameters).  1: it holds
+                            * sigma itself -- the argument convention of utils.py:122-137, whose callers apply st() and the
+                            * encoded-group masks first (prior_model.py:140-145, test_model.py:289-298); generic kernel only */
 } rcb_level;
 
 int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t samples,
@@ -170,10 +186,11 @@ int rcb_gauss_kl(const float* loc, const float* log_scale, const float* p_loc, c
                  const int32_t* seg_end, double* kl_row, double* kl_group, rcb_stream_t stream);
 
 /* Per-parameter KL summed over rows: the statistic behind get_grouping (prior_model.py:264-271); q_scale holds sigma (or
- * log-scales if q_scale_is_log).  out_fx[j] = sum of the 256-row partial sums (fp64, fixed order) rounded to
- * RCB_COLSUM_FX_SCALE units per nat, accumulated as 64-bit integers: the result does not depend on the order in which the
- * workgroups (or, after an integer all-reduce, the ranks) contribute -- bitwise reproducible, and the same sharded or not
- * when the shards are cut at multiples of 256 rows.                                                                 */
+ * log-scales if q_scale_is_log).  out_fx is int64 [cols + 1]: out_fx[j] = sum over the rows of every ELEMENT's KL rounded to
+ * RCB_COLSUM_FX_SCALE units per nat (each element enters the integer grid on its own), accumulated as 64-bit integers:
+ * the result does not depend on the order in which the workgroups (or, after an integer all-reduce, the ranks) contribute
+ * nor on where the rows are cut into shards -- bitwise reproducible, sharded or not.  out_fx[cols] = number of elements
+ * whose KL was NaN / Inf / >= 2^12 nats (counted, not summed; the caller turns a non-zero count into NaN).            */
 #define RCB_COLSUM_FX_SCALE 1073741824.0        /* 2^30 */
 int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32_t q_scale_is_log, const float* p_loc,
                         const float* p_scale, int32_t rows, int32_t cols, int64_t* out_fx, rcb_stream_t stream);
@@ -226,7 +243,9 @@ typedef struct {
   float* m_loc; float* v_loc; float* m_ls; float* v_ls;   /* Adam state            */
   int64_t* kl_accum;       /* nullable [RCB_KL_SLOTS], fixed point (RCB_KL_FX_SCALE units per nat, integer atomics: the sum does
                             * not depend on the order of the workgroups): partial sums of the unweighted elementwise KL (before the
-                              update) are atomically added to the slots; their total is the KL           */
+                            * update) are atomically added to slots [0, RCB_KL_SLOTS - 1); their total is the KL.  The LAST slot
+                            * counts workgroup sums that were NaN / Inf or beyond 2^30 nats (not representable): rcb_step_end
+                            * logs NaN for such a step, as the reference's diverged run would                            */
   const float* kl_scalar_dev; /* nullable device scalar: the KL weight becomes kl_scalar * (*kl_scalar_dev), so a
                               captured graph can be replayed with a new beta (main_prior_training.py:144-154) */
   /* Optional (plain levels on the flat path only; next_out == NULL: off): the NEXT step's reparameterised sample drawn in
@@ -320,10 +339,13 @@ int rcb_step_end(const float* sse, int32_t n_sse, double mse_scale, const int64_
 
 /* ---------------------------------------------------------------------------------------------
  * K12: column moments for the closed-form prior refit (main_prior_training.py:157-172), as EXACT fixed-point sums.
- * For x = loc[rows, cols] and sigma = softplus(log_scale) / 6, every term v in {x, x^2, sigma^2} (|v| < 2^12; up to 2^20
- * rows over all ranks) is split at 2^-30:  hi = floor(v 2^30), lo = rint((v 2^30 - hi) 2^32), and the parts are summed as
- * 64-bit integers:  out_fx[q][0][j] = sum_r hi,  out_fx[q][1][j] = sum_r lo  for q = 0: x, 1: x^2, 2: sigma^2
- * (out_fx is int64 [3][2][cols]; value = (hi + lo 2^-32) 2^-30, resolution 2^-62).  Integer addition is associative,
+ * For x = loc[rows, cols] and sigma = softplus(log_scale) / 6, every term v in {x, x^2, sigma^2} is split at 2^-30:
+ * hi = floor(v 2^30), lo = rint((v 2^30 - hi) 2^32), and the parts are summed as 64-bit integers:
+ * out_fx[q][0][j] = sum_r hi,  out_fx[q][1][j] = sum_r lo  for q = 0: x, 1: x^2, 2: sigma^2  (out_fx is int64
+ * [3][2][cols] followed by ONE more element; value = (hi + lo 2^-32) 2^-30, resolution 2^-62).  Range: every term must
+ * satisfy |v| < 2^12 -- i.e. |x| < 2^6 and sigma < 2^6, since x^2 and sigma^2 are terms -- for up to 2^20 rows over all
+ * ranks (2^12 2^30 2^20 = 2^62).  Terms outside that range, NaN and Inf are not summed but counted in out_fx[6 cols]
+ * (summed over ranks like the rest): a non-zero count means the refit must be NaN.  Integer addition is associative,
  * so the sums -- and the prior refit from them -- are bitwise independent of the order of the workgroups and, after an
  * integer all-reduce, of how the rows are sharded over ranks.  mean = sum x / n, M2 = sum x^2 - (sum x)^2 / n in fp64.
  * ------------------------------------------------------------------------------------------- */

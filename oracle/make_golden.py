@@ -927,6 +927,34 @@ def gen_wide_cases(out):
         np.savez_compressed(os.path.join(out, f"wide_{name}_w{width}.npz"), **d)
         print("wide", name, width, "ok", flush=True)
 
+def gen_hier_map(out):
+    """round-4 addition: utils.map_hierarchical_model_to_int_weights itself (utils.py:122-198; A5), called directly on small
+    random posteriors of every patched geometry and of the un-patched case, sample sizes 1 and 3.  The noise is the CPU
+    generator's stream after torch.manual_seed(seed): three [N, S, D] draws in the order level 1, 2, 3 (one draw un-patched)."""
+    P, n_inr = presets()
+    d, D = {}, 37
+    for name in ("patch1d", "patch2d", "patch3d", "cifar"):
+        cfg, N = P[name], n_inr[name]
+        pn, hp, dd = cfg["patch_nums"], cfg["hierarchical_patch_nums"], cfg["data_dim"]
+        g = torch.Generator().manual_seed(1000 + len(name))
+        r2 = N // int(np.prod(hp["level2"])) if cfg["patch"] else 1
+        r3 = N // int(np.prod(hp["level3"])) if cfg["patch"] else 1
+        loc, h_loc, hh_loc = (torch.randn(r, D, generator=g) for r in (N, r2, r3))
+        sc, h_sc, hh_sc = (torch.rand(r, D, generator=g) * 0.3 + 0.01 for r in (N, r2, r3))
+        for k, v in zip(("loc", "scale", "h_loc", "h_scale", "hh_loc", "hh_scale"), (loc, sc, h_loc, h_sc, hh_loc, hh_sc)):
+            d[f"{name}_{k}"] = tnp(v)
+        for S in (1, 3):
+            torch.manual_seed(77 + S)
+            o = ref_utils.map_hierarchical_model_to_int_weights(bool(cfg["patch"]), loc, sc, h_loc, h_sc, hh_loc, hh_sc, S,
+                                                                hp, pn, dd)
+            assert tuple(o.shape) == (N, S, D)
+            d[f"{name}_S{S}_out"] = tnp(o)
+            d[f"{name}_S{S}_seed"] = np.int64(77 + S)
+        d[f"{name}_cfg"] = np.array(jsonable(cfg))
+        d[f"{name}_n"] = np.int64(N)
+    np.savez_compressed(os.path.join(out, "hier_map.npz"), **d)
+    print("hier_map ok", flush=True)
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -959,4 +987,7 @@ if __name__ == "__main__":
     # round-3 addition
     if "rd" in todo:
         gen_rd_trained(a.out)
+    # round-4 addition
+    if "hier" in todo:
+        gen_hier_map(a.out)
     print("done")

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RCB_LIB: alternative build of the same ABI (same-box A/B timing of kernel changes); never a different backend
 LIB_PATH = os.environ.get("RCB_LIB") or os.path.join(_HERE, "lib", "librcb_hip.so")
 
-EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
+EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_struct_bytes", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_rec_commit", "rcb_rec_workspace_bytes", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
@@ -39,7 +39,7 @@ class Level(C.Structure):
     _fields_ = [("loc", C.c_void_p), ("log_scale", C.c_void_p), ("enc_sample", C.c_void_p),
                 ("enc_mask", C.c_void_p), ("row_map", C.c_void_p), ("row_perm", C.c_void_p),
                 ("col_map", C.c_void_p), ("eps", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("cols_out", C.c_int32)]
+                ("cols_out", C.c_int32), ("scale_is_sigma", C.c_int32)]
 
 
 class RecDesc(C.Structure):
@@ -74,6 +74,9 @@ class LevelBwd(C.Structure):
 
 
 _lib = None
+# the header these mirrors were written against (include/rcb.h: RCB_VERSION) and the structures load() verifies by size
+ABI_VERSION = 400
+_MIRRORS = {0: SirenDesc, 1: Level, 2: LevelBwd, 3: AdamCfg, 4: AdamTensor, 5: RecDesc}
 
 
 def load():
@@ -94,6 +97,14 @@ def load():
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RcbError(f"{LIB_PATH} does not export {name}")
+        lib.rcb_struct_bytes.restype = C.c_int64
+        if lib.rcb_version() != ABI_VERSION:
+            raise RcbError(f"{LIB_PATH} is ABI version {lib.rcb_version()}, this binding was written against {ABI_VERSION}: "
+                           "rebuild with `python -m recombiner_amd.build --force`")
+        for which, cls in _MIRRORS.items():
+            if lib.rcb_struct_bytes(which) != C.sizeof(cls):
+                raise RcbError(f"{cls.__name__}: the library's structure has {lib.rcb_struct_bytes(which)} bytes, the ctypes "
+                               f"mirror {C.sizeof(cls)} -- _lib.py has drifted from include/rcb.h")
         _lib = lib
     return _lib
 

@@ -38,13 +38,30 @@ using namespace rcb;
 // addition is associative, so the result does not depend on the order in which the contributions arrive -- bitwise
 // reproducible from run to run, and identical whether the rows sit on one GPU or are sharded (the all-reduce over ranks
 // is an integer sum as well).  A contribution is rounded once, to the fixed-point grid, where it enters.
-__device__ __forceinline__ void fx_add(int64_t* dst, double v, double scale) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double2ll_rn(v * scale));
-}
 constexpr double KL_FX = 16777216.0;          // RCB_KL_FX_SCALE = 2^24 units per nat
+// KL accumulators of a step: slots [0, RCB_KL_SLOTS - 1) hold partial sums, the LAST slot counts the contributions that
+// could not be represented (NaN / Inf, or beyond 2^30 nats from one workgroup): a diverged run must surface as NaN in the
+// ELBO log, as it does in the reference, not as an arbitrary finite integer (__double2ll_rn(NaN) is 0).
+__device__ __forceinline__ void fx_add_kl(int64_t* slots, unsigned which, double v) {
+  if (fabs(v) < 1073741824.0)
+    atomicAdd(reinterpret_cast<unsigned long long*>(slots + which % (RCB_KL_SLOTS - 1)), (unsigned long long)__double2ll_rn(v * KL_FX));
+  else
+    atomicAdd(reinterpret_cast<unsigned long long*>(slots + (RCB_KL_SLOTS - 1)), 1ull);
+}
 
 extern "C" int rcb_version(void) { return RCB_VERSION; }
 extern "C" const char* rcb_last_error_string(void) { return last_error_buf(); }
+extern "C" int64_t rcb_struct_bytes(int32_t which) {
+  switch (which) {
+    case RCB_STRUCT_SIREN_DESC: return (int64_t)sizeof(rcb_siren_desc);
+    case RCB_STRUCT_LEVEL: return (int64_t)sizeof(rcb_level);
+    case RCB_STRUCT_LEVEL_BWD: return (int64_t)sizeof(rcb_level_bwd);
+    case RCB_STRUCT_ADAM_CFG: return (int64_t)sizeof(rcb_adam_cfg);
+    case RCB_STRUCT_ADAM_TENSOR: return (int64_t)sizeof(rcb_adam_tensor);
+    case RCB_STRUCT_REC_DESC: return (int64_t)sizeof(rcb_rec_desc);
+    default: return -1;
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // softplus/6
@@ -89,7 +106,7 @@ __device__ __forceinline__ void level_mu_sigma(const rcb_level& L, int n, int d,
   if (L.row_perm) r = L.row_perm[(long long)r * L.cols + j];
   long long o = (long long)r * L.cols + j;
   float loc = L.loc[o];
-  float s = st_f32(L.log_scale[o]);
+  float s = L.scale_is_sigma ? L.log_scale[o] : st_f32(L.log_scale[o]);
   if (L.enc_mask) {
     float m = L.enc_mask[o];
     float z = L.enc_sample[o];
@@ -354,7 +371,7 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
     const rcb_level& L = a.lv[0];
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!g_generic_only && n_levels == 1 && samples == 1 && !L.enc_mask && !L.row_map && !L.row_perm && !L.col_map &&
-        L.cols == out_cols && L.rows == n_inr && al16(L.loc) && al16(L.log_scale) && al16(L.eps) && al16(out)) {
+        !L.scale_is_sigma && L.cols == out_cols && L.rows == n_inr && al16(L.loc) && al16(L.log_scale) && al16(L.eps) && al16(out)) {
       const long long n = (long long)n_inr * out_cols;
       int blocks = cdiv(n >> 2, 256);
       if (blocks > 16384) blocks = 16384;
@@ -364,7 +381,7 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
       return RCB_OK;
     }
   }
-  if (!g_generic_only && n_levels == 1 && a.lv[0].col_map && !a.lv[0].row_map && !a.lv[0].row_perm && a.lv[0].rows == n_inr &&
+  if (!g_generic_only && n_levels == 1 && !a.lv[0].scale_is_sigma && a.lv[0].col_map && !a.lv[0].row_map && !a.lv[0].row_perm && a.lv[0].rows == n_inr &&
       a.lv[0].cols_out == out_cols && (size_t)a.lv[0].cols * 16 <= 150 * 1024) {
     // (per launch: the attribute belongs to the (function, device) pair; a process may drive several devices)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reparam_staged_kernel),
@@ -606,7 +623,7 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
     __syncthreads();
     // one (integer, fixed-point) atomic per block, spread over RCB_KL_SLOTS addresses (a single address serialises)
     if (threadIdx.x == 0)
-      fx_add(L.kl_accum + ((blockIdx.x * 7 + blockIdx.y) & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]), KL_FX);
+      fx_add_kl(L.kl_accum, blockIdx.x * 7 + blockIdx.y, (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
   }
   if (w != 0.0f) {
     float sp = L.p_scale_is_log ? st_f32(L.p_scale[j]) : L.p_scale[j];
@@ -702,7 +719,7 @@ __global__ void __launch_bounds__(1024) posterior_staged_kernel(PostBwdArgs a) {
     if (threadIdx.x == 0) {
       double t = 0.0;
       for (int k = 0; k < 16; ++k) t += s_kl[k];
-      fx_add(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), t, KL_FX);
+      fx_add_kl(L.kl_accum, blockIdx.x, t);
     }
   }
 }
@@ -769,7 +786,7 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
     __syncthreads();
     if (threadIdx.x == 0)
-      fx_add(L.kl_accum + (blockIdx.x & (RCB_KL_SLOTS - 1)), (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]), KL_FX);
+      fx_add_kl(L.kl_accum, blockIdx.x, (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
   }
   if (!act) return;
   RCB_ST4P(L.loc + b, loc4);
@@ -884,7 +901,7 @@ __global__ void __launch_bounds__(1024) step_end_kernel(const float* __restrict_
   if (sse)
     for (int i = t; i < n_sse; i += 1024) a += (double)sse[i];
   red[t] = a;
-  redk[t] = kl_slots ? kl_slots[t] : 0;
+  redk[t] = (kl_slots && t < RCB_KL_SLOTS - 1) ? kl_slots[t] : 0;       // (the last slot is the not-representable counter)
   __syncthreads();
   for (int off = 512; off > 0; off >>= 1) {
     if (t < off) {
@@ -897,7 +914,8 @@ __global__ void __launch_bounds__(1024) step_end_kernel(const float* __restrict_
     const long long s = *step;
     if (s >= 0 && s < n_log) {
       if (mse_log && sse) mse_log[s] = red[0] * mse_scale;
-      if (kl_log && kl_slots) kl_log[s] = (double)redk[0] * (1.0 / KL_FX);
+      if (kl_log && kl_slots)
+        kl_log[s] = kl_slots[RCB_KL_SLOTS - 1] ? __builtin_nan("") : (double)redk[0] * (1.0 / KL_FX);
     }
     *step = s + 1;
     if (aux_counter) *aux_counter += 1;      // e.g. the noise counter, which is NOT reset between train() calls
@@ -1001,13 +1019,21 @@ extern "C" int rcb_adam_flat(float* p, const float* g, float* m, float* v, int64
 // ------------------------------------------------------------------------------------------
 // K12 column moments: exact fixed-point sums (order-independent, see fx_add).  Every term v (x, x^2, sigma^2; each exact
 // in fp64) is split at 2^-30:  hi = floor(v 2^30),  lo = rint((v 2^30 - hi) 2^32)  and both parts are summed as 64-bit
-// integers: resolution 2^-62, range |v| < 2^12 with up to 2^20 rows over all ranks.
+// integers: resolution 2^-62; every TERM must satisfy |v| < 2^12 (so |x| < 2^6 because x^2 is a term, sigma < 2^6) for up
+// to 2^20 rows over all ranks (2^12 * 2^30 * 2^20 = 2^62); terms outside that range, NaN and Inf are counted, not summed.
 //   out[q][0][j] = sum_r hi,  out[q][1][j] = sum_r lo   for q = 0: x = loc[r, j], 1: x^2, 2: sigma^2 = (softplus(ls) / 6)^2
+//   out[6 * cols] = number of terms that were not representable
 // ------------------------------------------------------------------------------------------
 constexpr int kMomRowsPerBlock = 256;
 constexpr double MOM_FX = 1073741824.0, MOM_FX_LO = 4294967296.0, SQ_FX = 1073741824.0;   // 2^30, 2^32; 2^30 (KL column sums)
 
-__device__ __forceinline__ void fx_split(double v, long long& hi, long long& lo) {
+// terms outside the representable range (|v| >= 2^12, NaN, Inf) are not summed but COUNTED (`bad`): the consumer turns a
+// non-zero count back into NaN instead of refitting a prior from garbage
+__device__ __forceinline__ void fx_split(double v, long long& hi, long long& lo, long long& bad) {
+  if (!(fabs(v) < 4096.0)) {
+    ++bad;
+    return;
+  }
   const double s = v * MOM_FX;                 // exact (power of two)
   const double f = floor(s);
   hi += __double2ll_rn(f);
@@ -1020,16 +1046,17 @@ __global__ void __launch_bounds__(256) col_moments_kernel(const float* __restric
   if (j >= cols) return;
   int r0 = blockIdx.y * kMomRowsPerBlock;
   int r1 = min(rows, r0 + kMomRowsPerBlock);
-  long long acc[6] = {0, 0, 0, 0, 0, 0};
+  long long acc[6] = {0, 0, 0, 0, 0, 0}, bad = 0;
   for (int r = r0; r < r1; ++r) {
     const double x = (double)loc[(long long)r * cols + j];
-    fx_split(x, acc[0], acc[1]);
-    fx_split(x * x, acc[2], acc[3]);
+    fx_split(x, acc[0], acc[1], bad);
+    fx_split(x * x, acc[2], acc[3], bad);
     const float s = st_f32(ls[(long long)r * cols + j]);
-    fx_split((double)mul_rn(s, s), acc[4], acc[5]);
+    fx_split((double)mul_rn(s, s), acc[4], acc[5], bad);
   }
 #pragma unroll
   for (int q = 0; q < 6; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(out + (long long)q * cols + j), (unsigned long long)acc[q]);
+  if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(out + 6ll * cols), (unsigned long long)bad);
 }
 
 extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t rows, int32_t cols, int64_t* out_fx,
@@ -1037,7 +1064,7 @@ extern "C" int rcb_col_moments(const float* loc, const float* log_scale, int32_t
   RCB_REQUIRE(loc && log_scale && out_fx, RCB_ERR_ARG, "col_moments: null pointer");
   RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "col_moments: empty shape");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out_fx, 0, sizeof(int64_t) * 6 * cols, st);
+  hipError_t e = hipMemsetAsync(out_fx, 0, sizeof(int64_t) * (6 * (size_t)cols + 1), st);
   if (e != hipSuccess) return fail((int)e, "memset");
   int row_blocks = cdiv(rows, kMomRowsPerBlock);
   RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "col_moments: too many rows");
@@ -1059,13 +1086,21 @@ __global__ void __launch_bounds__(256) kl_colsum_kernel(const float* __restrict_
   int r0 = blockIdx.y * kMomRowsPerBlock;
   int r1 = min(rows, r0 + kMomRowsPerBlock);
   float mp = p_loc[j], sp = p_scale[j];
-  double acc = 0.0;
+  long long acc = 0, bad = 0;
   for (int r = r0; r < r1; ++r) {
     float s = sc[(long long)r * cols + j];
     if (q_is_log) s = st_f32(s);
-    acc += (double)kl_elem_f32(loc[(long long)r * cols + j], s, mp, sp);
+    // EVERY element enters the integer grid on its own (2^30 units per nat; the product with the power of two is exact in
+    // fp64, the rounding to the grid happens once, here): the sum is then independent of where the 256-row blocks -- and
+    // the shards of a sharded run -- are cut, not only of the order in which they arrive
+    const double k = (double)kl_elem_f32(loc[(long long)r * cols + j], s, mp, sp);
+    if (fabs(k) < 4096.0)
+      acc += __double2ll_rn(k * SQ_FX);
+    else
+      ++bad;                                                           // NaN / Inf / beyond 2^12 nats: counted, not summed
   }
-  fx_add(reinterpret_cast<int64_t*>(&out[j]), acc, SQ_FX);            // 2^30 units per nat: exact, order-independent accumulation
+  atomicAdd(reinterpret_cast<unsigned long long*>(out + j), (unsigned long long)acc);
+  if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(out + cols), (unsigned long long)bad);
 }
 
 extern "C" int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32_t q_scale_is_log, const float* p_loc,
@@ -1074,7 +1109,7 @@ extern "C" int rcb_gauss_kl_colsum(const float* loc, const float* q_scale, int32
   RCB_REQUIRE(loc && q_scale && p_loc && p_scale && out_fx, RCB_ERR_ARG, "kl_colsum: null pointer");
   RCB_REQUIRE(rows > 0 && cols > 0, RCB_ERR_SHAPE, "kl_colsum: empty shape");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out_fx, 0, sizeof(int64_t) * cols, st);
+  hipError_t e = hipMemsetAsync(out_fx, 0, sizeof(int64_t) * ((size_t)cols + 1), st);
   if (e != hipSuccess) return fail((int)e, "memset");
   int row_blocks = cdiv(rows, kMomRowsPerBlock);
   RCB_REQUIRE(row_blocks <= 65535, RCB_ERR_SHAPE, "kl_colsum: too many rows");

@@ -74,7 +74,7 @@ def refit_prior(loc: torch.Tensor, log_scale: torch.Tensor, group=None):
     if ws > 1:
         td.all_reduce(pack, group=group)
     n = int(pack[-1])
-    s, m2, sg = ops.moments_from_fx(pack[:-1].view(3, 2, -1), n)
+    s, m2, sg = ops.moments_from_fx(pack[:-1], n)
     return prior_from_moments(torch.tensor(float(n), dtype=torch.float64), s, m2, sg, loc.shape[1:])
 
 
@@ -88,15 +88,16 @@ def allreduce_scalar(v: torch.Tensor, group=None) -> torch.Tensor:
 
 def grouping_weights(kl_colsum: torch.Tensor, n_rows_local: int, group=None) -> np.ndarray:
     """mean-over-INRs KL in bits per parameter across ranks -> fp32 numpy weights for get_grouping_by_kl.  kl_colsum: the
-    exact fixed-point column sums of ops.gauss_kl_colsum_fx (int64: summed over ranks as integers, so the grouping does
-    not depend on the sharding) or plain fp64 sums."""
+    exact fixed-point column sums of ops.gauss_kl_colsum_fx (int64 [cols + 1]: every element is rounded to the integer grid
+    on its own and the ranks' results are added as integers, so the grouping does not depend on how the rows are sharded --
+    any cut, not only multiples of the kernel's 256-row blocks) or plain fp64 sums."""
     rank, ws = world(group)
     if kl_colsum.dtype == torch.int64:
         from . import ops
         pack = torch.cat([kl_colsum, torch.tensor([n_rows_local], dtype=torch.int64, device=kl_colsum.device)])
         if ws > 1:
             td.all_reduce(pack, group=group)
-        return (pack[:-1].to(torch.float64) / ops.COLSUM_FX / np.log(2.) / float(pack[-1])).to(torch.float32).cpu().numpy()
+        return (ops.colsum_from_fx(pack[:-1]) / np.log(2.) / float(pack[-1])).to(torch.float32).cpu().numpy()
     pack = torch.cat([kl_colsum.to(torch.float64), torch.tensor([float(n_rows_local)], dtype=torch.float64,
                                                                 device=kl_colsum.device)])
     if ws > 1:

@@ -284,8 +284,9 @@ class LevelSpec:
     index maps that scatter it onto INRs (hierarchy) and un-permute it (test-time grouping)."""
 
     def __init__(self, loc, log_scale, cols_out, n_inr, row_map=None, row_perm=None, col_map=None,
-                 enc_sample=None, enc_mask=None):
+                 enc_sample=None, enc_mask=None, scale_is_sigma=False):
         self.loc, self.log_scale = loc, log_scale
+        self.scale_is_sigma = bool(scale_is_sigma)     # `log_scale` holds sigma itself (rcb_level.scale_is_sigma)
         self.rows, self.cols = loc.shape[0], loc.shape[1]
         self.cols_out, self.n_inr = int(cols_out), int(n_inr)
         dev = loc.device
@@ -323,7 +324,7 @@ class LevelSpec:
             raise RcbError("eps last dim must equal cols_out")
         return Level(addr(self.loc.detach(), f32), addr(self.log_scale.detach(), f32), addr(self.enc_sample, f32),
                      addr(self.enc_mask, f32), addr(self.row_map, i32), addr(self.row_perm, i32),
-                     addr(self.col_map, i32), addr(eps, f32), self.rows, self.cols, self.cols_out)
+                     addr(self.col_map, i32), addr(eps, f32), self.rows, self.cols, self.cols_out, int(self.scale_is_sigma))
 
 
 def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], samples: int):
@@ -343,7 +344,7 @@ def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], sample
 def rng_eligible(lv: LevelSpec):
     """plain level (no maps, no masks, every column produced): the in-kernel noise path applies"""
     return (lv.row_map is None and lv.row_perm is None and lv.col_map is None and lv.enc_mask is None
-            and lv.cols_out == lv.cols and lv.n_inr == lv.rows and lv.loc.is_contiguous() and lv.log_scale.is_contiguous())
+            and not lv.scale_is_sigma and lv.cols_out == lv.cols and lv.n_inr == lv.rows and lv.loc.is_contiguous() and lv.log_scale.is_contiguous())
 
 
 def sample_buffers(lv: LevelSpec, want_bf16=False):
@@ -518,13 +519,14 @@ MOM_FX, MOM_FX_LO = 2.0 ** 30, 2.0 ** 32      # RCB_MOM_FX_SCALE, RCB_MOM_FX_LO_
 
 
 def gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log=False):
-    """-> int64 [cols]: sum over rows of the elementwise KL in units of 1 / COLSUM_FX nats (exact integer accumulation:
-    bitwise independent of the order of the workgroups; summed over ranks with an integer all-reduce)."""
+    """-> int64 [cols + 1]: sum over rows of the elementwise KL in units of 1 / COLSUM_FX nats (every element rounded to the
+    integer grid on its own, exact integer accumulation: bitwise independent of the order of the workgroups and of how the
+    rows are sharded; summed over ranks with an integer all-reduce) + the count of not-representable elements."""
     lib = _lib.load()
     l2 = loc.detach().reshape(loc.shape[0], -1).contiguous()
     s2 = q_scale.detach().reshape(loc.shape[0], -1).contiguous()
     rows, cols = l2.shape
-    out = torch.empty(cols, device=loc.device, dtype=torch.int64)
+    out = torch.empty(cols + 1, device=loc.device, dtype=torch.int64)     # [cols] sums + the not-representable counter
     check(lib.rcb_gauss_kl_colsum(ptr(l2, f32), ptr(s2, f32), int(bool(q_is_log)), ptr(p_loc.reshape(-1).contiguous(), f32),
                                   ptr(p_scale.reshape(-1).contiguous(), f32), rows, cols, ptr(out), stream_ptr()),
           "rcb_gauss_kl_colsum")
@@ -532,8 +534,15 @@ def gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log=False):
 
 
 def gauss_kl_colsum(loc, q_scale, p_loc, p_scale, q_is_log=False):
-    """-> fp64 [cols]: sum over rows of the elementwise KL."""
-    return gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log).to(f64) / COLSUM_FX
+    """-> fp64 [cols]: sum over rows of the elementwise KL (NaN everywhere if any element's KL was not finite)."""
+    return colsum_from_fx(gauss_kl_colsum_fx(loc, q_scale, p_loc, p_scale, q_is_log))
+
+
+def colsum_from_fx(fx):
+    """fp64 column sums from the [cols + 1] fixed-point result (last element: count of non-finite / out-of-range elements,
+    which the reference would have propagated as NaN / Inf)"""
+    v = fx[:-1].to(f64) / COLSUM_FX
+    return torch.where(fx[-1] != 0, torch.full_like(v, float("nan")), v)
 
 
 def beta_update(kl_group, beta, done_u8, bits=16.0, upper=0.0, lower=0.4, step=0.05):
@@ -603,20 +612,24 @@ def adam_multi(params, grads, ms, vs, cfg: AdamCfg):
 
 
 def col_moments_fx(loc, log_scale):
-    """-> int64 [3, 2, cols]: exact fixed-point sums over the rows of loc (rcb_col_moments): (hi, lo) parts of sum x,
-    sum x^2, sum sigma^2.  Integer sums: add them over ranks with an integer all-reduce, then moments_from_fx."""
+    """-> int64 [6 * cols + 1]: exact fixed-point sums over the rows of loc (rcb_col_moments): as [3, 2, cols] the (hi, lo)
+    parts of sum x, sum x^2, sum sigma^2, then the count of terms that were NaN / Inf / out of range.  Integer sums: add them
+    over ranks with an integer all-reduce, then moments_from_fx."""
     lib = _lib.load()
     l2 = loc.detach().reshape(loc.shape[0], -1)
     s2 = log_scale.detach().reshape(loc.shape[0], -1)
     rows, cols = l2.shape
-    out = torch.empty(3, 2, cols, device=loc.device, dtype=torch.int64)
+    out = torch.empty(6 * cols + 1, device=loc.device, dtype=torch.int64)
     check(lib.rcb_col_moments(ptr(l2, f32), ptr(s2, f32), rows, cols, ptr(out), stream_ptr()), "rcb_col_moments")
     return out
 
 
 def moments_from_fx(fx, n_rows):
-    """(sum, M2 = sum (x - mean)^2, sum sigma^2) in fp64 from the fixed-point sums of n_rows rows"""
+    """(sum, M2 = sum (x - mean)^2, sum sigma^2) in fp64 from the fixed-point sums of n_rows rows (col_moments_fx layout);
+    all NaN when the kernel counted a term it could not represent (a diverged posterior must not refit a finite prior)"""
+    bad, fx = fx[-1], fx[:-1].view(3, 2, -1)
     v = (fx[:, 0].to(f64) + fx[:, 1].to(f64) / MOM_FX_LO) / MOM_FX
+    v = torch.where(bad != 0, torch.full_like(v, float("nan")), v)
     return v[0], v[1] - v[0] * v[0] / float(n_rows), v[2]
 
 

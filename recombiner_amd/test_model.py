@@ -23,6 +23,7 @@ from .ops import LevelSpec, SirenMeta
 from .upsample_fast import (hip_path_supported, tiled_2d_preferred, phase_form_preferred, phase_module,
                             stitched2d_module, upsample_cifar_hip)
 from .utils import count_net_params, hierarchy_row_maps, map_lpe_to_inr_inputs, metric
+from .utils import map_hierarchical_model_to_int_weights  # noqa: F401  (module-level name, as upstream imports it)
 
 LN2 = np.log(2.)
 

@@ -1,8 +1,10 @@
 """Host-side helpers of the hot path: layer bookkeeping, patch stitching around the upsampling
 net, synthetic coordinate inputs, metrics.  Mirrors the helper surface of the reference's
-utils.py (names and argument meaning); the arithmetic-heavy helper of the reference
-(`map_hierarchical_model_to_int_weights`, utils.py:122-198) is replaced by the HIP sampling
-kernel (`ops.sample_levels` over `LevelSpec` index maps built by `hierarchy_row_maps`).
+utils.py (names and argument meaning).  The arithmetic-heavy helper of the reference,
+`map_hierarchical_model_to_int_weights` (utils.py:122-198), is the HIP sampling kernel
+(`rcb_reparam_fwd` over index maps built by `hierarchy_row_maps`): the model classes call the
+kernel on their own parameters, the function of that name below keeps the reference's signature
+for code that calls it directly.
 """
 import numpy as np
 import torch
@@ -34,6 +36,69 @@ def hierarchy_row_maps(n_inr, patch_nums, hierarchical_patch_nums, data_dim):
     pos = np.unravel_index(local, patch_nums)
     grp = np.ravel_multi_index(tuple(pos[i] // l2[i] for i in range(data_dim)), ngrp)
     return (datum * int(np.prod(ngrp)) + grp).astype(np.int64), datum.astype(np.int64)
+
+
+class _HierSampleFn(torch.autograd.Function):
+    """sum over the levels of loc_L[row_L(n)] + scale_L[row_L(n)] * eps_L[n, s]: rcb_reparam_fwd with
+    rcb_level.scale_is_sigma; the adjoint (sums over samples and over the patches that share a row) is torch plumbing."""
+
+    @staticmethod
+    def forward(ctx, S, maps, eps, *params):
+        from . import ops
+        n = params[0].shape[0]
+        lv = [ops.LevelSpec(params[2 * i].detach().contiguous(), params[2 * i + 1].detach().contiguous(), params[0].shape[1], n,
+                            row_map=maps[i], scale_is_sigma=True) for i in range(len(maps))]
+        ctx.maps, ctx.eps, ctx.rows = maps, eps, [p.shape[0] for p in params[::2]]
+        return ops.reparam_fwd(lv, eps, S)
+
+    @staticmethod
+    def backward(ctx, g):
+        out = []
+        for m, e, r in zip(ctx.maps, ctx.eps, ctx.rows):
+            gl, gs = g.sum(1), (g * e).sum(1)
+            if m is not None:
+                idx = torch.as_tensor(m, device=g.device, dtype=torch.long)
+                gl = torch.zeros(r, g.shape[-1], device=g.device, dtype=g.dtype).index_add_(0, idx, gl)
+                gs = torch.zeros(r, g.shape[-1], device=g.device, dtype=g.dtype).index_add_(0, idx, gs)
+            out += [gl, gs]
+        return (None, None, None, *out)
+
+
+def map_hierarchical_model_to_int_weights(use_hierarchical_model, loc, scale, h_loc, h_scale, hh_loc, hh_scale, sample_size,
+                                          hierarchical_patch_nums, patch_nums, data_dim, noise_source=None):
+    """Samples the (1- or 3-level) hierarchical model to the INR weights before the linear transform, `h_w`
+    [N, sample_size, D] -- the reference's function of this name (utils.py:122-198; same positional arguments: `scale` etc.
+    are standard deviations, i.e. st(log_scale) with the encoded-group masks already applied, as prior_model.py:140-145 and
+    test_model.py:289-298 pass them).  Per element, in the reference's operation order:
+        h_w[n, s] = (loc[n] + scale[n] * e1[n, s]) + (h_loc[r2(n)] + e2[n, s] * h_scale[r2(n)]) + (hh_loc[r3(n)] + hh_scale[r3(n)] * e3[n, s])
+    with r2 / r3 the level-2 / level-3 rows of patch n (`hierarchy_row_maps`; the reference materialises them with
+    reshape / repeat).  One launch of `rcb_reparam_fwd` (rcb_level.scale_is_sigma = 1); differentiable in all six tensors.
+    Noise: three standard-normal draws of shape [N, sample_size, D] in the order level 1, 2, 3 (one draw when
+    `use_hierarchical_model` is false) from the device generator, as `torch.randn_like` upstream, or from
+    `noise_source(shape)` (extra keyword, used by the parity tests to inject the reference's stream)."""
+    from . import ops
+    if not loc.is_cuda:
+        raise ops.RcbError("map_hierarchical_model_to_int_weights: tensors must live on the GPU (no CPU fallback exists)")
+    N, D = loc.shape
+    S = int(sample_size)
+
+    def draw():
+        if noise_source is not None:
+            return noise_source((N, S, D)).to(loc.device, torch.float32).reshape(N, S, D).contiguous()
+        return torch.randn(N, S, D, device=loc.device, dtype=torch.float32)
+
+    if use_hierarchical_model:
+        if data_dim not in (1, 2, 3):
+            raise NotImplementedError
+        m2, m3 = hierarchy_row_maps(N, patch_nums, hierarchical_patch_nums, data_dim)
+        if h_loc.shape[0] != int(m2.max()) + 1 or hh_loc.shape[0] != int(m3.max()) + 1:
+            raise ops.RcbError("map_hierarchical_model_to_int_weights: level-2 / level-3 rows do not match the patch hierarchy")
+        maps, params = (None, m2, m3), (loc, scale, h_loc, h_scale, hh_loc, hh_scale)
+    else:
+        maps, params = (None,), (loc, scale)
+    eps = tuple(draw() for _ in maps)
+    params = tuple(p.to(torch.float32) for p in params)
+    return _HierSampleFn.apply(S, maps, eps, *params)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -835,16 +835,59 @@ def test_col_moments_and_kl_colsum():
     ref = O.gauss_kl_elem(loc, O.st(ls), pl, ps).double().sum(0)
     np.testing.assert_allclose(cs.cpu().numpy(), ref.numpy(), rtol=1e-5)
     # the sums are exact fixed-point integers: bitwise the same from call to call, and the same when the rows are summed in
-    # shards and the integers added (any split for the moments; shards cut at multiples of 256 rows for the KL sums)
+    # shards and the integers added -- for ANY cut, of the moments and of the KL sums alike (every element is rounded to the
+    # integer grid on its own; round 3 rounded 256-row partial sums, which tied the KL sums to multiples of 256 rows)
     fx = ops.col_moments_fx(g(loc), g(ls))
+    assert fx.shape == (6 * cols + 1,) and int(fx[-1]) == 0
     assert torch.equal(fx, ops.col_moments_fx(g(loc), g(ls)))
-    for cut in (1, 256, 333):
+    kfx = ops.gauss_kl_colsum_fx(g(loc), g(ls), g(pl), g(ps), q_is_log=True)
+    assert kfx.shape == (cols + 1,) and int(kfx[-1]) == 0
+    assert torch.equal(kfx, ops.gauss_kl_colsum_fx(g(loc), g(ls), g(pl), g(ps), q_is_log=True))
+    for cut in (1, 256, 333, 512):
         parts = ops.col_moments_fx(g(loc[:cut]), g(ls[:cut])) + ops.col_moments_fx(g(loc[cut:]), g(ls[cut:]))
         assert torch.equal(fx, parts)
-    kfx = ops.gauss_kl_colsum_fx(g(loc), g(ls), g(pl), g(ps), q_is_log=True)
-    assert torch.equal(kfx, ops.gauss_kl_colsum_fx(g(loc), g(ls), g(pl), g(ps), q_is_log=True))
-    assert torch.equal(kfx, ops.gauss_kl_colsum_fx(g(loc[:512]), g(ls[:512]), g(pl), g(ps), q_is_log=True)
-                       + ops.gauss_kl_colsum_fx(g(loc[512:]), g(ls[512:]), g(pl), g(ps), q_is_log=True))
+        kparts = (ops.gauss_kl_colsum_fx(g(loc[:cut]), g(ls[:cut]), g(pl), g(ps), q_is_log=True)
+                  + ops.gauss_kl_colsum_fx(g(loc[cut:]), g(ls[cut:]), g(pl), g(ps), q_is_log=True))
+        assert torch.equal(kfx, kparts), cut
+    # a diverged posterior must not turn into a finite prior or a finite grouping statistic: NaN / Inf / out-of-range terms
+    # are counted, and the wrappers turn a non-zero count back into NaN (the reference propagates NaN by itself)
+    for poison in (float("nan"), float("inf"), 100.0):          # 100^2 is beyond the documented |x| < 2^6
+        bad = loc.clone()
+        bad[5, 7] = poison
+        fxb = ops.col_moments_fx(g(bad), g(ls))
+        assert int(fxb[-1]) >= 1
+        s_b, m2_b, sg_b = ops.moments_from_fx(fxb, rows)
+        assert torch.isnan(m2_b).all() and (torch.isnan(s_b).all() or poison == 100.0)
+    bad = loc.clone()
+    bad[3, 11] = float("nan")
+    kb = ops.gauss_kl_colsum_fx(g(bad), g(ls), g(pl), g(ps), q_is_log=True)
+    assert int(kb[-1]) == 1 and torch.equal(kb[:11], kfx[:11]) and torch.equal(kb[12:-1], kfx[12:-1])
+    assert torch.isnan(ops.gauss_kl_colsum(g(bad), g(O.st(ls)), g(pl), g(ps))).all()
+
+
+def test_kl_log_of_a_diverged_step_is_nan():
+    """the per-step KL accumulators are fixed-point integers; a workgroup sum that is NaN / Inf (a diverged posterior) is
+    counted in the last slot and rcb_step_end logs NaN for that step, as the reference's ELBO list would show"""
+    gen = torch.Generator().manual_seed(3)
+    rows, cols = 64, 300
+    loc = torch.nn.Parameter(g(0.05 * torch.randn(rows, cols, generator=gen)))
+    ls = torch.nn.Parameter(g(-4 + 0.1 * torch.randn(rows, cols, generator=gen)))
+    lv = LevelSpec(loc, ls, cols, rows)
+    pl, ps = g(torch.zeros(cols)), g(torch.full((cols,), 0.02))
+    d, e = g(torch.randn(rows, 1, cols, generator=gen)), g(torch.randn(rows, 1, cols, generator=gen))
+    state = {k: torch.zeros(rows, cols, device=DEV) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+    tab, dyn = ops.adam_table(1e-3, 4).to(DEV), torch.zeros(2, device=DEV)
+    step, slots = torch.zeros(1, device=DEV, dtype=torch.long), torch.zeros(1024, device=DEV, dtype=torch.int64)
+    kl_log = torch.zeros(4, device=DEV, dtype=torch.float64)
+    for it in range(2):
+        if it == 1:
+            with torch.no_grad():
+                loc[2, 5] = float("nan")
+        ops.step_begin(tab, step, dyn, slots)
+        ops.posterior_bwd(lv, pl, ps, False, 1e-4, d, e, 1, adam=ops.adam_cfg(1e-3, 1, dyn=dyn), state=state, kl_accum=slots)
+        ops.step_end(step, None, 1.0, slots, None, kl_log)
+    out = kl_log.cpu().numpy()
+    assert np.isfinite(out[0]) and out[0] > 0 and np.isnan(out[1]), out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1036,3 +1079,37 @@ def test_posterior_update_draws_the_next_sample_bit_for_bit():
     with pytest.raises(ops.RcbError):
         ops.posterior_bwd(lv_c, p_loc, p_scale, False, 1.0, d[:3].contiguous(), bc[1], 1, adam=cfg, state=state(lv_c),
                           next_sample=ops.NextSample(bc, seed, 0, step, 1))
+
+
+def test_integration_md_binding_stub_runs_and_matches_the_oracle():
+    """The ctypes stub INTEGRATION.md shows a maintainer is EXTRACTED from that file and executed as written (working
+    directory = the repository root, as its relative library path assumes): its structure mirror must have the library's
+    size (the stub asserts rcb_struct_bytes itself) and its results must equal the product binding's bit for bit and the
+    fp32 oracle's within the fp32 kernel's tolerance."""
+    import re
+    from golden_util import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "class SirenDesc" in b]
+    assert len(blocks) == 1, "INTEGRATION.md must hold exactly one SirenDesc stub"
+    ns, cwd = {}, os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(blocks[0], "INTEGRATION.md:stub", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    from recombiner_amd import _lib
+    import ctypes
+    assert ctypes.sizeof(ns["SirenDesc"]) == ctypes.sizeof(_lib.SirenDesc)
+    assert [f[0] for f in ns["SirenDesc"]._fields_] == [f[0] for f in _lib.SirenDesc._fields_]
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=1024, N=5, S=1)
+    dims, D, xf, pe, wv, y = _siren_case(seed=21, **case)
+    sse, dw, dpe = ns["siren_loss_bwd"](g(xf), g(pe), g(wv), g(y))
+    torch.cuda.synchronize()
+    meta = SirenMeta(1, 1024, 16, 16, 3, 32, 3)
+    s2, w2, p2 = ops.siren_loss_bwd(g(xf), g(pe), g(wv), g(y), 1.0 / (1024 * 3), meta)
+    assert torch.equal(sse, s2) and torch.equal(dw, w2) and torch.equal(dpe, p2)
+    pe_r, wv_r = pe.clone().requires_grad_(True), wv.clone().requires_grad_(True)
+    y_ref = _oracle_mlp(dims, xf, pe_r, wv_r, 1)
+    (((y_ref - y) ** 2).sum() / (1024 * 3)).backward()
+    assert rel_err(sse, ((y_ref.detach() - y) ** 2).sum((1, 2))) < 2e-5
+    assert rel_err(dw, wv_r.grad) < 1e-4 and rel_err(dpe, pe_r.grad) < 1e-4

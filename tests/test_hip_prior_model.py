@@ -482,3 +482,41 @@ def test_fused_next_sample_equals_separate_sampling_kernels():
                     [p.detach().clone() for p in lt.parameters()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["patch1d", "patch2d", "patch3d", "cifar"])
+def test_map_hierarchical_model_to_int_weights_against_the_reference_function(name):
+    """A5 as a callable with the reference's signature (utils.py:122-137): outputs of the reference function itself
+    (tests/golden/hier_map.npz) on the same noise stream.  The kernel performs the reference's operations in its order
+    (mul, add per level; levels summed left to right), un-fused: bit-identical.  Gradients against the fp64 adjoint."""
+    import json
+    from recombiner_amd import utils as U
+    d = load("hier_map.npz")
+    cfg = json.loads(str(d[f"{name}_cfg"]))
+    args = [torch.from_numpy(d[f"{name}_{k}"]).to(DEV) for k in ("loc", "scale", "h_loc", "h_scale", "hh_loc", "hh_scale")]
+    N, D = args[0].shape
+    for S in (1, 3):
+        torch.manual_seed(int(d[f"{name}_S{S}_seed"]))
+        eps = [torch.randn(N, S, D) for _ in range(3 if cfg["patch"] else 1)]
+        q = [e.clone() for e in eps]
+        leaf = [a.clone().requires_grad_(True) for a in args]
+        out = U.map_hierarchical_model_to_int_weights(bool(cfg["patch"]), *leaf, S, cfg["hierarchical_patch_nums"],
+                                                      cfg["patch_nums"], cfg["data_dim"], noise_source=lambda shape: q.pop(0))
+        assert tuple(out.shape) == (N, S, D)
+        assert np.array_equal(out.detach().cpu().numpy(), d[f"{name}_S{S}_out"]), (name, S)
+        # adjoint: d/d(loc_L) = sum of the upstream gradient over samples and member patches, d/d(scale_L) the same of g * eps
+        g = torch.randn(N, S, D, dtype=torch.float64)
+        out.backward(g.float().to(DEV))
+        geo = O.Geometry.from_config(cfg)
+        maps = [torch.arange(N)] + ([m.long() for m in geo.level_maps(N)] if cfg["patch"] else [])
+        for lvl, (m, e) in enumerate(zip(maps, eps)):
+            rows = args[2 * lvl].shape[0]
+            gl = torch.zeros(rows, D, dtype=torch.float64).index_add_(0, m, g.sum(1))
+            gs = torch.zeros(rows, D, dtype=torch.float64).index_add_(0, m, (g * e.double()).sum(1))
+            np.testing.assert_allclose(leaf[2 * lvl].grad.cpu().double().numpy(), gl.numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(leaf[2 * lvl + 1].grad.cpu().double().numpy(), gs.numpy(), rtol=1e-5, atol=1e-5)
+        if not cfg["patch"]:
+            assert leaf[2].grad is None and leaf[4].grad is None
+    # the name is importable where upstream imports it from (prior_model.py:10, test_model.py:12)
+    from recombiner_amd import test_model as TM
+    assert PM.map_hierarchical_model_to_int_weights is U.map_hierarchical_model_to_int_weights is TM.map_hierarchical_model_to_int_weights

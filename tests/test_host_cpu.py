@@ -22,7 +22,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rcb.h but not exported"
     assert sorted(_lib.EXPORTS) == declared
-    assert _lib.load().rcb_version() == 100
+    assert _lib.load().rcb_version() == _lib.ABI_VERSION == int(re.search(r"#define RCB_VERSION (\d+)", hdr).group(1))
+
+
+def test_descriptor_mirrors_have_the_library_sizes():
+    """every ctypes mirror of a descriptor is as large as the structure the library was compiled with (rcb_struct_bytes) --
+    _lib.load() refuses to bind otherwise -- and an unknown selector is rejected"""
+    lib = _lib.load()
+    for which, cls in _lib._MIRRORS.items():
+        assert lib.rcb_struct_bytes(which) == ctypes.sizeof(cls), cls.__name__
+    assert lib.rcb_struct_bytes(99) == -1
 
 
 def test_product_refuses_cpu_tensors():

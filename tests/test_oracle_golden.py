@@ -269,3 +269,20 @@ def test_rec_long_groups():
         np.testing.assert_allclose(lw[:256].numpy(), d[f"enc_{row}_{grp}_lw_head"], rtol=1e-9, atol=1e-9)
         top2 = torch.topk(lw, 2).values
         np.testing.assert_allclose(float(top2[0] - top2[1]), margin, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["patch1d", "patch2d", "patch3d", "cifar"])
+def test_hierarchical_sampling_against_the_reference_function(name):
+    """A5: the oracle's sample_latent_weights against utils.map_hierarchical_model_to_int_weights itself
+    (tests/golden/hier_map.npz, written by oracle/make_golden.py --only hier): same noise stream, bit for bit."""
+    import json
+    d = load("hier_map.npz")
+    cfg = json.loads(str(d[f"{name}_cfg"]))
+    geo = O.Geometry.from_config(cfg)
+    args = [torch.from_numpy(d[f"{name}_{k}"]) for k in ("loc", "scale", "h_loc", "h_scale", "hh_loc", "hh_scale")]
+    N, D = args[0].shape
+    for S in (1, 3):
+        torch.manual_seed(int(d[f"{name}_S{S}_seed"]))
+        eps = [torch.randn(N, S, D) for _ in range(3 if cfg["patch"] else 1)]
+        got = O.sample_latent_weights(geo, *args, S, O.Noise(eps))
+        assert np.array_equal(got.numpy(), d[f"{name}_S{S}_out"]), (name, S)

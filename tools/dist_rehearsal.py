@@ -115,17 +115,18 @@ if __name__ == "__main__":
     #    prior_model.py:268-270): exact fixed-point column sums + integer all-reduce -> BITWISE equal to the unsharded refit
     from recombiner_amd import dist as rdist, ops
     gen = torch.Generator().manual_seed(5)
-    rows = 512 * ws
+    per = 437                                           # NOT a multiple of the kernels' 256-row blocks: the sums must not care
+    rows = per * ws
     loc = (0.05 * torch.randn(rows, 777, generator=gen)).cuda()
     ls = (-4 + 0.5 * torch.randn(rows, 777, generator=gen)).cuda()
     mu_all, sig_all = rdist.refit_prior(loc, ls, group=dist.new_group([rank]))            # unsharded: a group of one
-    lo = rank * 512
-    mu_sh, sig_sh = rdist.refit_prior(loc[lo:lo + 512].contiguous(), ls[lo:lo + 512].contiguous())
+    lo = rank * per
+    mu_sh, sig_sh = rdist.refit_prior(loc[lo:lo + per].contiguous(), ls[lo:lo + per].contiguous())
     assert torch.equal(mu_all, mu_sh) and torch.equal(sig_all, sig_sh), "sharded prior refit differs from the unsharded one"
     pl, ps = loc.mean(0), loc.std(0) + 0.01
     w_all = rdist.grouping_weights(ops.gauss_kl_colsum_fx(loc, ls, pl, ps, q_is_log=True), rows, group=dist.new_group([rank]))
-    w_sh = rdist.grouping_weights(ops.gauss_kl_colsum_fx(loc[lo:lo + 512].contiguous(), ls[lo:lo + 512].contiguous(), pl, ps,
-                                                          q_is_log=True), 512)
+    w_sh = rdist.grouping_weights(ops.gauss_kl_colsum_fx(loc[lo:lo + per].contiguous(), ls[lo:lo + per].contiguous(), pl, ps,
+                                                          q_is_log=True), per)
     assert (w_all == w_sh).all(), "sharded grouping weights differ from the unsharded ones"
     if rank == 0:
         print("SHARDED == UNSHARDED OK ws=%d  ELBO rel err %.1e (fp32) %.1e (bf16); prior refit and grouping weights bitwise equal"
