@@ -106,6 +106,10 @@ typedef struct {
   int32_t hidden_dims[4];    /* all zero: every hidden layer is `hidden` wide.  Otherwise the widths of the n_hidden hidden
                               * layers one by one (the reference builds its INR from any list, prior_model.py:84-85): fp32
                               * mode only (1 .. 64 each; the plain-FMA parity kernel), `hidden` = their maximum            */
+  void* dw_lo;               /* nullable, with dw_bf16 (the HIGH plane): the LOW plane bf16(dwvec - dw_bf16), same layout and
+                              * stride.  The pair is the plane operand of the A transform's data gradient (rcb_atrans_apply
+                              * x_hi / x_lo): the same 4 bytes per element as the fp32 dwvec, which may then be NULL in
+                              * rcb_siren_bwd / _loss_bwd (unchunked launches) and rcb_siren_reduce_chunks                */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */
@@ -161,15 +165,17 @@ int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, in
 /* Noise drawn in the kernel (prior_model.py:140-145 draws torch.randn_like and then forms loc + st(log_scale) * eps):
  * eps[i] ~ N(0,1) from Philox4x32-10 + Box-Muller, a pure function of (seed, rng_stream, step, i), where `step` is read
  * from device memory so that a replayed HIP graph draws fresh noise.  rcb_reparam_rng_fwd: plain case (one level, one
- * sample, no maps), flat over n = rows * cols elements; writes eps_out (for rcb_posterior_bwd) and out, and, if out_bf16
- * != NULL, a bf16 copy of out as [n / cols][ld_bf16] rows (the operand of the A transform's batched bf16 weight-gradient
- * GEMM, written while the values are in registers).
+ * sample, no maps), flat over n = rows * cols elements; writes eps_out (for rcb_posterior_bwd; nullable: a consumer with
+ * rcb_level_bwd.eps_from_rng re-draws it) and out, and, if out_bf16 != NULL, a bf16 copy of out as [n / cols][ld_bf16] rows
+ * (the operand of the A transform's batched bf16 weight-gradient GEMM, written while the values are in registers); with
+ * out_lo != NULL also the low plane bf16(out - out_bf16) in the same layout: (out_bf16, out_lo) are the plane operands of
+ * rcb_atrans_apply, and `out` may then be NULL.
  * rcb_philox_normal materialises the same stream (step from step_dev if non-NULL, else step_host).              */
 int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev, int64_t step_host,
                       rcb_stream_t stream);
 int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
-                        const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, int32_t cols, int64_t ld_bf16,
-                        rcb_stream_t stream);
+                        const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, void* out_lo, int32_t cols,
+                        int64_t ld_bf16, rcb_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -252,15 +258,21 @@ typedef struct {
    * the same pass from the parameters just updated -- what rcb_reparam_rng_fwd would compute at step counter
    * *rng_step_dev + rng_step_add, bit for bit -- so that the sampling kernel of the next step (a second read of loc and
    * log_scale) disappears.  next_eps may alias eps: every element is read before it is written. */
-  float* next_out;         /* [rows * cols] fp32 sample                                                          */
-  float* next_eps;         /* [rows * cols] the noise of that sample (read by the next step's call as `eps`)     */
-  void* next_out_bf16;     /* nullable: bf16 copy of next_out as [rows][next_ld_bf16]                            */
+  float* next_out;         /* nullable: [rows * cols] fp32 sample                                                */
+  float* next_eps;         /* nullable: [rows * cols] the noise of that sample (read by the next step's call as `eps`;
+                            * not needed when that call sets eps_from_rng)                                       */
+  void* next_out_bf16;     /* nullable: bf16 copy of the sample as [rows][next_ld_bf16] -- the HIGH plane         */
   int64_t next_ld_bf16;
   uint64_t rng_seed;
   const int64_t* rng_step_dev;
   int64_t rng_step_add;
   uint32_t rng_stream;
-  uint32_t reserved0;
+  uint32_t eps_from_rng;   /* 1 (flat path, eps = NULL): this step's noise is not read from memory but re-drawn -- the noise
+                            * of (rng_seed, rng_stream, counter *rng_step_dev + rng_step_add - 1), i.e. what the sampler of
+                            * THIS step drew (rcb_reparam_rng_fwd at *rng_step_dev, or the previous call's next sample):
+                            * the same bits, 8 bytes of traffic per element less                                  */
+  void* next_out_lo;       /* nullable, with next_out_bf16: the LOW plane bf16(sample - high plane), same layout.  With both
+                            * planes next_out may be NULL: rcb_atrans_apply reads the planes (x_hi / x_lo)          */
 } rcb_level_bwd;
 
 int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* adam, rcb_stream_t stream);
@@ -305,10 +317,23 @@ int rcb_debug_generic_kernels_only(int32_t on);
  *                         entries on the host (plan[0] = workgroups, plan[2] = slices of the contraction: launches of few
  *                         rows cut it and add the partial sums in a fixed order) for rcb_atrans_apply
  * rcb_atrans_workspace_floats : fp32 elements of the workspace rcb_atrans_apply needs for that plan (0: none)
- * rcb_atrans_apply      : transpose = 0: out = x @ A (forward), 1: out = x @ A^T (data gradient)
+ *                         (plan = NULL with max_ints = 0: nothing is written, the return value is the number of ints needed;
+ *                         a buffer that is too small is RCB_ERR_SHAPE, any other error RCB_ERR_ARG)
+ * rcb_atrans_apply      : transpose = 0: out = x @ A (forward), 1: out = x @ A^T (data gradient).  The per-row operand comes
+ *                         EITHER as fp32 rows `x` (x_hi = x_lo = NULL; split hi + lo inside the kernel) OR -- x = NULL -- as
+ *                         the two bf16 PLANES its producer wrote: x_hi[r][c] = bf16(v), x_lo[r][c] = bf16(v - x_hi[r][c]),
+ *                         rows ld_x16 elements apart (a multiple of 8; 32 = 64-byte rows stream best), same column layout.
+ *                         The planes are the same 4 bytes per element as the fp32 row, carry exactly what the kernel would
+ *                         have formed from it -- results are bit-identical -- and arrive in LDS as operand bits (no
+ *                         conversion work); hi alone is the weight-gradient GEMM's operand.  Producers:
+ *                         rcb_reparam_rng_fwd (out_bf16 + out_lo), rcb_level_bwd.next_out_bf16 + next_out_lo,
+ *                         rcb_siren_desc.dw_bf16 + dw_lo.  x_lo may be NULL with terms = 1
  * rcb_atrans_wgrad_narrow : dA = h^T @ d for ONE narrow layer (the 99-wide output layer) in fp32, exact-product arithmetic,
- *                         fixed summation order; h / d point at the layer's first column; workspace:
- *                         rcb_atrans_wgrad_narrow_workspace(L, n_slabs) floats
+ *                         fixed summation order; each operand EITHER as fp32 rows (h / d, pointing at the layer's first
+ *                         column; the plane pointers NULL) OR as its (hi, lo) planes (h_hi, h_lo / d_hi, d_lo pointing at the
+ *                         layer's first column, the fp32 pointer NULL; read as float(hi) + float(lo)); ld_h / ld_d = the row
+ *                         stride in elements of whichever form is given; workspace: rcb_atrans_wgrad_narrow_workspace(L,
+ *                         n_slabs) floats
  * ------------------------------------------------------------------------------------------- */
 #define RCB_ATRANS_MAX_LAYERS 8
 #define RCB_ATRANS_PLAN_HEAD 12
@@ -316,13 +341,14 @@ int64_t rcb_atrans_pack_elems(int32_t n_layers, const int32_t* sizes);
 int rcb_atrans_pack(const float* const* A, int32_t n_layers, const int32_t* sizes, void* packed, int32_t want_lo,
                     rcb_stream_t stream);
 int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* sizes, int32_t n_cu, int32_t* plan, int32_t max_ints);
-int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_t ld_out, int64_t rows, int32_t n_layers,
-                     const int32_t* sizes, const void* packed, int32_t transpose, int32_t terms, const int32_t* plan_dev,
-                     const int32_t* plan_head, float* workspace, rcb_stream_t stream);
+int rcb_atrans_apply(const float* x, int64_t ld_x, const void* x_hi, const void* x_lo, int64_t ld_x16, float* out,
+                     int64_t ld_out, int64_t rows, int32_t n_layers, const int32_t* sizes, const void* packed, int32_t transpose,
+                     int32_t terms, const int32_t* plan_dev, const int32_t* plan_head, float* workspace, rcb_stream_t stream);
 int64_t rcb_atrans_workspace_floats(int64_t rows, int32_t n_layers, const int32_t* sizes, const int32_t* plan_head);
 int64_t rcb_atrans_wgrad_narrow_workspace(int32_t L, int32_t n_slabs);
-int rcb_atrans_wgrad_narrow(const float* h, int64_t ld_h, const float* d, int64_t ld_d, int64_t rows, int32_t L, float* dA,
-                            float* workspace, int32_t n_slabs, rcb_stream_t stream);
+int rcb_atrans_wgrad_narrow(const float* h, const void* h_hi, const void* h_lo, int64_t ld_h, const float* d, const void* d_hi,
+                            const void* d_lo, int64_t ld_d, int64_t rows, int32_t L, float* dA, float* workspace,
+                            int32_t n_slabs, rcb_stream_t stream);
 
 /* Bookkeeping of one optimisation step whose counter lives on the device, so that the whole step can be captured
  * once as a HIP graph and replayed (prior_model.py train() / test_model.py train() loop bodies):

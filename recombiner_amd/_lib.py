@@ -32,7 +32,8 @@ class SirenDesc(C.Structure):
                 ("xf_inr_stride", C.c_int64), ("w_row_stride", C.c_int64), ("w0", C.c_float),
                 ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_bf16", C.c_void_p), ("pixel_chunks", C.c_int32),
                 ("xf_bf16", C.c_void_p), ("pe_grid_dims", C.c_int32), ("pe_patch_nums", C.c_int32 * 3),
-                ("pe_patch_size", C.c_int32 * 3), ("dw_bf16_stride", C.c_int64), ("hidden_dims", C.c_int32 * 4)]
+                ("pe_patch_size", C.c_int32 * 3), ("dw_bf16_stride", C.c_int64), ("hidden_dims", C.c_int32 * 4),
+                ("dw_lo", C.c_void_p)]
 
 
 class Level(C.Structure):
@@ -70,7 +71,8 @@ class LevelBwd(C.Structure):
                 ("m_ls", C.c_void_p), ("v_ls", C.c_void_p), ("kl_accum", C.c_void_p), ("kl_scalar_dev", C.c_void_p),
                 ("next_out", C.c_void_p), ("next_eps", C.c_void_p), ("next_out_bf16", C.c_void_p),
                 ("next_ld_bf16", C.c_int64), ("rng_seed", C.c_uint64), ("rng_step_dev", C.c_void_p),
-                ("rng_step_add", C.c_int64), ("rng_stream", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("rng_step_add", C.c_int64), ("rng_stream", C.c_uint32), ("eps_from_rng", C.c_uint32),
+                ("next_out_lo", C.c_void_p)]
 
 
 _lib = None

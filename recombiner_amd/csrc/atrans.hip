@@ -87,6 +87,9 @@ __device__ unsigned long long g_stamps[8][40][6];
 
 struct AtArgs {
   const float* x;
+  const __bf16* xh;            // PLANES form: the per-row operand as two bf16 planes, x = hi + lo, written by its producer
+  const __bf16* xl;            //   (rcb_reparam_rng_fwd / rcb_posterior_bwd next sample / rcb_siren_desc.dw_bf16 + dw_lo)
+  long long ld_x16;            //   elements between the rows of a plane (a multiple of 8)
   float* out;
   long long ld_x, ld_out, rows;
   int n_layers;
@@ -114,7 +117,12 @@ struct Geo {
 constexpr int LDS_MAX_BYTES = 3 * (XT_BYTES + MAXSEG * 32 * BK * 2);        // = 2 stages of the three-term form (138 KB)
 
 // one segment: out[row0 .. row0 + 255, off_l + 32 cb0 .. + 32 ncb) of layer l
-template <int NCB, int TERMS, bool RAGGED>
+// PLANES: x arrives as the bf16 planes hi / lo instead of fp32 rows.  The x stage then holds two [256 rows][32 bf16] images
+// (64-byte rows, swizzled like the mapping image: their fragment reads are the mapping's conflict-free pattern), filled by
+// the same four DMAs per wave (two per plane, 16 rows each), and the fragments are READ as operand bits: the ~6 VALU
+// instructions per element of the in-register split -- about as long as the matrix work of a chunk -- are gone, and with
+// them the registers that spilled.  Same products in the same order as the fp32 form: bit-identical results.
+template <int NCB, int TERMS, bool RAGGED, bool PLANES>
 __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, const int4 sk, char* __restrict__ lds) {
   typedef Geo<NCB, TERMS> G;
   const int t = threadIdx.x, lane = t & 63;
@@ -124,7 +132,7 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
   const int kc0 = sk.x, nk = sk.y - sk.x;          // this segment's slice of the contraction (all of it unless the launch is K-split)
   const __bf16* __restrict__ bh = a.bh[l];
   const __bf16* __restrict__ bl = a.bl[l];
-  const float* __restrict__ xl0 = a.x + a.off[l];
+  const float* __restrict__ xl0 = PLANES ? nullptr : a.x + a.off[l];
 
   f32x16 acc[NCB];
 #pragma unroll
@@ -135,15 +143,27 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
   // ---- DMA sources of this lane (fixed over the chunks but for the contraction offset) ---------------------------------------
   // x: DMA i of wave w fills rows 32 w + 8 i .. + 7 of the tile (8 lanes per 128-byte row); lane -> (row, physical chunk),
   //    it fetches the logical chunk that belongs there.  Rows past the end repeat the last row (computed, never stored).
+  //    PLANES: DMA i fills rows 32 w + 16 (i & 1) .. + 15 of plane i >> 1 (4 lanes per 64-byte row)
   const float* xsrc[4];
+  const __bf16* psrc[4];
   int xk[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = 32 * wave + 8 * i + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    const long long gr = min((long long)row0 + row, a.rows - 1);
-    xsrc[i] = xl0 + gr * a.ld_x;
-    xk[i] = 4 * c;
+    if (PLANES) {
+      const int row = 32 * wave + 16 * (i & 1) + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const long long gr = min((long long)row0 + row, a.rows - 1);
+      psrc[i] = ((i >> 1) ? a.xl : a.xh) + gr * a.ld_x16 + a.off[l];
+      xk[i] = 8 * c;
+      xsrc[i] = nullptr;
+    } else {
+      const int row = 32 * wave + 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      const long long gr = min((long long)row0 + row, a.rows - 1);
+      xsrc[i] = xl0 + gr * a.ld_x;
+      xk[i] = 4 * c;
+      psrc[i] = nullptr;
+    }
   }
   // mapping: DMA j of wave w fills rows 16 (w + 8 j) .. + 15 of the image (4 lanes per 64-byte row); images shorter than
   // 8 NBW DMAs: the surplus DMAs repeat the last one (same bytes to the same place)
@@ -167,8 +187,13 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
     if (i < 4) {
       // chunks past the end of the layer (its padding to a multiple of 32) meet zero rows of the mapping: any finite
       // values do, so they repeat the layer's last chunk instead of reading past the row
-      const int k = RAGGED ? 0 : min(kc * BK + xk[i], K - 4);
-      dma16(xsrc[i] + k, st + (32 * wave + 8 * i) * 128);
+      if (PLANES) {
+        const int k = RAGGED ? 0 : min(kc * BK + xk[i], K - 8);
+        dma16(psrc[i] + k, st + (i >> 1) * (XT_BYTES / 2) + (32 * wave + 16 * (i & 1)) * 64);
+      } else {
+        const int k = RAGGED ? 0 : min(kc * BK + xk[i], K - 4);
+        dma16(xsrc[i] + k, st + (32 * wave + 8 * i) * 128);
+      }
     } else if (TERMS == 3) {
       const int j = (i - 4) >> 1;
       if ((i - 4) & 1) dma16(bsrc2[j] + kc * BK, st + G::BL_OFF + bdst[j]);
@@ -185,13 +210,27 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
   const int frow = lane & 31, fh = lane >> 5;
   const int xrow = 32 * wave + frow;
   // the wave's two x fragments (k-steps 0, 1) of a chunk: fp32 from its own rows of the stage, split hi + lo in registers
+  // (PLANES: they are read as they are -- raw[] then holds the NEXT chunk's four fragments until the current chunk's last
+  // MFMA has been issued, and x_convert is a register move)
   bf16x8 xh[2], xlo[2];
   f32x4 raw[4];
   auto x_read = [&](const char* __restrict__ st) {
+    if (PLANES) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const f32x4*>(st + xswz(xrow, 4 * (q >> 1) + 2 * fh + (q & 1)));
+      for (int q = 0; q < 4; ++q)
+        if (TERMS >= 2 || q < 2)
+          raw[q] = *reinterpret_cast<const f32x4*>(st + (q >> 1) * (XT_BYTES / 2) + bswz(xrow, 2 * (q & 1) + fh));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const f32x4*>(st + xswz(xrow, 4 * (q >> 1) + 2 * fh + (q & 1)));
+    }
   };
   auto x_convert = [&](int q) {                 // quarter q: elements 4 (q & 1) .. + 3 of k-step q >> 1
+    if (PLANES) {                               // q = 0, 1: hi fragments of k-steps 0, 1;  q = 2, 3: lo fragments
+      if (q < 2) xh[q] = __builtin_bit_cast(bf16x8, raw[q]);
+      else if (TERMS >= 2) xlo[q - 2] = __builtin_bit_cast(bf16x8, raw[q]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float v = raw[q][i];
@@ -269,13 +308,22 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = 32 * wave + 8 * i + (lane >> 3), pc = lane & 7;
         const int k0 = kc * BK + xk[i];
-        const bool rok = (long long)row0 + row < a.rows;
-        f32x4 v;
+        if (PLANES) {
+          const int row = 32 * wave + 16 * (i & 1) + (lane >> 2), pc = lane & 3;
+          const bool rok = (long long)row0 + row < a.rows;
+          bf16x8 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (rok && k0 + e < K) ? xsrc[i][k0 + e] : 0.f;
-        *reinterpret_cast<f32x4*>(lds + row * 128 + pc * 16) = v;
+          for (int e = 0; e < 8; ++e) v[e] = (rok && k0 + e < K) ? psrc[i][k0 + e] : (__bf16)0.f;
+          *reinterpret_cast<bf16x8*>(lds + (i >> 1) * (XT_BYTES / 2) + row * 64 + pc * 16) = v;
+        } else {
+          const int row = 32 * wave + 8 * i + (lane >> 3), pc = lane & 7;
+          const bool rok = (long long)row0 + row < a.rows;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (rok && k0 + e < K) ? xsrc[i][k0 + e] : 0.f;
+          *reinterpret_cast<f32x4*>(lds + row * 128 + pc * 16) = v;
+        }
       }
       wait_vm<0>();
       __syncthreads();
@@ -365,20 +413,42 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
   }
 }
 
-template <int TERMS, bool RAGGED>
-__device__ __forceinline__ void dispatch_segment(const AtArgs& a, const int4 sg, const int4 sk, char* lds) {
+template <int TERMS, bool RAGGED, bool PLANES>
+__device__ __forceinline__ void dispatch_upto4(const AtArgs& a, const int4 sg, const int4 sk, char* lds) {
   switch (sg.w) {
-    case 1: run_segment<1, TERMS, RAGGED>(a, sg, sk, lds); break;
-    case 2: run_segment<2, TERMS, RAGGED>(a, sg, sk, lds); break;
-    case 3: run_segment<3, TERMS, RAGGED>(a, sg, sk, lds); break;
-    case 4: run_segment<4, TERMS, RAGGED>(a, sg, sk, lds); break;
-    case 5: run_segment<5, TERMS, RAGGED>(a, sg, sk, lds); break;
-    case 6: run_segment<6, TERMS, RAGGED>(a, sg, sk, lds); break;
-    default: run_segment<7, TERMS, RAGGED>(a, sg, sk, lds); break;
+    case 1: run_segment<1, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 2: run_segment<2, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 3: run_segment<3, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    default: run_segment<4, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
   }
 }
 
-template <int TERMS>
+template <int TERMS, bool RAGGED, bool PLANES>
+__device__ __forceinline__ void dispatch_segment(const AtArgs& a, const int4 sg, const int4 sk, char* lds) {
+  if constexpr (TERMS == 3) {
+    // the three-term form holds a second set of mapping fragments: beyond four column blocks its accumulators no longer
+    // fit 256 registers (148 spilled at seven), so a longer segment runs as two halves, one after the other
+    if (sg.w > 4) {
+      const int n1 = (sg.w + 1) / 2;
+      dispatch_upto4<TERMS, RAGGED, PLANES>(a, make_int4(sg.x, sg.y, sg.z, n1), sk, lds);
+      dispatch_upto4<TERMS, RAGGED, PLANES>(a, make_int4(sg.x, sg.y, sg.z + n1, sg.w - n1), sk, lds);
+    } else {
+      dispatch_upto4<TERMS, RAGGED, PLANES>(a, sg, sk, lds);
+    }
+    return;
+  }
+  switch (sg.w) {
+    case 1: run_segment<1, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 2: run_segment<2, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 3: run_segment<3, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 4: run_segment<4, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 5: run_segment<5, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    case 6: run_segment<6, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+    default: run_segment<7, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
+  }
+}
+
+template <int TERMS, bool PLANES>
 __global__ void __launch_bounds__(NT, 2) atrans_kernel(AtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // workgroups that share a row tile (consecutive logical ids) onto one XCD: blocks b, b + 8, ... share an XCD
@@ -388,10 +458,10 @@ __global__ void __launch_bounds__(NT, 2) atrans_kernel(AtArgs a) {
   for (int s = s0; s < s1; ++s) {
     const int4 sg = a.segs[2 * s], sk = a.segs[2 * s + 1];
     if (a.L[sg.x] & 7) {           // (the planner cuts such layers into segments of <= 2 blocks)
-      if (sg.w > 1) run_segment<2, TERMS, true>(a, sg, sk, lds);
-      else run_segment<1, TERMS, true>(a, sg, sk, lds);
+      if (sg.w > 1) run_segment<2, TERMS, true, PLANES>(a, sg, sk, lds);
+      else run_segment<1, TERMS, true, PLANES>(a, sg, sk, lds);
     } else {
-      dispatch_segment<TERMS, false>(a, sg, sk, lds);
+      dispatch_segment<TERMS, false, PLANES>(a, sg, sk, lds);
     }
   }
 }
@@ -545,8 +615,8 @@ extern "C" int rcb_atrans_pack(const float* const* A, int32_t n_layers, const in
 
 extern "C" int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* sizes, int32_t n_cu, int32_t* plan,
                                int32_t max_ints) {
-  RCB_REQUIRE(sizes && plan && n_layers >= 1 && n_layers <= MAXL && rows >= 1 && n_cu >= 1, RCB_ERR_ARG,
-              "atrans_plan: bad arguments");
+  RCB_REQUIRE(sizes && (plan || max_ints == 0) && n_layers >= 1 && n_layers <= MAXL && rows >= 1 && n_cu >= 1 && max_ints >= 0,
+              RCB_ERR_ARG, "atrans_plan: bad arguments");
   std::vector<Blk> blks;
   for (int l = 0; l < n_layers; ++l) {
     RCB_REQUIRE(sizes[l] >= 1, RCB_ERR_ARG, "atrans_plan: layer %d empty", l);
@@ -621,6 +691,8 @@ extern "C" int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* si
   // layout: [n_wg, n_segs, S, 0, slabs[8], seg_begin (n_wg + 1; padded so that the segments start on 16 bytes), segs (2 x 4 ints each)]
   const long long head = ((RCB_ATRANS_PLAN_HEAD + n_wg + 1) + 3) / 4 * 4;
   const long long need = head + 4 * (long long)segs.size();
+  RCB_REQUIRE(need < (1ll << 31), RCB_ERR_SHAPE, "atrans_plan: plan of %lld ints", need);
+  if (max_ints == 0) return (int)need;            // size query: nothing written
   if (need > max_ints) return rcb::fail(RCB_ERR_SHAPE, "atrans_plan: %lld ints needed, %d given", need, max_ints);
   memset(plan, 0, sizeof(int32_t) * head);
   plan[0] = (int32_t)n_wg;
@@ -632,11 +704,16 @@ extern "C" int rcb_atrans_plan(int64_t rows, int32_t n_layers, const int32_t* si
   return (int)need;
 }
 
-extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_t ld_out, int64_t rows, int32_t n_layers,
-                                const int32_t* sizes, const void* packed, int32_t transpose, int32_t terms,
-                                const int32_t* plan_dev, const int32_t* plan_head, float* workspace, rcb_stream_t stream) {
-  RCB_REQUIRE(x && out && sizes && packed && plan_dev && plan_head && n_layers >= 1 && n_layers <= MAXL && rows >= 1, RCB_ERR_ARG,
-              "atrans_apply: bad arguments");
+extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, const void* x_hi, const void* x_lo, int64_t ld_x16, float* out,
+                                int64_t ld_out, int64_t rows, int32_t n_layers, const int32_t* sizes, const void* packed,
+                                int32_t transpose, int32_t terms, const int32_t* plan_dev, const int32_t* plan_head,
+                                float* workspace, rcb_stream_t stream) {
+  RCB_REQUIRE((x || x_hi) && out && sizes && packed && plan_dev && plan_head && n_layers >= 1 && n_layers <= MAXL && rows >= 1,
+              RCB_ERR_ARG, "atrans_apply: bad arguments");
+  const bool planes = x_hi != nullptr;
+  RCB_REQUIRE(!planes || (x == nullptr && (x_lo != nullptr || terms == 1) && (ld_x16 & 7) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo)) & 15) == 0),
+              RCB_ERR_ARG, "atrans_apply: operand planes: give x_hi and x_lo (terms >= 2) INSTEAD of x, 16-byte aligned, row stride a multiple of 8");
   const int n_wg = plan_head[0], ksplit = plan_head[2];
   RCB_REQUIRE(n_wg >= 1 && ksplit >= 1 && ksplit <= 8 && (ksplit == 1 || workspace), RCB_ERR_ARG,
               "atrans_apply: plan head (workgroups %d, slices %d) / workspace", n_wg, ksplit);
@@ -658,9 +735,15 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
     off += sizes[l];
     poff += (long long)a.Lp[l] * a.Lp[l];
   }
-  RCB_REQUIRE(ld_x >= off && ld_out >= off, RCB_ERR_SHAPE, "atrans_apply: row strides %lld / %lld below %lld columns", (long long)ld_x,
-              (long long)ld_out, off);
+  RCB_REQUIRE((planes ? ld_x16 : ld_x) >= off && ld_out >= off, RCB_ERR_SHAPE, "atrans_apply: row strides %lld / %lld below %lld columns",
+              (long long)(planes ? ld_x16 : ld_x), (long long)ld_out, off);
+  if (planes)        // the DMAs fetch 16-byte pieces at 8-element steps from the start of every layer
+    for (int l = 0; l < n_layers; ++l)
+      RCB_REQUIRE((sizes[l] & 7) != 0 || (a.off[l] & 7) == 0, RCB_ERR_SHAPE, "atrans_apply: operand planes: layer %d starts at column %d (not a multiple of 8)", l, a.off[l]);
   a.x = x; a.out = out; a.ld_x = ld_x; a.ld_out = ld_out; a.rows = rows; a.n_layers = n_layers;
+  a.xh = reinterpret_cast<const __bf16*>(x_hi);
+  a.xl = reinterpret_cast<const __bf16*>(x_lo ? x_lo : x_hi);          // (terms = 1 never multiplies the lo fragments)
+  a.ld_x16 = ld_x16;
   a.nt_out = transpose ? 1 : 0;
   const long long head = ((RCB_ATRANS_PLAN_HEAD + (long long)n_wg + 1) + 3) / 4 * 4;
   a.seg_begin = plan_dev + RCB_ATRANS_PLAN_HEAD;
@@ -670,15 +753,16 @@ extern "C" int rcb_atrans_apply(const float* x, int64_t ld_x, float* out, int64_
   a.ld_ws = (off + 3) / 4 * 4;
   const int lds = LDS_MAX_BYTES;
   hipError_t e;
+  auto go = [&](auto kfn) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) kfn<<<n_wg, NT, lds, (hipStream_t)stream>>>(a);
+  };
   if (terms == 1) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(atrans_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) atrans_kernel<1><<<n_wg, NT, lds, (hipStream_t)stream>>>(a);
+    if (planes) go(atrans_kernel<1, true>); else go(atrans_kernel<1, false>);
   } else if (terms == 2) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(atrans_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) atrans_kernel<2><<<n_wg, NT, lds, (hipStream_t)stream>>>(a);
+    if (planes) go(atrans_kernel<2, true>); else go(atrans_kernel<2, false>);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(atrans_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) atrans_kernel<3><<<n_wg, NT, lds, (hipStream_t)stream>>>(a);
+    if (planes) go(atrans_kernel<3, true>); else go(atrans_kernel<3, false>);
   }
   RCB_REQUIRE(e == hipSuccess, (int)e, "atrans_apply: hipFuncSetAttribute: %s", hipGetErrorString(e));
   RCB_LAUNCH_CHECK();
@@ -716,8 +800,19 @@ extern "C" int64_t rcb_atrans_workspace_floats(int64_t rows, int32_t n_layers, c
 // in slab order: no atomics, bitwise reproducible.  A few MFLOP per step: the library's heuristics take 29 us for this
 // shape, this takes a few.
 namespace {
-__global__ void __launch_bounds__(256) wgrad_narrow_kernel(const float* __restrict__ h, long long ld_h, const float* __restrict__ d,
-                                                           long long ld_d, long long rows, int L, int n_slabs,
+// P16: an operand given as bf16 planes is read as float(hi) + float(lo) (exact: both terms and their sum fit fp32)
+struct NarrowOp {
+  const float* f;
+  const __bf16* hi;
+  const __bf16* lo;
+  long long ld;
+  __device__ __forceinline__ float at(long long m, int c) const {
+    if (f) return f[m * ld + c];
+    return (float)hi[m * ld + c] + (float)lo[m * ld + c];
+  }
+};
+
+__global__ void __launch_bounds__(256) wgrad_narrow_kernel(NarrowOp hop, NarrowOp dop, long long rows, int L, int n_slabs,
                                                            float* __restrict__ part) {
   __shared__ float red[4][16][64];
   const int nt = (L + 31) / 32;
@@ -727,8 +822,7 @@ __global__ void __launch_bounds__(256) wgrad_narrow_kernel(const float* __restri
   const long long m_begin = slab * per, m_end = min(rows, m_begin + per);
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, kh = lane >> 5;
   const bool kin = k0 + i < L, nin = n0 + i < L;
-  const float* __restrict__ hp = h + k0 + (kin ? i : 0);
-  const float* __restrict__ dp = d + n0 + (nin ? i : 0);
+  const int hc = k0 + (kin ? i : 0), dc = n0 + (nin ? i : 0);
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -740,8 +834,8 @@ __global__ void __launch_bounds__(256) wgrad_narrow_kernel(const float* __restri
       const long long m = m0 + 8 * u + kh;
       const bool ok = m < m_end;
       const long long mc = ok ? m : m_begin;
-      av[u] = hp[mc * ld_h];
-      bv[u] = dp[mc * ld_d];
+      av[u] = hop.at(mc, hc);
+      bv[u] = dop.at(mc, dc);
       av[u] = (ok && kin) ? av[u] : 0.f;
       bv[u] = (ok && nin) ? bv[u] : 0.f;
     }
@@ -788,13 +882,18 @@ extern "C" int64_t rcb_atrans_wgrad_narrow_workspace(int32_t L, int32_t n_slabs)
   return (int64_t)n_slabs * nt * nt * 1024;
 }
 
-extern "C" int rcb_atrans_wgrad_narrow(const float* h, int64_t ld_h, const float* d, int64_t ld_d, int64_t rows, int32_t L,
-                                       float* dA, float* workspace, int32_t n_slabs, rcb_stream_t stream) {
-  RCB_REQUIRE(h && d && dA && workspace && rows >= 1 && L >= 1 && L <= 1024 && n_slabs >= 1 && n_slabs <= 4096, RCB_ERR_ARG,
+extern "C" int rcb_atrans_wgrad_narrow(const float* h, const void* h_hi, const void* h_lo, int64_t ld_h, const float* d,
+                                       const void* d_hi, const void* d_lo, int64_t ld_d, int64_t rows, int32_t L, float* dA,
+                                       float* workspace, int32_t n_slabs, rcb_stream_t stream) {
+  RCB_REQUIRE(dA && workspace && rows >= 1 && L >= 1 && L <= 1024 && n_slabs >= 1 && n_slabs <= 4096, RCB_ERR_ARG,
               "atrans_wgrad_narrow: bad arguments (L = %d, slabs = %d)", L, n_slabs);
+  RCB_REQUIRE((h != nullptr) != (h_hi != nullptr && h_lo != nullptr) && (d != nullptr) != (d_hi != nullptr && d_lo != nullptr), RCB_ERR_ARG,
+              "atrans_wgrad_narrow: each operand either as fp32 rows or as a (hi, lo) pair of bf16 planes");
   RCB_REQUIRE(ld_h >= L && ld_d >= L, RCB_ERR_SHAPE, "atrans_wgrad_narrow: row strides below the layer size");
   const int nt = (L + 31) / 32;
-  wgrad_narrow_kernel<<<nt * nt * n_slabs, 256, 0, (hipStream_t)stream>>>(h, ld_h, d, ld_d, rows, L, n_slabs, workspace);
+  const NarrowOp hop{h, reinterpret_cast<const __bf16*>(h_hi), reinterpret_cast<const __bf16*>(h_lo), ld_h};
+  const NarrowOp dop{d, reinterpret_cast<const __bf16*>(d_hi), reinterpret_cast<const __bf16*>(d_lo), ld_d};
+  wgrad_narrow_kernel<<<nt * nt * n_slabs, 256, 0, (hipStream_t)stream>>>(hop, dop, rows, L, n_slabs, workspace);
   RCB_LAUNCH_CHECK();
   wgrad_narrow_sum_kernel<<<(L * L + 255) / 256, 256, 0, (hipStream_t)stream>>>(workspace, L, n_slabs, dA);
   RCB_LAUNCH_CHECK();

@@ -255,16 +255,29 @@ __device__ __forceinline__ void store_bf16_row4(__bf16* __restrict__ out16, long
   }
 }
 
+// the (hi, lo) bf16 planes of four consecutive flat elements: hi = bf16(v), lo = bf16(v - hi) -- the split the A-transform
+// kernel would form from the fp32 value, made by the producer instead (rcb_atrans_apply's plane operands)
+__device__ __forceinline__ void store_planes_row4(__bf16* __restrict__ hi, __bf16* __restrict__ lo, long long first, int cols,
+                                                  long long ld16, float4 o) {
+  store_bf16_row4(hi, first, cols, ld16, o);
+  if (lo) {
+    const float4 r = make_float4(o.x - (float)(__bf16)o.x, o.y - (float)(__bf16)o.y, o.z - (float)(__bf16)o.z, o.w - (float)(__bf16)o.w);
+    store_bf16_row4(lo, first, cols, ld16, r);
+  }
+}
+
 // reparameterised sample with the noise drawn in the kernel: out = loc + st(log_scale) * eps, eps written once for the
 // posterior update.  Replaces torch.randn + the flat reparam kernel (the generated values never make a round trip
 // through HBM before their first use); same arithmetic as reparam_flat_kernel on the same eps.
 // out16 (nullable): a bf16 copy of out as [n / cols][ld16] rows -- the operand of the A transform's batched bf16
-// weight-gradient GEMM, written while the values are in registers.
+// weight-gradient GEMM, written while the values are in registers; lo16 (nullable, with out16): the low plane, bf16(out -
+// out16), same layout -- with both the fp32 `out` may be NULL (the A transform then reads the planes); eps_out nullable
+// (a consumer that re-draws the noise from the counter needs no copy of it).
 __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restrict__ loc, const float* __restrict__ ls,
                                                           float* __restrict__ eps_out, float* __restrict__ out, long long n,
                                                           unsigned long long seed, unsigned stream,
                                                           const long long* __restrict__ step_dev, __bf16* __restrict__ out16,
-                                                          int cols, long long ld16) {
+                                                          __bf16* __restrict__ lo16, int cols, long long ld16) {
   const unsigned long long step = (unsigned long long)*step_dev;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -277,18 +290,20 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
     o.y = add_rn(m.y, mul_rn(st_f32(l.y), e.y));
     o.z = add_rn(m.z, mul_rn(st_f32(l.z), e.z));
     o.w = add_rn(m.w, mul_rn(st_f32(l.w), e.w));
-    reinterpret_cast<float4*>(eps_out)[i] = e;
-    reinterpret_cast<float4*>(out)[i] = o;
-    if (out16) store_bf16_row4(out16, 4 * i, cols, ld16, o);
+    if (eps_out) reinterpret_cast<float4*>(eps_out)[i] = e;
+    if (out) reinterpret_cast<float4*>(out)[i] = o;
+    if (out16) store_planes_row4(out16, lo16, 4 * i, cols, ld16, o);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 3)) {      // tail group
     const float4 e = philox_normal4((unsigned long long)n4, stream, step, seed);
     const float ev[4] = {e.x, e.y, e.z, e.w};
     for (int k = 0; k < (int)(n & 3); ++k) {
       const long long i = (n4 << 2) + k;
-      eps_out[i] = ev[k];
-      out[i] = add_rn(loc[i], mul_rn(st_f32(ls[i]), ev[k]));
-      if (out16) out16[(i / cols) * ld16 + i % cols] = (__bf16)out[i];
+      if (eps_out) eps_out[i] = ev[k];
+      const float o = add_rn(loc[i], mul_rn(st_f32(ls[i]), ev[k]));
+      if (out) out[i] = o;
+      if (out16) out16[(i / cols) * ld16 + i % cols] = (__bf16)o;
+      if (out16 && lo16) lo16[(i / cols) * ld16 + i % cols] = (__bf16)(o - (float)(__bf16)o);
     }
   }
 }
@@ -306,9 +321,11 @@ extern "C" int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t 
 }
 
 extern "C" int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
-                                   const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, int32_t cols,
-                                   int64_t ld_bf16, rcb_stream_t stream) {
-  RCB_REQUIRE(loc && log_scale && step_dev && eps_out && out && n > 0, RCB_ERR_ARG, "reparam_rng_fwd: null pointer / empty");
+                                   const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, void* out_lo,
+                                   int32_t cols, int64_t ld_bf16, rcb_stream_t stream) {
+  RCB_REQUIRE(loc && log_scale && step_dev && n > 0, RCB_ERR_ARG, "reparam_rng_fwd: null pointer / empty");
+  RCB_REQUIRE(out || (out_bf16 && out_lo), RCB_ERR_ARG, "reparam_rng_fwd: no output (fp32 `out`, or both planes out_bf16 + out_lo)");
+  RCB_REQUIRE(!out_lo || out_bf16, RCB_ERR_ARG, "reparam_rng_fwd: the low plane comes with the high plane");
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   RCB_REQUIRE(al16(loc) && al16(log_scale) && al16(eps_out) && al16(out), RCB_ERR_ARG, "reparam_rng_fwd: 16-byte alignment");
   RCB_REQUIRE(out_bf16 == nullptr || (cols >= 1 && n % cols == 0 && ld_bf16 >= cols), RCB_ERR_SHAPE,
@@ -318,7 +335,7 @@ extern "C" int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int
   if (blocks < 1) blocks = 1;
   reparam_rng_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(loc, log_scale, eps_out, out, (long long)n, seed, rng_stream,
                                                               (const long long*)step_dev, reinterpret_cast<__bf16*>(out_bf16),
-                                                              out_bf16 ? cols : 1, (long long)ld_bf16);
+                                                              reinterpret_cast<__bf16*>(out_lo), out_bf16 ? cols : 1, (long long)ld_bf16);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -754,7 +771,11 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   float4 loc4 = RCB_LD4P(L.loc + b);
   float4 ls4 = RCB_LD4P(L.log_scale + b);
   const float4 go4 = RCB_LD4(L.d_out + b);
-  const float4 ep4 = RCB_LD4(L.eps + b);
+  // eps: the stored noise of this step's sample, or -- eps_from_rng -- re-drawn from the counter it was drawn from (a pure
+  // function of (seed, stream, counter, element): the same bits), which saves its 4-byte write and 4-byte read per element
+  const float4 ep4 = L.eps_from_rng
+                         ? philox_normal4((unsigned long long)i4, L.rng_stream, (unsigned long long)(*L.rng_step_dev + L.rng_step_add - 1), L.rng_seed)
+                         : RCB_LD4(L.eps + b);
   float4 m14 = RCB_LD4(L.m_loc + b), v14 = RCB_LD4(L.v_loc + b);
   float4 m24 = RCB_LD4(L.m_ls + b), v24 = RCB_LD4(L.v_ls + b);
   float* locv = &loc4.x; float* lsv = &ls4.x;
@@ -795,7 +816,7 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   RCB_ST4(L.v_loc + b, v14);
   RCB_ST4(L.m_ls + b, m24);
   RCB_ST4(L.v_ls + b, v24);
-  if (L.next_out) {
+  if (L.next_out || L.next_out_bf16) {
     // the next step's sample from the updated parameters: the arithmetic of reparam_rng_kernel on Philox group i4 at the
     // step counter the next step will see
     const unsigned long long step = (unsigned long long)(*L.rng_step_dev + L.rng_step_add);
@@ -805,9 +826,10 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     o.y = add_rn(loc4.y, mul_rn(st_f32(ls4.y), e.y));
     o.z = add_rn(loc4.z, mul_rn(st_f32(ls4.z), e.z));
     o.w = add_rn(loc4.w, mul_rn(st_f32(ls4.w), e.w));
-    nt_st(L.next_eps + b, e);            // (read again by the NEXT step's update only: non-temporal, as above)
-    reinterpret_cast<float4*>(L.next_out + b)[0] = o;
-    if (L.next_out_bf16) store_bf16_row4(reinterpret_cast<__bf16*>(L.next_out_bf16), b, L.cols, L.next_ld_bf16, o);
+    if (L.next_eps) nt_st(L.next_eps + b, e);            // (read again by the NEXT step's update only: non-temporal, as above)
+    if (L.next_out) reinterpret_cast<float4*>(L.next_out + b)[0] = o;
+    if (L.next_out_bf16)
+      store_planes_row4(reinterpret_cast<__bf16*>(L.next_out_bf16), reinterpret_cast<__bf16*>(L.next_out_lo), b, L.cols, L.next_ld_bf16, o);
   }
 #undef RCB_LD4
 #undef RCB_ST4
@@ -819,14 +841,19 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
   RCB_REQUIRE(lv, RCB_ERR_ARG, "posterior_bwd: null level");
   RCB_REQUIRE(lv->loc && lv->log_scale && lv->p_loc && lv->p_scale, RCB_ERR_ARG, "posterior_bwd: null tensor");
   RCB_REQUIRE(lv->rows > 0 && lv->cols > 0 && lv->cols <= 65535 * 256, RCB_ERR_SHAPE, "posterior_bwd: shape %d x %d", lv->rows, lv->cols);
-  RCB_REQUIRE(!lv->d_out || (lv->eps && lv->samples > 0 && lv->cols_out > 0), RCB_ERR_ARG, "posterior_bwd: d_out needs eps");
+  RCB_REQUIRE(!lv->d_out || (lv->samples > 0 && lv->cols_out > 0), RCB_ERR_ARG, "posterior_bwd: d_out needs samples / cols_out");
   RCB_REQUIRE((lv->member_ptr == nullptr) == (lv->member_idx == nullptr), RCB_ERR_ARG, "posterior_bwd: members");
   RCB_REQUIRE(!lv->beta || (lv->group_idx && lv->n_groups > 0), RCB_ERR_ARG, "posterior_bwd: beta needs group_idx");
   RCB_REQUIRE(adam || (lv->g_loc && lv->g_log_scale), RCB_ERR_ARG, "posterior_bwd: neither adam nor grad outputs");
   RCB_REQUIRE(!adam || (lv->m_loc && lv->v_loc && lv->m_ls && lv->v_ls && adam->step >= 1), RCB_ERR_ARG,
               "posterior_bwd: adam state missing");
-  RCB_REQUIRE(!lv->next_out || (!lv->col_inv && adam), RCB_ERR_UNSUPPORTED,
+  const bool want_next = lv->next_out || lv->next_out_bf16;
+  RCB_REQUIRE(!want_next || (!lv->col_inv && adam), RCB_ERR_UNSUPPORTED,
               "posterior_bwd: the fused next sample needs the plain (flat) case with Adam");
+  RCB_REQUIRE(!lv->next_out_lo || lv->next_out_bf16, RCB_ERR_ARG, "posterior_bwd: next_out_lo comes with next_out_bf16");
+  RCB_REQUIRE(!lv->d_out || lv->eps || lv->eps_from_rng, RCB_ERR_ARG, "posterior_bwd: d_out needs eps (stored, or eps_from_rng)");
+  RCB_REQUIRE(!lv->eps_from_rng || (lv->rng_step_dev && !lv->eps && !lv->col_inv), RCB_ERR_ARG,
+              "posterior_bwd: eps_from_rng re-draws the noise from rng_seed / rng_stream / *rng_step_dev + rng_step_add - 1: give those, and eps = NULL");
   PostBwdArgs a;
   a.L = *lv;
   a.adam = make_adam(adam);
@@ -845,17 +872,18 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
     }
     if (!g_generic_only && adam && lv->d_out && lv->samples == 1 && lv->cols_out == lv->cols && !lv->enc_mask && !lv->beta && !lv->member_ptr &&
         !lv->row_perm_inv && !lv->col_inv && !lv->g_loc && !lv->g_log_scale && (n_total & 3) == 0 && al16(lv->loc) &&
-        al16(lv->log_scale) && al16(lv->d_out) && al16(lv->eps) && al16(lv->m_loc) && al16(lv->v_loc) && al16(lv->m_ls) &&
+        al16(lv->log_scale) && al16(lv->d_out) && (lv->eps_from_rng || al16(lv->eps)) && al16(lv->m_loc) && al16(lv->v_loc) && al16(lv->m_ls) &&
         al16(lv->v_ls)) {
-      RCB_REQUIRE(!lv->next_out || (lv->next_eps && lv->rng_step_dev && al16(lv->next_out) && al16(lv->next_eps) &&
-                                    (!lv->next_out_bf16 || lv->next_ld_bf16 >= lv->cols)),
-                  RCB_ERR_ARG, "posterior_bwd: next sample: null pointer, alignment or bf16 row stride");
+      RCB_REQUIRE(!want_next || (lv->rng_step_dev && al16(lv->next_out) && al16(lv->next_eps) &&
+                                 (lv->next_out || lv->next_out_lo) && (!lv->next_out_bf16 || lv->next_ld_bf16 >= lv->cols)),
+                  RCB_ERR_ARG, "posterior_bwd: next sample: null pointer (fp32 next_out, or both planes), alignment or bf16 row stride");
       posterior_flat_kernel<<<cdiv(n_total >> 2, 256), 256, 0, (hipStream_t)stream>>>(a, n_total);
       RCB_LAUNCH_CHECK();
       return RCB_OK;
     }
   }
-  RCB_REQUIRE(!lv->next_out, RCB_ERR_UNSUPPORTED, "posterior_bwd: the fused next sample needs the plain (flat) case");
+  RCB_REQUIRE(!want_next && !lv->eps_from_rng, RCB_ERR_UNSUPPORTED,
+              "posterior_bwd: the fused next sample / re-drawn noise need the plain (flat) case");
   dim3 grid(lv->rows, cdiv(lv->cols, 256));
   posterior_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   RCB_LAUNCH_CHECK();

@@ -30,6 +30,7 @@ struct SirenArgs {
   float w0, dy_scale;
   int pe_bf16;        // pe / dpe hold bf16 elements (16-bit kernels only)
   __bf16* dw16;       // nullable: bf16 copy of dwvec, rows dw16_stride elements apart (rcb_siren_desc.dw_bf16)
+  __bf16* dwlo;       // nullable (with dw16): the low plane bf16(dwvec - dw16), same layout; dwvec may then be NULL
   long long dw16_stride;
   int chunks;         // >= 1: workgroups per row of wvec (pixel tiles split; dwvec / sse hold per-chunk partials)
   const void* xf16;   // nullable: bf16 copy of xf, same shape and strides (rcb_siren_desc.xf_bf16)

@@ -397,6 +397,22 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
               d->pe_dim);
   RCB_REQUIRE(d->dw_bf16 == nullptr || d->precision >= 1, RCB_ERR_UNSUPPORTED,
               "siren: the bf16 copy of the gradient exists in the 16-bit kernels only");
+  RCB_REQUIRE(d->dw_lo == nullptr || d->dw_bf16 != nullptr, RCB_ERR_ARG, "siren: dw_lo (low plane) comes with dw_bf16 (high plane)");
+  {
+    const int nl = d->n_hidden + 1;
+    long long dn = 0;
+    for (int l = 0; l < nl; ++l) {
+      const int hw_in = l == 0 ? 0 : (d->hidden_dims[0] ? d->hidden_dims[l - 1] : d->hidden);
+      const int hw_out = d->hidden_dims[0] && l < d->n_hidden ? d->hidden_dims[l] : d->hidden;
+      const int li = l == 0 ? d->fourier_dim + d->pe_dim : hw_in, lo = l == nl - 1 ? d->out_dim : hw_out;
+      dn += (long long)lo * (li + 1);
+    }
+    RCB_REQUIRE(d->w_row_stride >= dn, RCB_ERR_SHAPE, "siren: w_row_stride %lld below the %lld elements of a row of layer vectors",
+                (long long)d->w_row_stride, dn);
+    // (a C caller that sets dw_bf16 but leaves the stride field zero would make every row of the copy overlap)
+    RCB_REQUIRE(d->dw_bf16 == nullptr || d->dw_bf16_stride >= dn, RCB_ERR_SHAPE,
+                "siren: dw_bf16_stride %lld below the %lld elements of a row of layer vectors", (long long)d->dw_bf16_stride, dn);
+  }
   const int chunks = d->pixel_chunks > 1 ? d->pixel_chunks : 1;
   RCB_REQUIRE(chunks == 1 || (d->precision >= 1 && chunks <= (d->n_pix + 31) / 32 && d->dw_bf16 == nullptr &&
                               (long long)d->n_rows * chunks < (1ll << 30)),
@@ -430,6 +446,7 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   a.chunks = chunks;
   a.pe_bf16 = d->pe_bf16;
   a.dw16 = reinterpret_cast<__bf16*>(d->dw_bf16);
+  a.dwlo = reinterpret_cast<__bf16*>(d->dw_lo);
   a.dw16_stride = d->dw_bf16_stride;
   a.xf16 = d->xf_bf16;
   a.G = d->n_rows;
@@ -454,6 +471,7 @@ struct ReduceArgs {
   float* dw;
   float* sse;
   __bf16* dw16;
+  __bf16* dwlo;
   long long stride, stride16;
   int G, chunks, dnet;
 };
@@ -464,8 +482,9 @@ __global__ void __launch_bounds__(256) siren_reduce_chunks_kernel(ReduceArgs r) 
     const int g = (int)(e / r.dnet), j = (int)(e - (long long)g * r.dnet);
     float v = 0.f;
     for (int k = 0; k < r.chunks; ++k) v += r.part[((long long)k * r.G + g) * r.stride + j];
-    r.dw[(long long)g * r.stride + j] = v;
+    if (r.dw) r.dw[(long long)g * r.stride + j] = v;
     if (r.dw16) r.dw16[(long long)g * r.stride16 + j] = (__bf16)v;
+    if (r.dwlo) r.dwlo[(long long)g * r.stride16 + j] = (__bf16)(v - (float)(__bf16)v);
   }
   if (r.sse && blockIdx.x == 0) {
     for (int g = threadIdx.x; g < r.G; g += 256) {
@@ -497,7 +516,9 @@ extern "C" int rcb_siren_bwd(const rcb_siren_desc* d, const float* xf, const voi
   SirenArgs a;
   int rc = fill_args(d, a);
   if (rc) return rc;
-  RCB_REQUIRE(xf && wvec && dy && dwvec && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_bwd: null pointer");
+  RCB_REQUIRE(xf && wvec && dy && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_bwd: null pointer");
+  RCB_REQUIRE(dwvec || (d->dw_bf16 && d->dw_lo && a.chunks == 1), RCB_ERR_ARG,
+              "siren_bwd: dwvec may be NULL only when both planes (dw_bf16, dw_lo) receive the gradient of an unchunked launch");
   a.xf = xf;
   a.pe = static_cast<const float*>(pe);
   a.wvec = wvec;
@@ -514,7 +535,9 @@ extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, cons
   SirenArgs a;
   int rc = fill_args(d, a);
   if (rc) return rc;
-  RCB_REQUIRE(xf && wvec && target && sse && dwvec && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_loss_bwd: null pointer");
+  RCB_REQUIRE(xf && wvec && target && sse && (pe || d->pe_dim == 0), RCB_ERR_ARG, "siren_loss_bwd: null pointer");
+  RCB_REQUIRE(dwvec || (d->dw_bf16 && d->dw_lo && a.chunks == 1), RCB_ERR_ARG,
+              "siren_loss_bwd: dwvec may be NULL only when both planes (dw_bf16, dw_lo) receive the gradient of an unchunked launch");
   a.xf = xf;
   a.pe = static_cast<const float*>(pe);
   a.wvec = wvec;
@@ -529,8 +552,9 @@ extern "C" int rcb_siren_loss_bwd(const rcb_siren_desc* d, const float* xf, cons
 
 extern "C" int rcb_siren_reduce_chunks(const rcb_siren_desc* d, const float* dw_partial, const float* sse_partial, float* dwvec,
                                        float* sse, rcb_stream_t stream) {
-  RCB_REQUIRE(d && dw_partial && dwvec && ((sse_partial == nullptr) == (sse == nullptr)), RCB_ERR_ARG,
-              "siren_reduce_chunks: null pointer");
+  RCB_REQUIRE(d && dw_partial && ((sse_partial == nullptr) == (sse == nullptr)), RCB_ERR_ARG, "siren_reduce_chunks: null pointer");
+  RCB_REQUIRE(dwvec || (d->dw_bf16 && d->dw_lo), RCB_ERR_ARG, "siren_reduce_chunks: dwvec may be NULL only when both planes are given");
+  RCB_REQUIRE(d->dw_lo == nullptr || d->dw_bf16 != nullptr, RCB_ERR_ARG, "siren_reduce_chunks: dw_lo comes with dw_bf16");
   RCB_REQUIRE(d->pixel_chunks >= 1 && d->n_rows > 0 && d->n_hidden >= 1 && d->n_hidden <= 4, RCB_ERR_SHAPE,
               "siren_reduce_chunks: chunks=%d rows=%d", d->pixel_chunks, d->n_rows);
   ReduceArgs r;
@@ -540,6 +564,7 @@ extern "C" int rcb_siren_reduce_chunks(const rcb_siren_desc* d, const float* dw_
   r.dw = dwvec;
   r.sse = sse;
   r.dw16 = reinterpret_cast<__bf16*>(d->dw_bf16);
+  r.dwlo = reinterpret_cast<__bf16*>(d->dw_lo);
   r.stride16 = d->dw_bf16_stride;
   r.stride = d->w_row_stride;
   r.G = d->n_rows;

@@ -570,8 +570,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
           src = ro + o * rs + i;
         }
         const float v = (((smem[src] + smem[G::RED_WAVE + src]) + smem[2 * G::RED_WAVE + src]) + smem[3 * G::RED_WAVE + src]) * (1.0f / GS);
-        dst[ol + e] = v;
-        if (a.dw16 != nullptr) a.dw16[(long long)g * a.dw16_stride + ol + e] = (__bf16)v;   // operand of the weight-gradient GEMM
+        if (a.dwvec != nullptr) dst[ol + e] = v;
+        if (a.dw16 != nullptr) {                  // high plane: operand of the weight-gradient GEMM; with the low plane the
+          const __bf16 hb = (__bf16)v;            // pair is the A transform's data-gradient operand (rcb_atrans_apply x_hi / x_lo)
+          a.dw16[(long long)g * a.dw16_stride + ol + e] = hb;
+          if (a.dwlo != nullptr) a.dwlo[(long long)g * a.dw16_stride + ol + e] = (__bf16)(v - (float)hb);
+        }
       }
     }
   }

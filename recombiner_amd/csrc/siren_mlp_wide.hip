@@ -844,9 +844,14 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
       constexpr int l = decltype(l_c)::value;
       constexpr int no = G::lout(l), ni = G::lin(l), ol = G::off(l);
       __bf16* sp = a.dw16 != nullptr ? a.dw16 + (long long)g * a.dw16_stride + ol : nullptr;
+      __bf16* sl = a.dwlo != nullptr ? a.dwlo + (long long)g * a.dw16_stride + ol : nullptr;
       auto emit = [&](int e, float v) {
-        dst[ol + e] = v;
-        if (sp != nullptr) sp[e] = (__bf16)v;        // bf16 copy: operand of the weight-gradient GEMM
+        if (a.dwvec != nullptr) dst[ol + e] = v;
+        if (sp != nullptr) {                         // high plane: operand of the weight-gradient GEMM; + low plane: the pair is
+          const __bf16 hb = (__bf16)v;               // the A transform's data-gradient operand
+          sp[e] = hb;
+          if (sl != nullptr) sl[e] = (__bf16)(v - (float)hb);
+        }
       };
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll

@@ -140,7 +140,7 @@ class PeLayout:
         return (meta.samples * (n_inr // per),) + tuple(a * b for a, b in zip(self.patch_nums, self.patch_size)) + (meta.pe_dim,)
 
 
-def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_layout=None, xf16=None):
+def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_layout=None, xf16=None, dw_planes=None):
     if wvec.dim() != 2 or wvec.stride(1) != 1:
         raise RcbError("wvec must be 2-D with unit column stride")
     G = wvec.shape[0]
@@ -152,6 +152,10 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_l
                   meta.out_dim, _xf_stride(xf, meta, G // meta.samples), int(wvec.stride(0)), meta.w0,
                   meta.precision, int(pe is not None and pe.dtype == bf16), None if dw_bf16 is None else dw_bf16.data_ptr(), int(chunks), None)
     d.dw_bf16_stride = 0 if dw_bf16 is None else int(dw_bf16.stride(0))
+    if dw_planes is not None:              # the gradient as (hi, lo) planes (ops.Planes)
+        if (dw_planes.rows, dw_planes.cols) != (G, meta.d_net):
+            raise RcbError("siren: gradient planes do not match the rows of wvec")
+        d.dw_bf16, d.dw_lo, d.dw_bf16_stride = dw_planes.buf[0].data_ptr(), dw_planes.buf[1].data_ptr(), int(dw_planes.ld)
     if meta.hidden_dims and len(set(meta.hidden_dims)) > 1:
         if meta.precision != 0 or len(meta.hidden_dims) != meta.n_hidden:
             raise RcbError("per-layer hidden widths: fp32 mode only, one width per hidden layer")
@@ -224,12 +228,38 @@ def siren_wide_layers(meta: SirenMeta):
 
 
 def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_bf16=False,
-                   pixel_chunks=None, pe_layout=None, xf16=None):
+                   pixel_chunks=None, pe_layout=None, xf16=None, want_planes=False):
     """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_bf16 (16-bit modes) also a
     bf16 copy of dwvec, [G, d_net] with a row stride that is a multiple of 8 (rcb_siren_desc.dw_bf16: the operand of the
-    A transform's batched weight-gradient GEMM, written by the kernel's epilogue)."""
+    A transform's batched weight-gradient GEMM, written by the kernel's epilogue).
+    want_planes (16-bit modes): -> (sse, None, dpe, Planes): the gradient as its (hi, lo) bf16 planes INSTEAD of fp32
+    (rcb_siren_desc.dw_bf16 + dw_lo): the operand form of ATransform.dgrad / .wgrad."""
     lib = _lib.load()
     G = wvec.shape[0]
+    if want_planes:
+        if meta.precision == 0:
+            raise RcbError("gradient planes need a 16-bit precision mode")
+        planes = Planes(G, meta.d_net, wvec.device)
+        chunks = pixel_chunks or siren_pixel_chunks(G, meta)
+        d, G = _siren_desc(meta, wvec, xf, pe, None, chunks, pe_layout, xf16, dw_planes=planes if chunks == 1 else None)
+        _check_pe(pe, G, meta, pe_layout)
+        N = G // meta.samples
+        if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
+            raise RcbError(f"target must be [{N},{meta.n_pix},{meta.out_dim}], got {tuple(target.shape)}")
+        sse = torch.empty(G, device=wvec.device, dtype=f32)
+        dpe = torch.empty_like(pe) if (want_dpe and meta.pe_dim) else None
+        part = sse_part = None
+        if chunks > 1:
+            part = torch.empty(chunks, G, wvec.stride(0), device=wvec.device, dtype=f32)
+            sse_part = torch.empty(chunks, G, device=wvec.device, dtype=f32)
+        check(lib.rcb_siren_loss_bwd(C.byref(d), _dev_ptr_strided(xf), ptr(pe, None, True), _dev_ptr_strided(wvec),
+                                     ptr(target, f32), C.c_float(dy_scale), ptr(sse if part is None else sse_part),
+                                     ptr(part, f32, True), ptr(dpe, None, True), stream_ptr()), "rcb_siren_loss_bwd")
+        if part is not None:
+            d2, _ = _siren_desc(meta, wvec, xf, pe, None, chunks, None, xf16, dw_planes=planes)
+            check(lib.rcb_siren_reduce_chunks(C.byref(d2), ptr(part), ptr(sse_part), C.c_void_p(0), ptr(sse), stream_ptr()),
+                  "rcb_siren_reduce_chunks")
+        return sse, None, dpe, planes
     dw16 = None
     if want_bf16:
         if meta.precision == 0:
@@ -341,18 +371,55 @@ def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], sample
     return out
 
 
+class Planes:
+    """A [rows, cols] fp32 matrix held as its two bf16 PLANES, x = hi + lo: hi = bf16(x), lo = bf16(x - hi) -- what the
+    A-transform kernels split a row into, written by the PRODUCER of the row instead (rcb_reparam_rng_fwd, the fused next
+    sample of rcb_posterior_bwd, the SIREN kernels' gradient epilogue): the same 4 bytes per element as fp32, no conversion
+    work in the consumer, and `hi` alone is the weight-gradient GEMM's operand.  One buffer [2, rows, ld], ld a multiple of
+    32 elements (64-byte rows: the LDS-DMA streams of rcb_atrans_apply)."""
+
+    def __init__(self, rows, cols, device):
+        self.rows, self.cols = int(rows), int(cols)
+        self.ld = (self.cols + 31) // 32 * 32
+        self.buf = torch.zeros(2, self.rows, self.ld, device=device, dtype=bf16)
+
+    @property
+    def hi(self):
+        return self.buf[0, :, :self.cols]
+
+    @property
+    def lo(self):
+        return self.buf[1, :, :self.cols]
+
+    def float(self):
+        """the fp32 values the planes stand for (tests, fallbacks)"""
+        return self.hi.float() + self.lo.float()
+
+    @classmethod
+    def from_float(cls, x):
+        p = cls(x.shape[0], x.shape[1], x.device)
+        h = x.to(bf16)
+        p.hi.copy_(h)
+        p.lo.copy_((x - h.float()).to(bf16))
+        return p
+
+
 def rng_eligible(lv: LevelSpec):
     """plain level (no maps, no masks, every column produced): the in-kernel noise path applies"""
     return (lv.row_map is None and lv.row_perm is None and lv.col_map is None and lv.enc_mask is None
             and not lv.scale_is_sigma and lv.cols_out == lv.cols and lv.n_inr == lv.rows and lv.loc.is_contiguous() and lv.log_scale.is_contiguous())
 
 
-def sample_buffers(lv: LevelSpec, want_bf16=False):
+def sample_buffers(lv: LevelSpec, want_bf16=False, planes=False, want_eps=True):
     """(out [n, 1, cols], eps [n, 1, cols], bf16 copy [n, ld16] or None): the buffers of one level's sample, for callers
-    that keep them across steps (PriorBNNmodel.train: the posterior update of step t writes the sample of step t + 1)"""
+    that keep them across steps (PriorBNNmodel.train: the posterior update of step t writes the sample of step t + 1).
+    planes: the sample as a Planes pair INSTEAD of fp32 (out = None, third entry = the Planes).  want_eps=False: no copy of
+    the noise (the posterior update re-draws it, rcb_level_bwd.eps_from_rng)."""
     n, cols = lv.rows, lv.cols
+    eps = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32) if want_eps else None
+    if planes:
+        return None, eps, Planes(n, cols, lv.loc.device)
     out = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
-    eps = torch.empty(n, 1, cols, device=lv.loc.device, dtype=f32)
     o16 = torch.empty(n, (cols + 7) // 8 * 8, device=lv.loc.device, dtype=bf16) if want_bf16 else None
     return out, eps, o16
 
@@ -361,9 +428,12 @@ class NextSample:
     """argument of posterior_bwd(next_sample=): draw the next step's sample in the same pass (rcb_level_bwd.next_*) into
     the buffers of sample_buffers(); step = the device step counter, the sample is that of counter + step_add"""
 
-    def __init__(self, buffers, seed: int, rng_stream: int, step, step_add=1):
+    def __init__(self, buffers, seed: int, rng_stream: int, step, step_add=1, redraw_eps=False):
         self.out, self.eps, self.o16 = buffers
         self.seed, self.rng_stream, self.step, self.step_add = seed, rng_stream, step, step_add
+        # redraw_eps: THIS step's noise is re-drawn from the counter it came from (rcb_level_bwd.eps_from_rng) instead of
+        # being read back from memory -- posterior_bwd is then called with eps = None
+        self.redraw_eps = bool(redraw_eps)
 
 
 def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False, buffers=None):
@@ -376,14 +446,21 @@ def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False
         raise RcbError("reparam_rng: plain levels only")
     n, cols = lv.rows, lv.cols
     out, eps, o16 = buffers if buffers is not None else sample_buffers(lv, want_bf16)
+    if isinstance(o16, Planes):            # the sample as (hi, lo) planes (sample_buffers(planes=True)): -> (None, eps, Planes)
+        check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
+                                      C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64),
+                                      ptr(eps, f32, True), ptr(out, f32, True), C.c_void_p(o16.buf[0].data_ptr()),
+                                      C.c_void_p(o16.buf[1].data_ptr()), int(cols), C.c_int64(o16.ld), stream_ptr()),
+              "rcb_reparam_rng_fwd")
+        return out, eps, o16
     if want_bf16 and o16 is None:
         raise RcbError("reparam_rng: the buffers have no bf16 copy")
     if not want_bf16:
         o16 = None
     check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
-                                  C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64), ptr(eps),
-                                  ptr(out), ptr(o16, bf16, True), int(cols), C.c_int64(0 if o16 is None else o16.stride(0)),
-                                  stream_ptr()), "rcb_reparam_rng_fwd")
+                                  C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64),
+                                  ptr(eps, f32, True), ptr(out), ptr(o16, bf16, True), C.c_void_p(0), int(cols),
+                                  C.c_int64(0 if o16 is None else o16.stride(0)), stream_ptr()), "rcb_reparam_rng_fwd")
     return (out, eps, o16[:, :cols]) if want_bf16 else (out, eps)
 
 
@@ -420,11 +497,23 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  addr(kl_scalar_dev, f32))
     if next_sample is not None:
         ns = next_sample
-        if tuple(ns.out.shape) != (lv.rows, 1, lv.cols) or tuple(ns.eps.shape) != (lv.rows, 1, lv.cols):
-            raise RcbError("posterior_bwd: next-sample buffers do not match the level")
+        for t_ in (ns.out, ns.eps):
+            if t_ is not None and tuple(t_.shape) != (lv.rows, 1, lv.cols):
+                raise RcbError("posterior_bwd: next-sample buffers do not match the level")
         b.next_out, b.next_eps = addr(ns.out, f32), addr(ns.eps, f32)
-        b.next_out_bf16 = addr(ns.o16, bf16)
-        b.next_ld_bf16 = 0 if ns.o16 is None else int(ns.o16.stride(0))
+        if isinstance(ns.o16, Planes):
+            if (ns.o16.rows, ns.o16.cols) != (lv.rows, lv.cols):
+                raise RcbError("posterior_bwd: next-sample planes do not match the level")
+            b.next_out_bf16, b.next_out_lo = ns.o16.buf[0].data_ptr(), ns.o16.buf[1].data_ptr()
+            b.next_ld_bf16 = int(ns.o16.ld)
+        else:
+            if ns.out is None:
+                raise RcbError("posterior_bwd: the next sample needs an fp32 buffer or planes")
+            b.next_out_bf16 = addr(ns.o16, bf16)
+            b.next_ld_bf16 = 0 if ns.o16 is None else int(ns.o16.stride(0))
+        b.eps_from_rng = int(ns.redraw_eps)
+        if ns.redraw_eps and eps is not None:
+            raise RcbError("posterior_bwd: redraw_eps takes eps = None")
         b.rng_seed = ns.seed & (2 ** 64 - 1)
         b.rng_step_dev = addr(ns.step, torch.int64)
         b.rng_step_add = int(ns.step_add)
@@ -1125,15 +1214,13 @@ class ATransform:
         pl = self._plans.get(rows)
         if pl is None:
             lib = _lib.load()
-            cap = 1 << 16
-            while True:
-                buf = (C.c_int32 * cap)()
-                n = lib.rcb_atrans_plan(C.c_int64(rows), len(self.sizes), self._sizes_c, int(self.n_cu), buf, cap)
-                if n > 0:
-                    break
-                if cap >= 1 << 26:
-                    check(n, "rcb_atrans_plan")
-                cap *= 8
+            need = lib.rcb_atrans_plan(C.c_int64(rows), len(self.sizes), self._sizes_c, int(self.n_cu), None, 0)   # size query
+            if need <= 0:
+                check(need or -1, "rcb_atrans_plan")
+            buf = (C.c_int32 * need)()
+            n = lib.rcb_atrans_plan(C.c_int64(rows), len(self.sizes), self._sizes_c, int(self.n_cu), buf, need)
+            if n != need:
+                check(n if n < 0 else -1, "rcb_atrans_plan")
             host = torch.frombuffer(buf, dtype=torch.int32, count=n).clone()
             head = (C.c_int32 * 12)(*[int(v) for v in host[:12]])
             nws = int(lib.rcb_atrans_workspace_floats(C.c_int64(rows), len(self.sizes), self._sizes_c, head))
@@ -1142,18 +1229,25 @@ class ATransform:
         return pl
 
     def _apply(self, x, out, transpose, terms):
-        rows = x.shape[0]
-        for t_ in (x, out):
+        """x: fp32 rows, or a Planes pair (the producer's hi / lo split of the same rows: bit-identical result)"""
+        planes = isinstance(x, Planes)
+        rows = x.rows if planes else x.shape[0]
+        for t_ in ((out,) if planes else (x, out)):
             if t_.dtype != f32 or not t_.is_cuda or t_.dim() != 2 or t_.stride(1) != 1 or t_.shape[1] != self.cols:
                 raise RcbError(f"ATransform: fp32 GPU rows of {self.cols} columns expected")
+        if planes and x.cols != self.cols:
+            raise RcbError(f"ATransform: planes of {self.cols} columns expected")
         if out.shape[0] != rows:
             raise RcbError("ATransform: row counts differ")
         plan, head, nws = self._plan(rows)
         ws = torch.empty(nws, device=self.device, dtype=f32) if nws else None      # (few rows: slabs of the K-split launch)
-        check(_lib.load().rcb_atrans_apply(C.c_void_p(x.data_ptr()), C.c_int64(x.stride(0)), C.c_void_p(out.data_ptr()),
-                                          C.c_int64(out.stride(0)), C.c_int64(rows), len(self.sizes), self._sizes_c,
-                                          ptr(self.packed), int(transpose), int(terms), ptr(plan), head, ptr(ws, f32, True),
-                                          stream_ptr()), "rcb_atrans_apply")
+        if planes:
+            xa = (C.c_void_p(0), C.c_int64(0), C.c_void_p(x.buf[0].data_ptr()), C.c_void_p(x.buf[1].data_ptr()), C.c_int64(x.ld))
+        else:
+            xa = (C.c_void_p(x.data_ptr()), C.c_int64(x.stride(0)), C.c_void_p(0), C.c_void_p(0), C.c_int64(0))
+        check(_lib.load().rcb_atrans_apply(*xa, C.c_void_p(out.data_ptr()), C.c_int64(out.stride(0)), C.c_int64(rows),
+                                          len(self.sizes), self._sizes_c, ptr(self.packed), int(transpose), int(terms),
+                                          ptr(plan), head, ptr(ws, f32, True), stream_ptr()), "rcb_atrans_apply")
         return out
 
     def forward(self, h_w, out):
@@ -1177,11 +1271,18 @@ class ATransform:
         h16 / dw16: bf16 copies of h_w / dw ([rows, cols], row stride a multiple of 8) written by their producers
         (reparam_rng(want_bf16), siren_loss_bwd(want_bf16)); cast here when absent.  Narrow layers (the output layer):
         rcb_atrans_wgrad_narrow, exact fp32 products in a fixed order; anything else: fp32 GEMMs."""
+        hp, dp = isinstance(h_w, Planes), isinstance(dw, Planes)
+        if hp:                      # operands as planes: hi is the bf16 copy, the narrow layers read float(hi) + float(lo)
+            h16 = h_w.hi
+        if dp:
+            dw16 = dw.hi
+        if (hp or dp) and not bf16_hi:
+            h_w, dw, hp, dp = (h_w.float() if hp else h_w), (dw.float() if dp else dw), False, False
         out = [None] * len(self.sizes)
         big = max(self.sizes)
         wide = [i for i, n in enumerate(self.sizes) if n == big]
         adjacent = all(b == a + 1 for a, b in zip(wide, wide[1:]))
-        rows = h_w.shape[0]
+        rows = h_w.rows if hp else h_w.shape[0]
         if bf16_hi and big >= 256 and big % 8 == 0 and adjacent and self.slices[wide[0]][0] % 8 == 0:
             k, lo0 = len(wide), self.slices[wide[0]][0]
 
@@ -1203,10 +1304,16 @@ class ATransform:
                 slabs = max(1, min(64, (rows + 63) // 64))
                 ws = torch.empty(int(lib.rcb_atrans_wgrad_narrow_workspace(n, slabs)), device=self.device, dtype=f32)
                 g = torch.empty(n, n, device=self.device, dtype=f32)
-                check(lib.rcb_atrans_wgrad_narrow(C.c_void_p(h_w[:, lo:hi].data_ptr()), C.c_int64(h_w.stride(0)),
-                                                  C.c_void_p(dw[:, lo:hi].data_ptr()), C.c_int64(dw.stride(0)), C.c_int64(rows),
-                                                  n, ptr(g), ptr(ws), slabs, stream_ptr()), "rcb_atrans_wgrad_narrow")
+                def operand(t, is_planes):
+                    if is_planes:
+                        return (C.c_void_p(0), C.c_void_p(t.buf[0, :, lo:hi].data_ptr()), C.c_void_p(t.buf[1, :, lo:hi].data_ptr()),
+                                C.c_int64(t.ld))
+                    return (C.c_void_p(t[:, lo:hi].data_ptr()), C.c_void_p(0), C.c_void_p(0), C.c_int64(t.stride(0)))
+                check(lib.rcb_atrans_wgrad_narrow(*operand(h_w, hp), *operand(dw, dp), C.c_int64(rows), n, ptr(g), ptr(ws), slabs,
+                                                  stream_ptr()), "rcb_atrans_wgrad_narrow")
                 out[i] = g
             else:
-                out[i] = torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi])
+                hf = h_w.float() if hp else h_w
+                df = dw.float() if dp else dw
+                out[i] = torch.mm(hf[:, lo:hi].t(), df[:, lo:hi])
         return out

@@ -123,6 +123,13 @@ class PriorBNNmodel(nn.Module):
         # with fused_noise: the posterior update of step t also draws the sample of step t + 1 (rcb_level_bwd.next_*), so
         # the sampling kernels -- a second read of every loc / log_scale -- run once per train() call instead of once per step
         self.fuse_next_sample = os.environ.get("RCB_FUSE_NEXT", "1") != "0"      # (the switch is for same-box A/B runs)
+        # with split_gemm + fused_noise: the A transform's per-INR operands (h_w, and the SIREN gradient dwvec) travel as the
+        # (hi, lo) bf16 planes their producers write (ops.Planes) instead of fp32 rows + a bf16 copy: identical bits, no
+        # conversion work in the A-transform kernels, 4 instead of 6 bytes per element written
+        self.operand_planes = os.environ.get("RCB_PLANES", "1") != "0"
+        # with fuse_next_sample: the posterior update re-draws its step's noise from the counter instead of reading the copy
+        # the sampler stored (rcb_level_bwd.eps_from_rng: same bits, 8 bytes per element less traffic)
+        self.redraw_noise = os.environ.get("RCB_REDRAW_EPS", "1") != "0"
         self._train_calls = 0
         self._ws = None              # persistent training workspace (captured graphs + everything they reference)
         self._rng_ctr_init = 0       # first value of the noise counter of a new workspace (tests build exact twins)
@@ -274,6 +281,7 @@ class PriorBNNmodel(nn.Module):
         key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
+               self.operand_planes, self.redraw_noise,
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
                # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
@@ -354,12 +362,19 @@ class PriorBNNmodel(nn.Module):
         lpe16_want = bool(use_rng and self.stage1_bf16 and self.precision != 0 and not self.patch)
         # (the fused form lives on the posterior update's flat path: element counts divisible by 4)
         fuse_next = bool(use_rng and self.fuse_next_sample and (N * D) % 4 == 0 and (N * self._d_lpe) % 4 == 0)
+        # the A transform's operands as (hi, lo) planes written by their producers (single-level presets with in-kernel noise;
+        # layers must start at multiples of 8 columns for the 16-byte LDS-DMA pieces)
+        planes = bool(split is not None and use_rng and self.operand_planes
+                      and all(lo % 8 == 0 for (lo, hi) in slices if (hi - lo) % 8 == 0))
+        redraw = bool(fuse_next and self.redraw_noise)
         smp_net = smp_lpe = None
         if fuse_next:
             if "smp_net" not in ws:
-                ws["smp_net"] = ops.sample_buffers(net[0], True)
-                ws["smp_lpe"] = ops.sample_buffers(lpe_lv, True)
+                ws["smp_net"] = ops.sample_buffers(net[0], True, planes=planes, want_eps=not redraw)
+                ws["smp_lpe"] = ops.sample_buffers(lpe_lv, True, want_eps=not redraw)
             smp_net, smp_lpe = ws["smp_net"], ws["smp_lpe"]
+        elif planes and "smp_net" not in ws:
+            ws["smp_net"] = ops.sample_buffers(net[0], planes=True)
 
         def prime():
             """the sample of the call's first step (every later one comes out of the previous step's posterior update)"""
@@ -399,7 +414,11 @@ class PriorBNNmodel(nn.Module):
 
             def net_forward():
                 h16 = None
-                if fuse_next:
+                if planes:                   # h_w as its (hi, lo) planes: from the previous step's update, or sampled here
+                    if not fuse_next:
+                        ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, buffers=ws["smp_net"])
+                    h_w, eps = ws["smp_net"][2], [ws["smp_net"][1]]
+                elif fuse_next:
                     h_w, e0, h16 = smp_net[0], smp_net[1], (smp_net[2][:, :D] if want16 else None)
                     eps, h_w = [e0], h_w.view(N, D)
                 elif use_rng:
@@ -442,7 +461,10 @@ class PriorBNNmodel(nn.Module):
             # ---- fused SIREN forward + MSE + backward ---------------------------------------------------
             meta = self._meta(x, pe_c.shape[-1])
             dw16 = None
-            if want16:        # the kernel's epilogue also writes the bf16 copy of the gradient
+            if planes:        # the gradient leaves the kernel as its (hi, lo) planes: the A transform's operand form
+                sse, _, dpe, dw = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_planes=True,
+                                                    pe_layout=pe_lay, xf16=ws["xf16"])
+            elif want16:        # the kernel's epilogue also writes the bf16 copy of the gradient
                 sse, dw, dpe, dw16 = ops.siren_loss_bwd(x, pe_c.detach(), wvec, y, 1.0 / (P * Cc), meta, want_bf16=True,
                                                         pe_layout=pe_lay, xf16=ws["xf16"])
             else:
@@ -508,7 +530,8 @@ class PriorBNNmodel(nn.Module):
             # fused posterior update (also accumulates the pre-update KL for the ELBO log)
             nxt_net = None
             if fuse_next:            # the next step sees the noise counter + 1 (rcb_step_end increments it after this segment)
-                nxt_net = ops.NextSample((smp_net[0], smp_net[1], smp_net[2] if want16 else None), rng_seed, 0, rng_ctr, 1)
+                nxt_net = ops.NextSample((smp_net[0], smp_net[1], smp_net[2] if (want16 or planes) else None), rng_seed, 0, rng_ctr, 1,
+                                         redraw_eps=redraw)
             for lv, (pl, ps), e, stt in zip(net, net_priors, st["eps"], net_state):
                 ops.posterior_bwd(lv, pl, ps, False, 1.0, st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots,
                                   kl_scalar_dev=beta_dev, next_sample=nxt_net)
@@ -516,7 +539,8 @@ class PriorBNNmodel(nn.Module):
         def seg2_lpe():
             nxt_lpe = None
             if fuse_next:
-                nxt_lpe = ops.NextSample((smp_lpe[0], smp_lpe[1], smp_lpe[2] if lpe16_want else None), rng_seed, 1, rng_ctr, 1)
+                nxt_lpe = ops.NextSample((smp_lpe[0], smp_lpe[1], smp_lpe[2] if lpe16_want else None), rng_seed, 1, rng_ctr, 1,
+                                         redraw_eps=redraw)
             ops.posterior_bwd(lpe_lv, pri_d[2].reshape(-1), pri_d[3].reshape(-1), False, 1.0, st["d_lpe"],
                               st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots, kl_scalar_dev=beta_dev,
                               next_sample=nxt_lpe)

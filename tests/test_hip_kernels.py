@@ -1113,3 +1113,94 @@ def test_integration_md_binding_stub_runs_and_matches_the_oracle():
     (((y_ref - y) ** 2).sum() / (1024 * 3)).backward()
     assert rel_err(sse, ((y_ref.detach() - y) ** 2).sum((1, 2))) < 2e-5
     assert rel_err(dw, wv_r.grad) < 1e-4 and rel_err(dpe, pe_r.grad) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: the A transform's per-row operands as (hi, lo) bf16 planes written by their producers
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,sizes", [(37, [1056, 1056, 1056, 99]), (4096, [1056, 1056, 1056, 99]), (192, [1584, 2352, 2352, 147]),
+                                        (130, [424, 440, 63]), (129, [64, 8, 40])])
+def test_atrans_plane_operands_are_bit_identical_to_fp32_rows(rows, sizes):
+    """rcb_atrans_apply with x_hi / x_lo (ops.Planes) instead of fp32 rows: hi = bf16(x), lo = bf16(x - hi) is exactly what the
+    kernel forms from an fp32 row, and the plane kernel multiplies the same fragments in the same order -- forward and data
+    gradient must equal the fp32-row launch BIT FOR BIT for every number of terms, incl. the ragged 99- / 147- / 63-wide
+    layers, K-split launches (few rows) and layer sizes that are not a multiple of 32 (424, 440: a partial last chunk)."""
+    gen = torch.Generator().manual_seed(rows * 3 + len(sizes))
+    D = sum(sizes)
+    cum = np.cumsum([0] + sizes)
+    slices = [(int(cum[i]), int(cum[i + 1])) for i in range(len(sizes))]
+    x = g(torch.randn(rows, D, generator=gen) * 0.03)
+    A = [g(torch.randn(n, n, generator=gen) / n ** 0.5) for n in sizes]
+    xp = ops.Planes.from_float(x)
+    assert xp.ld % 32 == 0 and torch.equal(xp.hi, x.bfloat16()) and rel_err(xp.float(), x) < 2.0 ** -15
+    for terms in (2, 3, 1):
+        tr = ops.ATransform(slices, DEV, terms=terms)
+        tr.prepare(A)
+        w32 = tr.forward(x, torch.empty(rows, D, device=DEV))
+        w16 = tr.forward(xp, torch.full((rows, D), float("nan"), device=DEV))
+        assert torch.equal(w32, w16), (terms, "forward")
+        d32 = tr.dgrad(x, torch.empty(rows, D, device=DEV))
+        d16 = tr.dgrad(xp, torch.full((rows, D), float("nan"), device=DEV))
+        assert torch.equal(d32, d16), (terms, "data gradient")
+    # weight gradient: wide layers on the hi planes == the bf16 copies; narrow layers read float(hi) + float(lo)
+    dw = g(torch.randn(rows, D, generator=gen) * 1e-3)
+    dp = ops.Planes.from_float(dw)
+    tr = ops.ATransform(slices, DEV, terms=2)
+    gp = tr.wgrad(xp, dp)
+    gr = tr.wgrad(xp.float(), dp.float(), xp.hi, dp.hi, True)
+    for a_, b_ in zip(gp, gr):
+        assert torch.equal(a_, b_)
+
+
+def test_producers_write_the_operand_planes():
+    """the three producers of plane operands write hi = bf16(v), lo = bf16(v - hi) of exactly the fp32 value they would have
+    stored: rcb_reparam_rng_fwd (out_bf16 + out_lo, fp32 output optional), the fused next sample of rcb_posterior_bwd
+    (next_out_bf16 + next_out_lo) together with the re-drawn noise (eps_from_rng: eps = NULL, the update is bit-identical to
+    the one that reads the stored noise), and the SIREN gradient epilogue (dw_bf16 + dw_lo, dwvec = NULL), chunked or not."""
+    torch.manual_seed(5)
+    rows, cols = 8, 3267
+    loc = (torch.randn(rows, cols) * 0.05).to(DEV)
+    ls = (torch.randn(rows, cols) * 0.3 - 4).to(DEV)
+    lv_a = ops.LevelSpec(loc.clone(), ls.clone(), cols, rows)
+    lv_b = ops.LevelSpec(loc.clone(), ls.clone(), cols, rows)
+    step = torch.tensor([41], device=DEV, dtype=torch.int64)
+    seed = 0x1234567890ABCDEF
+    # 1. sampler
+    out_a, eps_a = ops.reparam_rng(lv_a, seed, 0, step)
+    buf = ops.sample_buffers(lv_b, planes=True, want_eps=False)
+    assert buf[0] is None and buf[1] is None
+    ops.reparam_rng(lv_b, seed, 0, step, buffers=buf)
+    pl = buf[2]
+    ref = ops.Planes.from_float(out_a.view(rows, cols))
+    assert torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
+    assert float(pl.buf[:, :, cols:].abs().max()) == 0.0                  # the row padding is never written
+    # 2. posterior update: stored noise + fp32 next sample  vs  re-drawn noise + planes
+    p_loc, p_scale = torch.zeros(cols, device=DEV), torch.full((cols,), 0.02, device=DEV)
+    d = (torch.randn(rows, 1, cols) * 1e-3).to(DEV)
+    cfg = ops.adam_cfg(2e-4, 3)
+    st_a = {k: torch.zeros_like(loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+    st_b = {k: torch.zeros_like(loc) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+    buf_a = ops.sample_buffers(lv_a, True)
+    ops.posterior_bwd(lv_a, p_loc, p_scale, False, 1.0, d, eps_a, 1, adam=cfg, state=st_a,
+                      next_sample=ops.NextSample(buf_a, seed, 0, step, 1))
+    ops.posterior_bwd(lv_b, p_loc, p_scale, False, 1.0, d, None, 1, adam=cfg, state=st_b,
+                      next_sample=ops.NextSample(buf, seed, 0, step, 1, redraw_eps=True))
+    assert torch.equal(lv_a.loc, lv_b.loc) and torch.equal(lv_a.log_scale, lv_b.log_scale)
+    for k in st_a:
+        assert torch.equal(st_a[k], st_b[k]), k
+    ref = ops.Planes.from_float(buf_a[0].view(rows, cols))
+    assert torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo) and torch.equal(pl.hi, buf_a[2][:, :cols])
+    with pytest.raises(ops.RcbError):                                       # re-drawn noise and a stored copy exclude each other
+        ops.posterior_bwd(lv_b, p_loc, p_scale, False, 1.0, d, eps_a, 1, adam=cfg, state=st_b,
+                          next_sample=ops.NextSample(buf, seed, 0, step, 1, redraw_eps=True))
+    # 3. SIREN gradient epilogue (width 32 bf16 kernel, a wide kernel, and a chunked launch through rcb_siren_reduce_chunks)
+    for hidden, P, chunks in ((32, 256, None), (64, 256, None), (32, 2048, 2)):
+        case = dict(F=16, E=16, n_hidden=3, C=3, P=P, N=5, S=1, hidden=hidden)
+        dims, D, xf, pe, wv, y = _siren_case(seed=33, **case)
+        meta = SirenMeta(1, P, 16, 16, 3, hidden, 3, precision=1)
+        pe16 = g(pe).bfloat16()
+        sse, dw, dpe = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), 1.0 / (P * 3), meta, pixel_chunks=chunks)
+        sse2, none, dpe2, dwp = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), 1.0 / (P * 3), meta, pixel_chunks=chunks, want_planes=True)
+        assert none is None and torch.equal(sse, sse2) and torch.equal(dpe, dpe2)
+        ref = ops.Planes.from_float(dw.contiguous())
+        assert torch.equal(dwp.hi, ref.hi) and torch.equal(dwp.lo, ref.lo), (hidden, P, chunks)

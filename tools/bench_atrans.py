@@ -43,6 +43,13 @@ t_dg = timeit(lambda: tr.dgrad(dw, out))
 flops = 2.0 * rows * sum(n * n for n in sizes) * terms
 print(f"atrans rows={rows} terms={terms} pad={pad}: pack {t_pack:.1f} us, forward {t_fwd:.1f} us ({flops / t_fwd / 1e6:.0f} TFLOP/s), "
       f"dgrad {t_dg:.1f} us ({flops / t_dg / 1e6:.0f} TFLOP/s)")
+xp, dp = ops.Planes.from_float(x.contiguous()), ops.Planes.from_float(dw.contiguous())
+t_fwd_p = timeit(lambda: tr.forward(xp, out))
+t_dg_p = timeit(lambda: tr.dgrad(dp, out))
+print(f"  operands as (hi, lo) planes: forward {t_fwd_p:.1f} us ({flops / t_fwd_p / 1e6:.0f} TFLOP/s), dgrad {t_dg_p:.1f} us "
+      f"({flops / t_dg_p / 1e6:.0f} TFLOP/s)")
+t_wg_p = timeit(lambda: tr.wgrad(xp, dp))
+print(f"  wgrad on the planes {t_wg_p:.1f} us")
 h16 = x.bfloat16()
 d16 = dw.bfloat16()
 t_wg = timeit(lambda: tr.wgrad(x, dw, h16, d16, True))

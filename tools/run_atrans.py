@@ -1,4 +1,4 @@
-"""Launches the A-transform kernels a few times (profiling target).  usage: python tools/run_atrans.py [rows] [terms] [reps]"""
+"""Launches the A-transform kernels a few times (profiling target).  usage: python tools/run_atrans.py [rows] [terms] [reps] [planes]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +20,9 @@ dw = torch.randn(rows, D, device="cuda") * 1e-3
 A = [torch.randn(n, n, device="cuda") / n ** 0.5 for n in sizes]
 out = torch.empty(rows, D, device="cuda")
 tr = ops.ATransform(slices, "cuda", terms=terms)
+planes = len(sys.argv) > 4 and sys.argv[4] == "planes"          # operands as the producers' (hi, lo) bf16 planes
+if planes:
+    x, dw = ops.Planes.from_float(x), ops.Planes.from_float(dw)
 for _ in range(reps):
     tr.prepare(A)
     tr.forward(x, out)
