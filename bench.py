@@ -438,7 +438,7 @@ def comm_report(m, lt, up, dev):
     del scratch
     live = [q.data for q in list(m.parameters()) + list(lt.parameters()) + list(up.parameters())]
     live += [w[k] for k in ("state_flat", "step_t", "rng_ctr", "mse_buf", "kl_buf", "flat")]
-    live += [t for k in ("smp_net", "smp_lpe") if k in w for t in w[k] if t is not None]
+    live += [getattr(t, "buf", t) for k in ("smp_net", "smp_lpe") if k in w for t in w[k] if t is not None]   # (ops.Planes -> its buffer)
     saved = [t.clone() for t in live]
     graphs = w["graphs"][1]
     seg = []

@@ -170,12 +170,15 @@ int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, in
  * (the operand of the A transform's batched bf16 weight-gradient GEMM, written while the values are in registers); with
  * out_lo != NULL also the low plane bf16(out - out_bf16) in the same layout: (out_bf16, out_lo) are the plane operands of
  * rcb_atrans_apply, and `out` may then be NULL.
- * rcb_philox_normal materialises the same stream (step from step_dev if non-NULL, else step_host).              */
+ * rcb_philox_normal materialises the same stream (step from step_dev if non-NULL, else step_host).
+ * group_offset: element i draws from Philox group i / 4 + group_offset.  A launch over rows [r0, r0 + m) of a larger
+ * [rows, cols] array with group_offset = r0 * cols / 4 (r0 * cols a multiple of 4) draws exactly the noise those rows get in
+ * a launch over the whole array: a shard -- or a sub-batch -- sees the noise of the unsharded run.                  */
 int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev, int64_t step_host,
-                      rcb_stream_t stream);
+                      uint64_t group_offset, rcb_stream_t stream);
 int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
                         const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, void* out_lo, int32_t cols,
-                        int64_t ld_bf16, rcb_stream_t stream);
+                        int64_t ld_bf16, uint64_t group_offset, rcb_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -271,6 +274,7 @@ typedef struct {
                             * of (rng_seed, rng_stream, counter *rng_step_dev + rng_step_add - 1), i.e. what the sampler of
                             * THIS step drew (rcb_reparam_rng_fwd at *rng_step_dev, or the previous call's next sample):
                             * the same bits, 8 bytes of traffic per element less                                  */
+  uint64_t rng_group_offset; /* Philox group of element 0 (rcb_reparam_rng_fwd's group_offset), for the next sample and eps_from_rng */
   void* next_out_lo;       /* nullable, with next_out_bf16: the LOW plane bf16(sample - high plane), same layout.  With both
                             * planes next_out may be NULL: rcb_atrans_apply reads the planes (x_hi / x_lo)          */
 } rcb_level_bwd;

@@ -72,7 +72,7 @@ class LevelBwd(C.Structure):
                 ("next_out", C.c_void_p), ("next_eps", C.c_void_p), ("next_out_bf16", C.c_void_p),
                 ("next_ld_bf16", C.c_int64), ("rng_seed", C.c_uint64), ("rng_step_dev", C.c_void_p),
                 ("rng_step_add", C.c_int64), ("rng_stream", C.c_uint32), ("eps_from_rng", C.c_uint32),
-                ("next_out_lo", C.c_void_p)]
+                ("rng_group_offset", C.c_uint64), ("next_out_lo", C.c_void_p)]
 
 
 _lib = None

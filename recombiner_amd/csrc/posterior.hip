@@ -215,12 +215,12 @@ __device__ __forceinline__ float4 philox_normal4(unsigned long long group, unsig
 
 __global__ void __launch_bounds__(256) philox_normal_kernel(float* __restrict__ out, long long n, unsigned long long seed,
                                                             unsigned stream, const long long* __restrict__ step_dev,
-                                                            long long step_host) {
+                                                            long long step_host, unsigned long long goff) {
   const unsigned long long step = step_dev ? (unsigned long long)*step_dev : (unsigned long long)step_host;
   const long long n4 = (n + 3) >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 e = philox_normal4((unsigned long long)i, stream, step, seed);
+    const float4 e = philox_normal4((unsigned long long)i + goff, stream, step, seed);
     const float ev[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -277,14 +277,15 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
                                                           float* __restrict__ eps_out, float* __restrict__ out, long long n,
                                                           unsigned long long seed, unsigned stream,
                                                           const long long* __restrict__ step_dev, __bf16* __restrict__ out16,
-                                                          __bf16* __restrict__ lo16, int cols, long long ld16) {
+                                                          __bf16* __restrict__ lo16, int cols, long long ld16,
+                                                          unsigned long long goff) {
   const unsigned long long step = (unsigned long long)*step_dev;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 m = reinterpret_cast<const float4*>(loc)[i];
     const float4 l = reinterpret_cast<const float4*>(ls)[i];
-    const float4 e = philox_normal4((unsigned long long)i, stream, step, seed);
+    const float4 e = philox_normal4((unsigned long long)i + goff, stream, step, seed);
     float4 o;
     o.x = add_rn(m.x, mul_rn(st_f32(l.x), e.x));
     o.y = add_rn(m.y, mul_rn(st_f32(l.y), e.y));
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
     if (out16) store_planes_row4(out16, lo16, 4 * i, cols, ld16, o);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 3)) {      // tail group
-    const float4 e = philox_normal4((unsigned long long)n4, stream, step, seed);
+    const float4 e = philox_normal4((unsigned long long)n4 + goff, stream, step, seed);
     const float ev[4] = {e.x, e.y, e.z, e.w};
     for (int k = 0; k < (int)(n & 3); ++k) {
       const long long i = (n4 << 2) + k;
@@ -309,20 +310,21 @@ __global__ void __launch_bounds__(256) reparam_rng_kernel(const float* __restric
 }
 
 extern "C" int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev,
-                                 int64_t step_host, rcb_stream_t stream) {
+                                 int64_t step_host, uint64_t group_offset, rcb_stream_t stream) {
   RCB_REQUIRE(out && n >= 0, RCB_ERR_ARG, "philox_normal: null pointer");
   if (n == 0) return RCB_OK;
   int blocks = cdiv((n + 3) >> 2, 256);
   if (blocks > 16384) blocks = 16384;
   philox_normal_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(out, (long long)n, seed, rng_stream,
-                                                                (const long long*)step_dev, (long long)step_host);
+                                                                (const long long*)step_dev, (long long)step_host,
+                                                                (unsigned long long)group_offset);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
 
 extern "C" int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,
                                    const int64_t* step_dev, float* eps_out, float* out, void* out_bf16, void* out_lo,
-                                   int32_t cols, int64_t ld_bf16, rcb_stream_t stream) {
+                                   int32_t cols, int64_t ld_bf16, uint64_t group_offset, rcb_stream_t stream) {
   RCB_REQUIRE(loc && log_scale && step_dev && n > 0, RCB_ERR_ARG, "reparam_rng_fwd: null pointer / empty");
   RCB_REQUIRE(out || (out_bf16 && out_lo), RCB_ERR_ARG, "reparam_rng_fwd: no output (fp32 `out`, or both planes out_bf16 + out_lo)");
   RCB_REQUIRE(!out_lo || out_bf16, RCB_ERR_ARG, "reparam_rng_fwd: the low plane comes with the high plane");
@@ -335,7 +337,8 @@ extern "C" int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int
   if (blocks < 1) blocks = 1;
   reparam_rng_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(loc, log_scale, eps_out, out, (long long)n, seed, rng_stream,
                                                               (const long long*)step_dev, reinterpret_cast<__bf16*>(out_bf16),
-                                                              reinterpret_cast<__bf16*>(out_lo), out_bf16 ? cols : 1, (long long)ld_bf16);
+                                                              reinterpret_cast<__bf16*>(out_lo), out_bf16 ? cols : 1, (long long)ld_bf16,
+                                                              (unsigned long long)group_offset);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -774,7 +777,8 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   // eps: the stored noise of this step's sample, or -- eps_from_rng -- re-drawn from the counter it was drawn from (a pure
   // function of (seed, stream, counter, element): the same bits), which saves its 4-byte write and 4-byte read per element
   const float4 ep4 = L.eps_from_rng
-                         ? philox_normal4((unsigned long long)i4, L.rng_stream, (unsigned long long)(*L.rng_step_dev + L.rng_step_add - 1), L.rng_seed)
+                         ? philox_normal4((unsigned long long)i4 + L.rng_group_offset, L.rng_stream,
+                                          (unsigned long long)(*L.rng_step_dev + L.rng_step_add - 1), L.rng_seed)
                          : RCB_LD4(L.eps + b);
   float4 m14 = RCB_LD4(L.m_loc + b), v14 = RCB_LD4(L.v_loc + b);
   float4 m24 = RCB_LD4(L.m_ls + b), v24 = RCB_LD4(L.v_ls + b);
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     // the next step's sample from the updated parameters: the arithmetic of reparam_rng_kernel on Philox group i4 at the
     // step counter the next step will see
     const unsigned long long step = (unsigned long long)(*L.rng_step_dev + L.rng_step_add);
-    const float4 e = philox_normal4((unsigned long long)i4, L.rng_stream, step, L.rng_seed);
+    const float4 e = philox_normal4((unsigned long long)i4 + L.rng_group_offset, L.rng_stream, step, L.rng_seed);
     float4 o;
     o.x = add_rn(loc4.x, mul_rn(st_f32(ls4.x), e.x));
     o.y = add_rn(loc4.y, mul_rn(st_f32(ls4.y), e.y));

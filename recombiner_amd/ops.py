@@ -428,15 +428,24 @@ class NextSample:
     """argument of posterior_bwd(next_sample=): draw the next step's sample in the same pass (rcb_level_bwd.next_*) into
     the buffers of sample_buffers(); step = the device step counter, the sample is that of counter + step_add"""
 
-    def __init__(self, buffers, seed: int, rng_stream: int, step, step_add=1, redraw_eps=False):
+    def __init__(self, buffers, seed: int, rng_stream: int, step, step_add=1, redraw_eps=False, group_offset=0):
         self.out, self.eps, self.o16 = buffers
+        self.group_offset = int(group_offset)      # Philox group of element 0 (see reparam_rng)
         self.seed, self.rng_stream, self.step, self.step_add = seed, rng_stream, step, step_add
         # redraw_eps: THIS step's noise is re-drawn from the counter it came from (rcb_level_bwd.eps_from_rng) instead of
         # being read back from memory -- posterior_bwd is then called with eps = None
         self.redraw_eps = bool(redraw_eps)
 
 
-def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False, buffers=None):
+def rng_group_offset(row0: int, cols: int):
+    """Philox group offset with which a launch over rows [row0, ...) of a [rows, cols] level draws the noise those rows have
+    in a launch over all rows (rcb_reparam_rng_fwd group_offset); row0 * cols must be a multiple of 4"""
+    if (int(row0) * int(cols)) % 4:
+        raise RcbError(f"rng_group_offset: row offset {row0} x {cols} columns is not a multiple of 4 elements")
+    return int(row0) * int(cols) // 4
+
+
+def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False, buffers=None, group_offset=0):
     """-> (out [n, 1, cols], eps [n, 1, cols]): reparameterised sample with the noise drawn inside the kernel
     (rcb_reparam_rng_fwd).  `step` is the device-resident int64 step counter.  want_bf16: third result, a bf16 copy of
     out as [n, cols] with a row stride that is a multiple of 8 (operand of the A transform's weight-gradient GEMM).
@@ -450,8 +459,8 @@ def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False
         check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
                                       C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64),
                                       ptr(eps, f32, True), ptr(out, f32, True), C.c_void_p(o16.buf[0].data_ptr()),
-                                      C.c_void_p(o16.buf[1].data_ptr()), int(cols), C.c_int64(o16.ld), stream_ptr()),
-              "rcb_reparam_rng_fwd")
+                                      C.c_void_p(o16.buf[1].data_ptr()), int(cols), C.c_int64(o16.ld), C.c_uint64(group_offset),
+                                      stream_ptr()), "rcb_reparam_rng_fwd")
         return out, eps, o16
     if want_bf16 and o16 is None:
         raise RcbError("reparam_rng: the buffers have no bf16 copy")
@@ -460,18 +469,19 @@ def reparam_rng(lv: LevelSpec, seed: int, rng_stream: int, step, want_bf16=False
     check(lib.rcb_reparam_rng_fwd(ptr(lv.loc.detach(), f32), ptr(lv.log_scale.detach(), f32), C.c_int64(n * cols),
                                   C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream), ptr(step, torch.int64),
                                   ptr(eps, f32, True), ptr(out), ptr(o16, bf16, True), C.c_void_p(0), int(cols),
-                                  C.c_int64(0 if o16 is None else o16.stride(0)), stream_ptr()), "rcb_reparam_rng_fwd")
+                                  C.c_int64(0 if o16 is None else o16.stride(0)), C.c_uint64(group_offset), stream_ptr()),
+          "rcb_reparam_rng_fwd")
     return (out, eps, o16[:, :cols]) if want_bf16 else (out, eps)
 
 
-def philox_normal(n, seed: int, rng_stream: int, step, device="cuda"):
+def philox_normal(n, seed: int, rng_stream: int, step, device="cuda", group_offset=0):
     """the noise stream of reparam_rng as a tensor (step: python int or device int64 tensor)"""
     lib = _lib.load()
     out = torch.empty(n, device=device, dtype=f32)
     dev_step = step if torch.is_tensor(step) else None
     check(lib.rcb_philox_normal(ptr(out), C.c_int64(n), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(rng_stream),
                                 ptr(dev_step, torch.int64, True), C.c_int64(0 if dev_step is not None else int(step)),
-                                stream_ptr()), "rcb_philox_normal")
+                                C.c_uint64(group_offset), stream_ptr()), "rcb_philox_normal")
     return out
 
 
@@ -512,6 +522,7 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
             b.next_out_bf16 = addr(ns.o16, bf16)
             b.next_ld_bf16 = 0 if ns.o16 is None else int(ns.o16.stride(0))
         b.eps_from_rng = int(ns.redraw_eps)
+        b.rng_group_offset = ns.group_offset
         if ns.redraw_eps and eps is not None:
             raise RcbError("posterior_bwd: redraw_eps takes eps = None")
         b.rng_seed = ns.seed & (2 ** 64 - 1)

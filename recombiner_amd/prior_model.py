@@ -130,6 +130,11 @@ class PriorBNNmodel(nn.Module):
         # with fuse_next_sample: the posterior update re-draws its step's noise from the counter instead of reading the copy
         # the sampler stored (rcb_level_bwd.eps_from_rng: same bits, 8 bytes per element less traffic)
         self.redraw_noise = os.environ.get("RCB_REDRAW_EPS", "1") != "0"
+        # in-kernel noise: first row of this model's INRs inside a larger (virtual) batch.  Row r of the model draws the noise of
+        # row rng_row_offset + r of that batch (ops.rng_group_offset): a shard or a sub-batch trained on its own then sees
+        # exactly the noise of the unsharded run, given the same seed (`rng_seed_override`, else derived per model and rank)
+        self.rng_row_offset = 0
+        self.rng_seed_override = None
         self._train_calls = 0
         self._ws = None              # persistent training workspace (captured graphs + everything they reference)
         self._rng_ctr_init = 0       # first value of the noise counter of a new workspace (tests build exact twins)
@@ -281,7 +286,7 @@ class PriorBNNmodel(nn.Module):
         key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
-               self.operand_planes, self.redraw_noise,
+               self.operand_planes, self.redraw_noise, self.rng_row_offset, self.rng_seed_override,
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
                # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
@@ -356,7 +361,9 @@ class PriorBNNmodel(nn.Module):
         # never reset, so every step of every train() call draws fresh noise, replayed or not
         use_rng = (self.fused_noise and self.noise_source is None and len(net) == 1 and ops.rng_eligible(net[0])
                    and ops.rng_eligible(lpe_lv))
-        rng_seed = ws["seed"]
+        rng_seed = ws["seed"] if self.rng_seed_override is None else int(self.rng_seed_override) & (2 ** 64 - 1)
+        goff_net = ops.rng_group_offset(self.rng_row_offset, D) if use_rng else 0
+        goff_lpe = ops.rng_group_offset(self.rng_row_offset, self._d_lpe) if use_rng else 0
 
         want16 = split is not None and training_mappings and self.wgrad_bf16     # bf16 operands of the weight gradient
         lpe16_want = bool(use_rng and self.stage1_bf16 and self.precision != 0 and not self.patch)
@@ -378,8 +385,8 @@ class PriorBNNmodel(nn.Module):
 
         def prime():
             """the sample of the call's first step (every later one comes out of the previous step's posterior update)"""
-            ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=want16, buffers=smp_net)
-            ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe)
+            ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=want16, buffers=smp_net, group_offset=goff_net)
+            ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe, group_offset=goff_lpe)
 
         pe_lay = self._pe_layout()
         if split is not None and not training_mappings:
@@ -396,9 +403,9 @@ class PriorBNNmodel(nn.Module):
                 if fuse_next:                # written by the previous step's posterior update (or by prime() before the first)
                     lpe, e_lpe, lpe16 = smp_lpe[0], smp_lpe[1], (smp_lpe[2][:, :lpe_lv.cols] if lpe16_want else None)
                 elif use_rng and lpe16_want:
-                    lpe, e_lpe, lpe16 = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=True)   # bf16 copy: stage-1 operand
+                    lpe, e_lpe, lpe16 = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=True, group_offset=goff_lpe)   # bf16 copy: stage-1 operand
                 elif use_rng:
-                    lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr)
+                    lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, group_offset=goff_lpe)
                 else:
                     e_lpe = self._noise((N, 1, self._d_lpe))
                     lpe = ops.reparam_fwd([lpe_lv], [e_lpe], 1)
@@ -416,16 +423,16 @@ class PriorBNNmodel(nn.Module):
                 h16 = None
                 if planes:                   # h_w as its (hi, lo) planes: from the previous step's update, or sampled here
                     if not fuse_next:
-                        ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, buffers=ws["smp_net"])
+                        ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, buffers=ws["smp_net"], group_offset=goff_net)
                     h_w, eps = ws["smp_net"][2], [ws["smp_net"][1]]
                 elif fuse_next:
                     h_w, e0, h16 = smp_net[0], smp_net[1], (smp_net[2][:, :D] if want16 else None)
                     eps, h_w = [e0], h_w.view(N, D)
                 elif use_rng:
                     if want16:
-                        h_w, e0, h16 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=True)
+                        h_w, e0, h16 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=True, group_offset=goff_net)
                     else:
-                        h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr)
+                        h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, group_offset=goff_net)
                     eps, h_w = [e0], h_w.view(N, D)
                 else:
                     eps = [self._noise((N, 1, D)) for _ in net]
@@ -531,7 +538,7 @@ class PriorBNNmodel(nn.Module):
             nxt_net = None
             if fuse_next:            # the next step sees the noise counter + 1 (rcb_step_end increments it after this segment)
                 nxt_net = ops.NextSample((smp_net[0], smp_net[1], smp_net[2] if (want16 or planes) else None), rng_seed, 0, rng_ctr, 1,
-                                         redraw_eps=redraw)
+                                         redraw_eps=redraw, group_offset=goff_net)
             for lv, (pl, ps), e, stt in zip(net, net_priors, st["eps"], net_state):
                 ops.posterior_bwd(lv, pl, ps, False, 1.0, st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots,
                                   kl_scalar_dev=beta_dev, next_sample=nxt_net)
@@ -540,7 +547,7 @@ class PriorBNNmodel(nn.Module):
             nxt_lpe = None
             if fuse_next:
                 nxt_lpe = ops.NextSample((smp_lpe[0], smp_lpe[1], smp_lpe[2] if lpe16_want else None), rng_seed, 1, rng_ctr, 1,
-                                         redraw_eps=redraw)
+                                         redraw_eps=redraw, group_offset=goff_lpe)
             ops.posterior_bwd(lpe_lv, pri_d[2].reshape(-1), pri_d[3].reshape(-1), False, 1.0, st["d_lpe"],
                               st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots, kl_scalar_dev=beta_dev,
                               next_sample=nxt_lpe)

@@ -520,3 +520,46 @@ def test_map_hierarchical_model_to_int_weights_against_the_reference_function(na
     # the name is importable where upstream imports it from (prior_model.py:10, test_model.py:12)
     from recombiner_amd import test_model as TM
     assert PM.map_hierarchical_model_to_int_weights is U.map_hierarchical_model_to_int_weights is TM.map_hierarchical_model_to_int_weights
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_two_hidden_layers_of_width_32_at_model_level(prec):
+    """BASELINE configs[0] read literally: a "2-layer width-32 SIREN" (hidden_dims = [32, 32]) on the CIFAR geometry, 16 INRs.
+    The reference builds its INR from whatever list it is given (prior_model.py:84-85); three Adam steps of the whole model
+    incl. the mappings against the oracle on the same noise -- fp32 parity mode at fp32 tolerance, bf16 mode within operand
+    rounding."""
+    from recombiner_amd import config, utils
+    cfg = dict(config.configs["cifar"], hidden_dims=[32, 32])
+    n = 16
+    geo = O.Geometry.from_config(cfg)
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                         cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                         cfg["hierarchical_patch_nums"], random_seed=42, device=DEV)
+    m.precision = prec
+    assert m._d_net == geo.d_net == 32 * 33 + 32 * 33 + 3 * 33
+    torch.manual_seed(123)
+    lt = PM.LinearTransform(m.dims).to(DEV)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    steps = 3
+    torch.manual_seed(7)
+    eps = []
+    for _ in range(steps):
+        eps += [torch.randn(n, 1, 512), torch.randn(n, 1, geo.d_net)]
+    feed(m, eps)
+    s0 = 0.0211547
+    pri = [torch.zeros(geo.d_net), torch.full((geo.d_net,), s0), torch.zeros(2, 2, 128), torch.full((2, 2, 128), s0)]
+    prg = [p.to(DEV) for p in pri] + [None] * 4
+    mse, kl, elbo = m.train(steps, 2e-4, X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV), *prg, lt, up, 1e-8, training_mappings=True)
+    p = O.init_prior_params(geo, n, seed=42)
+    A = O.make_linear_transform(geo.dims, seed=123)
+    upo = O.UpsampleNet(geo.data_dim, geo.paddings, geo.layerwise_scale_factors, seed=124)
+    replay = []
+    for k in range(steps):
+        replay += [eps[2 * k].reshape(n, 2, 2, 128), eps[2 * k + 1]]
+    mse_o, kl_o, elbo_o = O.prior_train(geo, p, X[None].repeat(n, 1, 1), Y, pri + [None] * 4, A, upo, steps, 2e-4, 1e-8, True,
+                                        O.Noise(replay))
+    np.testing.assert_allclose(elbo, elbo_o, rtol=2e-4 if prec == 0 else 1e-3)
+    assert_close_mostly(m.loc, p["loc"].numpy(), rtol=1e-4, atol=3e-5 if prec == 0 else 1e-4, what="loc")
+    np.testing.assert_allclose(kl, kl_o, rtol=1e-4 if prec == 0 else 2e-3)
