@@ -566,10 +566,13 @@ def main():
     if a.warmup > 0:
         run(a.warmup)
     fence()
+    ck0 = ops.clock_stamp(dev)           # (hardware counters read in stream order: one tiny launch on either side of the region)
     t0 = time.perf_counter()
     run(a.steps)
+    ck1 = ops.clock_stamp(dev)
     fence()
     el = time.perf_counter() - t0
+    step_clock_ghz = ops.sustained_clock_ghz(ck0, ck1)
     if ws > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -601,18 +604,22 @@ def main():
             return ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta, want_bf16=want16, xf16=xf16)
         for _ in range(2):
             launch()
+    cks = []
     for e0, e1 in evs:
         run(2)
         if rank == 0:
             # an untimed launch first: the stream is busy while the host submits e0 / kernel / e1, so the interval holds
             # the kernel and not the host's launch latency
             launch()
+            c0 = ops.clock_stamp(dev)
             e0.record()
             launch()
             e1.record()
+            cks.append((c0, ops.clock_stamp(dev)))
     if rank == 0:
         torch.cuda.synchronize()
         ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+        siren_clock_ghz = sum(ops.sustained_clock_ghz(c0, c1) for c0, c1 in cks) / reps
         dims = m.dims
         flops = 6.0 * 1024 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n   # fwd + 2x bwd
         # algorithmic HBM bytes per INR: pe read + dpe written (P*16 elements each, 2 B in bf16 storage, else 4 B),
@@ -644,12 +651,39 @@ def main():
             except (OSError, KeyError, ValueError):
                 traffic = None
             ach = alg_bytes / t / 1e9
-            roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm",
+            # What actually limits this kernel is neither of the two: it is vector-ISSUE bound (one sine and one cosine per
+            # hidden unit and pixel, packed conversions, the address / loss arithmetic).  `valu` prices the tile loop's
+            # instruction census (tools/siren_census.py, from the compiler's assembly of these very sources) at the SIMD's issue
+            # costs and at the shader clock MEASURED around the timed launches (rcb_clock_stamp: s_memtime against the 100 MHz
+            # s_memrealtime): floor = tiles per SIMD x issue cycles per tile / clock.  `bound` keeps the contract's vocabulary
+            # (the higher of the HBM and MFMA fractions); `limiter` names the real one.
+            valu = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r04_siren_isa_census.json")) as f:
+                    cen = json.load(f)
+                if cen.get("source_sha16") == siren_source_sha16():
+                    n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                    tiles = n * (1024 // 32)
+                    cyc = cen["vector_issue_cycles_per_tile"]
+                    floor_ms = tiles / n_simd * cyc / (siren_clock_ghz * 1e9) * 1e3
+                    floor_peak_ms = tiles / n_simd * cyc / 2.4e9 * 1e3
+                    valu = {"instructions_per_tile": cen["instructions"], "by_class": cen["by_class"],
+                            "vector_issue_cycles_per_tile": cyc, "transcendental_cycles_per_tile": cen["transcendental_cycles_per_tile"],
+                            "tiles_per_launch": tiles, "simds": n_simd, "shader_clock_ghz_measured": round(siren_clock_ghz, 3),
+                            "issue_floor_ms_at_measured_clock": round(floor_ms, 4), "issue_floor_ms_at_2.4ghz": round(floor_peak_ms, 4),
+                            "frac_of_issue_floor": round(floor_ms / ms, 4),
+                            "source": "profiles/r04_siren_isa_census.json (tools/siren_census.py)"}
+                else:
+                    valu = {"note": "stale census: the SIREN kernel sources changed since tools/siren_census.py ran"}
+            except (OSError, KeyError, ValueError):
+                valu = None
+            roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm", "limiter": "valu-issue",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" % PMC_FILE[pe16],
                     "traffic_note": traffic_note,
                     "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": alg_bytes, "alg_flops_per_launch": flops,
-                    "mfma_tflops": round(flops / t / 1e12, 1), "share_of_step": share}
+                    "mfma_tflops": round(flops / t / 1e12, 1), "mfma_frac": round(flops / t / 2.5e15, 4), "valu": valu,
+                    "share_of_step": share}
     # ---- sharded runs: what the per-step collectives move, and how much compute they have to hide behind -----------------
     comm = None
     if ws > 1:
@@ -675,7 +709,18 @@ def main():
                "config": {"workload": f"CIFAR-10 32x32, {n} INRs/GPU, 3x32 SIREN (in 32 = 16 Fourier + 16 upsampled pe), "
                                       f"S=1, training_mappings={tm}, Adam lr 2e-4", "inrs_per_gpu": n,
                           "parallelism": f"datapoint-sharded x{ws}", "tuned_library_gemms": bool(tuned)},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu,
+               "shader_clock_ghz_over_timed_steps": round(step_clock_ghz, 3)}
+        # the WHOLE step against the two chip rooflines, with SURVEY section 8(d)'s algorithmic figures per INR-step (CIFAR
+        # preset, S = 1): unavoidable HBM traffic 0.34 MB (posterior parameters + Adam moments read and written, noise, targets,
+        # pe in and its gradient out), arithmetic 19.46 (MLP) + 20.13 (A transform) + 191.9 (upsampling net as the reference
+        # evaluates it) MFLOP.  The `roofline` object above describes the largest kernel (a fifth of the step); this one says
+        # how far the step as a sequence of kernels sits from a fused ideal.
+        if m.precision != 0 and cfg["pixel_sizes"] == [32, 32]:
+            sb, sf, ts = 0.34e6 * n, (19.46 + 20.13 + 191.9) * 1e6 * n, el / a.steps
+            out["step_roofline"] = {"alg_bytes_per_step": sb, "alg_flops_per_step": sf, "hbm_frac": round(sb / ts / 8e12, 4),
+                                    "mfma_frac": round(sf / ts / 2.5e15, 4), "ms_per_step": round(ts * 1e3, 4),
+                                    "source": "SURVEY.md section 8(d) per-INR-step figures x INRs per GPU"}
         if comm is not None:
             out["comm"] = comm
         out.update(extras)

@@ -46,6 +46,10 @@ const char* rcb_last_error_string(void);
 #define RCB_STRUCT_ADAM_TENSOR 4
 #define RCB_STRUCT_REC_DESC 5
 int64_t rcb_struct_bytes(int32_t which);
+/* Measurement aid (bench.py's roofline): dst[0] = s_memtime (ticks of the shader clock), dst[1] = s_memrealtime (100 MHz),
+ * read by one lane of a one-wave kernel in stream order.  Two stamps around a launch give the shader clock that launch
+ * sustained, (dst'[0] - dst[0]) / ((dst'[1] - dst[1]) / 1e8) -- what an issue-bound kernel's roofline is priced at.     */
+int rcb_clock_stamp(uint64_t* dst, rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3 + K4: batched SIREN coordinate-MLP, one workgroup per (INR, sample).

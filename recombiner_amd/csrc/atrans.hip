@@ -71,22 +71,6 @@ __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// Register-destination loads that share the counted vmcnt ring with the LDS-DMAs.  Written as asm on purpose: the compiler's
-// own wait insertion treats a vmcnt queue that mixes LDS-DMAs and ordinary loads as out of order and answers every use of a
-// loaded register with vmcnt(0) -- which would also drain the DMAs of the chunk after next, issued a moment earlier.  Here
-// the loads are invisible to that pass; the counted wait below carries the loaded registers as in/out operands, so nothing
-// that reads them can be scheduled above it.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 gload16(const void* p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void wait_vm_frags(u32x4& f0, u32x4& f1, u32x4& f2, u32x4& f3) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N) : "memory");
-}
-
 #if ATRANS_STAMPS
 __device__ unsigned long long g_stamps[8][40][6];
 #define STAMP(it, pt)                                                                 \
@@ -428,182 +412,8 @@ __device__ __forceinline__ void run_segment(const AtArgs& a, const int4 sg, cons
   }
 }
 
-// ---- PLANES, direct form ----------------------------------------------------------------------------------------------------
-// A wave multiplies only ITS 32 rows of x: nothing of x is shared between the waves of a workgroup, so x has no business in
-// LDS at all (and the LDS-DMA path that carried it -- 32 of the 46 KB per chunk -- moves ~12-23 B/clk/CU, which, not the
-// matrix pipe, set the pace of the fp32 form: DMA-only build 43-51 us of its 80).  With the planes every lane's fragment is
-// 16 contiguous bytes of its own row, hi and lo alike: four global_load_dwordx4 per chunk and wave go STRAIGHT into the
-// operand registers, one chunk ahead of their use; LDS stages only the mapping (<= 14 KB per chunk, two DMAs per wave).
-#ifndef ATRANS_PLANES_DIRECT
-#define ATRANS_PLANES_DIRECT 1
-#endif
-template <int NCB, int TERMS>
-__device__ __forceinline__ void run_segment_direct(const AtArgs& a, const int4 sg, const int4 sk, char* __restrict__ lds) {
-  constexpr int NBW = (2 * NCB + 7) / 8;                       // mapping DMAs per wave, stage and plane of the mapping
-  constexpr int NB = NBW * (TERMS == 3 ? 2 : 1);               // ... per wave and stage
-  constexpr int NX = TERMS >= 2 ? 4 : 2;                       // fragment loads of x per wave and chunk
-  constexpr int BT = NCB * 32 * BK * 2, STG = BT * (TERMS == 3 ? 2 : 1), NST = 3;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int l = sg.x, row0 = sg.y, cb0 = sg.z, ncb = sg.w;
-  const int K = a.L[l], Lp = a.Lp[l];
-  const int kc0 = sk.x, nk = sk.y - sk.x;
-  const int frow = lane & 31, fh = lane >> 5;
-
-  f32x16 acc[NCB];
-#pragma unroll
-  for (int i = 0; i < NCB; ++i)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-
-  // this lane's row of both planes (rows past the end repeat the last row: computed, never stored)
-  const long long gr = min((long long)row0 + 32 * wave + frow, a.rows - 1);
-  const __bf16* __restrict__ xhp = a.xh + gr * a.ld_x16 + a.off[l];
-  const __bf16* __restrict__ xlp = a.xl + gr * a.ld_x16 + a.off[l];
-  // fragments of chunk kc: k-step ks, lane half fh <- elements 32 kc + 16 ks + 8 fh .. + 7 (past the end of the layer: the
-  // layer's last eight -- they meet zero rows of the mapping)
-  auto xload = [&](int kc_, u32x4 (&f)[4]) {                       // f[0 .. 1]: hi of k-steps 0, 1;  f[2 .. 3]: lo
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int k = min((kc0 + kc_) * BK + 16 * ks + 8 * fh, K - 8);
-      f[ks] = gload16(xhp + k);
-      if (TERMS >= 2) f[2 + ks] = gload16(xlp + k);
-      else f[2 + ks] = f[ks];
-    }
-  };
-  // mapping: as in run_segment
-  const __bf16* bsrc[NBW];
-  const __bf16* bsrc2[NBW];
-  int bdst[NBW];
-#pragma unroll
-  for (int j = 0; j < NBW; ++j) {
-    const int d = min(wave + 8 * j, 2 * NCB - 1);
-    const int row = 16 * d + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
-    const int grow = min(cb0 * 32 + row, Lp - 1);
-    bsrc[j] = a.bh[l] + (long long)grow * Lp + 8 * c;
-    bsrc2[j] = a.bl[l] + (long long)grow * Lp + 8 * c;
-    bdst[j] = __builtin_amdgcn_readfirstlane(d * 1024);
-  }
-  auto issue_b_one = [&](int kc_, int i) {
-    char* __restrict__ st = lds + (kc_ % NST) * STG;
-    const int kc = kc0 + kc_;
-    if (TERMS == 3) {
-      if (i & 1) dma16(bsrc2[i >> 1] + kc * BK, st + BT + bdst[i >> 1]);
-      else dma16(bsrc[i >> 1] + kc * BK, st + bdst[i >> 1]);
-    } else {
-      dma16(bsrc[i] + kc * BK, st + bdst[i]);
-    }
-  };
-  auto issue_b = [&](int kc_) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) issue_b_one(kc_, i);
-  };
-
-  bf16x8 xh[2], xlo[2];
-  u32x4 nf[4];
-  auto adopt = [&]() {                                             // the landed fragment set becomes the operands
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      xh[ks] = __builtin_bit_cast(bf16x8, nf[ks]);
-      if (TERMS >= 2) xlo[ks] = __builtin_bit_cast(bf16x8, nf[2 + ks]);
-    }
-  };
-  // vm queue, oldest first: B(0), X(0), B(1) | iteration kc adds X(kc + 1), then B(kc + 2).  At the top of iteration kc the
-  // mapping stage B(kc) and the fragments X(kc) have landed (waited for at the end of the iteration before; before the loop
-  // for chunk 0) and at most B(kc + 1) is still in flight.
-  issue_b(0);
-  xload(0, nf);
-  if (nk > 1) {
-    issue_b(1);
-    wait_vm_frags<NB>(nf[0], nf[1], nf[2], nf[3]);
-  } else {
-    wait_vm_frags<0>(nf[0], nf[1], nf[2], nf[3]);
-  }
-  adopt();
-  auto iter = [&](int kc, auto more2_c, auto more_c) {
-    constexpr bool MORE2 = decltype(more2_c)::value, MORE = decltype(more_c)::value;
-    if (MORE) xload(kc + 1, nf);                                   // one chunk ahead, into the spare fragment set
-    __builtin_amdgcn_s_barrier();                                  // every wave's pieces of stage kc are in LDS; stage kc - 1 is free
-    __builtin_amdgcn_sched_barrier(0);
-    const char* __restrict__ cur = lds + (kc % NST) * STG;
-    bf16x8 b0 = *reinterpret_cast<const bf16x8*>(cur + bswz(frow, fh));
-    bf16x8 b1 = *reinterpret_cast<const bf16x8*>(cur + bswz(frow, 2 + fh));
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      const bf16x8 c0 = b0, c1 = b1;
-      if (cb + 1 < NCB) {
-        b0 = *reinterpret_cast<const bf16x8*>(cur + bswz((cb + 1) * 32 + frow, fh));
-        b1 = *reinterpret_cast<const bf16x8*>(cur + bswz((cb + 1) * 32 + frow, 2 + fh));
-      }
-      acc[cb] = mma(xh[0], c0, acc[cb]);
-      if (TERMS >= 2) acc[cb] = mma(xlo[0], c0, acc[cb]);
-      acc[cb] = mma(xh[1], c1, acc[cb]);
-      if (TERMS >= 2) acc[cb] = mma(xlo[1], c1, acc[cb]);
-      if (TERMS == 3) {
-        const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(cur + BT + bswz(cb * 32 + frow, fh));
-        const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(cur + BT + bswz(cb * 32 + frow, 2 + fh));
-        acc[cb] = mma(xh[0], d0, acc[cb]);
-        acc[cb] = mma(xh[1], d1, acc[cb]);
-      }
-      if (MORE2) {                                                 // the mapping pieces of chunk kc + 2, spread over the blocks
-#pragma unroll
-        for (int i = cb * NB / NCB; i < (cb + 1) * NB / NCB; ++i) issue_b_one(kc + 2, i);
-      }
-#if ATRANS_SPREAD_PIN
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    if (MORE) {
-      // X(kc + 1) and (older) B(kc + 1) have landed once only this iteration's B(kc + 2) pieces remain
-      if (MORE2) wait_vm_frags<NB>(nf[0], nf[1], nf[2], nf[3]);
-      else wait_vm_frags<0>(nf[0], nf[1], nf[2], nf[3]);
-      adopt();
-    }
-  };
-  auto yes = std::integral_constant<bool, true>{};
-  auto no = std::integral_constant<bool, false>{};
-  int kc = 0;
-  for (; kc + 2 < nk; ++kc) iter(kc, yes, yes);
-  if (kc + 1 < nk) {
-    iter(kc, no, yes);
-    ++kc;
-  }
-  iter(kc, no, no);
-  __builtin_amdgcn_s_barrier();                                    // (the next segment's first DMAs overwrite stages still being read)
-
-  const bool direct = sk.z < 0;
-  float* __restrict__ ob = (direct ? a.out : a.ws + (long long)sk.z * a.rows * a.ld_ws) + a.off[l];
-  const long long ldo = direct ? a.ld_out : a.ld_ws;
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) {
-    if (cb < ncb) {
-      const int col = (cb0 + cb) * 32 + frow;
-      if (col < K) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const long long row = (long long)row0 + 32 * wave + rho(q, fh);
-          if (row < a.rows) {
-            if (a.nt_out) __builtin_nontemporal_store(acc[cb][q], ob + row * ldo + col);
-            else ob[row * ldo + col] = acc[cb][q];
-          }
-        }
-      }
-    }
-  }
-}
-
 template <int TERMS, bool RAGGED, bool PLANES>
 __device__ __forceinline__ void dispatch_upto4(const AtArgs& a, const int4 sg, const int4 sk, char* lds) {
-  if constexpr (PLANES && !RAGGED && ATRANS_PLANES_DIRECT) {
-    switch (sg.w) {
-      case 1: run_segment_direct<1, TERMS>(a, sg, sk, lds); break;
-      case 2: run_segment_direct<2, TERMS>(a, sg, sk, lds); break;
-      case 3: run_segment_direct<3, TERMS>(a, sg, sk, lds); break;
-      default: run_segment_direct<4, TERMS>(a, sg, sk, lds); break;
-    }
-    return;
-  }
   switch (sg.w) {
     case 1: run_segment<1, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
     case 2: run_segment<2, TERMS, RAGGED, PLANES>(a, sg, sk, lds); break;
@@ -623,18 +433,6 @@ __device__ __forceinline__ void dispatch_segment(const AtArgs& a, const int4 sg,
       dispatch_upto4<TERMS, RAGGED, PLANES>(a, make_int4(sg.x, sg.y, sg.z + n1, sg.w - n1), sk, lds);
     } else {
       dispatch_upto4<TERMS, RAGGED, PLANES>(a, sg, sk, lds);
-    }
-    return;
-  }
-  if constexpr (PLANES && !RAGGED && ATRANS_PLANES_DIRECT) {
-    switch (sg.w) {
-      case 1: run_segment_direct<1, TERMS>(a, sg, sk, lds); break;
-      case 2: run_segment_direct<2, TERMS>(a, sg, sk, lds); break;
-      case 3: run_segment_direct<3, TERMS>(a, sg, sk, lds); break;
-      case 4: run_segment_direct<4, TERMS>(a, sg, sk, lds); break;
-      case 5: run_segment_direct<5, TERMS>(a, sg, sk, lds); break;
-      case 6: run_segment_direct<6, TERMS>(a, sg, sk, lds); break;
-      default: run_segment_direct<7, TERMS>(a, sg, sk, lds); break;
     }
     return;
   }

@@ -738,6 +738,19 @@ def col_moments(loc, log_scale):
     return moments_from_fx(col_moments_fx(loc, log_scale), loc.shape[0])
 
 
+def clock_stamp(device="cuda"):
+    """int64 tensor [2] = (s_memtime: shader-clock ticks, s_memrealtime: 100 MHz ticks) at this point of the stream"""
+    out = torch.zeros(2, device=device, dtype=torch.int64)
+    check(_lib.load().rcb_clock_stamp(ptr(out), stream_ptr()), "rcb_clock_stamp")
+    return out
+
+
+def sustained_clock_ghz(stamp0, stamp1):
+    """shader clock between two clock_stamp()s (call after a synchronisation)"""
+    d = (stamp1 - stamp0).cpu().double()
+    return float(d[0] / (d[1] / 1e8) / 1e9) if float(d[1]) > 0 else float("nan")
+
+
 def softplus_scale(log_scale):
     lib = _lib.load()
     out = torch.empty_like(log_scale)

@@ -123,10 +123,13 @@ class PriorBNNmodel(nn.Module):
         # with fused_noise: the posterior update of step t also draws the sample of step t + 1 (rcb_level_bwd.next_*), so
         # the sampling kernels -- a second read of every loc / log_scale -- run once per train() call instead of once per step
         self.fuse_next_sample = os.environ.get("RCB_FUSE_NEXT", "1") != "0"      # (the switch is for same-box A/B runs)
-        # with split_gemm + fused_noise: the A transform's per-INR operands (h_w, and the SIREN gradient dwvec) travel as the
+        # with split_gemm + fused_noise: the A transform's per-INR operands (h_w, and the SIREN gradient dwvec) may travel as the
         # (hi, lo) bf16 planes their producers write (ops.Planes) instead of fp32 rows + a bf16 copy: identical bits, no
-        # conversion work in the A-transform kernels, 4 instead of 6 bytes per element written
-        self.operand_planes = os.environ.get("RCB_PLANES", "1") != "0"
+        # conversion work in the A-transform kernels, 4 instead of 6 bytes per element written.  OFF by default: measured on
+        # MI355X (round 4, same-box A/B) the plane kernels are no faster (forward 84.9 vs 80.6 us: the kernel is bound by the
+        # operand stream into LDS and the lockstep of its eight waves, not by the conversion) and the producers' 2-byte plane
+        # stores cost more than the bytes they save: 1.120 vs 1.095 ms per step.  Kept as a tested option (RCB_PLANES=1).
+        self.operand_planes = os.environ.get("RCB_PLANES", "0") != "0"
         # with fuse_next_sample: the posterior update re-draws its step's noise from the counter instead of reading the copy
         # the sampler stored (rcb_level_bwd.eps_from_rng: same bits, 8 bytes per element less traffic)
         self.redraw_noise = os.environ.get("RCB_REDRAW_EPS", "1") != "0"

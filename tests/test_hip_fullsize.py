@@ -174,7 +174,7 @@ def test_whole_step_at_configs1_size_is_reproducible_and_batch_invariant():
     rows = slice(1000, 1008)
     m8, (mse8, kl8, e8) = run(rows)
     for k in ("loc", "log_scale", "lpe_loc", "lpe_log_scale"):
-        assert_close_mostly(getattr(m8, k), getattr(m1, k)[rows].cpu().numpy(), rtol=0, atol=2e-6, max_frac=1e-3,
+        assert_close_mostly(getattr(m8, k), getattr(m1, k)[rows].detach().cpu().numpy(), rtol=0, atol=2e-6, max_frac=1e-3,
                             hard_atol=2.5 * lr * steps, what=k)
     assert torch.isfinite(m1.loc).all() and abs(mse8 - mse1) < 0.2 * mse1        # (eight INRs against the mean over 4096)
 

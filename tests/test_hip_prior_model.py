@@ -563,3 +563,42 @@ def test_two_hidden_layers_of_width_32_at_model_level(prec):
     np.testing.assert_allclose(elbo, elbo_o, rtol=2e-4 if prec == 0 else 1e-3)
     assert_close_mostly(m.loc, p["loc"].numpy(), rtol=1e-4, atol=3e-5 if prec == 0 else 1e-4, what="loc")
     np.testing.assert_allclose(kl, kl_o, rtol=1e-4 if prec == 0 else 2e-3)
+
+
+def test_redrawn_noise_and_operand_planes_train_like_the_stored_forms():
+    """Two round-4 switches of the bf16 training step against the forms they replace, eager and replayed, mappings trained:
+    `redraw_noise` (the posterior update re-draws its step's noise from the counter, rcb_level_bwd.eps_from_rng, instead of
+    reading the copy the sampler stored) is BITWISE the same training; `operand_planes` (h_w and the SIREN gradient as (hi, lo)
+    bf16 planes) gives bitwise the same forward / data-gradient products and the same wide-layer weight gradients -- only the
+    99-wide output layer's weight gradient reads float(hi) + float(lo) instead of the fp32 value (2^-17 relative), so the run
+    agrees to fp32 rounding, not bit for bit."""
+    from recombiner_amd import config, utils
+    cfg = config.configs["cifar"]
+    n = 8
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 3, seed=2)
+    Xd, Yd = X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV)
+    outs = {}
+    for tag, redraw, planes in (("base", False, False), ("redraw", True, False), ("planes", True, True)):
+        torch.manual_seed(77)
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], False, None, None, random_seed=42, device=DEV)
+        m.precision, m.redraw_noise, m.operand_planes = 1, redraw, planes
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(m.dims).to(DEV)
+        torch.manual_seed(124)
+        up = PM.Upsample(2, cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+        D, s0 = m._d_net, 0.0211547
+        pri = [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV), torch.zeros(2, 2, 128, device=DEV),
+               torch.full((2, 2, 128), s0, device=DEV)] + [None] * 4
+        elbos = []
+        for n_steps in (2, 7):
+            elbos += m.train(n_steps, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)[2]
+        outs[tag] = [torch.tensor(elbos), m.loc.detach().clone(), m.lpe_loc.detach().clone(), m.log_scale.detach().clone()] + \
+                    [p.detach().clone() for p in lt.parameters()]
+    for a, b in zip(outs["base"], outs["redraw"]):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(outs["planes"][0].numpy(), outs["base"][0].numpy(), rtol=1e-6)
+    for a, b in zip(outs["base"][1:4], outs["planes"][1:4]):
+        assert_close_mostly(b, a.cpu().numpy(), rtol=0, atol=1e-6, max_frac=1e-3, hard_atol=2.5 * 2e-4 * 9)
+    for a, b in zip(outs["base"][4:], outs["planes"][4:]):
+        assert_close_mostly(b, a.cpu().numpy(), rtol=0, atol=1e-6, max_frac=1e-3, hard_atol=2.5 * 2e-4 * 9)
