@@ -392,6 +392,8 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   RCB_REQUIRE(d->n_rows > 0 && d->samples > 0 && d->n_pix > 0 && d->n_rows % d->samples == 0, RCB_ERR_SHAPE,
               "siren: rows=%d samples=%d pix=%d", d->n_rows, d->samples, d->n_pix);
   RCB_REQUIRE(d->precision >= 0 && d->precision <= 2, RCB_ERR_UNSUPPORTED, "siren: precision %d not built", d->precision);
+  RCB_REQUIRE((long long)d->n_pix * d->out_dim < (1ll << 31), RCB_ERR_SHAPE, "siren: n_pix x out_dim = %lld elements per row of targets (32-bit offsets inside a row)",
+              (long long)d->n_pix * d->out_dim);
   RCB_REQUIRE(d->pe_bf16 == 0 || (d->pe_bf16 == 1 && d->precision >= 1 && d->pe_dim % 8 == 0), RCB_ERR_UNSUPPORTED,
               "siren: bf16 pe storage needs a 16-bit precision mode and pe_dim %% 8 == 0 (precision=%d, E=%d)", d->precision,
               d->pe_dim);

@@ -316,13 +316,16 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     // targets / upstream gradient of this tile, issued early
     float yv[16];
     if (MODE != MODE_FWD) {
-      const long long ybase = ((MODE == MODE_LOSS ? (long long)n : (long long)g) * P + pc) * C;
+      // wave-uniform row base (scalar registers) + a 32-bit per-lane offset: the loads take the saddr + voffset form instead
+      // of a 64-bit address computed per lane and tile (P * C < 2^31 elements per row is checked by the launcher)
+      const float* __restrict__ yrow = a.yin + (MODE == MODE_LOSS ? (long long)n : (long long)g) * P * C;
+      const int yoff = pc * C;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         yv[r] = 0.f;
         if (rho(r, 0) < C || rho(r, 1) < C) {
           const int row = rho(r, h);
-          yv[r] = a.yin[ybase + (row < C ? row : 0)];
+          yv[r] = yrow[yoff + (row < C ? row : 0)];
         }
       }
     }
@@ -367,16 +370,20 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       }
     }
     {
+      // output layer: the accumulator starts from the inline constant 0 and the bias is added to the C rows that exist
+      // afterwards (a bias-initialised accumulator is a 16-register tuple of which 13 are zeros that have to be materialised
+      // and moved into place every tile: ~20 instructions for three useful values)
       const float* Bl = wl + G::off(NL - 1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = (rho(r, 0) < C || rho(r, 1) < C) ? ((rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] * WS : 0.f) : 0.f;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) acc = Op16<T>::mfma(FA(K0S + 2 * (NH - 1) + s), S[NH - 1][s], acc);
-      if (WS != 1.0f) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (rho(r, 0) < C || rho(r, 1) < C) acc[r] *= (1.0f / WS);
-      }
+      for (int r = 0; r < 16; ++r)
+        if (rho(r, 0) < C || rho(r, 1) < C) {
+          const float b = (rho(r, h) < C) ? Bl[rho(r, h) < C ? rho(r, h) : 0] : 0.f;
+          acc[r] = (WS != 1.0f) ? (acc[r] * (1.0f / WS) + b) : (acc[r] + b);
+        }
     }
     if (MODE == MODE_FWD) {
       if (valid) {
@@ -416,7 +423,22 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 #ifdef RCB_SIREN_STAMPS
       if (t == t0 + wave) RCB_STAMP(9 + (NL - 1 - l));
 #endif
-      bf16x8 dzb[2] = {pack8<T>(dz, 0), pack8<T>(dz, 1)};
+      // the output layer's dz has C of its 32 rows set (registers r with rho(r, .) < C); packed straight from those, the other
+      // entries as literal zeros: the generic pack8 of the tile made the compiler materialise the 13 zero registers of a
+      // C = 3 tile and move them into place every tile (20 moves + 6 conversions of zeros per tile)
+      bf16x8 dzb[2];
+      if (l == NL - 1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * s + j;
+            dzb[s][j] = (rho(r, 0) < C || rho(r, 1) < C) ? (T)dz[r] : (T)0.0f;
+          }
+      } else {
+        dzb[0] = pack8<T>(dz, 0);
+        dzb[1] = pack8<T>(dz, 1);
+      }
       // (1) data gradient FIRST: dz -> dh -> dz of the next layer is the serial chain of the backward pass; the weight
       // gradient below (LDS transpose + MFMAs nothing waits for) then fills the latency of these MFMAs instead of delaying them
       if (l > 0) {

