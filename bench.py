@@ -303,20 +303,23 @@ def rd_trained(dev, precision, runs_per_rate=3):
 
 def presets_table(dev):
     """BASELINE configs[2..4] (and the reference presets they vary) plus the test-time path on this box, untimed by the
-    driver's step clock but inside its run: prior-training step of each preset in its 16-bit mode (production path: device
-    noise, graph replay; 50 replayed steps between events) with its dominant kernel from a 10-step profile, the
-    TestBNNmodel.train step (N = 500 images, S = 5) and one A* encode round."""
+    driver's step clock but inside its run.
+    prior_training: the training step of each preset in its 16-bit mode (production path: device noise, graph replay) at the
+      SMALL size the reference's drivers touch per call (2 photos / 8 clips / 4 clips) and at a GPU-FILLING shard (24 Kodak
+      photos, 1024 audio clips = the per-GPU shard of configs[3], 32 video clips), each with its dominant kernel from a
+      profile of a few steps and, where that kernel is the SIREN one, its recomputed roofline fractions.
+    test_time: TestBNNmodel.train (S = 5) and one A* encode round of the first level -- what main_compression.py:87-162
+      runs -- for the CIFAR batch of 500, for ONE Kodak photo / audio clip / video clip (the reference's unit of work, built
+      from a briefly trained prior through drivers.build_checkpoint / build_test_model) and for a batch of 8 of each."""
     import contextlib
     import io
     import warnings
     import numpy as np
     from torch.profiler import ProfilerActivity, profile
-    from recombiner_amd import config, utils
+    from recombiner_amd import config, drivers, utils
     from recombiner_amd import prior_model as PM
-    runs = [("kodak-w48 (configs[2])", "kodak", 2, 48, 1), ("audio (configs[3], one rank's presets step on 8 clips)", "audio", 8, 32, 1),
-            ("video-w64-f16 (configs[4])", "video", 4, 64, 2), ("kodak", "kodak", 2, 32, 1), ("video", "video", 4, 32, 1)]
-    out = []
-    for label, name, n_data, width, prec in runs:
+
+    def prior_setup(name, n_data, width, prec):
         cfg = dict(config.configs[name])
         cfg["hidden_dims"] = [width] * len(cfg["hidden_dims"])
         per = int(np.prod(cfg["patch_nums"])) if cfg["patch"] else 1
@@ -333,67 +336,108 @@ def presets_table(dev):
         lat = list(m.lpe_loc.shape[1:])
         pri = [torch.zeros(D, device=dev), torch.full((D,), s0, device=dev), torch.zeros(lat, device=dev), torch.full(lat, s0, device=dev)]
         pri += ([torch.zeros(D, device=dev), torch.full((D,), s0, device=dev)] * 2) if cfg["patch"] else [None] * 4
-        Xd, Yd = X.to(dev)[None].expand(n, -1, -1), Y.to(dev)
+        return cfg, n, m, lt, up, pri, X.to(dev), Y.to(dev)
+
+    runs = [("kodak-w48 (configs[2]), 2 photos", "kodak", 2, 48, 1, 50), ("kodak-w48 (configs[2]), 24 photos", "kodak", 24, 48, 1, 20),
+            ("audio (configs[3]), 8 clips", "audio", 8, 32, 1, 50),
+            ("audio (configs[3]), 1024 clips = one rank's shard of the 8192", "audio", 1024, 32, 1, 8),
+            ("video-w64-f16 (configs[4]), 4 clips", "video", 4, 64, 2, 50), ("video-w64-f16 (configs[4]), 32 clips", "video", 32, 64, 2, 10),
+            ("kodak, 2 photos", "kodak", 2, 32, 1, 50), ("video, 4 clips", "video", 4, 32, 1, 50)]
+    out = []
+    for label, name, n_data, width, prec, steps in runs:
+        cfg, n, m, lt, up, pri, X, Yd = prior_setup(name, n_data, width, prec)
+        Xd = X[None].expand(n, -1, -1)
 
         def run(k):
             return m.train(k, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            run(8)
+            run(6)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
-            _, _, elbo = run(50)
+            _, _, elbo = run(steps)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 50
+            ms = e0.elapsed_time(e1) / steps
+            nprof = max(2, min(10, steps // 2))
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                run(10)
+                run(nprof)
                 torch.cuda.synchronize()
-        rows = sorted(((float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)) / 10, e.key)
+        rows = sorted(((float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)) / nprof, e.key)
                        for e in prof.key_averages()), reverse=True)
         total = sum(r[0] for r in rows) or 1.0
         top_us, top = rows[0]
-        px, C, E = int(np.prod(cfg["pixel_sizes"])), cfg["output_dim"], 16
-        rec = {"preset": label, "inrs": n, "pixels_per_inr": px, "hidden": width, "operands": "bf16" if prec == 1 else "f16",
-               "ms_per_step": round(ms, 4), "inr_steps_per_sec": round(n / (ms * 1e-3)), "graph_replay": m._ws is not None and m._ws["graphs"] is not None,
-               "finite": bool(np.isfinite(elbo).all()), "dominant_kernel": top[:80], "dominant_kernel_us": round(top_us, 1),
-               "dominant_kernel_share": round(top_us / total, 3)}
-        if "siren" in top:
-            b = (2 * px * E * 2 + px * C * 4 + 2 * D * 4 + 4) * n       # pe + dpe (bf16), target, wvec + dwvec, sse
+        px, C, E, D = int(np.prod(cfg["pixel_sizes"])), cfg["output_dim"], 16, m._d_net
+        rec = {"preset": label, "datapoints": n_data, "inrs": n, "pixels_per_inr": px, "hidden": width,
+               "operands": "bf16" if prec == 1 else "f16", "ms_per_step": round(ms, 4), "inr_steps_per_sec": round(n / (ms * 1e-3)),
+               "pixel_steps_per_sec": round(n * px / (ms * 1e-3)), "graph_replay": m._ws is not None and m._ws["graphs"] is not None,
+               "finite": bool(np.isfinite(elbo).all()), "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+               "dominant_kernel": top[:80], "dominant_kernel_us": round(top_us, 1), "dominant_kernel_share": round(top_us / total, 3)}
+        siren = [r for r in rows if "siren" in r[1]]
+        if siren:      # the SIREN kernel of this preset (dominant or not): recomputed fractions of the two chip rooflines
+            s_us = sum(r[0] for r in siren)
+            bts = (2 * px * E * 2 + px * C * 4 + 2 * D * 4 + 4) * n       # pe + dpe (bf16), target, wvec + dwvec, sse
             dims = m.dims
             fl = 6.0 * px * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n
-            rec.update(dominant_alg_bytes=b, dominant_hbm_frac=round(b / (top_us * 1e-6) / 8e12, 4), dominant_alg_flops=fl,
-                       dominant_mfma_frac=round(fl / (top_us * 1e-6) / 2.5e15, 4))
+            rec.update(siren_us=round(s_us, 1), siren_share=round(s_us / total, 3), siren_alg_bytes=bts,
+                       siren_hbm_frac=round(bts / (s_us * 1e-6) / 8e12, 4), siren_alg_flops=fl,
+                       siren_mfma_frac=round(fl / (s_us * 1e-6) / 2.5e15, 4))
         out.append(rec)
-        del m, lt, up, Xd, Yd, X, Y, pri
+        del m, lt, up, Xd, Yd, X, pri
         torch.cuda.empty_cache()
-    # test-time path (main_compression.py: 500 CIFAR images per batch, S = 5)
+        torch.cuda.reset_peak_memory_stats()
+
+    # ---- test-time path ------------------------------------------------------------------------------------------------
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_rec as BR
+
+    def time_test_model(tm, Xd, Yd, what, steps=60):
+        tm.precision = 1
+        tm.train(Xd, Yd, 24, torch.optim.Adam(tm.parameters(), lr=2e-4), False, sample_size=5)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        tm.train(Xd, Yd, steps, torch.optim.Adam(tm.parameters(), lr=2e-4), False, sample_size=5)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_tt = e0.elapsed_time(e1) / steps
+        lv = tm._levels[-1]                       # the level the reference encodes first (level 3 when patched, else level 1)
+        for glen in np.unique((lv.end - lv.start)):
+            tm._table(lv, int(glen), 65536)
+        tm._encode_round(lv, True, 0)
+        ms_round = BR.timed(lambda: tm._encode_round(lv, True, 1), 6)
+        n = Yd.shape[0]
+        return {"what": what, "inrs": n, "samples": 5, "ms_per_step": round(ms_tt, 4), "inr_sample_steps_per_sec": round(5 * n / (ms_tt * 1e-3)),
+                "encode_round_ms": round(ms_round, 4), "encode_round_rows": int(lv.loc.shape[0]), "encode_round_groups_in_level": int(lv.n_groups)}
+
+    tt = []
     with contextlib.redirect_stdout(io.StringIO()):
         tm = BR.build(500, 4.0, dev)
-    tm.precision = 1
-    cfg = config.configs["cifar"]
-    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], 500, 3, seed=0)
-    Xd, Yd = X.to(dev)[None].expand(500, -1, -1), Y.to(dev)
-    tm.train(Xd, Yd, 24, torch.optim.Adam(tm.parameters(), lr=2e-4), False, sample_size=5)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    tm.train(Xd, Yd, 100, torch.optim.Adam(tm.parameters(), lr=2e-4), False, sample_size=5)
-    e1.record()
-    torch.cuda.synchronize()
-    ms_tt = e0.elapsed_time(e1) / 100
-    lv = tm._l1
-    for glen in np.unique((lv.end - lv.start)):
-        tm._table(lv, int(glen), 65536)
-    tm._encode_round(lv, True, 0)
-    ms_round = BR.timed(lambda: tm._encode_round(lv, True, 1), 10)
-    return {"prior_training": out,
-            "test_time": {"what": "TestBNNmodel.train, 500 CIFAR INRs, S = 5, bf16 mode, graph replay", "ms_per_step": round(ms_tt, 4),
-                          "inr_sample_steps_per_sec": round(2500 / (ms_tt * 1e-3)),
-                          "encode_round_ms": round(ms_round, 4), "encode_round_what": "500 rows, K = 65536: group choice, A* scoring, commit"}}
+    cfgc = config.configs["cifar"]
+    X, Y = utils.synthetic_inputs(cfgc["pixel_sizes"], cfgc["fourier_dim"], 500, 3, seed=0)
+    tt.append(time_test_model(tm, X.to(dev)[None].expand(500, -1, -1), Y.to(dev),
+                              "TestBNNmodel.train + encode round, CIFAR batch of 500 (data/load_data.py:92-94), bf16 mode, graph replay", 100))
+    del tm
+    for name, width, prec in (("kodak", 48, 1), ("audio", 32, 1), ("video", 64, 1)):
+        # a prior to compress from: a few training steps on two datapoints, then the checkpoint objects of main_prior_training.py
+        cfg, n, m, lt, up, pri, X, Yd = prior_setup(name, 2, width, 1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.train(12, 1e-3, X[None].expand(n, -1, -1), Yd, *pri, lt, up, 1e-6, training_mappings=True)
+        ck = drivers.build_checkpoint(m, lt, up, *pri, 1e-6)
+        per = int(np.prod(cfg["patch_nums"]))
+        del m
+        for n_data in (1, 8):
+            Xn, Yn = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n_data * per, cfg["output_dim"], seed=3)
+            with contextlib.redirect_stdout(io.StringIO()):
+                tm = drivers.build_test_model(cfg, name, ck, n_data * per, dev, 42)
+            tt.append(time_test_model(tm, Xn.to(dev)[None].expand(n_data * per, -1, -1), Yn.to(dev),
+                                      f"{name} (width {width}): {n_data} datapoint(s) = {n_data * per} INRs "
+                                      f"(main_compression.py:87-162 runs one per process), bf16 mode", 40))
+            del tm
+            torch.cuda.empty_cache()
+    return {"prior_training": out, "test_time": tt}
 
 
 def comm_report(m, lt, up, dev):
@@ -566,13 +610,10 @@ def main():
     if a.warmup > 0:
         run(a.warmup)
     fence()
-    ck0 = ops.clock_stamp(dev)           # (hardware counters read in stream order: one tiny launch on either side of the region)
     t0 = time.perf_counter()
     run(a.steps)
-    ck1 = ops.clock_stamp(dev)
     fence()
     el = time.perf_counter() - t0
-    step_clock_ghz = ops.sustained_clock_ghz(ck0, ck1)
     if ws > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -600,26 +641,30 @@ def main():
         want16 = bool(m.precision != 0 and m.split_gemm and not m.lowp_gemm and m.wgrad_bf16)
         xf16 = ops.xf_bf16(Xd) if m.precision == 1 else None
 
+        probe = torch.zeros(256, 4, device=dev, dtype=torch.int64)     # per-workgroup clock stamps of the LAST launch
+
         def launch():
-            return ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta, want_bf16=want16, xf16=xf16)
+            return ops.siren_loss_bwd(Xd, pe, wv, Yd, 1.0 / 3072, meta, want_bf16=want16, xf16=xf16,
+                                      clock_probe=probe if m.precision == 1 else None)
         for _ in range(2):
             launch()
-    cks = []
+    clocks = []
     for e0, e1 in evs:
         run(2)
         if rank == 0:
             # an untimed launch first: the stream is busy while the host submits e0 / kernel / e1, so the interval holds
             # the kernel and not the host's launch latency
             launch()
-            c0 = ops.clock_stamp(dev)
             e0.record()
             launch()
             e1.record()
-            cks.append((c0, ops.clock_stamp(dev)))
+            if m.precision == 1:
+                e1.synchronize()
+                clocks.append(ops.shader_clock_ghz(probe))
     if rank == 0:
         torch.cuda.synchronize()
         ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
-        siren_clock_ghz = sum(ops.sustained_clock_ghz(c0, c1) for c0, c1 in cks) / reps
+        siren_clock_ghz = (sum(clocks) / len(clocks)) if clocks else float("nan")
         dims = m.dims
         flops = 6.0 * 1024 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n   # fwd + 2x bwd
         # algorithmic HBM bytes per INR: pe read + dpe written (P*16 elements each, 2 B in bf16 storage, else 4 B),
@@ -654,8 +699,9 @@ def main():
             # What actually limits this kernel is neither of the two: it is vector-ISSUE bound (one sine and one cosine per
             # hidden unit and pixel, packed conversions, the address / loss arithmetic).  `valu` prices the tile loop's
             # instruction census (tools/siren_census.py, from the compiler's assembly of these very sources) at the SIMD's issue
-            # costs and at the shader clock MEASURED around the timed launches (rcb_clock_stamp: s_memtime against the 100 MHz
-            # s_memrealtime): floor = tiles per SIMD x issue cycles per tile / clock.  `bound` keeps the contract's vocabulary
+            # costs and at the shader clock MEASURED inside the timed launches (rcb_siren_desc.clock_probe: every one of the
+            # first 256 workgroups reads s_memtime and the 100 MHz s_memrealtime on its own CU at its start and end): floor =
+            # tiles per SIMD x issue cycles per tile / clock.  `bound` keeps the contract's vocabulary
             # (the higher of the HBM and MFMA fractions); `limiter` names the real one.
             valu = None
             try:
@@ -677,7 +723,11 @@ def main():
                     valu = {"note": "stale census: the SIREN kernel sources changed since tools/siren_census.py ran"}
             except (OSError, KeyError, ValueError):
                 valu = None
-            roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm", "limiter": "valu-issue",
+            busy = (valu or {}).get("frac_of_issue_floor")
+            limiter = ("vector issue" if (busy is not None and busy >= 0.8) else
+                       "dependency latency at two waves per SIMD (MFMA -> sin/cos -> conversion chains and LDS round trips); "
+                       "vector issue is the nearest roofline" if busy is not None else "unknown (no census)")
+            roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm", "limiter": limiter,
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" % PMC_FILE[pe16],
                     "traffic_note": traffic_note,
@@ -709,8 +759,7 @@ def main():
                "config": {"workload": f"CIFAR-10 32x32, {n} INRs/GPU, 3x32 SIREN (in 32 = 16 Fourier + 16 upsampled pe), "
                                       f"S=1, training_mappings={tm}, Adam lr 2e-4", "inrs_per_gpu": n,
                           "parallelism": f"datapoint-sharded x{ws}", "tuned_library_gemms": bool(tuned)},
-               "roofline": roof, "cpu_baseline": cpu,
-               "shader_clock_ghz_over_timed_steps": round(step_clock_ghz, 3)}
+               "roofline": roof, "cpu_baseline": cpu}
         # the WHOLE step against the two chip rooflines, with SURVEY section 8(d)'s algorithmic figures per INR-step (CIFAR
         # preset, S = 1): unavoidable HBM traffic 0.34 MB (posterior parameters + Adam moments read and written, noise, targets,
         # pe in and its gradient out), arithmetic 19.46 (MLP) + 20.13 (A transform) + 191.9 (upsampling net as the reference

@@ -46,10 +46,6 @@ const char* rcb_last_error_string(void);
 #define RCB_STRUCT_ADAM_TENSOR 4
 #define RCB_STRUCT_REC_DESC 5
 int64_t rcb_struct_bytes(int32_t which);
-/* Measurement aid (bench.py's roofline): dst[0] = s_memtime (ticks of the shader clock), dst[1] = s_memrealtime (100 MHz),
- * read by one lane of a one-wave kernel in stream order.  Two stamps around a launch give the shader clock that launch
- * sustained, (dst'[0] - dst[0]) / ((dst'[1] - dst[1]) / 1e8) -- what an issue-bound kernel's roofline is priced at.     */
-int rcb_clock_stamp(uint64_t* dst, rcb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3 + K4: batched SIREN coordinate-MLP, one workgroup per (INR, sample).
@@ -114,6 +110,12 @@ typedef struct {
                               * stride.  The pair is the plane operand of the A transform's data gradient (rcb_atrans_apply
                               * x_hi / x_lo): the same 4 bytes per element as the fp32 dwvec, which may then be NULL in
                               * rcb_siren_bwd / _loss_bwd (unchunked launches) and rcb_siren_reduce_chunks                */
+  uint64_t* clock_probe;     /* nullable measurement aid (width-32 16-bit kernel): workgroup b < 256 writes clock_probe[4 b ..
+                              * 4 b + 3] = {s_memtime, s_memrealtime at its start, s_memtime, s_memrealtime at its end}.  Both
+                              * counters are read on the workgroup's own CU (s_memtime is not comparable between CUs), so
+                              * (t2 - t0) / ((t3 - t1) / 1e8) is the SHADER CLOCK that workgroup ran at (s_memrealtime counts
+                              * 100 MHz): the figure an issue-bound kernel's roofline is priced at -- MI355X lowers its clock
+                              * under matrix / vector load, peak-clock rooflines overstate what such kernels can reach      */
 } rcb_siren_desc;
 
 /* y_out[G, P, C] = MLP(x)                                                           */

@@ -785,7 +785,12 @@ def gen_rd_trained(out):
     import time
     P, _ = presets()
     cfg = P["cifar"]
-    n_train, n_test = 64, 16
+    n_train, n_test = 64, int(os.environ.get("RD_N_TEST", "16"))
+    # round 4: RD_N_TEST=64 RD_N_SEEDS=4 RD_RATE=<0|1> python oracle/make_golden.py --only rd   writes
+    # rd_trained_cifar_n64_r<0|1>.npz: the same experiment with 64 held-out images (the per-run mean is then a mean over four
+    # times as many images), one rate per process so that the two rates run side by side
+    only_rate = os.environ.get("RD_RATE")
+    fname = "rd_trained_cifar.npz" if (n_test == 16 and only_rate is None) else "rd_trained_cifar_n%d_r%s.npz" % (n_test, only_rate or "all")
     n_iter, first_epochs, epochs, lr = 30, 200, 60, 1e-3
     n_opt, n_ft = 300, 4
     _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
@@ -800,12 +805,14 @@ def gen_rd_trained(out):
              "n_ft": np.array(n_ft), "Y_train_stats": stats(Ytr), "Y_test_stats": stats(Yte)})
     px = np.prod(cfg["pixel_sizes"])
     rates = [3.0, 1.5]
-    n_seeds = 4                   # independent repetitions per rate: a single run's PSNR scatters by ~0.5 dB (every A* index is a
+    n_seeds = int(os.environ.get("RD_N_SEEDS", "4"))   # independent repetitions per rate: a single run's PSNR scatters by ~0.5 dB (every A* index is a
     #                               random draw and the prior differs with the noise), the comparison is between means
     d["max_bitrate"] = np.array(rates)
     d["n_seeds"] = np.array(n_seeds)
     t0 = time.time()
     for ri, max_bitrate in enumerate(rates):
+        if only_rate is not None and ri != int(only_rate):
+            continue
         acc = {k: [] for k in ("traj", "em_seed", "psnr_train", "n_groups", "bpp", "psnr_after_opt", "psnr")}
         for si in range(n_seeds):
             pm = build_prior(cfg, n_train, seed=42 + si)
@@ -875,7 +882,7 @@ def gen_rd_trained(out):
                 max_bitrate, si, n_groups, tm.bpp, psnr_train.mean(), after_opt.mean(), np.mean(dist), time.time() - t0), flush=True)
             for k, v in acc.items():
                 d[f"r{ri}_{k}"] = np.array(v)
-            np.savez_compressed(os.path.join(out, "rd_trained_cifar.npz"), **d)
+            np.savez_compressed(os.path.join(out, fname), **d)
     print("rd ok (%.0f s)" % (time.time() - t0), flush=True)
 
 

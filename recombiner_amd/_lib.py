@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RCB_LIB: alternative build of the same ABI (same-box A/B timing of kernel changes); never a different backend
 LIB_PATH = os.environ.get("RCB_LIB") or os.path.join(_HERE, "lib", "librcb_hip.so")
 
-EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_struct_bytes", "rcb_clock_stamp", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
+EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_struct_bytes", "rcb_siren_fwd", "rcb_siren_bwd", "rcb_siren_loss_bwd",
            "rcb_reparam_fwd", "rcb_gauss_kl", "rcb_beta_update", "rcb_posterior_bwd", "rcb_adam_flat",
            "rcb_col_moments", "rcb_rec_score_argmax", "rcb_rec_commit", "rcb_rec_workspace_bytes", "rcb_softplus_scale", "rcb_gauss_kl_colsum", "rcb_upconv_fwd",
            "rcb_upconv_dgrad", "rcb_upconv_wgrad", "rcb_upconv_wgrad_workspace", "rcb_adam_multi", "rcb_step_begin",
@@ -33,7 +33,7 @@ class SirenDesc(C.Structure):
                 ("precision", C.c_int32), ("pe_bf16", C.c_int32), ("dw_bf16", C.c_void_p), ("pixel_chunks", C.c_int32),
                 ("xf_bf16", C.c_void_p), ("pe_grid_dims", C.c_int32), ("pe_patch_nums", C.c_int32 * 3),
                 ("pe_patch_size", C.c_int32 * 3), ("dw_bf16_stride", C.c_int64), ("hidden_dims", C.c_int32 * 4),
-                ("dw_lo", C.c_void_p)]
+                ("dw_lo", C.c_void_p), ("clock_probe", C.c_void_p)]
 
 
 class Level(C.Structure):

@@ -51,23 +51,6 @@ __device__ __forceinline__ void fx_add_kl(int64_t* slots, unsigned which, double
 
 extern "C" int rcb_version(void) { return RCB_VERSION; }
 extern "C" const char* rcb_last_error_string(void) { return last_error_buf(); }
-// two hardware counters read by one lane, in stream order: dst[0] = s_memtime (counts at the SHADER clock the chip is running
-// at), dst[1] = s_memrealtime (constant 100 MHz).  Two stamps around a kernel of interest give the clock it sustained:
-// d(memtime) / (d(memrealtime) / 1e8) -- the figure a VALU- or MFMA-issue roofline has to be priced at (MI355X lowers its
-// clock under matrix / vector load: peak-clock rooflines overstate what such kernels can reach).
-__global__ void clock_stamp_kernel(unsigned long long* __restrict__ dst) {
-  if (threadIdx.x == 0) {
-    dst[0] = __builtin_amdgcn_s_memtime();
-    dst[1] = __builtin_amdgcn_s_memrealtime();
-  }
-}
-extern "C" int rcb_clock_stamp(uint64_t* dst, rcb_stream_t stream) {
-  RCB_REQUIRE(dst, RCB_ERR_ARG, "clock_stamp: null pointer");
-  clock_stamp_kernel<<<1, 64, 0, (hipStream_t)stream>>>(reinterpret_cast<unsigned long long*>(dst));
-  RCB_LAUNCH_CHECK();
-  return RCB_OK;
-}
-
 extern "C" int64_t rcb_struct_bytes(int32_t which) {
   switch (which) {
     case RCB_STRUCT_SIREN_DESC: return (int64_t)sizeof(rcb_siren_desc);

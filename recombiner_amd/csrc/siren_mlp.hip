@@ -451,6 +451,7 @@ int fill_args(const rcb_siren_desc* d, SirenArgs& a) {
   a.dwlo = reinterpret_cast<__bf16*>(d->dw_lo);
   a.dw16_stride = d->dw_bf16_stride;
   a.xf16 = d->xf_bf16;
+  a.clock_probe = reinterpret_cast<unsigned long long*>(d->clock_probe);
   a.G = d->n_rows;
   a.S = d->samples;
   a.P = d->n_pix;

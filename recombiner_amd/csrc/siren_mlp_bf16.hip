@@ -109,6 +109,10 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   T* bufA = reinterpret_cast<T*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
   T* bufB = bufA + 32 * G::TSA;
 
+  if (a.clock_probe != nullptr && blockIdx.x < 256 && tid == 0) {      // measurement aid: rcb_siren_desc.clock_probe
+    a.clock_probe[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   RCB_STAMP(0);
   // ---- stage weights, build MFMA A-fragments, clear the zero padding of bufB ---------------------
   {
@@ -288,9 +292,30 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     }
     }
   };
+  float ynext[16];
+  auto fetch_targets = [&](int tile) {
+    if (MODE == MODE_FWD) return;
+    const int pp = tile * 32 + q;
+    const int pcl = pp < P ? pp : P - 1;
+    // wave-uniform row base (scalar registers) + a 32-bit per-lane offset: the loads take the saddr + voffset form instead
+    // of a 64-bit address computed per lane and tile (P * C < 2^31 elements per row is checked by the launcher)
+    const float* __restrict__ yrow = a.yin + (MODE == MODE_LOSS ? (long long)n : (long long)g) * P * C;
+    const int yoff = pcl * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ynext[r] = 0.f;
+      if (rho(r, 0) < C || rho(r, 1) < C) {
+        const int row = rho(r, h);
+        ynext[r] = yrow[yoff + (row < C ? row : 0)];
+      }
+    }
+  };
   // this workgroup's share of the 32-pixel tiles (all of them unless rcb_siren_desc.pixel_chunks > 1)
   const int t0 = (int)((long long)chunk * ntiles / a.chunks), t1 = (int)((long long)(chunk + 1) * ntiles / a.chunks);
-  if (t0 + wave < t1) fetch(t0 + wave);
+  if (t0 + wave < t1) {
+    fetch(t0 + wave);
+    fetch_targets(t0 + wave);
+  }
   for (int t = t0 + wave; t < t1; t += 4) {
 #ifdef RCB_SIREN_STAMPS
     if (t == t0 + wave) RCB_STAMP(14);
@@ -313,24 +338,15 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
         xin[s][4] = (T)v1.x; xin[s][5] = (T)v1.y; xin[s][6] = (T)v1.z; xin[s][7] = (T)v1.w;
       }
     }
-    // targets / upstream gradient of this tile, issued early
+    // targets / upstream gradient of this tile: requested ONE TILE AHEAD, with the inputs (they are read once per step from
+    // HBM; requested at the top of their own tile they arrive ~1 us later, i.e. after the forward pass has already reached the loss)
     float yv[16];
     if (MODE != MODE_FWD) {
-      // wave-uniform row base (scalar registers) + a 32-bit per-lane offset: the loads take the saddr + voffset form instead
-      // of a 64-bit address computed per lane and tile (P * C < 2^31 elements per row is checked by the launcher)
-      const float* __restrict__ yrow = a.yin + (MODE == MODE_LOSS ? (long long)n : (long long)g) * P * C;
-      const int yoff = pc * C;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        yv[r] = 0.f;
-        if (rho(r, 0) < C || rho(r, 1) < C) {
-          const int row = rho(r, h);
-          yv[r] = yrow[yoff + (row < C ? row : 0)];
-        }
-      }
+      for (int r = 0; r < 16; ++r) yv[r] = ynext[r];
     }
-    // next tile's rows are requested after the targets, so the wait at the loss does not cover them
     fetch(t + 4 < t1 ? t + 4 : t);
+    fetch_targets(t + 4 < t1 ? t + 4 : t);
     // ---- forward ----------------------------------------------------------------------------------
     // cosines: packed bf16 (8 registers per layer; unpacked again for dz = dh * cos) or, in the IN16 variant whose register
     // budget allows it, the fp32 values themselves (16 per layer, no pack / unpack: -72 VALU instructions per tile; the
@@ -603,6 +619,10 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
   }
   RCB_STAMP(6);
   RCB_STAMP(7);
+  if (a.clock_probe != nullptr && blockIdx.x < 256 && tid == 0) {
+    a.clock_probe[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <typename T, int NH, int F, int E, int C, int MODE, bool IN16>

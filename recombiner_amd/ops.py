@@ -228,7 +228,7 @@ def siren_wide_layers(meta: SirenMeta):
 
 
 def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_dpe=True, want_bf16=False,
-                   pixel_chunks=None, pe_layout=None, xf16=None, want_planes=False):
+                   pixel_chunks=None, pe_layout=None, xf16=None, want_planes=False, clock_probe=None):
     """-> (sse [G], dwvec [G, d_net] (row stride = wvec's), dpe [G,P,E] or None); with want_bf16 (16-bit modes) also a
     bf16 copy of dwvec, [G, d_net] with a row stride that is a multiple of 8 (rcb_siren_desc.dw_bf16: the operand of the
     A transform's batched weight-gradient GEMM, written by the kernel's epilogue).
@@ -267,6 +267,10 @@ def siren_loss_bwd(xf, pe, wvec, target, dy_scale: float, meta: SirenMeta, want_
         dw16 = torch.empty(G, (meta.d_net + 7) // 8 * 8, device=wvec.device, dtype=bf16)[:, :meta.d_net]
     chunks = pixel_chunks or siren_pixel_chunks(G, meta)
     d, G = _siren_desc(meta, wvec, xf, pe, None if chunks > 1 else dw16, chunks, pe_layout, xf16)
+    if clock_probe is not None:          # int64 [256, 4]: per-workgroup clock stamps (rcb_siren_desc.clock_probe; shader_clock_ghz)
+        if clock_probe.dtype != torch.int64 or clock_probe.numel() < 1024 or not clock_probe.is_contiguous():
+            raise RcbError("clock_probe: contiguous int64 [256, 4] expected")
+        d.clock_probe = clock_probe.data_ptr()
     _check_pe(pe, G, meta, pe_layout)
     N = G // meta.samples
     if tuple(target.shape) != (N, meta.n_pix, meta.out_dim):
@@ -738,17 +742,14 @@ def col_moments(loc, log_scale):
     return moments_from_fx(col_moments_fx(loc, log_scale), loc.shape[0])
 
 
-def clock_stamp(device="cuda"):
-    """int64 tensor [2] = (s_memtime: shader-clock ticks, s_memrealtime: 100 MHz ticks) at this point of the stream"""
-    out = torch.zeros(2, device=device, dtype=torch.int64)
-    check(_lib.load().rcb_clock_stamp(ptr(out), stream_ptr()), "rcb_clock_stamp")
-    return out
-
-
-def sustained_clock_ghz(stamp0, stamp1):
-    """shader clock between two clock_stamp()s (call after a synchronisation)"""
-    d = (stamp1 - stamp0).cpu().double()
-    return float(d[0] / (d[1] / 1e8) / 1e9) if float(d[1]) > 0 else float("nan")
+def shader_clock_ghz(probe):
+    """mean shader clock of the workgroups that filled a rcb_siren_desc.clock_probe buffer (int64 [256, 4]; call after a
+    synchronisation): (memtime end - start) / ((memrealtime end - start) / 100 MHz) per workgroup, averaged"""
+    p = probe.cpu().double()
+    p = p[(p[:, 3] > p[:, 1])]
+    if p.shape[0] == 0:
+        return float("nan")
+    return float(((p[:, 2] - p[:, 0]) / ((p[:, 3] - p[:, 1]) / 1e8)).mean() / 1e9)
 
 
 def softplus_scale(log_scale):

@@ -133,6 +133,8 @@ class PriorBNNmodel(nn.Module):
         # with fuse_next_sample: the posterior update re-draws its step's noise from the counter instead of reading the copy
         # the sampler stored (rcb_level_bwd.eps_from_rng: same bits, 8 bytes per element less traffic)
         self.redraw_noise = os.environ.get("RCB_REDRAW_EPS", "1") != "0"
+        # concurrent streams inside the step (bit mask, see train()); 0 = one stream
+        self.stream_forks = 0
         # in-kernel noise: first row of this model's INRs inside a larger (virtual) batch.  Row r of the model draws the noise of
         # row rng_row_offset + r of that batch (ops.rng_group_offset): a shard or a sub-batch trained on its own then sees
         # exactly the noise of the unsharded run, given the same seed (`rng_seed_override`, else derived per model and rank)
@@ -290,6 +292,7 @@ class PriorBNNmodel(nn.Module):
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
                self.operand_planes, self.redraw_noise, self.rng_row_offset, self.rng_seed_override,
+               os.environ.get("RCB_FORK", str(self.stream_forks)),
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
                # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
@@ -392,11 +395,19 @@ class PriorBNNmodel(nn.Module):
             ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe, group_offset=goff_lpe)
 
         pe_lay = self._pe_layout()
-        fork = None
-        if os.environ.get("RCB_FORK", "0") == "1" and dev.type == "cuda":
+        # stream forks inside the (captured) step -- bit mask, same kernels on the same operands, so results are identical:
+        #   1: the A transform's forward beside the upsampling net's forward;  2: the A transform's backward beside the
+        #   upsampling net's backward;  4: the weight-gradient side of the upsampling net's backward beside its data path
+        #   (upsample_fast.WEIGHT_SIDE_STREAM);  8: the network level's posterior update right behind the A transform's backward
+        #   on the forked stream (it only needs dh)
+        fork_mask = int(os.environ.get("RCB_FORK", str(self.stream_forks))) if dev.type == "cuda" else 0
+        fork = side = None
+        if fork_mask:
             if "fork_stream" not in ws:
-                ws["fork_stream"] = torch.cuda.Stream(device=dev)
-            fork = ws["fork_stream"]
+                ws["fork_stream"], ws["side_stream"] = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            fork, side = ws["fork_stream"], ws["side_stream"]
+        from . import upsample_fast as _uf
+        _uf.WEIGHT_SIDE_STREAM = side if (fork_mask & 4) else None
         if split is not None and not training_mappings:
             split.prepare(A)                          # fixed mappings: packed once per call, outside the captured step
 
@@ -466,8 +477,8 @@ class PriorBNNmodel(nn.Module):
                         torch.mm(h_w[:, lo:hi], a.detach(), out=wvec[:, lo:hi])
                 return h_w, h16, eps, wvec, (A16 if lowp else None)
 
-            if fuse_next and fork is not None:
-                # experiment (RCB_FORK=1, same-box A/B only): the A transform of the sample on a second stream beside the
+            if fuse_next and fork is not None and (fork_mask & 1):
+                # experiment (RCB_FORK bit 1, same-box A/B only): the A transform of the sample on a second stream beside the
                 # upsampling net's forward -- the two are independent until the SIREN kernel
                 cur = torch.cuda.current_stream()
                 fork.wait_stream(cur)
@@ -496,7 +507,7 @@ class PriorBNNmodel(nn.Module):
                                                   xf16=ws["xf16"])
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
-            fork_bwd = fork is not None and os.environ.get("RCB_FORK_BWD", "0") == "1" and split is not None and flat is None and fuse_next
+            fork_bwd = fork is not None and (fork_mask & 2) and split is not None and flat is None and fuse_next
             if fork_bwd:      # experiment: the A transform's backward on the second stream beside the upsampling net's backward
                 fork.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(fork):
@@ -598,12 +609,17 @@ class PriorBNNmodel(nn.Module):
                 # one rank: the network level's update -- which writes the next step's h_w -- is the step's last big kernel, so
                 # that the next step's A transform (its first) finds h_w in the Infinity Cache
                 seg1a()
+                pending = st.pop("fork_pending", False)
+                if pending and (fork_mask & 8):
+                    with torch.cuda.stream(fork):      # the network level's update needs dh only: straight behind the A backward
+                        seg2_net()
                 seg1b()
-                if st.pop("fork_pending", False):
+                if pending:
                     torch.cuda.current_stream().wait_stream(fork)
                 seg2_lpe()
                 seg3_adam()
-                seg2_net()
+                if not (pending and (fork_mask & 8)):
+                    seg2_net()
                 seg3_end()
                 return
             seg1a()

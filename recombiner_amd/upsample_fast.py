@@ -381,6 +381,9 @@ def hip_path_supported(net, pixel_sizes, upsample_factors, patch, data_dim):
     return ok
 
 
+WEIGHT_SIDE_STREAM = None        # see _UpsampleCifarFn.backward
+
+
 class _UpsampleCifarFn(torch.autograd.Function):
     """lpe [B, 512] (channel-last 2x2x128) -> pe [B, 1024, 16].  Stage 1 is one dense GEMM against the
     pre-summed 512 x 4096 weight (hipBLASLt); stages 2 and 3 are the rcb_upconv_* kernels."""
@@ -420,11 +423,30 @@ class _UpsampleCifarFn(torch.autograd.Function):
             dz2, dWeff3, db3 = ops.upconv_bwd_fused(dpe, Weff3, h2, 16, 16, pack=pack)
         else:
             dz2 = ops.upconv_dgrad(dpe, Weff3, h2, 16, 16, pack=pack)      # bf16 [B,16,16,64]
+        # WEIGHT_SIDE_STREAM (set by PriorBNNmodel.train when its stream fork is on): the weight-gradient side of the backward
+        # (stage-2 weight gradient, stage-1 weight-gradient GEMM, the map back onto the conv weights) runs on a second stream
+        # beside the data path (stage-2 data gradient -> stage-1 data-gradient GEMM): the two only share their inputs, and
+        # the library GEMMs (160 macro-tiles) leave a third of the chip idle on their own.  Same kernels, same operands:
+        # identical results.
+        side = WEIGHT_SIDE_STREAM if (need_w and fused3) else None
+        main = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(main)                       # dz2 is complete
+            with torch.cuda.stream(side):
+                dWeff2, db2 = ops.upconv_wgrad(z1, dz2, 8, 64, preact=True)
         dz1, db1_part = ops.upconv_dgrad(dz2, Weff2, z1, 8, 64, preact=True, want_dbias=True, pack=pack)   # [B,8,8,64]
         dz1f = dz1.view(B, 4096)
+        if side is not None:
+            side.wait_stream(main)                       # dz1 / db1_part are complete
+            with torch.cuda.stream(side):
+                dWeff1 = torch.mm(lpe.t(), dz1f, out_dtype=torch.float32) if dz1f.dtype == torch.bfloat16 else lpe.t() @ dz1f
+                dW1, dW2, dW3, db1 = ops.upconv_weff_grad(dWeff1, dWeff2, dWeff3, db1_part)
         dlpe = None
         if ctx.needs_input_grad[0]:      # fp32 result straight from the GEMM (no cast pass)
             dlpe = torch.mm(dz1f, Weff1.t(), out_dtype=torch.float32) if dz1f.dtype == torch.bfloat16 else dz1f @ Weff1.t()
+        if side is not None:
+            main.wait_stream(side)
+            return dlpe, dW1, db1, dW2, db2, dW3, db3, None, None, None, None
         if not need_w:
             return dlpe, None, None, None, None, None, None, None, None, None, None
         if not fused3:
