@@ -338,11 +338,15 @@ def presets_table(dev):
         pri += ([torch.zeros(D, device=dev), torch.full((D,), s0, device=dev)] * 2) if cfg["patch"] else [None] * 4
         return cfg, n, m, lt, up, pri, X.to(dev), Y.to(dev)
 
-    runs = [("kodak-w48 (configs[2]), 2 photos", "kodak", 2, 48, 1, 50), ("kodak-w48 (configs[2]), 24 photos", "kodak", 24, 48, 1, 20),
-            ("audio (configs[3]), 8 clips", "audio", 8, 32, 1, 50),
-            ("audio (configs[3]), 1024 clips = one rank's shard of the 8192", "audio", 1024, 32, 1, 8),
-            ("video-w64-f16 (configs[4]), 4 clips", "video", 4, 64, 2, 50), ("video-w64-f16 (configs[4]), 32 clips", "video", 32, 64, 2, 10),
-            ("kodak, 2 photos", "kodak", 2, 32, 1, 50), ("video, 4 clips", "video", 4, 32, 1, 50)]
+    # (the small cases first: measured right after a 40 GB case the 192-INR Kodak step replayed at twice its usual time with
+    # the same kernel times -- launch gaps inside the replayed graph -- while tools/bench_presets.py in a fresh process gives
+    # 0.71 ms; the order below keeps every small case ahead of the large ones)
+    runs = [("kodak-w48 (configs[2]), 2 photos", "kodak", 2, 48, 1, 50), ("audio (configs[3]), 8 clips", "audio", 8, 32, 1, 50),
+            ("video-w64-f16 (configs[4]), 4 clips", "video", 4, 64, 2, 50), ("kodak, 2 photos", "kodak", 2, 32, 1, 50),
+            ("video, 4 clips", "video", 4, 32, 1, 50),
+            ("kodak-w48 (configs[2]), 24 photos", "kodak", 24, 48, 1, 20),
+            ("video-w64-f16 (configs[4]), 32 clips", "video", 32, 64, 2, 10),
+            ("audio (configs[3]), 1024 clips = one rank's shard of the 8192", "audio", 1024, 32, 1, 8)]
     out = []
     for label, name, n_data, width, prec, steps in runs:
         cfg, n, m, lt, up, pri, X, Yd = prior_setup(name, n_data, width, prec)
@@ -447,7 +451,8 @@ def comm_report(m, lt, up, dev):
     minus that bucket's all-reduce.  Also checks that the shared mappings are bit-identical on every rank after training."""
     import torch.distributed as dist
     w = m._ws
-    flat = w["flat"] if w is not None else None
+    buckets_obj = w["flat"] if w is not None else None          # dist.GradBuckets
+    flat = buckets_obj.flat if buckets_obj is not None else None
     n_a = sum(q.numel() for q in lt.A)
     chk = torch.stack([torch.cat([q.detach().double().reshape(-1) for q in list(lt.parameters()) + list(up.parameters())]).sum(),
                        torch.cat([(q.detach().double() ** 2).reshape(-1) for q in list(lt.parameters()) + list(up.parameters())]).sum()])
@@ -481,7 +486,7 @@ def comm_report(m, lt, up, dev):
     ar = [timed(lambda b=b: dist.all_reduce(b, group=m.dp_group)) for b in (scratch[:n_a], scratch[n_a:])]
     del scratch
     live = [q.data for q in list(m.parameters()) + list(lt.parameters()) + list(up.parameters())]
-    live += [w[k] for k in ("state_flat", "step_t", "rng_ctr", "mse_buf", "kl_buf", "flat")]
+    live += [w[k] for k in ("state_flat", "step_t", "rng_ctr", "mse_buf", "kl_buf")] + [flat]
     live += [getattr(t, "buf", t) for k in ("smp_net", "smp_lpe") if k in w for t in w[k] if t is not None]   # (ops.Planes -> its buffer)
     saved = [t.clone() for t in live]
     graphs = w["graphs"][1]
@@ -507,6 +512,53 @@ def comm_report(m, lt, up, dev):
                 "overlap_window_ms": [round(seg[1] + seg[2], 4), round(seg[2], 4)],
                 "slack_ms": [round(seg[1] + seg[2] - ar[0], 4), round(seg[2] - ar[1], 4)]})
     return rep
+
+
+def segment_host_cost(dev, cfg, n, tm, single_graph_ms):
+    """What the SHARDED form of the step costs on the host, measured without a second GPU: the same 4096-INR step run as the
+    four captured segments around the two all-reduces of a ONE-rank RCCL communicator (PriorBNNmodel.force_segments) against
+    the single-graph step of the main measurement.  The difference is what 8 ranks pay per step on top of the collectives
+    themselves: three extra graph launches, two collective enqueues and their stream events."""
+    import torch.distributed as dist
+    from recombiner_amd import utils
+    from recombiner_amd import prior_model as PM
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29687")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                             cfg["hierarchical_patch_nums"], random_seed=42, device=dev)
+        m.precision, m.dp_group, m.force_segments = 1, dist.group.WORLD, True
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(m.dims).to(dev)
+        torch.manual_seed(124)
+        up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(dev)
+        D, s0 = m._d_net, 0.0211547
+        pri = [torch.zeros(D, device=dev), torch.full((D,), s0, device=dev), torch.zeros(2, 2, 128, device=dev),
+               torch.full((2, 2, 128), s0, device=dev)] + [None] * 4
+        Xd, Yd = X.to(dev)[None].expand(n, -1, -1), Y.to(dev)
+
+        def run(k):
+            return m.train(k, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=tm)
+        run(6)
+        run(10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(100)
+        torch.cuda.synchronize()
+        seg_ms = (time.perf_counter() - t0) / 100 * 1e3
+        kind = m._ws["graphs"][0] if (m._ws is not None and m._ws["graphs"] is not None) else "eager"
+        return {"what": "4096 INRs, one rank, RCCL communicator of size 1: four captured segments + two host-enqueued all-reduces per "
+                        "step against the single-graph step", "step_form": kind, "segmented_ms_per_step": round(seg_ms, 4),
+                "single_graph_ms_per_step": round(single_graph_ms, 4), "host_cost_us_per_step": round((seg_ms - single_graph_ms) * 1e3, 1),
+                "note": "no N > 1 run exists on this pool: the scaling bench of the driver is the only place RCCL moves bytes between GPUs"}
+    finally:
+        if own:
+            dist.destroy_process_group()
 
 
 def launch_ranks(a):
@@ -742,7 +794,8 @@ def main():
     extras = {}
     if rank == 0 and ws == 1 and not a.no_extras:
         for key, fn in (("kernels", lambda: kernel_table(run, 10, n, D)), ("rec", lambda: rec_roofline(dev)),
-                        ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision)), ("presets", lambda: presets_table(dev))):
+                        ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision)), ("presets", lambda: presets_table(dev)),
+                        ("sharded_step_host_cost", lambda: segment_host_cost(dev, cfg, n, tm, el / a.steps * 1e3))):
             try:
                 extras[key] = fn()
             except Exception as exc:            # extras never take the bench line down; the failure is visible in it

@@ -78,6 +78,48 @@ def refit_prior(loc: torch.Tensor, log_scale: torch.Tensor, group=None):
     return prior_from_moments(torch.tensor(float(n), dtype=torch.float64), s, m2, sg, loc.shape[1:])
 
 
+class GradBuckets:
+    """The per-step collective of sharded prior training: the gradients of the shared mappings, summed over the ranks in TWO
+    buckets of ONE flat fp32 buffer -- [ A matrices (layer order) | parameters of the upsampling net (module order) ] -- so
+    that the large first bucket (13.4 of the 14.4 MB on the CIFAR preset) can travel while the upsampling net's backward
+    is still running (PriorBNNmodel.train: segment 1a -> reduce(0) || segment 1b -> reduce(1) || segment 2 -> wait ->
+    Adam).  `pack` copies a list of gradients into a bucket (one torch.cat with out=) and returns VIEWS of the flat buffer
+    in the gradients' shapes: what Adam reads after the wait.  Works on any device / backend (RCCL in production, gloo on
+    CPU tensors in tests/test_dist_gloo.py)."""
+
+    def __init__(self, a_shapes, conv_shapes, device, group=None, dtype=torch.float32):
+        self.group = group
+        self.shapes = ([tuple(s_) for s_ in a_shapes], [tuple(s_) for s_ in conv_shapes])
+        numel = [sum(int(np.prod(s_)) for s_ in part) for part in self.shapes]
+        self.n_a = numel[0]
+        self.flat = torch.empty(numel[0] + numel[1], device=device, dtype=dtype)
+        self.bounds = ((0, numel[0]), (numel[0], numel[0] + numel[1]))
+
+    def bucket(self, part: int) -> torch.Tensor:
+        lo, hi = self.bounds[part]
+        return self.flat[lo:hi]
+
+    def pack(self, part: int, grads):
+        """grads (tensors in the bucket's order and shapes) -> views of the flat buffer holding their values"""
+        shapes = self.shapes[part]
+        if len(grads) != len(shapes) or any(tuple(g.shape) != s_ for g, s_ in zip(grads, shapes)):
+            raise ValueError("GradBuckets.pack: gradients do not match the bucket's parameter list")
+        torch.cat([g.reshape(-1) for g in grads], out=self.bucket(part))
+        views, k = [], self.bounds[part][0]
+        for s_ in shapes:
+            n = int(np.prod(s_))
+            views.append(self.flat[k:k + n].view(s_))
+            k += n
+        return views
+
+    def reduce(self, part: int, async_op=True):
+        """sum of the bucket over the ranks of the group, in place; returns the work handle (None for a single process
+        without a process group)"""
+        if not (td.is_available() and td.is_initialized()):
+            return None
+        return td.all_reduce(self.bucket(part), group=self.group, async_op=async_op)
+
+
 def allreduce_scalar(v: torch.Tensor, group=None) -> torch.Tensor:
     rank, ws = world(group)
     if ws > 1:

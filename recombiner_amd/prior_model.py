@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import dist as rdist
 from . import ops
 from .ops import LevelSpec, SirenMeta
 from .upsample_fast import (hip_path_supported, tiled_2d_preferred, phase_form_preferred, phase_module,
@@ -133,8 +134,15 @@ class PriorBNNmodel(nn.Module):
         # with fuse_next_sample: the posterior update re-draws its step's noise from the counter instead of reading the copy
         # the sampler stored (rcb_level_bwd.eps_from_rng: same bits, 8 bytes per element less traffic)
         self.redraw_noise = os.environ.get("RCB_REDRAW_EPS", "1") != "0"
-        # concurrent streams inside the step (bit mask, see train()); 0 = one stream
-        self.stream_forks = 0
+        # concurrent streams inside the captured step (bit mask, see train(); 0 = one stream).  Measured on MI355X, same-box A/B of
+        # the 4096-INR CIFAR step (gpurun_out r04_ab5): one stream 1.162 ms; A-transform backward beside the upsampling net's
+        # backward (2) 1.125; + the net's weight-gradient side on a third stream (6) 1.109; + the network level's posterior
+        # update (HBM-bound) straight behind the A backward, i.e. beside the LDS / MFMA-bound upsampling kernels (14) 1.089:
+        # -6.2 %.  The forward fork (1) gains nothing (7: 1.113).  Same kernels on the same operands: bit-identical results.
+        self.stream_forks = 14
+        # measurement aid: take the SHARDED form of the step (four captured segments around two host-enqueued all-reduces)
+        # even when `dp_group` has a single rank -- what the segmentation costs on the host, without a second GPU
+        self.force_segments = False
         # in-kernel noise: first row of this model's INRs inside a larger (virtual) batch.  Row r of the model draws the noise of
         # row rng_row_offset + r of that batch (ops.rng_group_offset): a shard or a sub-batch trained on its own then sees
         # exactly the noise of the unsharded run, given the same seed (`rng_seed_override`, else derived per model and rank)
@@ -292,7 +300,7 @@ class PriorBNNmodel(nn.Module):
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
                self.operand_planes, self.redraw_noise, self.rng_row_offset, self.rng_seed_override,
-               os.environ.get("RCB_FORK", str(self.stream_forks)),
+               os.environ.get("RCB_FORK", str(self.stream_forks)), self.force_segments,
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
                # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
@@ -329,8 +337,9 @@ class PriorBNNmodel(nn.Module):
                       rng_ctr=torch.full((1,), int(self._rng_ctr_init), device=dev, dtype=torch.long), graphs=None,
                       seed=(int(self.random_seed) * 0x9E3779B97F4A7C15 + int(torch.initial_seed()) * 0xBF58476D1CE4E5B9
                             + self._train_calls * 0x94D049BB133111EB + rank_id * 0xD6E8FEB86659FD93) & (2 ** 64 - 1),
-                      flat=(torch.empty(sum(q.numel() for q in A + conv), device=dev, dtype=torch.float32)
-                            if (training_mappings and world > 1) else None),
+                      # sharded: the mapping gradients of a step travel in two buckets of one flat buffer (dist.GradBuckets)
+                      flat=(rdist.GradBuckets([q.shape for q in A], [q.shape for q in conv], dev, self.dp_group)
+                            if (training_mappings and (world > 1 or (self.force_segments and self.dp_group is not None))) else None),
                       # the bf16 copy of the coordinate grid the captured SIREN launches read: owned by the workspace,
                       # i.e. alive exactly as long as the graphs that reference its address
                       xf16=ops.xf_bf16(x) if (self.precision == 1 and dev.type == "cuda") else None)
@@ -533,12 +542,7 @@ class PriorBNNmodel(nn.Module):
             st.update(sse=sse, dh3=dh.view(N, 1, D), eps=eps, e_lpe=e_lpe, pe_c=pe_c, lpe_t=lpe_t, dpe=dpe)
             if training_mappings:
                 if flat is not None:
-                    torch.cat([g.reshape(-1) for g in gA], out=flat[:n_a])
-                    views, k = [], 0
-                    for g in gA:
-                        views.append(flat[k:k + g.numel()].view_as(g))
-                        k += g.numel()
-                    gA = views
+                    gA = flat.pack(0, gA)
                 st["gA"] = gA
 
         def seg1b():
@@ -549,12 +553,7 @@ class PriorBNNmodel(nn.Module):
             if training_mappings:
                 gc = [g.contiguous() for g in g_in[1:]]
                 if flat is not None:
-                    torch.cat([g.reshape(-1) for g in gc], out=flat[n_a:])
-                    views, k = [], n_a
-                    for g in gc:
-                        views.append(flat[k:k + g.numel()].view_as(g))
-                        k += g.numel()
-                    gc = views
+                    gc = flat.pack(1, gc)
                 st["grads"] = st["gA"] + gc
             # the autograd graph of this step must not outlive it: a graph kept alive from an eager warm-up step (default
             # stream) into the capture (side stream) makes its AccumulateGrad nodes cross streams and breaks the capture
@@ -566,8 +565,7 @@ class PriorBNNmodel(nn.Module):
             the 14.4 MB, ready before the upsampling backward starts), part 1 = the conv weights; returns the async handle"""
             if flat is None:
                 return None
-            buf = flat[:n_a] if part == 0 else flat[n_a:]
-            return torch.distributed.all_reduce(buf, group=self.dp_group, async_op=True)
+            return flat.reduce(part, async_op=True)
 
         def seg2_net():
             # fused posterior update (also accumulates the pre-update KL for the ELBO log)

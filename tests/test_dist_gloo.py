@@ -83,22 +83,63 @@ def test_shard_range_covers_everything():
             assert seen == list(range(n))
 
 
-def _mapping_grad_worker(rank, ws, port, out_dir):
-    """the per-step collective of sharded prior training: sum of the shared-mapping gradients."""
+def _bucket_worker(rank, ws, port, out_dir):
+    """PRODUCT code of the per-step collective (recombiner_amd.dist.GradBuckets, what PriorBNNmodel.train packs its mapping
+    gradients into and reduces between the captured segments) on CPU tensors over gloo: flat layout [A matrices | upsampling
+    net], the views Adam later reads alias the flat buffer in parameter order, bucket 0 can be reduced while bucket 1 is
+    still being packed (the segment order of the step), and the result is the sum over ranks."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=ws)
-    g = torch.Generator().manual_seed(1)
-    full = torch.randn(ws, 11, generator=g)
-    mine = full[rank].clone()
-    flat = torch.cat([mine[:4], mine[4:]])
-    td.all_reduce(flat)
-    np.testing.assert_allclose(flat.numpy(), full.sum(0).numpy(), rtol=1e-6)
+    from recombiner_amd import dist
+    a_shapes = [(7, 7), (5, 5), (3, 3)]                       # stand-ins for A[l] [L_l, L_l]
+    c_shapes = [(4, 2, 3), (4,), (2, 4, 3), (2,)]             # conv weights / biases of the upsampling net
+    gen = torch.Generator().manual_seed(100)
+    every = [[torch.randn(s_, generator=gen) for s_ in a_shapes + c_shapes] for _ in range(ws)]      # every rank's gradients
+    mine = every[rank]
+    b = dist.GradBuckets(a_shapes, c_shapes, "cpu", None)
+    assert b.flat.numel() == 83 + 24 + 4 + 24 + 2 and b.n_a == 83
+    va = b.pack(0, mine[:3])                                  # end of segment 1a: the A gradients are ready
+    h0 = b.reduce(0, async_op=True)                           # ... and travel
+    vc = b.pack(1, mine[3:])                                  # segment 1b: the conv gradients, packed while bucket 0 is in flight
+    h1 = b.reduce(1, async_op=True)
+    h0.wait()
+    h1.wait()
+    want = [sum(every[r][i] for r in range(ws)) for i in range(len(mine))]
+    for v, w_ in zip(va + vc, want):
+        np.testing.assert_allclose(v.numpy(), w_.numpy(), rtol=1e-6, atol=1e-6)
+    # the views ARE the flat buffer, A matrices first, each bucket in parameter order
+    off = 0
+    for v in va + vc:
+        assert v.data_ptr() == b.flat.data_ptr() + 4 * off and v.is_contiguous()
+        off += v.numel()
+    assert b.bucket(0).data_ptr() == b.flat.data_ptr() and b.bucket(1).data_ptr() == b.flat.data_ptr() + 4 * b.n_a
+    try:
+        b.pack(1, mine[:3])
+        raise AssertionError("a gradient list of the wrong bucket must be refused")
+    except ValueError:
+        pass
+    # the EXACT cross-rank sums of the prior refit / grouping (what the product's kernels return as int64 fixed point, here
+    # built with the same splitting rule on the CPU): an integer all-reduce makes the refit independent of the sharding
+    from recombiner_amd import ops
+    g2 = torch.Generator().manual_seed(7)
+    rows, cols = 11 * ws + 3, 29
+    loc = 0.3 + 0.05 * torch.randn(rows, cols, generator=g2)
+    lo, hi = dist.shard_range(rows, rank, ws)
+
+    def fx(x):                       # the rule of rcb_col_moments for one quantity: hi = floor(v 2^30), lo = rint(frac 2^32)
+        v = x.double() * ops.MOM_FX
+        f = torch.floor(v)
+        return torch.stack([f.sum(0), torch.round((v - f) * ops.MOM_FX_LO).sum(0)]).to(torch.int64)
+    part = fx(loc[lo:hi])
+    td.all_reduce(part)
+    assert torch.equal(part, fx(loc)), "integer sums must not depend on the sharding"
     open(os.path.join(out_dir, f"g{rank}"), "w").write("ok")
     td.destroy_process_group()
 
 
-def test_mapping_gradient_allreduce(tmp_path):
+@pytest.mark.parametrize("ws", [2, 3])
+def test_gradient_buckets_of_the_sharded_step(tmp_path, ws):
     port = _free_port()
-    mp.spawn(_mapping_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert os.path.exists(tmp_path / "g0") and os.path.exists(tmp_path / "g1")
+    mp.spawn(_bucket_worker, args=(ws, port, str(tmp_path)), nprocs=ws, join=True)
+    assert all(os.path.exists(tmp_path / f"g{r}") for r in range(ws))
