@@ -460,6 +460,28 @@ def comm_report(m, lt, up, dev):
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     rep = {"mappings_identical_across_ranks": bool(torch.equal(hi, lo)), "backend": dist.get_backend()}
+    if flat is not None and w["graphs"] is not None and w["graphs"][0] == "one":
+        # RCCL: both all-reduces are captured INSIDE the one step graph (issued from the forked streams, overlapped by the
+        # graph's own dependencies): no host work between segments; what can be timed from outside is the collective alone
+        def timed1(fn, reps=10):
+            evs = []
+            for _ in range(reps):
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            t = torch.tensor([sorted(a_.elapsed_time(b_) for a_, b_ in evs)[reps // 2]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        scratch = flat.clone()
+        ar = [timed1(lambda b=b: dist.all_reduce(b, group=m.dp_group)) for b in (scratch[:n_a], scratch[n_a:])]
+        rep.update({"step_form": "one captured graph per step, both all-reduces inside it (RCCL)",
+                    "allreduce_bytes_per_step": int(flat.numel() * 4), "bucket_bytes": [int(n_a * 4), int((flat.numel() - n_a) * 4)],
+                    "allreduce_ms_alone": [round(x, 4) for x in ar]})
+        return rep
     if flat is None or w["graphs"] is None or w["graphs"][0] != "segments":
         rep["note"] = "the step did not run as captured segments (frozen mappings or eager stepping)"
         return rep
@@ -514,25 +536,25 @@ def comm_report(m, lt, up, dev):
     return rep
 
 
-def segment_host_cost(dev, cfg, n, tm, single_graph_ms):
-    """What the SHARDED form of the step costs on the host, measured without a second GPU: the same 4096-INR step run as the
-    four captured segments around the two all-reduces of a ONE-rank RCCL communicator (PriorBNNmodel.force_segments) against
-    the single-graph step of the main measurement.  The difference is what 8 ranks pay per step on top of the collectives
-    themselves: three extra graph launches, two collective enqueues and their stream events."""
+def segment_host_cost(dev, cfg, n, tm, single_graph_ms, captured=False):
+    """What the SHARDED form of the step costs on top of the one-rank step, measured without a second GPU: the same 4096-INR
+    step with the two all-reduces of a ONE-rank RCCL communicator (PriorBNNmodel.force_segments), (captured=True) inside the
+    one step graph -- the production form on RCCL -- or (False) as four captured segments around host-enqueued collectives,
+    against the collective-free single-graph step of the main measurement."""
     import torch.distributed as dist
     from recombiner_amd import utils
     from recombiner_amd import prior_model as PM
     own = not dist.is_initialized()
     if own:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29687")
+        os.environ["MASTER_PORT"] = str(29687 + (1 if captured else 0))
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=0)
         m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
                              cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
                              cfg["hierarchical_patch_nums"], random_seed=42, device=dev)
-        m.precision, m.dp_group, m.force_segments = 1, dist.group.WORLD, True
+        m.precision, m.dp_group, m.force_segments, m.capture_collectives = 1, dist.group.WORLD, True, captured
         torch.manual_seed(123)
         lt = PM.LinearTransform(m.dims).to(dev)
         torch.manual_seed(124)
@@ -552,8 +574,9 @@ def segment_host_cost(dev, cfg, n, tm, single_graph_ms):
         torch.cuda.synchronize()
         seg_ms = (time.perf_counter() - t0) / 100 * 1e3
         kind = m._ws["graphs"][0] if (m._ws is not None and m._ws["graphs"] is not None) else "eager"
-        return {"what": "4096 INRs, one rank, RCCL communicator of size 1: four captured segments + two host-enqueued all-reduces per "
-                        "step against the single-graph step", "step_form": kind, "segmented_ms_per_step": round(seg_ms, 4),
+        return {"what": "4096 INRs, one rank, RCCL communicator of size 1: two all-reduces per step, " +
+                        ("captured inside the step graph" if captured else "host-enqueued between four captured segments") +
+                        ", against the collective-free single-graph step", "step_form": kind, "segmented_ms_per_step": round(seg_ms, 4),
                 "single_graph_ms_per_step": round(single_graph_ms, 4), "host_cost_us_per_step": round((seg_ms - single_graph_ms) * 1e3, 1),
                 "note": "no N > 1 run exists on this pool: the scaling bench of the driver is the only place RCCL moves bytes between GPUs"}
     finally:
@@ -795,7 +818,8 @@ def main():
     if rank == 0 and ws == 1 and not a.no_extras:
         for key, fn in (("kernels", lambda: kernel_table(run, 10, n, D)), ("rec", lambda: rec_roofline(dev)),
                         ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision)), ("presets", lambda: presets_table(dev)),
-                        ("sharded_step_host_cost", lambda: segment_host_cost(dev, cfg, n, tm, el / a.steps * 1e3))):
+                        ("sharded_step_cost_captured", lambda: segment_host_cost(dev, cfg, n, tm, el / a.steps * 1e3, True)),
+                        ("sharded_step_cost_segments", lambda: segment_host_cost(dev, cfg, n, tm, el / a.steps * 1e3, False))):
             try:
                 extras[key] = fn()
             except Exception as exc:            # extras never take the bench line down; the failure is visible in it

@@ -143,6 +143,9 @@ class PriorBNNmodel(nn.Module):
         # measurement aid: take the SHARDED form of the step (four captured segments around two host-enqueued all-reduces)
         # even when `dp_group` has a single rank -- what the segmentation costs on the host, without a second GPU
         self.force_segments = False
+        # sharded step: None = capture the all-reduces inside the step graph when the backend is RCCL ("nccl"), else four
+        # segments around host-enqueued collectives; True / False force one form
+        self.capture_collectives = None
         # in-kernel noise: first row of this model's INRs inside a larger (virtual) batch.  Row r of the model draws the noise of
         # row rng_row_offset + r of that batch (ops.rng_group_offset): a shard or a sub-batch trained on its own then sees
         # exactly the noise of the unsharded run, given the same seed (`rng_seed_override`, else derived per model and rank)
@@ -300,7 +303,7 @@ class PriorBNNmodel(nn.Module):
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
                self.operand_planes, self.redraw_noise, self.rng_row_offset, self.rng_seed_override,
-               os.environ.get("RCB_FORK", str(self.stream_forks)), self.force_segments,
+               os.environ.get("RCB_FORK", str(self.stream_forks)), self.force_segments, self.capture_collectives,
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
                # reference's way, main_prior_training.py:334-338) re-allocates param.data while id() stays equal
@@ -404,11 +407,17 @@ class PriorBNNmodel(nn.Module):
             ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe, group_offset=goff_lpe)
 
         pe_lay = self._pe_layout()
+        # sharded step: with RCCL the two all-reduces are CAPTURED inside the one step graph (measured on this stack: an
+        # all-reduce captures and replays correctly from the capturing stream and from a forked one, tools/rccl_capture_probe.py;
+        # the four-segment form costs 142 us of host work per 1.09 ms step, bench.py `sharded_step_host_cost`); other
+        # backends (gloo: the CPU rehearsals) keep the four captured segments around host-enqueued collectives
+        capture_coll = bool(flat is not None and self.capture_collectives is not False
+                            and (self.capture_collectives is True or torch.distributed.get_backend(self.dp_group) == "nccl"))
         # stream forks inside the (captured) step -- bit mask, same kernels on the same operands, so results are identical:
         #   1: the A transform's forward beside the upsampling net's forward;  2: the A transform's backward beside the
         #   upsampling net's backward;  4: the weight-gradient side of the upsampling net's backward beside its data path
         #   (upsample_fast.WEIGHT_SIDE_STREAM);  8: the network level's posterior update right behind the A transform's backward
-        #   on the forked stream (it only needs dh)
+        #   on the forked stream (it only needs dh);  16: Adam on the mappings on the third stream beside the lpe level's update
         fork_mask = int(os.environ.get("RCB_FORK", str(self.stream_forks))) if dev.type == "cuda" else 0
         fork = side = None
         if fork_mask:
@@ -516,13 +525,19 @@ class PriorBNNmodel(nn.Module):
                                                   xf16=ws["xf16"])
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
-            fork_bwd = fork is not None and (fork_mask & 2) and split is not None and flat is None and fuse_next
-            if fork_bwd:      # experiment: the A transform's backward on the second stream beside the upsampling net's backward
+            fork_bwd = fork is not None and (fork_mask & 2) and split is not None and (flat is None or capture_coll) and fuse_next
+            if fork_bwd:      # the A transform's backward on the second stream beside the upsampling net's backward
                 fork.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(fork):
                     dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
                     if training_mappings:
                         gA = split.wgrad(h_w, dw, h16, dw16, self.wgrad_bf16)
+                        if capture_coll:                # bucket 0 (13.4 of the 14.4 MB) leaves from this stream, inside the graph
+                            gA = flat.pack(0, gA)
+                            st["h0"] = flat.reduce(0, async_op=True)
+                    if fork_mask & 16:                  # the mapping gradients are complete here (Adam may start on another stream)
+                        st["ev_gA"] = torch.cuda.Event()
+                        st["ev_gA"].record(fork)
                 st["fork_pending"] = True
             elif lowp:
                 dw16 = dw.to(torch.bfloat16)
@@ -541,8 +556,10 @@ class PriorBNNmodel(nn.Module):
                         gA.append(torch.mm(h_w[:, lo:hi].t(), dw[:, lo:hi]))
             st.update(sse=sse, dh3=dh.view(N, 1, D), eps=eps, e_lpe=e_lpe, pe_c=pe_c, lpe_t=lpe_t, dpe=dpe)
             if training_mappings:
-                if flat is not None:
+                if flat is not None and "h0" not in st:
                     gA = flat.pack(0, gA)
+                    if capture_coll:
+                        st["h0"] = flat.reduce(0, async_op=True)
                 st["gA"] = gA
 
         def seg1b():
@@ -554,6 +571,8 @@ class PriorBNNmodel(nn.Module):
                 gc = [g.contiguous() for g in g_in[1:]]
                 if flat is not None:
                     gc = flat.pack(1, gc)
+                    if capture_coll:
+                        st["h1"] = flat.reduce(1, async_op=True)
                 st["grads"] = st["gA"] + gc
             # the autograd graph of this step must not outlive it: a graph kept alive from an eager warm-up step (default
             # stream) into the capture (side stream) makes its AccumulateGrad nodes cross streams and breaks the capture
@@ -591,6 +610,10 @@ class PriorBNNmodel(nn.Module):
             seg2_lpe()
 
         def seg3_adam():
+            for k_ in ("h0", "h1"):             # captured collectives: the stream that runs Adam waits for both buckets
+                h_ = st.pop(k_, None)
+                if h_ is not None:
+                    h_.wait()
             if training_mappings:
                 ops.adam_multi([p.data for p in A + conv], [g.contiguous() for g in st["grads"]],
                                [m for m, _ in map_state], [v for _, v in map_state], cfg)
@@ -603,8 +626,8 @@ class PriorBNNmodel(nn.Module):
             seg3_end()
 
         def body():
-            if fuse_next and flat is None:
-                # one rank: the network level's update -- which writes the next step's h_w -- is the step's last big kernel, so
+            if (fuse_next and flat is None) or capture_coll:
+                # one rank (or collectives inside the graph): the network level's update -- which writes the next step's h_w -- is the step's last big kernel, so
                 # that the next step's A transform (its first) finds h_w in the Infinity Cache
                 seg1a()
                 pending = st.pop("fork_pending", False)
@@ -612,10 +635,22 @@ class PriorBNNmodel(nn.Module):
                     with torch.cuda.stream(fork):      # the network level's update needs dh only: straight behind the A backward
                         seg2_net()
                 seg1b()
-                if pending:
+                ev = st.pop("ev_gA", None)
+                if pending and ev is not None and side is not None:
+                    # bit 16: Adam on the mappings on the third stream (it needs the A gradients -- the event -- and the
+                    # upsampling net's weight gradients, which that stream produced itself) beside the lpe level's update
+                    side.wait_stream(torch.cuda.current_stream())
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        seg3_adam()
+                    seg2_lpe()
                     torch.cuda.current_stream().wait_stream(fork)
-                seg2_lpe()
-                seg3_adam()
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    if pending:
+                        torch.cuda.current_stream().wait_stream(fork)
+                    seg2_lpe()
+                    seg3_adam()
                 if not (pending and (fork_mask & 8)):
                     seg2_net()
                 seg3_end()
@@ -658,10 +693,11 @@ class PriorBNNmodel(nn.Module):
                 left -= n_warm
                 torch.cuda.synchronize()
                 try:
-                    if flat is None:                   # one rank (or frozen mappings): the whole step is one graph
+                    if flat is None or capture_coll:   # one rank / frozen mappings / captured collectives: the whole step is one graph
                         graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph):      # records the step; nothing executes during capture
-                            body()
+                        # (thread_local: the process group's watchdog thread must not be able to invalidate the capture)
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local" if flat is not None else "global"):
+                            body()                         # records the step; nothing executes during capture
                         ws["graphs"] = ("one", graph)
                     else:                               # sharded: four graphs around the two eager, asynchronous all-reduces
                         pool = torch.cuda.graph_pool_handle()
