@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # PMC traffic of the SIREN training kernel per launch (4096 INRs), by pe/dpe storage type (True: bf16)
-PMC_FILE = {True: "r03_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
+PMC_FILE = {True: "r04_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
 STEPS_PER_INR = 200 + 549 * 100   # reference schedule
 
 

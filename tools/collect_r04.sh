@@ -1,0 +1,39 @@
+#!/bin/bash
+# rocprofv3 evidence of round 4 (run on the GPU box; tools/summarize_r04.py then writes what is kept under profiles/):
+#   bash tools/collect_r04.sh && python3 tools/summarize_r04.py
+# Kernel statistics of the bench step and of every preset, the A-transform kernels alone, and HBM traffic (PMC, passes of
+# their own, never combined with other trace domains) of the SIREN kernel and the A-transform kernel.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/prof_r04
+rm -rf $OUT && mkdir -p $OUT
+run() {
+  label=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$label -- "$@" > $OUT/$label.log 2> $OUT/$label.err
+  cp $OUT/$label/*/*kernel_stats.csv $OUT/${label}_kernel_stats.csv 2>/dev/null
+  echo "$label: $(tail -n 1 $OUT/$label.log | cut -c1-200)"
+}
+pmc() {
+  label=$1; shift; counters=$1; shift
+  rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $OUT/$label -- "$@" > $OUT/$label.log 2>&1
+  echo "$label: done"
+}
+run bench python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-extras
+run atrans python3 tools/run_atrans.py 4096 2 10
+run siren python3 tools/run_siren.py bf16 4096 10 pe16 32 step
+run testtime_compress python3 tools/bench_compress.py bf16
+run kodak python3 tools/prof_preset.py kodak 2 32 1
+run audio python3 tools/prof_preset.py audio 8 32 1
+run video python3 tools/prof_preset.py video 4 32 1
+run kodak_w48 python3 tools/prof_preset.py kodak 2 48 1
+run video_w64_f16 python3 tools/prof_preset.py video 4 64 2
+pmc pmc_siren_fetch FETCH_SIZE python3 tools/run_siren.py bf16 4096 3 pe16 32 step
+pmc pmc_siren_write WRITE_SIZE python3 tools/run_siren.py bf16 4096 3 pe16 32 step
+pmc pmc_atrans_fetch FETCH_SIZE python3 tools/run_atrans.py 4096 2 4
+pmc pmc_atrans_write WRITE_SIZE python3 tools/run_atrans.py 4096 2 4
+pmc pmc_atrans_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" python3 tools/run_atrans.py 4096 2 4
+# known-bytes probe of the read counter: ordinary 16-byte loads against LDS-DMA loads of the same 1 GiB (settles the x2 question)
+hipcc --offload-arch=gfx950 -O3 tools/native/glds_fetch_probe.cpp -o /tmp/glds_fetch 2>/dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_glds_probe -- /tmp/glds_fetch > $OUT/pmc_glds_probe.log 2>&1
+run atrans_planes python3 tools/run_atrans.py 4096 2 10 planes
+python3 tools/bench_presets.py > $OUT/presets.log 2>&1
+grep "ms/step" $OUT/presets.log
