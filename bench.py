@@ -272,7 +272,9 @@ def rd_trained(dev, precision, runs_per_rate=3):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from golden_util import smooth_images
     from recombiner_amd import drivers, utils
-    d = np.load(os.path.join(ROOT, "tests", "golden", "rd_trained_cifar.npz"), allow_pickle=False)
+    from golden_util import load_rd_fixture
+    n64 = all(os.path.exists(os.path.join(ROOT, "tests", "golden", "rd_trained_cifar_n64_r%d.npz" % r)) for r in (0, 1))
+    d = load_rd_fixture(64 if n64 else 16)          # round 4: the reference's runs on 64 held-out images when the fixture is there
     cfg = json.loads(str(d["cfg"]))
     Ytr = smooth_images(int(d["n_train"]), cfg["pixel_sizes"], int(d["train_seed"]))
     Yte = smooth_images(int(d["n_test"]), cfg["pixel_sizes"], int(d["test_seed"]))
@@ -295,7 +297,7 @@ def rd_trained(dev, precision, runs_per_rate=3):
                     "final_kl_bits_per_inr": round(float(np.mean([r["trajectory"][-1, 0] for r in runs])), 1),
                     "bit_budget": [float(v) for v in d[f"r{ri}_budget"]]})
     return {"points": out, "reference_slope_db_per_bpp": round(slope, 3), "seconds": round(time.perf_counter() - t0, 1),
-            "what": "64 smooth synthetic training images, 16 test images; EM loop %d iterations (%d + %d x %d Adam steps, lr %g, "
+            "what": "64 smooth synthetic training images, " + str(int(d["n_test"])) + " test images; EM loop %d iterations (%d + %d x %d Adam steps, lr %g, "
                     "training_mappings=True), then optimise %d epochs + A* encode every group with %d fine-tune epochs per round"
                     % (sched["n_em_iter"], sched["first_epochs"], sched["n_em_iter"] - 1, sched["epochs"], sched["lr"], sched["n_opt"],
                        sched["finetune_epochs"])}

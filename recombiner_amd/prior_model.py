@@ -539,6 +539,10 @@ class PriorBNNmodel(nn.Module):
                         st["ev_gA"] = torch.cuda.Event()
                         st["ev_gA"].record(fork)
                 st["fork_pending"] = True
+                # dw (and its bf16 copy) were allocated on the main stream and are READ on the forked one: they must stay
+                # allocated until the streams have joined, or the caching allocator hands their memory to the next main-stream
+                # allocation (the upsampling net's backward) while the A transform is still reading it
+                st["fork_keep"] = (dw, dw16, h_w, h16)
             elif lowp:
                 dw16 = dw.to(torch.bfloat16)
                 dh = torch.cat([torch.mm(dw16[:, lo:hi], a16.t()) for (lo, hi), a16 in zip(slices, A16)], 1).float()
@@ -646,9 +650,11 @@ class PriorBNNmodel(nn.Module):
                     seg2_lpe()
                     torch.cuda.current_stream().wait_stream(fork)
                     torch.cuda.current_stream().wait_stream(side)
+                    st.pop("fork_keep", None)
                 else:
                     if pending:
                         torch.cuda.current_stream().wait_stream(fork)
+                        st.pop("fork_keep", None)
                     seg2_lpe()
                     seg3_adam()
                 if not (pending and (fork_mask & 8)):

@@ -191,3 +191,20 @@ def smooth_images(n, pixel_sizes, seed):
 def moment_stats(t):
     a = t.detach().double()
     return np.array([a.sum().item(), a.abs().sum().item(), (a * a).sum().item()])
+
+
+def load_rd_fixture(n_test=64):
+    """The reference's rate-distortion runs with a prior it trained itself (oracle/make_golden.py --only rd): n_test = 16 ->
+    rd_trained_cifar.npz (round 3: 16 held-out images, four repetitions per rate, + the pinned noise stream of the first);
+    n_test = 64 -> rd_trained_cifar_n64_r0.npz / _r1.npz (round 4: 64 held-out images -- a run's mean PSNR is a mean over four
+    times as many images -- one file per rate).  Returns a dict with the union of the keys (r0_*, r1_*, schedule, data seeds)."""
+    if n_test == 16:
+        return dict(np.load(os.path.join(GOLDEN, "rd_trained_cifar.npz"), allow_pickle=False))
+    out = {}
+    for ri in (0, 1):
+        d = np.load(os.path.join(GOLDEN, "rd_trained_cifar_n%d_r%d.npz" % (n_test, ri)), allow_pickle=False)
+        for k in d.files:
+            if k.startswith("r") and k[1].isdigit() and not k.startswith("r%d_" % ri):
+                continue
+            out[k] = d[k]
+    return out

@@ -37,12 +37,13 @@ def test_prior_training_is_bitwise_reproducible():
     assert all(torch.equal(x, y) for x, y in zip(a[4] + a[5], b[4] + b[5]))
 
 
-def _rd_fixture():
-    """tests/golden/rd_trained_cifar.npz: for two rate targets, four independent repetitions each, the REFERENCE's own EM loop
-    with the mappings trained (main_prior_training.py:112-172) on 64 smooth images and its compression of 16 others
-    (main_compression.py:47-162): loop trajectories, groups, bpp, per-image PSNR (oracle/make_golden.py --only rd)."""
+def _rd_fixture(n_test=16):
+    """tests/golden/rd_trained_cifar*.npz: for two rate targets, four independent repetitions each, the REFERENCE's own EM loop
+    with the mappings trained (main_prior_training.py:112-172) on 64 smooth images and its compression of 16 (round 3) or 64
+    (round 4) others (main_compression.py:47-162): loop trajectories, groups, bpp, per-image PSNR (oracle/make_golden.py --only rd)."""
     import json
-    d = np.load(os.path.join(GOLDEN, "rd_trained_cifar.npz"), allow_pickle=False)
+    from golden_util import load_rd_fixture
+    d = load_rd_fixture(n_test)
     cfg = json.loads(str(d["cfg"]))
     Ytr = smooth_images(int(d["n_train"]), cfg["pixel_sizes"], int(d["train_seed"]))
     Yte = smooth_images(int(d["n_test"]), cfg["pixel_sizes"], int(d["test_seed"]))
@@ -81,6 +82,32 @@ def test_rd_points_of_a_product_trained_prior():
         bmin, bmax = d[f"r{ri}_budget"]
         for r in runs:
             assert 0.7 * bmin < r["trajectory"][-1, 0] < 1.3 * bmax
+
+
+def test_rd_points_with_64_held_out_images():
+    """The same comparison with statistical power (round 4): the reference compressed 64 held-out images per run (four runs per
+    rate; rd_trained_cifar_n64_r*.npz), the product does six runs per rate.  A run's mean PSNR now averages 64 images, the
+    product's mean 384: the difference of means at matched rate is held to 0.5 dB and the rate to 5 %; both are printed."""
+    d, cfg, X, Ytr, Yte, sched = _rd_fixture(64)
+    assert Yte.shape[0] == 64
+    ref = []
+    for ri in range(len(d["max_bitrate"])):
+        ref.append((np.asarray(d[f"r{ri}_bpp"], dtype=np.float64).mean(), np.asarray(d[f"r{ri}_psnr"], dtype=np.float64).mean(),
+                    np.asarray(d[f"r{ri}_psnr"], dtype=np.float64).mean(1).std(ddof=1) if np.asarray(d[f"r{ri}_psnr"]).shape[0] > 1 else 0.0))
+    slope = (ref[0][1] - ref[1][1]) / (ref[0][0] - ref[1][0])
+    assert 1.0 < slope < 4.0
+    for ri, rate in enumerate(d["max_bitrate"]):
+        runs = [drivers.rd_point(cfg, "cifar", X, Ytr, Yte, float(rate), device=DEV, seed=42 + s, precision=1, **sched)
+                for s in range(6)]
+        bpp = float(np.mean([r["bpp"] for r in runs]))
+        per_run = np.array([r["psnr"].mean() for r in runs])
+        psnr = float(per_run.mean())
+        delta = psnr - ref[ri][1] - slope * (bpp - ref[ri][0])
+        print("rate %.1f (64 held-out images): product %.3f bpp %.2f dB (run-to-run sigma %.2f), reference %.3f bpp %.2f dB (sigma %.2f, "
+              "%d runs), at matched rate %+.2f dB" % (rate, bpp, psnr, per_run.std(ddof=1), ref[ri][0], ref[ri][1], ref[ri][2],
+                                                      np.asarray(d[f"r{ri}_bpp"]).size, delta))
+        assert abs(bpp / ref[ri][0] - 1) < 0.05, (rate, bpp, ref[ri])
+        assert abs(delta) < 0.5, (rate, delta)
 
 
 def test_em_loop_trajectory_against_the_reference_fp32():

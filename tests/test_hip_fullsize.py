@@ -204,3 +204,29 @@ def test_whole_step_at_configs3_shard_size_captures_replays_and_stays_finite():
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     print("configs[3] shard: peak device memory %.1f GiB" % peak)
     assert peak < 200
+
+
+def test_forked_step_equals_one_stream_step_at_full_size():
+    """The captured step runs on three streams (PriorBNNmodel.stream_forks: the A transform's backward + the network level's
+    posterior update beside the upsampling net's backward, whose weight-gradient side has a stream of its own).  Same kernels
+    on the same operands, so the result must be BITWISE the one-stream step's -- at BASELINE configs[1] size with the
+    mappings trained, where a missing dependency or a buffer freed under a stream that still reads it shows (round 4: the
+    SIREN gradient, allocated on the main stream and read by the forked A transform, was released at the end of its scope
+    and overwritten by the upsampling net's backward: non-finite ELBO at 4096 INRs, invisible at 8)."""
+    from recombiner_amd import utils
+    steps, lr = 12, 2e-4
+    X, Y = utils.synthetic_inputs([32, 32], 16, N, 3, seed=0)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    outs = []
+    for forks in (0, 14, 14, 30):
+        cfg, m, lt, up, pri = _preset_model("cifar", N)
+        m.stream_forks, m.rng_seed_override = forks, 0xFACADE
+        mse, kl, elbo = m.train(steps, lr, Xd[None].expand(N, -1, -1), Yd, *pri, lt, up, 1e-8, training_mappings=True)
+        assert m._ws is not None and m._ws["graphs"] is not None
+        assert np.isfinite(elbo).all() and np.isfinite(mse) and np.isfinite(kl), (forks, elbo)
+        outs.append([torch.tensor(elbo), m.loc.detach().clone(), m.log_scale.detach().clone(), m.lpe_loc.detach().clone()]
+                    + [a.detach().clone() for a in lt.A] + [p.detach().clone() for p in up.parameters()])
+        del m, lt, up
+    for other in outs[1:]:
+        for a_, b_ in zip(outs[0], other):
+            assert torch.equal(a_, b_)
