@@ -33,6 +33,9 @@ extern "C" int rcb_debug_read_stamps(unsigned long long* dst, int n_entries) {
 #else
 #define RCB_STAMP(k) do { } while (0)
 #endif
+#ifndef RCB_SIREN_DEFER_WGRAD
+#define RCB_SIREN_DEFER_WGRAD 1     // 0: write and read the weight-gradient images of a layer back to back (rounds 1-3; A/B builds)
+#endif
 #ifndef RCB_W32_DIRECT_FRAGS
 #define RCB_W32_DIRECT_FRAGS 0      // 1: gather the fragments straight from global memory (measured slower: 0.265 vs 0.254 ms; A/B builds)
 #endif
@@ -73,8 +76,13 @@ struct Geo {
   static constexpr int TILE_OFF = FR_OFF + (NFA + NFB) * 1024;
   static constexpr int TSA = 32;                   // bufA row stride (bf16 elements), XOR-swizzled 8-byte chunks
   static constexpr int TSBB = 32 * NB0;            // bufB row stride
-  static constexpr int WAVE_TILE = 32 * (TSA + TSBB) * 2;   // bytes per wave
-  static constexpr int LDS_MAIN = TILE_OFF + 4 * WAVE_TILE;
+  static constexpr int WAVE_TILE = 32 * (TSA + TSBB) * 2;   // bytes per wave and image set
+  // TWO image sets per wave (RCB_SIREN_DEFER_WGRAD): layer l's [pixel][feature] images are written while layer l + 1's are read
+  // back transposed for its weight gradient -- the write -> read round trip through LDS then has a whole layer of other work
+  // in front of it instead of stalling the (in-order) wave twice per layer
+  // (one input block only: with two -- 34 inputs, the video geometry -- the extra fragments spill)
+  static constexpr int NSET = (RCB_SIREN_DEFER_WGRAD && NB0 == 1) ? 2 : 1;
+  static constexpr int LDS_MAIN = TILE_OFF + 4 * NSET * WAVE_TILE;
   // cross-wave reduction scratch: per wave, layer l stored [out][in] with row stride 33 (+ bias row)
   __host__ __device__ static constexpr int roff(int l) {
     int o = 0;
@@ -106,8 +114,11 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
 
   float* wl = smem;
   uint4* frags = reinterpret_cast<uint4*>(smem_raw + G::FR_OFF);
-  T* bufA = reinterpret_cast<T*>(smem_raw + G::TILE_OFF + wave * G::WAVE_TILE);
-  T* bufB = bufA + 32 * G::TSA;
+  T* bufA0 = reinterpret_cast<T*>(smem_raw + G::TILE_OFF + wave * G::NSET * G::WAVE_TILE);
+  T* bufB0 = bufA0 + 32 * G::TSA;
+  // image set of layer l: sets alternate between consecutive layers
+  auto bufA_of = [&](int l) -> T* { return bufA0 + (G::NSET == 2 ? (l & 1) * (G::WAVE_TILE / (int)sizeof(T)) : 0); };
+  auto bufB_of = [&](int l) -> T* { return bufB0 + (G::NSET == 2 ? (l & 1) * (G::WAVE_TILE / (int)sizeof(T)) : 0); };
 
   if (a.clock_probe != nullptr && blockIdx.x < 256 && tid == 0) {      // measurement aid: rcb_siren_desc.clock_probe
     a.clock_probe[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
@@ -128,7 +139,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     for (int l = 0; l < NL; ++l)
       if (tid < G::lout(l)) wl[G::off(l) + tid] = src[G::off(l) + tid] * (l < NH ? a.k_hi : 1.0f);
     if (32 * NB0 > IN0) {
-      for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
+      for (int p2 = 0; p2 < G::NSET; ++p2)
+        for (int i = lane; i < 32 * G::TSBB; i += 64) bufB_of(p2)[i] = (T)0.f;
     }
     RCB_STAMP(1);
 #else
@@ -150,7 +162,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       }
     }
     if (32 * NB0 > IN0) {
-      for (int i = lane; i < 32 * G::TSBB; i += 64) bufB[i] = (T)0.f;
+      for (int p2 = 0; p2 < G::NSET; ++p2)
+        for (int i = lane; i < 32 * G::TSBB; i += 64) bufB_of(p2)[i] = (T)0.f;
     }
     __syncthreads();
     RCB_STAMP(1);
@@ -226,6 +239,67 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
     for (int l = 0; l < NL; ++l) gb[l] = 0.f;
   }
   constexpr int KH0 = F, KH1 = E;
+
+  // ---- weight-gradient helpers (backward, per layer) --------------------------------------------------------------------
+  // images of layer l: dz (packed) into bufA, the layer's input (previous activations, or the tile's input features) into bufB
+  auto wg_write = [&](int l, const bf16x8 (&dzb)[2], const bf16x8 (*Sprev)[2], const bf16x8* xin_) __attribute__((always_inline)) {
+    T* bufA = bufA_of(l);
+    T* bufB = bufB_of(l);
+    const int q_ = lane & 31, h_ = lane >> 5;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    union { bf16x8 v; bf16x4 hlf[2]; } u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u.v = dzb[s];
+      *reinterpret_cast<bf16x4*>(bufA + swz(q_, 16 * s + 4 * h_, G::TSA)) = u.hlf[0];
+      *reinterpret_cast<bf16x4*>(bufA + swz(q_, 16 * s + 8 + 4 * h_, G::TSA)) = u.hlf[1];
+    }
+    if (l > 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u.v = Sprev[l - 1][s];
+        *reinterpret_cast<bf16x4*>(bufB + swz(q_, 16 * s + 4 * h_, G::TSBB)) = u.hlf[0];
+        *reinterpret_cast<bf16x4*>(bufB + swz(q_, 16 * s + 8 + 4 * h_, G::TSBB)) = u.hlf[1];
+      }
+    } else {
+      // input image: half-wave 0 holds features [0,F), half-wave 1 features [F, F+E)
+      const int base = (h_ == 0) ? 0 : F;
+      const int kh = (h_ == 0) ? F : E;
+#pragma unroll
+      for (int s = 0; s < K0S; ++s) {
+        union { bf16x8 v; bf16x2 pr[4]; bf16x4 hlf[2]; } x;
+        x.v = xin_[s];
+        if (F % 4 == 0 && E % 4 == 0) {
+          if (8 * s + 4 <= kh) *reinterpret_cast<bf16x4*>(bufB + swz(q_, base + 8 * s, G::TSBB)) = x.hlf[0];
+          if (8 * s + 8 <= kh) *reinterpret_cast<bf16x4*>(bufB + swz(q_, base + 8 * s + 4, G::TSBB)) = x.hlf[1];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j += 2)
+            if (8 * s + j + 1 < kh) *reinterpret_cast<bf16x2*>(bufB + swz(q_, base + 8 * s + j, G::TSBB)) = x.pr[j >> 1];
+        }
+      }
+    }
+  };
+  // transposed fragments of layer l's images
+  auto frag_read = [&](int l, bf16x8 (&av)[2], bf16x8 (&bv)[NB0][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) av[s] = read_tr<T>(bufA_of(l), G::TSA, s, lane, 0);
+#pragma unroll
+    for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bv[blk][s] = read_tr<T>(bufB_of(l), G::TSBB, s, lane, 32 * blk);
+  };
+  // dW_l += dz^T x input (contraction over the tile's 32 pixels: two k-steps), bias gradient from the transposed dz fragments
+  auto wg_mfma = [&](int l, const bf16x8 (&av)[2], const bf16x8 (&bv)[NB0][2]) __attribute__((always_inline)) {
+    gb[l] = sum8_16<T>(av[0], gb[l]);
+    gb[l] = sum8_16<T>(av[1], gb[l]);
+#pragma unroll
+    for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
+      const int gi = (l == 0) ? blk : (l + NB0 - 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) gW[gi] = Op16<T>::mfma(av[s], bv[blk][s], gW[gi]);
+    }
+  };
 
   const int ntiles = (P + 31) >> 5;
   constexpr bool VEC4 = (F % 4 == 0) && (E % 4 == 0) && (F % 8 == 0) && (E % 8 == 0);
@@ -434,6 +508,8 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       dz[r] = v;
     }
     // ---- backward ----------------------------------------------------------------------------------
+    constexpr bool DEFER = G::NSET == 2;
+    bf16x8 av_d[2], bv_d[NB0][2];          // deferred form: the fragments of the layer ABOVE, read at the top of an iteration
 #pragma unroll
     for (int l = NL - 1; l >= 0; --l) {
 #ifdef RCB_SIREN_STAMPS
@@ -454,6 +530,12 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
       } else {
         dzb[0] = pack8<T>(dz, 0);
         dzb[1] = pack8<T>(dz, 1);
+      }
+      if (DEFER && l < NL - 1) {
+        // layer l + 1's images were written an iteration ago: their transposed reads go out NOW, in front of this layer's
+        // data-gradient chain, and are consumed behind it
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        frag_read(l + 1, av_d, bv_d);
       }
       // (1) data gradient FIRST: dz -> dh -> dz of the next layer is the serial chain of the backward pass; the weight
       // gradient below (LDS transpose + MFMAs nothing waits for) then fills the latency of these MFMAs instead of delaying them
@@ -505,56 +587,23 @@ __global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
           }
         }
       }
-      // (2) weight gradient: [pixel][feature] images -> transposed reads (uses the packed copy dzb and the stored activations)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      {
-        union { bf16x8 v; bf16x4 hlf[2]; } u;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          u.v = dzb[s];
-          *reinterpret_cast<bf16x4*>(bufA + swz(q, 16 * s + 4 * h, G::TSA)) = u.hlf[0];
-          *reinterpret_cast<bf16x4*>(bufA + swz(q, 16 * s + 8 + 4 * h, G::TSA)) = u.hlf[1];
-        }
-        if (l > 0) {
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            u.v = S[l - 1][s];
-            *reinterpret_cast<bf16x4*>(bufB + swz(q, 16 * s + 4 * h, G::TSBB)) = u.hlf[0];
-            *reinterpret_cast<bf16x4*>(bufB + swz(q, 16 * s + 8 + 4 * h, G::TSBB)) = u.hlf[1];
-          }
-        } else {
-          // input image: half-wave 0 holds features [0,F), half-wave 1 features [F, F+E)
-          const int base = (h == 0) ? 0 : F;
-          const int kh = (h == 0) ? KH0 : KH1;
-#pragma unroll
-          for (int s = 0; s < K0S; ++s) {
-            union { bf16x8 v; bf16x2 pr[4]; bf16x4 hlf[2]; } x;
-            x.v = xin[s];
-            if (F % 4 == 0 && E % 4 == 0) {
-              if (8 * s + 4 <= kh) *reinterpret_cast<bf16x4*>(bufB + swz(q, base + 8 * s, G::TSBB)) = x.hlf[0];
-              if (8 * s + 8 <= kh) *reinterpret_cast<bf16x4*>(bufB + swz(q, base + 8 * s + 4, G::TSBB)) = x.hlf[1];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 8; j += 2)
-                if (8 * s + j + 1 < kh) *reinterpret_cast<bf16x2*>(bufB + swz(q, base + 8 * s + j, G::TSBB)) = x.pr[j >> 1];
-            }
-          }
-        }
+      // (2) weight gradient: [pixel][feature] images of dz and of the layer's input -> transposed reads -> 2 MFMAs per block.
+      // Deferred form: the images of layer l are WRITTEN here and read back one layer later (frag_read(l + 1) at the top of
+      // this iteration, its MFMAs behind the data-gradient chain), from the other image set.
+      wg_write(l, dzb, S, xin);
+      if (!DEFER) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        bf16x8 av[2], bv[NB0][2];
+        frag_read(l, av, bv);
+        wg_mfma(l, av, bv);
+      } else if (l < NL - 1) {
+        wg_mfma(l + 1, av_d, bv_d);
       }
+    }
+    if (DEFER) {                                        // layer 0's images: nothing left to overlap them with
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      {
-        bf16x8 av[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) av[s] = read_tr<T>(bufA, G::TSA, s, lane, 0);
-        gb[l] = sum8_16<T>(av[0], gb[l]);
-        gb[l] = sum8_16<T>(av[1], gb[l]);
-#pragma unroll
-        for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
-          const int gi = (l == 0) ? blk : (l + NB0 - 1);
-#pragma unroll
-          for (int s = 0; s < 2; ++s) gW[gi] = Op16<T>::mfma(av[s], read_tr<T>(bufB, G::TSBB, s, lane, 32 * blk), gW[gi]);
-        }
-      }
+      frag_read(0, av_d, bv_d);
+      wg_mfma(0, av_d, bv_d);
     }
   }
   if (MODE == MODE_FWD) return;
