@@ -790,7 +790,9 @@ def gen_rd_trained(out):
     # rd_trained_cifar_n64_r<0|1>.npz: the same experiment with 64 held-out images (the per-run mean is then a mean over four
     # times as many images), one rate per process so that the two rates run side by side
     only_rate = os.environ.get("RD_RATE")
-    fname = "rd_trained_cifar.npz" if (n_test == 16 and only_rate is None) else "rd_trained_cifar_n%d_r%s.npz" % (n_test, only_rate or "all")
+    seed0 = int(os.environ.get("RD_SEED0", "0"))     # first repetition index (more repetitions of an existing fixture: RD_SEED0=4 ...)
+    fname = "rd_trained_cifar.npz" if (n_test == 16 and only_rate is None) else "rd_trained_cifar_n%d_r%s%s.npz" % (
+        n_test, only_rate or "all", "" if seed0 == 0 else "_s%d" % seed0)
     n_iter, first_epochs, epochs, lr = 30, 200, 60, 1e-3
     n_opt, n_ft = 300, 4
     _, x = fourier_inputs(cfg["pixel_sizes"], cfg["fourier_dim"])
@@ -814,7 +816,7 @@ def gen_rd_trained(out):
         if only_rate is not None and ri != int(only_rate):
             continue
         acc = {k: [] for k in ("traj", "em_seed", "psnr_train", "n_groups", "bpp", "psnr_after_opt", "psnr")}
-        for si in range(n_seeds):
+        for si in range(seed0, seed0 + n_seeds):
             pm = build_prior(cfg, n_train, seed=42 + si)
             lt, up = build_maps(cfg, pm.dims)
             s0 = torch.nn.functional.softplus(torch.tensor(-2.0)) / 6
@@ -842,7 +844,7 @@ def gen_rd_trained(out):
                         pri[2] = pm.lpe_loc.clone().detach().mean(0)
                         pri[3] = ((pm.st(pm.lpe_log_scale.clone().detach()) ** 2).mean(0) + pm.lpe_loc.clone().detach().var(0)) ** 0.5
                     traj.append([kls, kl_beta, mse])
-                if si == 0:            # the noise stream of the first repetition is pinned (the fp32 test replays it)
+                if si == seed0:        # the noise stream of the first repetition is pinned (the fp32 test replays it)
                     d[f"r{ri}_noise_shapes"] = np.array(json.dumps([list(e.shape) for e in tap.log[:2]]))
                     d[f"r{ri}_noise_count"] = np.array(len(tap.log))
                     d[f"r{ri}_noise_first_stats"] = np.stack([stats(e) for e in tap.log[:2]])

@@ -85,6 +85,12 @@ extern "C" int rcb_softplus_scale(const float* log_scale, float* scale, int64_t 
 // test hook: 0 (default) = specialised kernels (flat 16-byte paths, LDS-staged gathers) where they apply;
 // 1 = always the generic kernels.  Lets the tests compare both on identical shapes.
 static int g_generic_only = 0;
+// workgroups per CU of the persistent posterior update (0 = one workgroup per 1024 elements, the form of rounds 1-3);
+// RCB_POSTERIOR_WG_PER_CU in the environment overrides the default at load time (same-box A/B)
+static int g_post_wg_per_cu = [] {
+  const char* e = getenv("RCB_POSTERIOR_WG_PER_CU");
+  return e ? atoi(e) : 8;
+}();
 extern "C" int rcb_debug_generic_kernels_only(int32_t on) {
   int old = g_generic_only;
   g_generic_only = on ? 1 : 0;
@@ -750,10 +756,15 @@ __global__ void __launch_bounds__(1024) posterior_staged_kernel(PostBwdArgs a) {
 // the flat arrays are); same per-element arithmetic, so the updated parameters are bit-identical.
 __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long long n_total) {
   const rcb_level_bwd& L = a.L;
-  const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // group of 4 consecutive elements
-  const long long base = i4 * 4;
-  const bool act = base < n_total;                                             // n_total % 4 == 0 on this path
-  const long long b = act ? base : 0;
+  // PERSISTENT grid-stride form (round 4): the launch is capped at a few workgroups per CU that walk the array, instead of one
+  // short-lived workgroup per 1024 elements.  Alone the kernel is as fast either way (HBM-bound); but it now runs BESIDE the
+  // upsampling net's backward on another stream, and 13 000 small workgroups flooding every free slot starved the large
+  // workgroups of the library GEMMs next to it (two 30 us GEMMs took 170 us each while the update ran).  A fixed, small
+  // footprint leaves the rest of every CU to the neighbours.
+  double kl = 0.0;
+  const float w = L.kl_scalar_dev ? mul_rn(L.kl_scalar, *L.kl_scalar_dev) : L.kl_scalar;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n_total; i4 += (long long)gridDim.x * blockDim.x) {
+  const long long b = i4 * 4;                                                  // n_total % 4 == 0 on this path
   // streaming accesses: everything here is read once and written once per step (900 MB against 256 MB of Infinity Cache).
   // Non-temporal loads / stores took the kernel from 93.6 to 86.3 us per launch (same box) and leave the sample written at
   // the end -- the next step's first operand -- a better chance to stay cached (with loc / log_scale non-temporal as well the
@@ -786,8 +797,6 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
   const float* gov = &go4.x; const float* epv = &ep4.x;
   float* m1v = &m14.x; float* v1v = &v14.x; float* m2v = &m24.x; float* v2v = &v24.x;
   int j = (int)(b % L.cols);
-  double kl = 0.0;
-  const float w = L.kl_scalar_dev ? mul_rn(L.kl_scalar, *L.kl_scalar_dev) : L.kl_scalar;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float loc = locv[k], ls = lsv[k];
@@ -805,15 +814,6 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     lsv[k] = ls;
     if (++j == L.cols) j = 0;
   }
-  if (L.kl_accum) {
-    __shared__ double s_kl[4];
-    const double kv = wave_sum(act ? kl : 0.0);
-    if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      fx_add_kl(L.kl_accum, blockIdx.x, (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
-  }
-  if (!act) return;
   RCB_ST4P(L.loc + b, loc4);
   RCB_ST4P(L.log_scale + b, ls4);
   RCB_ST4(L.m_loc + b, m14);
@@ -834,6 +834,15 @@ __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long
     if (L.next_out) reinterpret_cast<float4*>(L.next_out + b)[0] = o;
     if (L.next_out_bf16)
       store_planes_row4(reinterpret_cast<__bf16*>(L.next_out_bf16), reinterpret_cast<__bf16*>(L.next_out_lo), b, L.cols, L.next_ld_bf16, o);
+  }
+  }      // grid-stride loop
+  if (L.kl_accum) {      // one fixed-point contribution per workgroup (fixed grid for a given size: reproducible)
+    __shared__ double s_kl[4];
+    const double kv = wave_sum(kl);
+    if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      fx_add_kl(L.kl_accum, blockIdx.x, (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
   }
 #undef RCB_LD4
 #undef RCB_ST4
@@ -881,7 +890,17 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
       RCB_REQUIRE(!want_next || (lv->rng_step_dev && al16(lv->next_out) && al16(lv->next_eps) &&
                                  (lv->next_out || lv->next_out_lo) && (!lv->next_out_bf16 || lv->next_ld_bf16 >= lv->cols)),
                   RCB_ERR_ARG, "posterior_bwd: next sample: null pointer (fp32 next_out, or both planes), alignment or bf16 row stride");
-      posterior_flat_kernel<<<cdiv(n_total >> 2, 256), 256, 0, (hipStream_t)stream>>>(a, n_total);
+      // at most RCB_POSTERIOR_WG_PER_CU workgroups per CU (hipDeviceProp multiProcessorCount is read once per device)
+      static int n_cu[64] = {0};
+      int dev_id = 0;
+      (void)hipGetDevice(&dev_id);
+      if (dev_id >= 0 && dev_id < 64 && n_cu[dev_id] == 0) {
+        hipDeviceProp_t prop;
+        n_cu[dev_id] = (hipGetDeviceProperties(&prop, dev_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+      }
+      const long long want = cdiv(n_total >> 2, 256);
+      const long long cap = (long long)((dev_id >= 0 && dev_id < 64) ? n_cu[dev_id] : 256) * g_post_wg_per_cu;
+      posterior_flat_kernel<<<(int)(g_post_wg_per_cu > 0 && want > cap ? cap : want), 256, 0, (hipStream_t)stream>>>(a, n_total);
       RCB_LAUNCH_CHECK();
       return RCB_OK;
     }

@@ -1289,7 +1289,7 @@ class ATransform:
         ld = (self.cols + 31) // 32 * 32
         return torch.empty(rows, ld, device=self.device, dtype=f32)[:, :self.cols]
 
-    def wgrad(self, h_w, dw, h16=None, dw16=None, bf16_hi=True):
+    def wgrad(self, h_w, dw, h16=None, dw16=None, bf16_hi=True, part="all"):
         """dA[l] = h_w[:, lo:hi]^T @ dw[:, lo:hi], summed over the rows (INRs x samples).  With bf16_hi the widest layers
         (adjacent, one size, a multiple of 8) take bf16 operands in one batched GEMM with fp32 accumulation: the sum over
         thousands of rows averages the unbiased operand rounding down, unlike the per-row products of forward / dgrad.
@@ -1303,12 +1303,17 @@ class ATransform:
             dw16 = dw.hi
         if (hp or dp) and not bf16_hi:
             h_w, dw, hp, dp = (h_w.float() if hp else h_w), (dw.float() if dp else dw), False, False
+        # part: "all", or -- for callers that run the two halves on different streams -- "wide" (the batched GEMM of the widest
+        # layers: reads only the bf16 copies) / "rest" (everything else: reads the fp32 rows); entries of the other half are None
         out = [None] * len(self.sizes)
         big = max(self.sizes)
         wide = [i for i, n in enumerate(self.sizes) if n == big]
         adjacent = all(b == a + 1 for a, b in zip(wide, wide[1:]))
         rows = h_w.rows if hp else h_w.shape[0]
-        if bf16_hi and big >= 256 and big % 8 == 0 and adjacent and self.slices[wide[0]][0] % 8 == 0:
+        wide_ok = bool(bf16_hi and big >= 256 and big % 8 == 0 and adjacent and self.slices[wide[0]][0] % 8 == 0)
+        if part == "wide" and not wide_ok:
+            return out
+        if wide_ok and part != "rest":
             k, lo0 = len(wide), self.slices[wide[0]][0]
 
             def view(t16, t32):
@@ -1320,9 +1325,11 @@ class ATransform:
             g = torch.bmm(view(h16, h_w).transpose(1, 2), view(dw16, dw), out_dtype=f32)
             for j, i in enumerate(wide):
                 out[i] = g[j]
+        if part == "wide":
+            return out
         lib = _lib.load()
         for i, (lo, hi) in enumerate(self.slices):
-            if out[i] is not None:
+            if out[i] is not None or (part == "rest" and wide_ok and i in wide):
                 continue
             n = hi - lo
             if n <= 256:

@@ -400,6 +400,8 @@ class PriorBNNmodel(nn.Module):
             smp_net, smp_lpe = ws["smp_net"], ws["smp_lpe"]
         elif planes and "smp_net" not in ws:
             ws["smp_net"] = ops.sample_buffers(net[0], planes=True)
+        if fuse_next and not planes and "h16_next" not in ws and smp_net[2] is not None:
+            ws["h16_next"] = torch.empty_like(smp_net[2])
 
         def prime():
             """the sample of the call's first step (every later one comes out of the previous step's posterior update)"""
@@ -417,7 +419,8 @@ class PriorBNNmodel(nn.Module):
         #   1: the A transform's forward beside the upsampling net's forward;  2: the A transform's backward beside the
         #   upsampling net's backward;  4: the weight-gradient side of the upsampling net's backward beside its data path
         #   (upsample_fast.WEIGHT_SIDE_STREAM);  8: the network level's posterior update right behind the A transform's backward
-        #   on the forked stream (it only needs dh);  16: Adam on the mappings on the third stream beside the lpe level's update
+        #   on the forked stream (it only needs dh);  16: Adam on the mappings on the third stream beside the lpe level's update;
+        #   32 (with 2 and 8, one rank): that update right behind the data gradient, the wide weight-gradient GEMM on the third stream
         fork_mask = int(os.environ.get("RCB_FORK", str(self.stream_forks))) if dev.type == "cuda" else 0
         fork = side = None
         if fork_mask:
@@ -526,7 +529,27 @@ class PriorBNNmodel(nn.Module):
             # ---- backward through the A transform (first: its gradients are the bulk of the all-reduce bucket) -------
             gA = []
             fork_bwd = fork is not None and (fork_mask & 2) and split is not None and (flat is None or capture_coll) and fuse_next
-            if fork_bwd:      # the A transform's backward on the second stream beside the upsampling net's backward
+            early = bool(fork_bwd and (fork_mask & 32) and (fork_mask & 8) and flat is None and training_mappings and want16 and not planes
+                         and self.wgrad_bf16 and side is not None and h16 is not None and dw16 is not None)
+            if early:
+                # bit 32: the network level's posterior update as EARLY as possible -- right behind the data gradient -- so that
+                # this HBM-bound kernel runs beside the LDS / MFMA-bound upsampling backward instead of beside the step's last
+                # small GEMMs (measured: two 30 us GEMMs took 170 us each next to it).  What kept it late was a hazard: it
+                # writes the next step's sample over the buffers the weight gradient still reads.  The wide layers' GEMM
+                # (bf16 copies only) goes to the third stream and the update writes the next bf16 copy into a SECOND buffer,
+                # copied over at the end of the step (27 MB); the narrow layers' kernels (fp32 rows) run in front of the update.
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                fork.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    g_wide = split.wgrad(h_w, dw, h16, dw16, True, part="wide")
+                with torch.cuda.stream(fork):
+                    g_rest = split.wgrad(h_w, dw, h16, dw16, True, part="rest")
+                    dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
+                gA = [a_ if a_ is not None else b_ for a_, b_ in zip(g_wide, g_rest)]
+                st["fork_pending"] = st["early"] = True
+                st["fork_keep"] = (dw, dw16, h_w, h16)
+            elif fork_bwd:      # the A transform's backward on the second stream beside the upsampling net's backward
                 fork.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(fork):
                     dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
@@ -594,7 +617,10 @@ class PriorBNNmodel(nn.Module):
             # fused posterior update (also accumulates the pre-update KL for the ELBO log)
             nxt_net = None
             if fuse_next:            # the next step sees the noise counter + 1 (rcb_step_end increments it after this segment)
-                nxt_net = ops.NextSample((smp_net[0], smp_net[1], smp_net[2] if (want16 or planes) else None), rng_seed, 0, rng_ctr, 1,
+                o16_ = smp_net[2] if (want16 or planes) else None
+                if st.get("early"):                  # (bit 32: the next bf16 copy goes to the second buffer, see seg1a)
+                    o16_ = ws["h16_next"]
+                nxt_net = ops.NextSample((smp_net[0], smp_net[1], o16_), rng_seed, 0, rng_ctr, 1,
                                          redraw_eps=redraw, group_offset=goff_net)
             for lv, (pl, ps), e, stt in zip(net, net_priors, st["eps"], net_state):
                 ops.posterior_bwd(lv, pl, ps, False, 1.0, st["dh3"], e, 1, adam=cfg, state=stt, kl_accum=kl_slots,
@@ -639,6 +665,11 @@ class PriorBNNmodel(nn.Module):
                     with torch.cuda.stream(fork):      # the network level's update needs dh only: straight behind the A backward
                         seg2_net()
                 seg1b()
+                if st.pop("early", False):
+                    # join both streams, then the next step's bf16 copy moves into the buffer the step reads (see seg1a)
+                    torch.cuda.current_stream().wait_stream(fork)
+                    torch.cuda.current_stream().wait_stream(side)
+                    smp_net[2].copy_(ws["h16_next"])
                 ev = st.pop("ev_gA", None)
                 if pending and ev is not None and side is not None:
                     # bit 16: Adam on the mappings on the third stream (it needs the A gradients -- the event -- and the

@@ -201,10 +201,19 @@ def load_rd_fixture(n_test=64):
     if n_test == 16:
         return dict(np.load(os.path.join(GOLDEN, "rd_trained_cifar.npz"), allow_pickle=False))
     out = {}
+    import glob
     for ri in (0, 1):
-        d = np.load(os.path.join(GOLDEN, "rd_trained_cifar_n%d_r%d.npz" % (n_test, ri)), allow_pickle=False)
-        for k in d.files:
-            if k.startswith("r") and k[1].isdigit() and not k.startswith("r%d_" % ri):
-                continue
-            out[k] = d[k]
+        files = [os.path.join(GOLDEN, "rd_trained_cifar_n%d_r%d.npz" % (n_test, ri))]
+        files += sorted(glob.glob(os.path.join(GOLDEN, "rd_trained_cifar_n%d_r%d_s*.npz" % (n_test, ri))))     # further repetitions
+        for fi, f in enumerate(files):
+            d = np.load(f, allow_pickle=False)
+            for k in d.files:
+                if k.startswith("r") and k[1].isdigit() and not k.startswith("r%d_" % ri):
+                    continue
+                per_run = k.startswith("r%d_" % ri) and k.split("_", 1)[1] in ("traj", "em_seed", "psnr_train", "n_groups", "bpp",
+                                                                              "psnr_after_opt", "psnr")
+                if fi == 0 or k not in out:
+                    out[k] = d[k]
+                elif per_run:                      # repetitions of the same experiment: stacked along the run axis
+                    out[k] = np.concatenate([np.asarray(out[k]), np.asarray(d[k])], 0)
     return out
