@@ -85,11 +85,13 @@ extern "C" int rcb_softplus_scale(const float* log_scale, float* scale, int64_t 
 // test hook: 0 (default) = specialised kernels (flat 16-byte paths, LDS-staged gathers) where they apply;
 // 1 = always the generic kernels.  Lets the tests compare both on identical shapes.
 static int g_generic_only = 0;
-// workgroups per CU of the persistent posterior update (0 = one workgroup per 1024 elements, the form of rounds 1-3);
-// RCB_POSTERIOR_WG_PER_CU in the environment overrides the default at load time (same-box A/B)
+// workgroups per CU of the PERSISTENT form of the flat posterior update; 0 (default) = one workgroup per 1024 elements, the form
+// of rounds 1-3.  Measured (round 4, same-box, the forked step): 0 / 4 / 8 / 16 -> 1.087 / 1.086 / 1.091 / 1.089 ms per step,
+// i.e. nothing: capping the update's footprint does not protect the library GEMMs that run beside it.  RCB_POSTERIOR_WG_PER_CU
+// in the environment sets it at load time (A/B runs).
 static int g_post_wg_per_cu = [] {
   const char* e = getenv("RCB_POSTERIOR_WG_PER_CU");
-  return e ? atoi(e) : 8;
+  return e ? atoi(e) : 0;
 }();
 extern "C" int rcb_debug_generic_kernels_only(int32_t on) {
   int old = g_generic_only;
@@ -756,11 +758,8 @@ __global__ void __launch_bounds__(1024) posterior_staged_kernel(PostBwdArgs a) {
 // the flat arrays are); same per-element arithmetic, so the updated parameters are bit-identical.
 __global__ void __launch_bounds__(256) posterior_flat_kernel(PostBwdArgs a, long long n_total) {
   const rcb_level_bwd& L = a.L;
-  // PERSISTENT grid-stride form (round 4): the launch is capped at a few workgroups per CU that walk the array, instead of one
-  // short-lived workgroup per 1024 elements.  Alone the kernel is as fast either way (HBM-bound); but it now runs BESIDE the
-  // upsampling net's backward on another stream, and 13 000 small workgroups flooding every free slot starved the large
-  // workgroups of the library GEMMs next to it (two 30 us GEMMs took 170 us each while the update ran).  A fixed, small
-  // footprint leaves the rest of every CU to the neighbours.
+  // grid-stride form: with g_post_wg_per_cu > 0 the launch is capped at a few workgroups per CU that walk the array (an
+  // experiment of round 4, see g_post_wg_per_cu: no effect on the forked step); uncapped, every workgroup makes one trip
   double kl = 0.0;
   const float w = L.kl_scalar_dev ? mul_rn(L.kl_scalar, *L.kl_scalar_dev) : L.kl_scalar;
   for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n_total; i4 += (long long)gridDim.x * blockDim.x) {

@@ -138,7 +138,9 @@ class PriorBNNmodel(nn.Module):
         # the 4096-INR CIFAR step (gpurun_out r04_ab5): one stream 1.162 ms; A-transform backward beside the upsampling net's
         # backward (2) 1.125; + the net's weight-gradient side on a third stream (6) 1.109; + the network level's posterior
         # update (HBM-bound) straight behind the A backward, i.e. beside the LDS / MFMA-bound upsampling kernels (14) 1.089:
-        # -6.2 %.  The forward fork (1) gains nothing (7: 1.113).  Same kernels on the same operands: bit-identical results.
+        # -6.2 %.  The forward fork (1) gains nothing (7: 1.113); the update EARLIER, right behind the data gradient and beside
+        # the stage-3 / stage-2 backward kernels (32; needs a second bf16 sample buffer) LOSES 7 % (46: 1.152 vs 1.079): the
+        # HBM-bound update slows the LDS-bound kernels more than it gains.  Same kernels on the same operands: bit-identical.
         self.stream_forks = 14
         # measurement aid: take the SHARDED form of the step (four captured segments around two host-enqueued all-reduces)
         # even when `dp_group` has a single rank -- what the segmentation costs on the host, without a second GPU
