@@ -140,7 +140,8 @@ class PriorBNNmodel(nn.Module):
         # update (HBM-bound) straight behind the A backward, i.e. beside the LDS / MFMA-bound upsampling kernels (14) 1.089:
         # -6.2 %.  The forward fork (1) gains nothing (7: 1.113); the update EARLIER, right behind the data gradient and beside
         # the stage-3 / stage-2 backward kernels (32; needs a second bf16 sample buffer) LOSES 7 % (46: 1.152 vs 1.079): the
-        # HBM-bound update slows the LDS-bound kernels more than it gains.  Same kernels on the same operands: bit-identical.
+        # HBM-bound update slows the LDS-bound kernels more than it gains; the wide weight-gradient GEMM on the third stream with
+        # the update behind it and the data gradient (64) loses 2 % (78: 1.142 vs 1.116).  Same kernels, same operands: bit-identical.
         self.stream_forks = 14
         # measurement aid: take the SHARDED form of the step (four captured segments around two host-enqueued all-reduces)
         # even when `dp_group` has a single rank -- what the segmentation costs on the host, without a second GPU
@@ -422,7 +423,8 @@ class PriorBNNmodel(nn.Module):
         #   upsampling net's backward;  4: the weight-gradient side of the upsampling net's backward beside its data path
         #   (upsample_fast.WEIGHT_SIDE_STREAM);  8: the network level's posterior update right behind the A transform's backward
         #   on the forked stream (it only needs dh);  16: Adam on the mappings on the third stream beside the lpe level's update;
-        #   32 (with 2 and 8, one rank): that update right behind the data gradient, the wide weight-gradient GEMM on the third stream
+        #   32 (with 2 and 8, one rank): that update right behind the data gradient, the wide weight-gradient GEMM on the third stream;
+        #   64 (with 2 and 8, one rank): the wide GEMM on the third stream, the update behind it AND the data gradient
         fork_mask = int(os.environ.get("RCB_FORK", str(self.stream_forks))) if dev.type == "cuda" else 0
         fork = side = None
         if fork_mask:
@@ -533,7 +535,27 @@ class PriorBNNmodel(nn.Module):
             fork_bwd = fork is not None and (fork_mask & 2) and split is not None and (flat is None or capture_coll) and fuse_next
             early = bool(fork_bwd and (fork_mask & 32) and (fork_mask & 8) and flat is None and training_mappings and want16 and not planes
                          and self.wgrad_bf16 and side is not None and h16 is not None and dw16 is not None)
-            if early:
+            split_w = bool(fork_bwd and (fork_mask & 64) and not (fork_mask & 32) and (fork_mask & 8) and flat is None and training_mappings
+                           and want16 and not planes and self.wgrad_bf16 and side is not None and h16 is not None and dw16 is not None)
+            if split_w:
+                # bit 64: the wide layers' weight-gradient GEMM on the third stream right behind the SIREN kernel; the forked
+                # stream runs the narrow layers' kernels and the data gradient, then WAITS for that GEMM (it reads the bf16 sample
+                # the update overwrites) before the network level's posterior update: the update starts as soon as both are done
+                # instead of behind the GEMM on its own stream
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                fork.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    g_wide = split.wgrad(h_w, dw, h16, dw16, True, part="wide")
+                    st["ev_wide"] = torch.cuda.Event()
+                    st["ev_wide"].record(side)
+                with torch.cuda.stream(fork):
+                    g_rest = split.wgrad(h_w, dw, h16, dw16, True, part="rest")
+                    dh = split.dgrad(dw, torch.empty(N, D, device=dev, dtype=torch.float32))
+                gA = [a_ if a_ is not None else b_ for a_, b_ in zip(g_wide, g_rest)]
+                st["fork_pending"] = st["side_pending"] = True
+                st["fork_keep"] = (dw, dw16, h_w, h16)
+            elif early:
                 # bit 32: the network level's posterior update as EARLY as possible -- right behind the data gradient -- so that
                 # this HBM-bound kernel runs beside the LDS / MFMA-bound upsampling backward instead of beside the step's last
                 # small GEMMs (measured: two 30 us GEMMs took 170 us each next to it).  What kept it late was a hazard: it
@@ -665,8 +687,13 @@ class PriorBNNmodel(nn.Module):
                 pending = st.pop("fork_pending", False)
                 if pending and (fork_mask & 8):
                     with torch.cuda.stream(fork):      # the network level's update needs dh only: straight behind the A backward
+                        ev_w = st.pop("ev_wide", None)
+                        if ev_w is not None:
+                            fork.wait_event(ev_w)
                         seg2_net()
                 seg1b()
+                if st.pop("side_pending", False):
+                    torch.cuda.current_stream().wait_stream(side)
                 if st.pop("early", False):
                     # join both streams, then the next step's bf16 copy moves into the buffer the step reads (see seg1a)
                     torch.cuda.current_stream().wait_stream(fork)

@@ -218,7 +218,7 @@ def test_forked_step_equals_one_stream_step_at_full_size():
     X, Y = utils.synthetic_inputs([32, 32], 16, N, 3, seed=0)
     Xd, Yd = X.to(DEV), Y.to(DEV)
     outs = []
-    for forks in (0, 14, 14, 30, 46):
+    for forks in (0, 14, 14, 30, 46, 78):
         cfg, m, lt, up, pri = _preset_model("cifar", N)
         m.stream_forks, m.rng_seed_override = forks, 0xFACADE
         mse, kl, elbo = m.train(steps, lr, Xd[None].expand(N, -1, -1), Yd, *pri, lt, up, 1e-8, training_mappings=True)
