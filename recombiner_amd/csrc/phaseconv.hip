@@ -650,6 +650,125 @@ __global__ void __launch_bounds__(512) pc_wgrad_kernel(WgArgs p) {
   }
 }
 
+// 1-D grids (audio, protein): a tile of the kernel above is two MFMAs per wave between two barriers, four of the eight waves
+// have no (phase, tap) to work on, and every (mb, nb) block re-reads its operands -- at a rank's shard of the audio preset
+// (61 440 INRs) that ran at 1 TB/s.  Here a workgroup owns ALL of dWeff (4 combos x 64 x COUT: wave = (combo, input block),
+// both output blocks in its accumulators), so x and dy are read from memory exactly once, in whole 128- / 32-byte pixels;
+// TB consecutive tiles are staged per barrier, and the small footprint (two image sets) lets two or three workgroups share a
+// CU so that one's staging overlaps another's loads.  Same slab layout as above: the sum and the fold are shared.
+template <int COUT, int TB>
+__global__ void __launch_bounds__(512) pc_wgrad1d_kernel(WgArgs p) {
+  constexpr int NBLK = (COUT + 31) / 32, PWX = 34, NC = COUT / 8;           // NC: 16-byte chunks of a dy pixel
+  constexpr int XT = 2 * PWX * 4, DT = 2 * NBLK * 32 * 4;                    // uint4 per tile: x [mb][34][4], dy [phase][nb][32][4]
+  constexpr int XPT = PWX * 8, DPT = 64 * NC;                                // chunks fetched per tile
+  constexpr int NXC = TB * XPT, NDC = TB * DPT;
+  constexpr int NITX = (NXC + 511) / 512, NITD = (NDC + 511) / 512;
+  static_assert(512 % NC == 0, "a thread stages the same channels of dy in every pass (bias sums)");
+  extern __shared__ uint4 wg1d_smem[];
+  uint4* ximg = wg1d_smem;                     // [2][TB][XT]
+  uint4* dyimg = wg1d_smem + 2 * TB * XT;      // [2][TB][DT]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+  const int combo = wave >> 1, a = combo >> 1, t = combo & 1, mb = wave & 1;
+  const int gl = p.g0;
+  for (int e = threadIdx.x; e < 2 * TB * DT; e += 512) dyimg[e] = make_uint4(0, 0, 0, 0);     // (padding columns at COUT = 16 stay zero)
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  float dbsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
+  uint4 sx[NITX], sd[NITD];
+  auto fetch = [&](int st) {
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int tt = e / XPT, r = e - tt * XPT, tile = st * TB + tt;
+      if (e < NXC && tile < p.n_tiles) {
+        const int b = tile / p.tiles_per_row, sl = 32 * (tile - b * p.tiles_per_row) - 1 + (r >> 3);
+        if (sl >= 0 && sl < gl) v = reinterpret_cast<const uint4*>(p.x + ((long long)b * gl + sl) * CIN)[r & 7];
+      }
+      sx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int tt = e / DPT, r = e - tt * DPT, tile = st * TB + tt;
+      if (e < NDC && tile < p.n_tiles) {
+        const int b = tile / p.tiles_per_row, sl = 64 * (tile - b * p.tiles_per_row) + r / NC;
+        if (sl < 2 * gl) v = reinterpret_cast<const uint4*>(p.dy + ((long long)b * 2 * gl + sl) * COUT)[r % NC];
+      }
+      sd[it] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      const int tt = e / XPT, r = e - tt * XPT, pp = r >> 3, c8 = r & 7;
+      if (e < NXC) ximg[(buf * TB + tt) * XT + ((c8 >> 2) * PWX + pp) * 4 + (c8 & 3)] = sx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      const int tt = e / DPT, r = e - tt * DPT, d = r / NC, c = r % NC;
+      if (e < NDC) {
+        dyimg[(buf * TB + tt) * DT + (((d & 1) * NBLK + (c >> 2)) * 32 + (d >> 1)) * 4 + (c & 3)] = sd[it];
+        Frag f;
+        f.u = sd[it];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
+      }
+    }
+  };
+  const int n_st = (p.n_tiles + TB - 1) / TB;
+  int st = blockIdx.x, buf = 0;
+  if (st < n_st) fetch(st);
+  __syncthreads();                                 // zero-fill of the dy images is complete
+  if (st < n_st) stash(0);
+  __syncthreads();
+  for (; st < n_st; st += gridDim.x, buf ^= 1) {
+    const int next = st + gridDim.x;
+    if (next < n_st) fetch(next);
+#pragma unroll
+    for (int tt = 0; tt < TB; ++tt) {
+      const __bf16* xi = reinterpret_cast<const __bf16*>(ximg + (buf * TB + tt) * XT + mb * PWX * 4) + (a + t) * 32;
+      const __bf16* dyi = reinterpret_cast<const __bf16*>(dyimg + (buf * TB + tt) * DT + a * NBLK * 128);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 aop = tr_read_plain(xi, ks, lane);
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma16(aop, tr_read_plain(dyi + nb * 1024, ks, lane), acc[nb]);
+      }
+    }
+    if (next < n_st) stash(buf ^ 1);               // (buffer buf ^ 1 was last read before the previous barrier)
+    __syncthreads();
+  }
+  float* slab = p.partial + (long long)blockIdx.x * (2 * NBLK * 4 * 1024);
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(((mb * NBLK + nb) * 4 + combo) * 32 + rho(r, h)) * 32 + (lane & 31)] = acc[nb][r];
+  // bias partials: thread e stages the channels 8 (e % NC) .. + 7 in every chunk of dy it handles
+  float* red_sm = reinterpret_cast<float*>(wg1d_smem);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red_sm[threadIdx.x * 8 + j] = dbsum[j];
+  __syncthreads();
+  if (threadIdx.x < 8 * NC) {
+    const int c = threadIdx.x / 8, j = threadIdx.x % 8;
+    float sacc = 0.f;
+    for (int th = c; th < 512; th += NC) sacc += red_sm[th * 8 + j];          // fixed order: deterministic
+    p.bias_part[(long long)blockIdx.x * COUT + 8 * c + j] = sacc;
+  }
+}
+template <int COUT, int TB>
+constexpr int wg1d_lds_bytes() {
+  return 2 * TB * (2 * 34 * 4 + 2 * ((COUT + 31) / 32) * 32 * 4) * 16;
+}
+
 // sum of the slabs in a fixed order (one thread per element of dWeff, coalesced over the slabs) ...
 __global__ void __launch_bounds__(256) pc_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_part,
                                                               int n_slabs, long long slab_floats, int cout,
@@ -807,12 +926,15 @@ extern "C" int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, cons
 // over the slabs is what costs (128 slabs = 134 MB: 30 us): 64 there (wgrad 47 -> 39 us, sum 30 -> 15 us)
 constexpr int kWgSlotsMax = 128;
 __host__ constexpr int wg_slots(int cout) { return cout == 64 ? 64 : 128; }
+// 1-D grids (pc_wgrad1d_kernel): one 64 KB / 32 KB slab per workgroup, two workgroups per CU
+constexpr int kWg1dSlots = 512;
+constexpr int kWg1dTiles64 = 2, kWg1dTiles16 = 4;      // tiles staged per barrier (COUT = 64 / 16)
 
 extern "C" int64_t rcb_phaseconv_wgrad_workspace(int32_t nd, int32_t cout) {
   if (nd < 1 || nd > 3 || (cout != 16 && cout != 64)) return -1;
   const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
   const int64_t slab = (int64_t)ny * np * np * 1024;
-  return (int64_t)kWgSlotsMax * (slab + cout) + slab;
+  return (int64_t)(nd == 1 ? kWg1dSlots : kWgSlotsMax) * (slab + cout) + slab;
 }
 
 extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW, float* dbias, float* workspace,
@@ -826,8 +948,10 @@ extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW,
   RCB_REQUIRE(workspace_floats >= rcb_phaseconv_wgrad_workspace(nd, cout), RCB_ERR_SHAPE, "phaseconv_wgrad: workspace too small");
   const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
   const long long slab = (long long)ny * np * np * 1024;
-  const int kWgSlots = wg_slots(cout);
-  const int gx = pc.n_tiles < kWgSlots ? pc.n_tiles : kWgSlots;
+  const int tb1 = cout == 64 ? kWg1dTiles64 : kWg1dTiles16;
+  const int kWgSlots = nd == 1 ? kWg1dSlots : wg_slots(cout);
+  const int units = nd == 1 ? cdiv(pc.n_tiles, tb1) : pc.n_tiles;
+  const int gx = units < kWgSlots ? units : kWgSlots;
   WgArgs w;
   w.x = static_cast<const __bf16*>(x_act);
   w.dy = static_cast<const __bf16*>(dy);
@@ -850,7 +974,19 @@ extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW,
     pc_wgrad_reduce_kernel<<<cdiv(slab, 256), 256, 0, s>>>(w.partial, w.bias_part, gx, slab, cout, weff_sum, dbias); \
     pc_wgrad_fold_kernel<NDv><<<fin, 256, 0, s>>>(weff_sum, cout, dW);                                               \
   }
-  RCB_WG(1, 64) RCB_WG(1, 16) RCB_WG(2, 64) RCB_WG(2, 16) RCB_WG(3, 64) RCB_WG(3, 16)
+#define RCB_WG1(Cv, TBv)                                                                                             \
+  if (nd == 1 && cout == Cv) {                                                                                       \
+    constexpr int lds = wg1d_lds_bytes<Cv, TBv>();                                                                   \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pc_wgrad1d_kernel<Cv, TBv>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                             \
+    RCB_REQUIRE(e == hipSuccess, (int)e, "phaseconv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));          \
+    pc_wgrad1d_kernel<Cv, TBv><<<gx, 512, lds, s>>>(w);                                                              \
+    pc_wgrad_reduce_kernel<<<cdiv(slab, 256), 256, 0, s>>>(w.partial, w.bias_part, gx, slab, cout, weff_sum, dbias); \
+    pc_wgrad_fold_kernel<1><<<fin, 256, 0, s>>>(weff_sum, cout, dW);                                                 \
+  }
+  RCB_WG1(64, kWg1dTiles64) RCB_WG1(16, kWg1dTiles16)
+  RCB_WG(2, 64) RCB_WG(2, 16) RCB_WG(3, 64) RCB_WG(3, 16)
+#undef RCB_WG1
 #undef RCB_WG
   RCB_LAUNCH_CHECK();
   return RCB_OK;
