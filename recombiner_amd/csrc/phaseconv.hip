@@ -792,10 +792,32 @@ __global__ void __launch_bounds__(256) pc_wgrad_reduce_kernel(const float* __res
       for (int k = 0; k < st; ++k) sa[k] += sa[k + st];
     weff_sum[e] = sa[0];
   }
-  if (blockIdx.x == 0 && threadIdx.x < cout) {
-    float s = 0.f;
-    for (int gI = 0; gI < n_slabs; ++gI) s += bias_part[(long long)gI * cout + threadIdx.x];
-    db[threadIdx.x] = s;
+  // bias: 256 / cout threads per channel, each with eight loads in flight (a single chain over 512 partials cost ~100 us);
+  // fixed association: partial g -> (thread g % P, accumulator (g / P) % 8), accumulators pairwise, threads in index order
+  __shared__ float bias_sm[256];
+  if (blockIdx.x == 0) {
+    const int P = 256 / cout, part = threadIdx.x / cout, ch = threadIdx.x % cout;       // cout = 16 or 64
+    float sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sb[k] = 0.f;
+    for (int g0 = part; g0 < n_slabs; g0 += 8 * P) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int gI = g0 + k * P;
+        if (gI < n_slabs) sb[k] += bias_part[(long long)gI * cout + ch];
+      }
+    }
+#pragma unroll
+    for (int st = 4; st >= 1; st >>= 1)
+#pragma unroll
+      for (int k = 0; k < st; ++k) sb[k] += sb[k + st];
+    bias_sm[threadIdx.x] = sb[0];
+    __syncthreads();
+    if (threadIdx.x < cout) {
+      float s2 = 0.f;
+      for (int q = 0; q < P; ++q) s2 += bias_sm[q * cout + threadIdx.x];
+      db[threadIdx.x] = s2;
+    }
   }
 }
 
@@ -951,7 +973,8 @@ extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW,
   const int tb1 = cout == 64 ? kWg1dTiles64 : kWg1dTiles16;
   const int kWgSlots = nd == 1 ? kWg1dSlots : wg_slots(cout);
   const int units = nd == 1 ? cdiv(pc.n_tiles, tb1) : pc.n_tiles;
-  const int gx = units < kWgSlots ? units : kWgSlots;
+  int gx = units < kWgSlots ? units : kWgSlots;
+  if (nd == 1 && gx > cdiv(units, 4)) gx = cdiv(units, 4);      // at least four passes per workgroup: its slab is 64 KB
   WgArgs w;
   w.x = static_cast<const __bf16*>(x_act);
   w.dy = static_cast<const __bf16*>(dy);

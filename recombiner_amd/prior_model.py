@@ -380,11 +380,13 @@ class PriorBNNmodel(nn.Module):
         st = {}
         # in-kernel noise: a pure function of (seed, stream, counter, element); the counter lives in the workspace and is
         # never reset, so every step of every train() call draws fresh noise, replayed or not
-        use_rng = (self.fused_noise and self.noise_source is None and len(net) == 1 and ops.rng_eligible(net[0])
-                   and ops.rng_eligible(lpe_lv))
+        # (the lpe is a single plain level in every preset; the latent weights are one only without patches: the three-level
+        # presets keep stored noise for the weights and draw the lpe's -- two thirds of what they sample -- in the kernels)
+        rng_lpe = bool(self.fused_noise and self.noise_source is None and ops.rng_eligible(lpe_lv))
+        use_rng = rng_lpe and len(net) == 1 and ops.rng_eligible(net[0])
         rng_seed = ws["seed"] if self.rng_seed_override is None else int(self.rng_seed_override) & (2 ** 64 - 1)
         goff_net = ops.rng_group_offset(self.rng_row_offset, D) if use_rng else 0
-        goff_lpe = ops.rng_group_offset(self.rng_row_offset, self._d_lpe) if use_rng else 0
+        goff_lpe = ops.rng_group_offset(self.rng_row_offset, self._d_lpe) if rng_lpe else 0
 
         want16 = split is not None and training_mappings and self.wgrad_bf16     # bf16 operands of the weight gradient
         lpe16_want = bool(use_rng and self.stage1_bf16 and self.precision != 0 and not self.patch)
@@ -394,13 +396,19 @@ class PriorBNNmodel(nn.Module):
         # layers must start at multiples of 8 columns for the 16-byte LDS-DMA pieces)
         planes = bool(split is not None and use_rng and self.operand_planes
                       and all(lo % 8 == 0 for (lo, hi) in slices if (hi - lo) % 8 == 0))
+        fuse_lpe = bool(fuse_next or (rng_lpe and self.fuse_next_sample and (N * self._d_lpe) % 4 == 0))
         redraw = bool(fuse_next and self.redraw_noise)
+        redraw_lpe = bool(fuse_lpe and self.redraw_noise)
         smp_net = smp_lpe = None
         if fuse_next:
             if "smp_net" not in ws:
                 ws["smp_net"] = ops.sample_buffers(net[0], True, planes=planes, want_eps=not redraw)
                 ws["smp_lpe"] = ops.sample_buffers(lpe_lv, True, want_eps=not redraw)
             smp_net, smp_lpe = ws["smp_net"], ws["smp_lpe"]
+        elif fuse_lpe:
+            if "smp_lpe" not in ws:
+                ws["smp_lpe"] = ops.sample_buffers(lpe_lv, lpe16_want, want_eps=not redraw_lpe)
+            smp_lpe = ws["smp_lpe"]
         elif planes and "smp_net" not in ws:
             ws["smp_net"] = ops.sample_buffers(net[0], planes=True)
         if fuse_next and not planes and "h16_next" not in ws and smp_net[2] is not None:
@@ -408,7 +416,8 @@ class PriorBNNmodel(nn.Module):
 
         def prime():
             """the sample of the call's first step (every later one comes out of the previous step's posterior update)"""
-            ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=want16, buffers=smp_net, group_offset=goff_net)
+            if fuse_next:
+                ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, want_bf16=want16, buffers=smp_net, group_offset=goff_net)
             ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=lpe16_want, buffers=smp_lpe, group_offset=goff_lpe)
 
         pe_lay = self._pe_layout()
@@ -444,11 +453,11 @@ class PriorBNNmodel(nn.Module):
             def pe_forward():
                 # ---- sample ---------------------------------------------------------------------------------
                 lpe16 = None
-                if fuse_next:                # written by the previous step's posterior update (or by prime() before the first)
+                if fuse_lpe:                 # written by the previous step's posterior update (or by prime() before the first)
                     lpe, e_lpe, lpe16 = smp_lpe[0], smp_lpe[1], (smp_lpe[2][:, :lpe_lv.cols] if lpe16_want else None)
-                elif use_rng and lpe16_want:
+                elif rng_lpe and lpe16_want:
                     lpe, e_lpe, lpe16 = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, want_bf16=True, group_offset=goff_lpe)   # bf16 copy: stage-1 operand
-                elif use_rng:
+                elif rng_lpe:
                     lpe, e_lpe = ops.reparam_rng(lpe_lv, rng_seed, 1, rng_ctr, group_offset=goff_lpe)
                 else:
                     e_lpe = self._noise((N, 1, self._d_lpe))
@@ -652,9 +661,9 @@ class PriorBNNmodel(nn.Module):
 
         def seg2_lpe():
             nxt_lpe = None
-            if fuse_next:
+            if fuse_lpe:
                 nxt_lpe = ops.NextSample((smp_lpe[0], smp_lpe[1], smp_lpe[2] if lpe16_want else None), rng_seed, 1, rng_ctr, 1,
-                                         redraw_eps=redraw, group_offset=goff_lpe)
+                                         redraw_eps=redraw_lpe, group_offset=goff_lpe)
             ops.posterior_bwd(lpe_lv, pri_d[2].reshape(-1), pri_d[3].reshape(-1), False, 1.0, st["d_lpe"],
                               st["e_lpe"], 1, adam=cfg, state=lpe_state, kl_accum=kl_slots, kl_scalar_dev=beta_dev,
                               next_sample=nxt_lpe)
@@ -748,7 +757,7 @@ class PriorBNNmodel(nn.Module):
                     w1.wait()
                     gr[3].replay()
 
-        if fuse_next:
+        if fuse_lpe:
             prime()
         if graphable and (ws["graphs"] is not None or n_epoch > n_warm):
             left = n_epoch

@@ -484,6 +484,43 @@ def test_fused_next_sample_equals_separate_sampling_kernels():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["audio", "kodak"])
+def test_fused_next_lpe_sample_of_the_three_level_presets(name):
+    """Patch presets: the latent weights are three levels (stored noise), the lpe -- two thirds of what a step samples -- is one
+    plain level whose noise is drawn in the kernels; with fuse_next_sample its next sample comes out of its posterior update.
+    Bitwise the same training as with the per-step sampling kernel, eager and replayed."""
+    from recombiner_amd import config, utils
+    cfg = config.configs[name]
+    n = int(np.prod(cfg["patch_nums"]))
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, cfg["output_dim"], seed=2)
+    Xd, Yd = X.to(DEV)[None].expand(n, -1, -1), Y.to(DEV)
+    outs = []
+    for fuse in (True, False):
+        torch.manual_seed(77)
+        m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                             cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                             cfg["hierarchical_patch_nums"], random_seed=42, device=DEV)
+        m.precision = 1
+        m.fuse_next_sample = fuse
+        torch.manual_seed(123)
+        lt = PM.LinearTransform(m.dims).to(DEV)
+        torch.manual_seed(124)
+        up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+        D, s0, lat = m._d_net, 0.0211547, list(m.lpe_loc.shape[1:])
+        pri = [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV), torch.zeros(lat, device=DEV), torch.full(lat, s0, device=DEV)]
+        pri += [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV)] * 2
+        elbos = []
+        torch.manual_seed(5)                       # the weights' stored noise comes from torch's generator
+        for n_steps in (2, 7):
+            elbos += m.train(n_steps, 2e-4, Xd, Yd, *pri, lt, up, 1e-8, training_mappings=True)[2]
+        assert ("smp_lpe" in m._ws) == fuse and "smp_net" not in m._ws
+        outs.append([torch.tensor(elbos), m.loc.detach().clone(), m.h_loc.detach().clone(), m.lpe_loc.detach().clone(),
+                     m.lpe_log_scale.detach().clone()] + [p.detach().clone() for p in lt.parameters()])
+    assert np.isfinite(outs[0][0].numpy()).all()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name", ["patch1d", "patch2d", "patch3d", "cifar"])
 def test_map_hierarchical_model_to_int_weights_against_the_reference_function(name):
     """A5 as a callable with the reference's signature (utils.py:122-137): outputs of the reference function itself

@@ -9,8 +9,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recombiner_amd import ops
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 61440
-for g, cout in ((200, 64), (400, 16)):
+CASES = [(int(sys.argv[1]), 200, 64), (int(sys.argv[1]), 400, 16)] if len(sys.argv) > 1 else \
+    [(61440, 200, 64), (61440, 400, 16), (480, 200, 64), (480, 400, 16), (4096, 24, 64), (4096, 48, 16)]   # audio shard, 8 clips, protein
+for B, g, cout in CASES:
     torch.manual_seed(0)
     x = torch.randn(B, g, 64, device="cuda", dtype=torch.bfloat16)
     dy = torch.randn(B, 2 * g, cout, device="cuda", dtype=torch.bfloat16) * 0.1
