@@ -87,7 +87,7 @@ def test_rd_points_of_a_product_trained_prior():
 
 
 def test_rd_points_with_64_held_out_images():
-    """The same comparison with statistical power (round 4): the reference compressed 64 held-out images per run (four runs per
+    """The same comparison with statistical power (round 4): the reference compressed 64 held-out images per run (eight runs per
     rate; rd_trained_cifar_n64_r*.npz), the product does six runs per rate.  A run's mean PSNR now averages 64 images, the
     product's mean 384: the difference of means at matched rate is held to 0.5 dB and the rate to 5 %; both are printed."""
     d, cfg, X, Ytr, Yte, sched = _rd_fixture(64)
