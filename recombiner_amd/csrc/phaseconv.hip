@@ -172,9 +172,11 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
   const int gl = g[ND - 1];
   const int groups_per_row = (p.tiles_per_row + TPB - 1) / TPB;
   const int n_groups = (p.n_tiles / p.tiles_per_row) * groups_per_row;
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    int rest = grp / groups_per_row;
-    const int tg = grp - rest * groups_per_row;
+  // the source rows of group n + 1 travel from memory while group n is multiplied (registers stg: free once stored to LDS)
+  uint4 stg[NIT];
+  auto fetch = [&](int grp_) {
+    int rest = grp_ / groups_per_row;
+    const int l0 = 32 * TPB * (grp_ - rest * groups_per_row);      // first pixel of the group along the last active axis
     int lead[3] = {0, 0, 0};
 #pragma unroll
     for (int ax = ND - 2; ax >= 0; --ax) {
@@ -182,9 +184,6 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
       rest /= g[ax];
     }
     const int b = rest;
-    const int l0 = 32 * TPB * tg;                 // first pixel of the group along the last active axis
-    // ---- stage the shared source rows (all loads first, then the LDS stores) ------------------------------------------
-    uint4 stg[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = threadIdx.x + 512 * it;
@@ -208,6 +207,18 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
       }
       stg[it] = v;
     }
+  };
+  if ((int)blockIdx.x < n_groups) fetch(blockIdx.x);
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    int rest = grp / groups_per_row;
+    const int tg = grp - rest * groups_per_row;
+    int lead[3] = {0, 0, 0};
+#pragma unroll
+    for (int ax = ND - 2; ax >= 0; --ax) {
+      lead[ax] = rest % g[ax];
+      rest /= g[ax];
+    }
+    const int b = rest;
     __syncthreads();                               // every wave is done reading the previous group's image
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -218,6 +229,7 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
       }
     }
     __syncthreads();
+    if (grp + (int)gridDim.x < n_groups) fetch(grp + gridDim.x);
     // ---- this wave's phase of its tile -----------------------------------------------------------------------------------
     const int ts = tg * TPB + tsub;
     if (ts >= p.tiles_per_row) continue;           // (no barrier below this point inside the iteration)
