@@ -781,6 +781,147 @@ constexpr int wg1d_lds_bytes() {
   return 2 * TB * (2 * 34 * 4 + 2 * ((COUT + 31) / 32) * 32 * 4) * 16;
 }
 
+// 2-D grids (stitched photos): the same idea.  A workgroup owns all of dWeff (16 combos x 64 x COUT: wave = (phase, tap pair),
+// both input blocks and all output blocks in its accumulators), so dy is read from memory once and x in whole pixels; a pass
+// covers TB VERTICALLY adjacent tiles, which share their source rows (TB + 2 instead of 3 TB rows staged), and costs one barrier.
+template <int COUT, int TB>
+__global__ void __launch_bounds__(512) pc_wgrad2d_kernel(WgArgs p) {
+  constexpr int NBLK = (COUT + 31) / 32, PWX = 34, NC = COUT / 8, XR = TB + 2;
+  constexpr int XT = 2 * XR * PWX * 4;                         // uint4 of the x images of a pass: [mb][row][34][4]
+  constexpr int DT = 4 * NBLK * 32 * 4;                        // dy images of one tile: [phase][nb][32][4]
+  constexpr int NXC = XR * PWX * 8, DPT = 2 * 64 * NC, NDC = TB * DPT;
+  constexpr int NITX = (NXC + 511) / 512, NITD = (NDC + 511) / 512;
+  static_assert(512 % NC == 0, "a thread stages the same channels of dy in every pass (bias sums)");
+  extern __shared__ uint4 wg2d_smem[];
+  uint4* ximg = wg2d_smem;                     // [2][XT]
+  uint4* dyimg = wg2d_smem + 2 * XT;           // [2][TB][DT]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+  const int a = wave >> 1, tgp = wave & 1, ay = a >> 1, ax = a & 1;
+  const int g0 = p.g0, gl = p.g1;
+  const int n_rb = (g0 + TB - 1) / TB, per_b = n_rb * p.tiles_per_row;
+  const int n_st = p.B * per_b;
+  for (int e = threadIdx.x; e < 2 * TB * DT; e += 512) dyimg[e] = make_uint4(0, 0, 0, 0);     // (padding columns at COUT = 16 stay zero)
+  f32x16 acc[2][2][NBLK];                      // [tap of the pair][input block][output block]
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NBLK; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][m][n][r] = 0.f;
+  float dbsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
+  uint4 sx[NITX], sd[NITD];
+  auto fetch = [&](int st) {
+    const int b = st / per_b, rem = st - b * per_b, rb = rem / p.tiles_per_row, l0 = 32 * (rem - rb * p.tiles_per_row);
+    const int r0 = rb * TB;
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < NXC) {
+        const int c8 = e & 7, pp = (e >> 3) % PWX, j = (e >> 3) / PWX;
+        const int s0 = r0 - 1 + j, sl = l0 - 1 + pp;
+        if (s0 >= 0 && s0 < g0 && sl >= 0 && sl < gl) v = reinterpret_cast<const uint4*>(p.x + (((long long)b * g0 + s0) * gl + sl) * CIN)[c8];
+      }
+      sx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < NDC) {
+        const int tt = e / DPT, r = e - tt * DPT, c = r % NC, d = (r / NC) & 63, rr = r / (NC * 64);
+        const int row = r0 + tt, sl = 2 * l0 + d;
+        if (row < g0 && sl < 2 * gl)
+          v = reinterpret_cast<const uint4*>(p.dy + (((long long)b * 2 * g0 + 2 * row + rr) * (2 * gl) + sl) * COUT)[c];
+      }
+      sd[it] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      if (e < NXC) {
+        const int c8 = e & 7, pix = e >> 3;                   // pix = row * 34 + pixel
+        ximg[buf * XT + ((c8 >> 2) * XR * PWX + pix) * 4 + (c8 & 3)] = sx[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int e = threadIdx.x + 512 * it;
+      if (e < NDC) {
+        const int tt = e / DPT, r = e - tt * DPT, c = r % NC, d = (r / NC) & 63, rr = r / (NC * 64);
+        dyimg[(buf * TB + tt) * DT + (((rr * 2 + (d & 1)) * NBLK + (c >> 2)) * 32 + (d >> 1)) * 4 + (c & 3)] = sd[it];
+        Frag f;
+        f.u = sd[it];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbsum[j] += (float)f.v[j];
+      }
+    }
+  };
+  int st = blockIdx.x, buf = 0;
+  if (st < n_st) fetch(st);
+  __syncthreads();                                 // zero-fill of the dy images is complete
+  if (st < n_st) stash(0);
+  __syncthreads();
+  for (; st < n_st; st += gridDim.x, buf ^= 1) {
+    const int next = st + gridDim.x;
+    if (next < n_st) fetch(next);
+#pragma unroll
+    for (int tt = 0; tt < TB; ++tt) {
+      const __bf16* dyi = reinterpret_cast<const __bf16*>(dyimg + (buf * TB + tt) * DT + a * NBLK * 128);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 bop[NBLK];
+#pragma unroll
+        for (int n = 0; n < NBLK; ++n) bop[n] = tr_read_plain(dyi + n * 1024, ks, lane);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int t = tgp * 2 + k, row = tt + ay + (t >> 1), sl = ax + (t & 1);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const __bf16* xi = reinterpret_cast<const __bf16*>(ximg + buf * XT + ((m * XR + row) * PWX + sl) * 4);
+            const bf16x8 aop = tr_read_plain(xi, ks, lane);
+#pragma unroll
+            for (int n = 0; n < NBLK; ++n) acc[k][m][n] = mfma16(aop, bop[n], acc[k][m][n]);
+          }
+        }
+      }
+    }
+    if (next < n_st) stash(buf ^ 1);               // (buffer buf ^ 1 was last read before the previous barrier)
+    __syncthreads();
+  }
+  float* slab = p.partial + (long long)blockIdx.x * (2 * NBLK * 16 * 1024);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NBLK; ++n) {
+        const int combo = a * 4 + tgp * 2 + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(((m * NBLK + n) * 16 + combo) * 32 + rho(r, h)) * 32 + (lane & 31)] = acc[k][m][n][r];
+      }
+  float* red_sm = reinterpret_cast<float*>(wg2d_smem);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red_sm[threadIdx.x * 8 + j] = dbsum[j];
+  __syncthreads();
+  if (threadIdx.x < 8 * NC) {
+    const int c = threadIdx.x / 8, j = threadIdx.x % 8;
+    float sacc = 0.f;
+    for (int th = c; th < 512; th += NC) sacc += red_sm[th * 8 + j];          // fixed order: deterministic
+    p.bias_part[(long long)blockIdx.x * COUT + 8 * c + j] = sacc;
+  }
+}
+template <int COUT, int TB>
+constexpr int wg2d_lds_bytes() {
+  return 2 * (2 * (TB + 2) * 34 * 4 + TB * 4 * ((COUT + 31) / 32) * 32 * 4) * 16;
+}
+
 // sum of the slabs in a fixed order (one thread per element of dWeff, coalesced over the slabs) ...
 __global__ void __launch_bounds__(256) pc_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_part,
                                                               int n_slabs, long long slab_floats, int cout,
@@ -963,12 +1104,15 @@ __host__ constexpr int wg_slots(int cout) { return cout == 64 ? 64 : 128; }
 // 1-D grids (pc_wgrad1d_kernel): one 64 KB / 32 KB slab per workgroup, two workgroups per CU
 constexpr int kWg1dSlots = 512;
 constexpr int kWg1dTiles64 = 2, kWg1dTiles16 = 4;      // tiles staged per barrier (COUT = 64 / 16)
+// 2-D grids (pc_wgrad2d_kernel): one workgroup per CU (100 / 118 KB of images), slabs of 256 / 128 KB
+constexpr int kWg2dSlots = 256;
+constexpr int kWg2dTiles64 = 2, kWg2dTiles16 = 4;      // vertically adjacent tiles per pass
 
 extern "C" int64_t rcb_phaseconv_wgrad_workspace(int32_t nd, int32_t cout) {
   if (nd < 1 || nd > 3 || (cout != 16 && cout != 64)) return -1;
   const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
   const int64_t slab = (int64_t)ny * np * np * 1024;
-  return (int64_t)(nd == 1 ? kWg1dSlots : kWgSlotsMax) * (slab + cout) + slab;
+  return (int64_t)(nd == 1 ? kWg1dSlots : (nd == 2 ? kWg2dSlots : kWgSlotsMax)) * (slab + cout) + slab;
 }
 
 extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW, float* dbias, float* workspace,
@@ -982,11 +1126,11 @@ extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW,
   RCB_REQUIRE(workspace_floats >= rcb_phaseconv_wgrad_workspace(nd, cout), RCB_ERR_SHAPE, "phaseconv_wgrad: workspace too small");
   const int np = 1 << nd, ny = 2 * ((cout + 31) / 32);
   const long long slab = (long long)ny * np * np * 1024;
-  const int tb1 = cout == 64 ? kWg1dTiles64 : kWg1dTiles16;
-  const int kWgSlots = nd == 1 ? kWg1dSlots : wg_slots(cout);
-  const int units = nd == 1 ? cdiv(pc.n_tiles, tb1) : pc.n_tiles;
+  const int tb1 = cout == 64 ? kWg1dTiles64 : kWg1dTiles16, tb2 = cout == 64 ? kWg2dTiles64 : kWg2dTiles16;
+  const int kWgSlots = nd == 1 ? kWg1dSlots : (nd == 2 ? kWg2dSlots : wg_slots(cout));
+  const int units = nd == 1 ? cdiv(pc.n_tiles, tb1) : (nd == 2 ? B * cdiv(g0, tb2) * pc.tiles_per_row : pc.n_tiles);
   int gx = units < kWgSlots ? units : kWgSlots;
-  if (nd == 1 && gx > cdiv(units, 4)) gx = cdiv(units, 4);      // at least four passes per workgroup: its slab is 64 KB
+  if (nd <= 2 && gx > cdiv(units, 4)) gx = cdiv(units, 4);      // at least four passes per workgroup: its slab is 64 ... 256 KB
   WgArgs w;
   w.x = static_cast<const __bf16*>(x_act);
   w.dy = static_cast<const __bf16*>(dy);
@@ -1020,7 +1164,19 @@ extern "C" int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW,
     pc_wgrad_fold_kernel<1><<<fin, 256, 0, s>>>(weff_sum, cout, dW);                                                 \
   }
   RCB_WG1(64, kWg1dTiles64) RCB_WG1(16, kWg1dTiles16)
-  RCB_WG(2, 64) RCB_WG(2, 16) RCB_WG(3, 64) RCB_WG(3, 16)
+#define RCB_WG2(Cv, TBv)                                                                                             \
+  if (nd == 2 && cout == Cv) {                                                                                       \
+    constexpr int lds = wg2d_lds_bytes<Cv, TBv>();                                                                   \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pc_wgrad2d_kernel<Cv, TBv>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                             \
+    RCB_REQUIRE(e == hipSuccess, (int)e, "phaseconv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));          \
+    pc_wgrad2d_kernel<Cv, TBv><<<gx, 512, lds, s>>>(w);                                                              \
+    pc_wgrad_reduce_kernel<<<cdiv(slab, 256), 256, 0, s>>>(w.partial, w.bias_part, gx, slab, cout, weff_sum, dbias); \
+    pc_wgrad_fold_kernel<2><<<fin, 256, 0, s>>>(weff_sum, cout, dW);                                                 \
+  }
+  RCB_WG2(64, kWg2dTiles64) RCB_WG2(16, kWg2dTiles16)
+  RCB_WG(3, 64) RCB_WG(3, 16)
+#undef RCB_WG2
 #undef RCB_WG1
 #undef RCB_WG
   RCB_LAUNCH_CHECK();

@@ -425,7 +425,8 @@ def _stage_ref(x, W, b, nd, leaky):
 
 @pytest.mark.parametrize("shape,cout,leaky", [((3, 70), 64, True), ((2, 45), 16, False), ((2, 5, 33), 64, True), ((2, 3, 4, 40), 64, True),
                                               ((1, 2, 3, 32), 16, False), ((2, 6, 32, 32), 64, True),
-                                              ((300, 200), 64, True), ((211, 400), 16, False)])    # audio stages: every workgroup walks
+                                              ((300, 200), 64, True), ((211, 400), 16, False),     # audio stages: every workgroup walks
+                                              ((3, 9, 70), 16, False), ((5, 37, 96), 64, True), ((2, 64, 40), 16, False)])   # 2-D: ragged row blocks
 def test_phaseconv_forward_and_data_gradient(shape, cout, leaky):
     """rcb_phaseconv_fwd / _dgrad on 1-D, 2-D and 3-D grids (ragged last tiles, borders on every axis) against the stage
     as the reference defines it (nearest-upsample + ConvNd, fp64) evaluated on the same bf16-rounded operands: what differs
