@@ -309,24 +309,28 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc = mfma16(wf[t][c], f[c].v, acc);
     }
-    if (il >= gl) continue;
     long long oo = b;
 #pragma unroll
     for (int ax = 0; ax < ND - 1; ++ax) oo = oo * (2 * g[ax]) + 2 * lead[ax] + ((a >> (ND - 1 - ax)) & 1);
     oo = oo * (2 * gl) + 2 * il + (a & 1);
-    __bf16* dst = p.y + oo * COUT + 32 * mb + 4 * h;
+    // the lane halves swap (v_permlane32_swap: every lane takes part, the bounds check comes after) so that lane (q, h) owns
+    // the 16 consecutive channels 32 mb + 16 h .. + 15 of its pixel: two 16-byte stores instead of four 8-byte pieces
+    uint4* dst = reinterpret_cast<uint4*>(p.y + oo * COUT + 32 * mb + 16 * h);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      if (32 * mb + 8 * g4 < COUT) {
-        bf16x4 ob;
+    for (int hf = 0; hf < 2; ++hf) {
+      Frag ob;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float v = acc[4 * g4 + k];
-          if (ACT) v = v > 0.f ? v : v * SLOPE;
-          ob[k] = (__bf16)v;
+      for (int k = 0; k < 4; ++k) {
+        float v0 = acc[4 * hf + k], v1 = acc[8 + 4 * hf + k];
+        if (ACT) {
+          v0 = v0 > 0.f ? v0 : v0 * SLOPE;
+          v1 = v1 > 0.f ? v1 : v1 * SLOPE;
         }
-        *reinterpret_cast<bf16x4*>(dst + 8 * g4) = ob;
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+        ob.v[k] = (__bf16)__uint_as_float(sw[0]);
+        ob.v[4 + k] = (__bf16)__uint_as_float(sw[1]);
       }
+      if (il < gl) dst[hf] = ob.u;
     }
   }
 }
@@ -459,24 +463,37 @@ __global__ void __launch_bounds__(256) pc_dgrad_kernel(PcArgs p) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int tile = grp * 4 + 2 * pair + k;
-      if (tile >= p.n_tiles) continue;
+      if (tile >= p.n_tiles) continue;               // (uniform over the wave)
       int rest = tile / p.tiles_per_row;
       const int il = 32 * (tile - rest * p.tiles_per_row) + q;
-      if (il >= gl) continue;
+      // the lane halves swap (v_permlane32_swap) so that lane (q, h) owns the 16 consecutive channels 32 mb + 16 h .. + 15 of its
+      // pixel: two 16-byte loads of the stored activation and two 16-byte stores instead of four 8-byte pieces each
       // rest = flattened (batch, leading indices): exactly the row index of dx
-      const long long e0 = ((long long)rest * gl + il) * CIN + 32 * mb + 4 * h;
+      const long long e0 = ((long long)rest * gl + il) * CIN + 32 * mb + 16 * h;
+      const bool on = il < gl;
+      Frag xa[2];
+      if (p.xact && on) {
+        xa[0].u = reinterpret_cast<const uint4*>(p.xact + e0)[0];
+        xa[1].u = reinterpret_cast<const uint4*>(p.xact + e0)[1];
+      }
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 ob;
-        bf16x4 xa;
-        if (p.xact) xa = *reinterpret_cast<const bf16x4*>(p.xact + e0 + 8 * g4);
+      for (int hf = 0; hf < 2; ++hf) {
+        float o[8];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          float v = acc[k][4 * g4 + kk];
-          if (p.xact) v *= ((float)xa[kk] > 0.f ? 1.0f : SLOPE);
-          ob[kk] = (__bf16)v;
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[k][4 * hf + kk]), __float_as_uint(acc[k][8 + 4 * hf + kk]),
+                                                     false, false);
+          o[kk] = __uint_as_float(sw[0]);
+          o[4 + kk] = __uint_as_float(sw[1]);
         }
-        *reinterpret_cast<bf16x4*>(p.y + e0 + 8 * g4) = ob;
+        Frag ob;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          float v = o[kk];
+          if (p.xact) v *= ((float)xa[hf].v[kk] > 0.f ? 1.0f : SLOPE);
+          ob.v[kk] = (__bf16)v;
+        }
+        if (on) reinterpret_cast<uint4*>(p.y + e0)[hf] = ob.u;
       }
     }
   }
