@@ -156,6 +156,46 @@ __global__ void reparam_fwd_kernel(ReparamArgs a) {
   }
 }
 
+// Training samples of the patched presets: two or three plain levels (level 0 one row per INR, the coarser ones behind row
+// maps), one sample, every column produced.  Flat over the [n_inr * cols] arrays with 16-byte accesses like reparam_flat_kernel
+// (the generic kernel's one thread per element ran at 2.3 TB/s at a rank's shard of the audio preset); the coarse levels'
+// parameters are a few rows that stay cached.  Same operations in the same order as the generic kernel: bit-identical.
+__global__ void __launch_bounds__(256) reparam_hier_flat_kernel(ReparamArgs a, long long n_total) {
+  const int D = a.out_cols;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n_total; i4 += stride) {
+    const long long b = i4 * 4;
+    const float4 m4 = reinterpret_cast<const float4*>(a.lv[0].loc + b)[0];
+    const float4 l4 = reinterpret_cast<const float4*>(a.lv[0].log_scale + b)[0];
+    float4 e4[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+      if (l < a.n_levels) e4[l] = reinterpret_cast<const float4*>(a.lv[l].eps + b)[0];
+    int n = (int)(b / D), d = (int)(b - (long long)n * D);
+    float o[4];
+    const float* mv = &m4.x;
+    const float* lv = &l4.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float acc = add_rn(mv[k], mul_rn(st_f32(lv[k]), (&e4[0].x)[k]));
+#pragma unroll
+      for (int l = 1; l < 3; ++l) {
+        if (l < a.n_levels) {
+          const rcb_level& L = a.lv[l];
+          const long long off = (long long)(L.row_map ? L.row_map[n] : n) * D + d;
+          acc = add_rn(acc, add_rn(L.loc[off], mul_rn(st_f32(L.log_scale[off]), (&e4[l].x)[k])));
+        }
+      }
+      o[k] = acc;
+      if (++d == D) {
+        d = 0;
+        ++n;
+      }
+    }
+    reinterpret_cast<float4*>(a.out + b)[0] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // Test-time layout (parameters stored in group order, read back through a column map): mu / sigma gathers are
 // scattered 4-byte reads, i.e. a 64-byte sector each.  One block per INR stages that INR's parameter rows in LDS with
 // coalesced loads and does the permuted reads there.  One level, no row maps.  Same arithmetic as the generic kernel.
@@ -418,6 +458,23 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
     reparam_staged_kernel<<<n_inr, 1024, (size_t)a.lv[0].cols * 16, (hipStream_t)stream>>>(a);
     RCB_LAUNCH_CHECK();
     return RCB_OK;
+  }
+  {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    bool plain = !g_generic_only && n_levels >= 2 && samples == 1 && ((long long)n_inr * out_cols) % 4 == 0 && al16(out) &&
+                 !a.lv[0].row_map && a.lv[0].rows == n_inr && al16(a.lv[0].loc) && al16(a.lv[0].log_scale);
+    for (int l = 0; l < n_levels && plain; ++l) {
+      const rcb_level& L = a.lv[l];
+      plain = !L.enc_mask && !L.row_perm && !L.col_map && !L.scale_is_sigma && L.cols == out_cols && L.cols_out == out_cols && al16(L.eps);
+    }
+    if (plain) {
+      const long long n = (long long)n_inr * out_cols;
+      int blocks = cdiv(n >> 2, 256);
+      if (blocks > 16384) blocks = 16384;
+      reparam_hier_flat_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, n);
+      RCB_LAUNCH_CHECK();
+      return RCB_OK;
+    }
   }
   dim3 grid(n_inr, cdiv(out_cols, 256));
   RCB_REQUIRE(grid.y <= 65535, RCB_ERR_SHAPE, "reparam_fwd: too many columns");
