@@ -24,7 +24,7 @@ extern "C" {
 /* major * 100 + minor; bumped with every change of a signature or of a structure layout (100: rounds 1-3; 400: round 4 --
  * rcb_level.scale_is_sigma, rcb_struct_bytes, the hi / lo operand planes of the A transform).  A binding compares
  * rcb_version() with the RCB_VERSION it was written against and rcb_struct_bytes() with the size of each of its mirrors. */
-#define RCB_VERSION 400
+#define RCB_VERSION 401
 #define RCB_OK 0
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
@@ -550,6 +550,22 @@ int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, const void* x_a
 int64_t rcb_phaseconv_wgrad_workspace(int32_t nd, int32_t cout);
 int rcb_phaseconv_wgrad(const void* x_act, const void* dy, float* dW, float* dbias, float* workspace, int64_t workspace_floats,
                         int32_t B, int32_t g0, int32_t g1, int32_t g2, int32_t nd, int32_t cout, rcb_stream_t stream);
+
+/* Stage 1 of the 1-D upsampling net, direct (prior_model.py:23-51 with Conv1d: up1 (x4) -> conv1 (128 -> 64, k 5, pad 2) ->
+ * act1; audio / protein presets): replaces the window-GEMM form (rcb_window_gather -> library GEMM -> LeakyReLU pass, and its
+ * backward GEMMs / rcb_window_fold / casts) for nd = 1.  wbig = rcb_phase_bigweight's result for the stage, bf16 [3 * 128][4 * 64]
+ * (row = tap * 128 + ci, column = phase * 64 + co; only two taps per phase are non-zero and only those are read).
+ *   rcb_stage1_1d_fwd  : x [B][g][128] fp32 (rounded to bf16 as the operand) -> x1 [B][4 g][64] bf16 = LeakyReLU(bf16(bias + conv))
+ *   rcb_stage1_1d_dgrad: dz [B][4 g][64] bf16 (gradient of the PRE-activation, as rcb_phaseconv_dgrad of stage 2 returns it)
+ *                        -> dx [B][g][128] fp32
+ *   rcb_stage1_1d_wgrad: -> dwbig [384][256] fp32 (zero where no phase reads; rcb_phase_bigweight_grad maps it onto the conv
+ *                        weight) and dbias [64] fp32; per-workgroup slabs added in a fixed order (no atomics); `workspace`:
+ *                        rcb_stage1_1d_wgrad_workspace() floats, caller-allocated.  All tensors 16-byte aligned.             */
+int rcb_stage1_1d_fwd(const float* x, const void* wbig, const float* bias, void* x1, int32_t B, int32_t g, rcb_stream_t stream);
+int rcb_stage1_1d_dgrad(const void* dz, const void* wbig, float* dx, int32_t B, int32_t g, rcb_stream_t stream);
+int64_t rcb_stage1_1d_wgrad_workspace(void);
+int rcb_stage1_1d_wgrad(const float* x, const void* dz, float* dwbig, float* dbias, float* workspace, int64_t workspace_floats,
+                        int32_t B, int32_t g, rcb_stream_t stream);
 
 /* 3^d-pixel windows of a channel-last bf16 grid x [B][g0][g1][g2][C] (nd = 1..3 windowed axes, unused trailing axes of size 1,
  * C % 8 == 0): the operand of the one-GEMM-per-stage phase form of the 1-D / 3-D upsampling nets (prior_model.py:23-59 with

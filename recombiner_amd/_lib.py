@@ -19,7 +19,8 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_struct_bytes", "rcb_sire
            "rcb_window_gather", "rcb_window_fold", "rcb_siren_reduce_chunks", "rcb_phaseconv_pack", "rcb_phaseconv_pack_uint4",
            "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace",
            "rcb_phase_bigweight", "rcb_phase_bigweight_grad", "rcb_atrans_pack_elems", "rcb_atrans_pack", "rcb_atrans_plan",
-           "rcb_atrans_apply", "rcb_atrans_workspace_floats", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow"]
+           "rcb_atrans_apply", "rcb_atrans_workspace_floats", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow",
+           "rcb_stage1_1d_fwd", "rcb_stage1_1d_dgrad", "rcb_stage1_1d_wgrad", "rcb_stage1_1d_wgrad_workspace"]
 
 
 class RcbError(RuntimeError):
@@ -77,7 +78,7 @@ class LevelBwd(C.Structure):
 
 _lib = None
 # the header these mirrors were written against (include/rcb.h: RCB_VERSION) and the structures load() verifies by size
-ABI_VERSION = 400
+ABI_VERSION = 401
 _MIRRORS = {0: SirenDesc, 1: Level, 2: LevelBwd, 3: AdamCfg, 4: AdamTensor, 5: RecDesc}
 
 
@@ -93,6 +94,7 @@ def load():
         lib.rcb_rec_workspace_bytes.restype = C.c_int64
         lib.rcb_phaseconv_pack_uint4.restype = C.c_int64
         lib.rcb_phaseconv_wgrad_workspace.restype = C.c_int64
+        lib.rcb_stage1_1d_wgrad_workspace.restype = C.c_int64
         lib.rcb_atrans_pack_elems.restype = C.c_int64
         lib.rcb_atrans_wgrad_narrow_workspace.restype = C.c_int64
         lib.rcb_atrans_workspace_floats.restype = C.c_int64

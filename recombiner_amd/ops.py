@@ -1093,6 +1093,51 @@ def phase_bigweight_grad(dbig, w_shape, factors, k, pad):
 
 
 # ---------------------------------------------------------------------------------------------------
+# stage 1 of the 1-D upsampling net, direct (rcb_stage1_1d_*)
+# ---------------------------------------------------------------------------------------------------
+def _s1_check(x, who):
+    if x.dim() != 3 or x.shape[-1] != 128 or x.dtype != f32 or not x.is_cuda or not x.is_contiguous():
+        raise RcbError(f"{who}: contiguous fp32 GPU latent grid [B, g, 128] expected")
+
+
+def stage1_1d_fwd(x, wbig, bias):
+    """x [B, g, 128] (fp32), wbig = phase_bigweight(conv1.weight, [4], 5, 2) (bf16 [384, 256]), bias [64] (fp32)
+    -> x1 [B, 4 g, 64] bf16 = LeakyReLU(bf16(conv1(up1(x)) + bias)) (rcb_stage1_1d_fwd)"""
+    _s1_check(x, "stage1_1d_fwd")
+    if tuple(wbig.shape) != (384, 256) or wbig.dtype != bf16 or not wbig.is_contiguous() or bias.numel() != 64:
+        raise RcbError("stage1_1d_fwd: wbig bf16 [384, 256] and bias [64] expected")
+    x1 = torch.empty(x.shape[0], 4 * x.shape[1], 64, device=x.device, dtype=bf16)
+    check(_lib.load().rcb_stage1_1d_fwd(ptr(x, f32), ptr(wbig), ptr(bias.detach().float().contiguous(), f32), ptr(x1), x.shape[0], x.shape[1],
+                                        stream_ptr()), "rcb_stage1_1d_fwd")
+    return x1
+
+
+def stage1_1d_dgrad(dz, wbig):
+    """dz [B, 4 g, 64] bf16 (gradient of the stage's PRE-activation) -> dx [B, g, 128] fp32 (rcb_stage1_1d_dgrad)"""
+    if dz.dim() != 3 or dz.shape[-1] != 64 or dz.shape[1] % 4 or dz.dtype != bf16 or not dz.is_cuda or not dz.is_contiguous():
+        raise RcbError("stage1_1d_dgrad: contiguous bf16 GPU tensor [B, 4 g, 64] expected")
+    dx = torch.empty(dz.shape[0], dz.shape[1] // 4, 128, device=dz.device, dtype=f32)
+    check(_lib.load().rcb_stage1_1d_dgrad(ptr(dz), ptr(wbig), ptr(dx, f32), dz.shape[0], dz.shape[1] // 4, stream_ptr()),
+          "rcb_stage1_1d_dgrad")
+    return dx
+
+
+def stage1_1d_wgrad(x, dz):
+    """-> (dwbig [384, 256] fp32: the gradient of phase_bigweight's result, zero where no phase reads; dbias [64] fp32)"""
+    _s1_check(x, "stage1_1d_wgrad")
+    if tuple(dz.shape) != (x.shape[0], 4 * x.shape[1], 64) or dz.dtype != bf16 or not dz.is_contiguous():
+        raise RcbError("stage1_1d_wgrad: dz must be contiguous bf16 [B, 4 g, 64]")
+    lib = _lib.load()
+    n_ws = int(lib.rcb_stage1_1d_wgrad_workspace())
+    ws = torch.empty(n_ws, device=x.device, dtype=f32)
+    dwbig = torch.empty(384, 256, device=x.device, dtype=f32)
+    db = torch.empty(64, device=x.device, dtype=f32)
+    check(lib.rcb_stage1_1d_wgrad(ptr(x, f32), ptr(dz), ptr(dwbig, f32), ptr(db, f32), ptr(ws, f32), C.c_int64(n_ws), x.shape[0],
+                                  x.shape[1], stream_ptr()), "rcb_stage1_1d_wgrad")
+    return dwbig, db
+
+
+# ---------------------------------------------------------------------------------------------------
 # direct sub-pixel convolutions for grids of any dimension (rcb_phaseconv_*)
 # ---------------------------------------------------------------------------------------------------
 def _pc_geo(shape):

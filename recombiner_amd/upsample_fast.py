@@ -13,6 +13,7 @@ INR; the up-sampled intermediates are never materialised.  Implemented here with
 (window gathers + GEMMs) so that autograd supplies the backward; it works for 1-D, 2-D and 3-D nets.
 """
 import itertools
+import os
 import math
 
 import numpy as np
@@ -272,9 +273,11 @@ class _PhaseConv23Fn(torch.autograd.Function):
     direct_wgrad = True
 
     @staticmethod
-    def forward(ctx, z1, W2, b2, W3, b3, stage2, stage3):
+    def forward(ctx, z1, W2, b2, W3, b3, stage2, stage3, post_act=False):
         from . import ops
-        x1 = F.leaky_relu(z1, 0.01).contiguous()
+        # post_act: the input IS x1 (stage 1's direct kernel applies the LeakyReLU itself, _Stage1Direct1dFn); the gradient
+        # returned for it is still that of the pre-activation
+        x1 = z1.contiguous() if post_act else F.leaky_relu(z1, 0.01).contiguous()
         f2, d2 = ops.phaseconv_pack(W2)
         f3, d3 = ops.phaseconv_pack(W3)
         h2 = ops.phaseconv_fwd(x1, f2, b2, 64, True)
@@ -299,7 +302,41 @@ class _PhaseConv23Fn(torch.autograd.Function):
             else:                                      # (A/B: GEMMs over 3^d-pixel windows)
                 dW3, db3 = _window_wgrad(h2, dpe, stage3, W3)
                 dW2, db2 = _window_wgrad(x1, dh2, stage2, W2)
-        return dz1, dW2, db2, dW3, db3, None, None
+        return dz1, dW2, db2, dW3, db3, None, None, None
+
+
+# RCB_STAGE1_DIRECT=0: the window-GEMM form of stage 1 also on 1-D grids (same-box A/B)
+STAGE1_DIRECT = os.environ.get("RCB_STAGE1_DIRECT", "1") != "0"
+
+
+class _Stage1Direct1dFn(torch.autograd.Function):
+    """stage 1 of the 1-D net through rcb_stage1_1d_*: x [B, g, 128] (fp32 latent grid, read in place) -> x1 [B, 4 g, 64] (bf16,
+    POST-LeakyReLU).  Contract with _PhaseConv23Fn(post_act=True): the gradient arriving here is that of the pre-activation
+    (the stage-2 data-gradient kernel multiplies by LeakyReLU' from the sign of x1).  dx comes back in fp32 (no cast pass), the
+    weight gradient as fp32 dWbig mapped onto conv1.weight by rcb_phase_bigweight_grad."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, stage):
+        from . import ops
+        x = x.contiguous()
+        Wbig = ops.phase_bigweight(W.detach(), stage.f, stage.k, stage.pad, torch.bfloat16)
+        x1 = ops.stage1_1d_fwd(x, Wbig, b)
+        ctx.save_for_backward(x, Wbig)
+        ctx.stage, ctx.w_shape = stage, tuple(W.shape)
+        return x1
+
+    @staticmethod
+    def backward(ctx, dz):
+        from . import ops
+        x, Wbig = ctx.saved_tensors
+        st = ctx.stage
+        dz = dz.contiguous()
+        dx = ops.stage1_1d_dgrad(dz, Wbig) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dwbig, db = ops.stage1_1d_wgrad(x, dz)
+            dW = ops.phase_bigweight_grad(dwbig, ctx.w_shape, st.f, st.k, st.pad)
+        return dx, dW, db, None
 
 
 class UpsampleFast(torch.nn.Module):
@@ -333,6 +370,12 @@ class UpsampleFast(torch.nn.Module):
     def forward_channel_last(self, x):
         n = self.net
         if self.window_gemm and self.stages[0].window3() and self._direct_ok(x):
+            st0 = self.stages[0]
+            if (STAGE1_DIRECT and self.dd == 1 and x.dtype == torch.float32 and tuple(n.conv1.weight.shape) == (64, 128, 5)
+                    and list(st0.f) == [4] and st0.k == 5 and st0.pad == 2 and n.conv1.bias is not None):
+                x1 = _Stage1Direct1dFn.apply(x, n.conv1.weight, n.conv1.bias, st0)
+                return _PhaseConv23Fn.apply(x1, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias,
+                                            self.stages[1], self.stages[2], True)
             z1 = self.stages[0].forward_gemm(x, n.conv1.weight, n.conv1.bias, torch.bfloat16)
             return _PhaseConv23Fn.apply(z1.contiguous(), n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias,
                                         self.stages[1], self.stages[2])

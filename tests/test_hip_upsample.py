@@ -465,6 +465,51 @@ def test_phaseconv_forward_and_data_gradient(shape, cout, leaky):
     print("phaseconv %s cout %d: fwd %.1e dgrad %.1e wgrad %.1e dbias %.1e" % (shape, cout, e_fwd, e_bwd, e_w, e_b))
 
 
+@pytest.mark.parametrize("B,g", [(3, 70), (2, 33), (5, 6), (4, 1000), (37, 50)])
+def test_stage1_1d_direct_kernels(B, g):
+    """rcb_stage1_1d_fwd / _dgrad / _wgrad (stage 1 of the 1-D net without the window matrix) against the stage as the reference
+    defines it (nearest-upsample(4) -> Conv1d(128 -> 64, 5, pad 2) -> LeakyReLU, fp64) on the same bf16-rounded latent grid:
+    what differs is the bf16 rounding of the pre-summed phase weights, of the stored pre-activation, and the fp32 accumulation
+    order; and against the window-GEMM form they replace (same Wbig, same roundings)."""
+    import torch.nn.functional as F
+    from recombiner_amd import ops
+    from recombiner_amd.upsample_fast import PhaseStage
+    torch.manual_seed(B * 1000 + g)
+    W = torch.randn(64, 128, 5, device=DEV) * (0.5 / (128 * 5) ** 0.5)
+    b = torch.randn(64, device=DEV) * 0.1
+    x = (torch.randn(B, g, 128, device=DEV) * 0.5).bfloat16().float()               # values the kernel's rounding keeps
+    st = PhaseStage(4, 5, 2, 1)
+    wbig = ops.phase_bigweight(W, st.f, st.k, st.pad, torch.bfloat16)
+    x1 = ops.stage1_1d_fwd(x, wbig, b)
+    assert tuple(x1.shape) == (B, 4 * g, 64) and x1.dtype == torch.bfloat16
+
+    def ref_lin(x64, W64, b64):
+        return F.conv1d(F.interpolate(x64.movedim(-1, 1), scale_factor=4, mode="nearest"), W64, b64, padding=2).movedim(1, -1)
+    x64 = x.double().requires_grad_(True)
+    Wd, bd = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    lin = ref_lin(x64, Wd, bd)
+    e_f = rel(x1, F.leaky_relu(lin, 0.01))
+    assert e_f < 8e-3, e_f                                   # bf16 pre-activation + bf16 output + bf16 phase weights
+    dz = (torch.randn(B, 4 * g, 64, device=DEV) * 0.1).bfloat16()
+    gx, gW, gb = torch.autograd.grad(lin, [x64, Wd, bd], dz.double())
+    dx = ops.stage1_1d_dgrad(dz, wbig)
+    assert dx.dtype == torch.float32 and tuple(dx.shape) == (B, g, 128)
+    e_d = rel(dx, gx)
+    assert e_d < 6e-3, e_d
+    dwbig, db = ops.stage1_1d_wgrad(x, dz)
+    dW = ops.phase_bigweight_grad(dwbig, tuple(W.shape), st.f, st.k, st.pad)
+    e_w, e_b = rel(dW, gW), rel(db, gb)
+    assert e_w < 2e-3 and e_b < 1e-5, (e_w, e_b)             # identical bf16 operands: fp32 accumulation order only
+    dwbig2, db2 = ops.stage1_1d_wgrad(x, dz)
+    assert torch.equal(dwbig, dwbig2) and torch.equal(db, db2)                  # no atomics: bitwise reproducible
+    # the window-GEMM form with the same Wbig: accumulation order and the bias (bf16-rounded there): a bf16 ulp or two of the result
+    cols = ops.window_gather(x.bfloat16())
+    z_w = torch.addmm(b.bfloat16().repeat(4), cols, wbig).view(B, g, 4, 64).reshape(B, 4 * g, 64)
+    x1_w = F.leaky_relu(z_w, 0.01)
+    assert rel(x1, x1_w) < 8e-3
+    print("stage-1 direct %dx%d: fwd %.1e dgrad %.1e wgrad %.1e dbias %.1e" % (B, g, e_f, e_d, e_w, e_b))
+
+
 @pytest.mark.parametrize("dd,f,k,pad,cin,cout", [(1, 4, 5, 2, 16, 8), (2, 4, 5, 2, 24, 16), (3, 4, 5, 2, 8, 8), (1, 6, 5, 2, 16, 8),
                                                  (3, 2, 3, 1, 8, 16), (2, 2, 3, 1, 64, 64)])
 def test_phase_bigweight_kernels_match_the_einsum_form(dd, f, k, pad, cin, cout):
