@@ -150,7 +150,12 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
   uint4* img = reinterpret_cast<uint4*>(pc_smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
-  const int a = wave % NP, tsub = wave / NP, mb = blockIdx.y;
+  // the two 32-channel output blocks of a tile group run as workgroups 8 apart in the 1-D grid: the same XCD (workgroup ids go
+  // round-robin over the 8 XCDs), dispatched together -- the second one finds the source rows in that XCD's L2 and the two
+  // 64-byte halves of every output line are written close in time.  (As grid.y the blocks ran a whole grid apart.)
+  const int walker = MB == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3));
+  const int n_walkers = gridDim.x / MB;
+  const int a = wave % NP, tsub = wave / NP, mb = MB == 1 ? 0 : (blockIdx.x >> 3) & 1;
   const int role = a * MB + mb;
   constexpr bool C16 = (COUT == 16);            // one row block of the 16 x 16 x 32 MFMA (see pc_pack_fwd_kernel)
   bf16x8 wf[NP][C16 ? 2 : 4];
@@ -208,8 +213,8 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
       stg[it] = v;
     }
   };
-  if ((int)blockIdx.x < n_groups) fetch(blockIdx.x);
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  if (walker < n_groups) fetch(walker);
+  for (int grp = walker; grp < n_groups; grp += n_walkers) {
     int rest = grp / groups_per_row;
     const int tg = grp - rest * groups_per_row;
     int lead[3] = {0, 0, 0};
@@ -229,7 +234,7 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
       }
     }
     __syncthreads();
-    if (grp + (int)gridDim.x < n_groups) fetch(grp + gridDim.x);
+    if (grp + n_walkers < n_groups) fetch(grp + n_walkers);
     // ---- this wave's phase of its tile -----------------------------------------------------------------------------------
     const int ts = tg * TPB + tsub;
     if (ts >= p.tiles_per_row) continue;           // (no barrier below this point inside the iteration)
@@ -1077,7 +1082,8 @@ extern "C" int rcb_phaseconv_fwd(const void* x, const void* fwd_frags, const flo
   const int tpb = 8 >> nd;                            // tiles per workgroup (8 waves = all phases of tpb tiles of one row)
   const long long groups = (long long)(p.n_tiles / p.tiles_per_row) * ((p.tiles_per_row + tpb - 1) / tpb);
   int gx = (int)(groups < 1024 ? groups : 1024);      // waves keep their fragments across the groups they walk
-  dim3 grid(gx, (cout + 31) / 32);
+  gx = (gx + 7) / 8 * 8;                              // (the kernel pairs workgroups 8 apart: see its comment)
+  dim3 grid(gx * ((cout + 31) / 32));
   const size_t lds = (size_t)(nd == 1 ? 1 : (nd == 2 ? 3 : 9)) * (32 * tpb + 2) * 128;
   hipStream_t s = (hipStream_t)stream;
 #define RCB_FWD(NDv, Cv)                                                                  \
