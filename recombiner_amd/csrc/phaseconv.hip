@@ -153,8 +153,12 @@ __global__ void __launch_bounds__(512) pc_fwd_kernel(PcArgs p) {
   // the two 32-channel output blocks of a tile group run as workgroups 8 apart in the 1-D grid: the same XCD (workgroup ids go
   // round-robin over the 8 XCDs), dispatched together -- the second one finds the source rows in that XCD's L2 and the two
   // 64-byte halves of every output line are written close in time.  (As grid.y the blocks ran a whole grid apart.)
-  const int walker = MB == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3));
   const int n_walkers = gridDim.x / MB;
+  const int pw = MB == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3));      // (pw & 7 = this workgroup's XCD)
+  // 1-D and 3-D grids: XCD k walks the k-th contiguous eighth of every sweep over the tile groups (round-robin ids put every
+  // neighbour on another XCD).  Same-box, 64 channels: audio stage 2 1.48 -> 1.33 ms, video stage 2 0.185 -> 0.172 ms; the 2-D
+  // photo grid lost what the pairing had gained (0.162 -> 0.180 ms) and keeps the round-robin order; no effect at 16 channels
+  const int walker = (ND != 2 && (n_walkers & 7) == 0) ? (pw & 7) * (n_walkers >> 3) + (pw >> 3) : pw;
   const int a = wave % NP, tsub = wave / NP, mb = MB == 1 ? 0 : (blockIdx.x >> 3) & 1;
   const int role = a * MB + mb;
   constexpr bool C16 = (COUT == 16);            // one row block of the 16 x 16 x 32 MFMA (see pc_pack_fwd_kernel)
