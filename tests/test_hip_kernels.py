@@ -779,6 +779,43 @@ def test_posterior_flat_fast_path_equals_generic_kernel():
     assert k0 == pytest.approx(k1, rel=1e-9) and k0 > 0       # (each workgroup's partial sum is rounded to 2^-24 nats once)
 
 
+def test_four_column_member_kernel_equals_generic_kernel():
+    """training update of a coarse level (members behind a row map, one sample, rows of 3201 floats: only 4-byte aligned): the
+    four-columns-per-thread kernel against the generic one (rcb_debug_generic_kernels_only): identical bits; the KL log differs
+    by the rounding of its per-workgroup partial sums only."""
+    from recombiner_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(29)
+    n, D = 36, 3201
+    for group in (4, 12):                                 # members per coarse row (a partial batch of four, three full ones)
+        rows = n // group
+        row_map = np.repeat(np.arange(rows), group).astype(np.int32)
+        loc = 0.02 * torch.randn(rows, D, generator=gen)
+        ls = -4 + 0.5 * torch.randn(rows, D, generator=gen)
+        pl = 0.01 * torch.randn(D, generator=gen)
+        pls = -3 + 0.2 * torch.randn(D, generator=gen)
+        eps = g(torch.randn(n, 1, D, generator=gen))
+        Gm = g(torch.randn(n, 1, D, generator=gen) * 1e-3)
+        outs = []
+        for generic in (1, 0):
+            lib.rcb_debug_generic_kernels_only(generic)
+            try:
+                dl, ds = g(loc.clone()), g(ls.clone())
+                lv = LevelSpec(dl, ds, D, n, row_map=row_map)
+                state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+                slots = torch.zeros(1024, device=DEV, dtype=torch.int64)
+                for step in (1, 2):
+                    ops.posterior_bwd(lv, g(pl), g(pls), True, 0.37, Gm, eps, 1, adam=ops.adam_cfg(2e-4, step), state=state,
+                                      kl_accum=slots)
+                outs.append((dl, ds, state, float(slots[:-1].sum()) / ops.KL_FX, int(slots[-1])))
+            finally:
+                lib.rcb_debug_generic_kernels_only(0)
+        (l0, s0, st0, k0, b0), (l1, s1, st1, k1, b1) = outs
+        assert torch.equal(l0, l1) and torch.equal(s0, s1) and all(torch.equal(st0[k], st1[k]) for k in st0)
+        assert k0 == pytest.approx(k1, rel=1e-9) and k0 > 0 and b0 == b1 == 0
+        assert float((l0 - g(loc)).abs().max()) > 0          # the update did something
+
+
 def test_lds_staged_gather_kernels_equal_generic_kernels():
     """test-time layout (column permutation, encode mask, per-group beta, S = 5): the LDS-staged reparam and posterior
     kernels against the generic ones (rcb_debug_generic_kernels_only) on identical inputs: identical bits."""
