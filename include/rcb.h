@@ -24,7 +24,7 @@ extern "C" {
 /* major * 100 + minor; bumped with every change of a signature or of a structure layout (100: rounds 1-3; 400: round 4 --
  * rcb_level.scale_is_sigma, rcb_struct_bytes, the hi / lo operand planes of the A transform).  A binding compares
  * rcb_version() with the RCB_VERSION it was written against and rcb_struct_bytes() with the size of each of its mirrors. */
-#define RCB_VERSION 401
+#define RCB_VERSION 402
 #define RCB_OK 0
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
@@ -180,6 +180,15 @@ int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, in
  * group_offset: element i draws from Philox group i / 4 + group_offset.  A launch over rows [r0, r0 + m) of a larger
  * [rows, cols] array with group_offset = r0 * cols / 4 (r0 * cols a multiple of 4) draws exactly the noise those rows get in
  * a launch over the whole array: a shard -- or a sub-batch -- sees the noise of the unsharded run.                  */
+/* rcb_reparam_hier_rng_fwd: the training sample of the patched presets (utils.py:122-198: level 1 one row per INR, the coarser
+ * levels behind row maps; one sample, every column produced, no masks / permutations) with the noise of every level drawn in
+ * the kernel: level l uses rng stream rng_streams[l] (host array) with the element index n * cols + d of the [n_inr, cols] noise
+ * array -- the indexing of rcb_reparam_rng_fwd, so level 1 on stream s draws what that call draws -- and the noise is written
+ * to eps_out[l] (host array of device pointers, [n_inr * cols] each) for rcb_posterior_bwd.  rcb_level.eps is ignored.  Same
+ * arithmetic and order as rcb_reparam_fwd on that noise: bit-identical.  n_inr * cols must be a multiple of 4.              */
+int rcb_reparam_hier_rng_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t out_cols, float* const* eps_out,
+                             float* out, uint64_t seed, const uint32_t* rng_streams, const int64_t* step_dev,
+                             uint64_t group_offset, rcb_stream_t stream);
 int rcb_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t rng_stream, const int64_t* step_dev, int64_t step_host,
                       uint64_t group_offset, rcb_stream_t stream);
 int rcb_reparam_rng_fwd(const float* loc, const float* log_scale, int64_t n, uint64_t seed, uint32_t rng_stream,

@@ -20,7 +20,8 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_struct_bytes", "rcb_sire
            "rcb_phaseconv_fwd", "rcb_phaseconv_dgrad", "rcb_phaseconv_wgrad", "rcb_phaseconv_wgrad_workspace",
            "rcb_phase_bigweight", "rcb_phase_bigweight_grad", "rcb_atrans_pack_elems", "rcb_atrans_pack", "rcb_atrans_plan",
            "rcb_atrans_apply", "rcb_atrans_workspace_floats", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow",
-           "rcb_stage1_1d_fwd", "rcb_stage1_1d_dgrad", "rcb_stage1_1d_wgrad", "rcb_stage1_1d_wgrad_workspace"]
+           "rcb_stage1_1d_fwd", "rcb_stage1_1d_dgrad", "rcb_stage1_1d_wgrad", "rcb_stage1_1d_wgrad_workspace",
+           "rcb_reparam_hier_rng_fwd"]
 
 
 class RcbError(RuntimeError):
@@ -78,7 +79,7 @@ class LevelBwd(C.Structure):
 
 _lib = None
 # the header these mirrors were written against (include/rcb.h: RCB_VERSION) and the structures load() verifies by size
-ABI_VERSION = 401
+ABI_VERSION = 402
 _MIRRORS = {0: SirenDesc, 1: Level, 2: LevelBwd, 3: AdamCfg, 4: AdamTensor, 5: RecDesc}
 
 

@@ -156,46 +156,6 @@ __global__ void reparam_fwd_kernel(ReparamArgs a) {
   }
 }
 
-// Training samples of the patched presets: two or three plain levels (level 0 one row per INR, the coarser ones behind row
-// maps), one sample, every column produced.  Flat over the [n_inr * cols] arrays with 16-byte accesses like reparam_flat_kernel
-// (the generic kernel's one thread per element ran at 2.3 TB/s at a rank's shard of the audio preset); the coarse levels'
-// parameters are a few rows that stay cached.  Same operations in the same order as the generic kernel: bit-identical.
-__global__ void __launch_bounds__(256) reparam_hier_flat_kernel(ReparamArgs a, long long n_total) {
-  const int D = a.out_cols;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n_total; i4 += stride) {
-    const long long b = i4 * 4;
-    const float4 m4 = reinterpret_cast<const float4*>(a.lv[0].loc + b)[0];
-    const float4 l4 = reinterpret_cast<const float4*>(a.lv[0].log_scale + b)[0];
-    float4 e4[3];
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-      if (l < a.n_levels) e4[l] = reinterpret_cast<const float4*>(a.lv[l].eps + b)[0];
-    int n = (int)(b / D), d = (int)(b - (long long)n * D);
-    float o[4];
-    const float* mv = &m4.x;
-    const float* lv = &l4.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float acc = add_rn(mv[k], mul_rn(st_f32(lv[k]), (&e4[0].x)[k]));
-#pragma unroll
-      for (int l = 1; l < 3; ++l) {
-        if (l < a.n_levels) {
-          const rcb_level& L = a.lv[l];
-          const long long off = (long long)(L.row_map ? L.row_map[n] : n) * D + d;
-          acc = add_rn(acc, add_rn(L.loc[off], mul_rn(st_f32(L.log_scale[off]), (&e4[l].x)[k])));
-        }
-      }
-      o[k] = acc;
-      if (++d == D) {
-        d = 0;
-        ++n;
-      }
-    }
-    reinterpret_cast<float4*>(a.out + b)[0] = make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
-
 // Test-time layout (parameters stored in group order, read back through a column map): mu / sigma gathers are
 // scattered 4-byte reads, i.e. a 64-byte sector each.  One block per INR stages that INR's parameter rows in LDS with
 // coalesced loads and does the permuted reads there.  One level, no row maps.  Same arithmetic as the generic kernel.
@@ -311,6 +271,63 @@ __device__ __forceinline__ void store_planes_row4(__bf16* __restrict__ hi, __bf1
   if (lo) {
     const float4 r = make_float4(o.x - (float)(__bf16)o.x, o.y - (float)(__bf16)o.y, o.z - (float)(__bf16)o.z, o.w - (float)(__bf16)o.w);
     store_bf16_row4(lo, first, cols, ld16, r);
+  }
+}
+
+// Training samples of the patched presets: two or three plain levels (level 0 one row per INR, the coarser ones behind row
+// maps), one sample, every column produced.  Flat over the [n_inr * cols] arrays with 16-byte accesses like reparam_flat_kernel
+// (the generic kernel's one thread per element ran at 2.3 TB/s at a rank's shard of the audio preset); the coarse levels'
+// parameters are a few rows that stay cached.  Same operations in the same order as the generic kernel: bit-identical.
+struct HierRng {           // eps_out[0] != NULL: the levels' noise is drawn here (and written for the posterior update)
+  float* eps_out[3];
+  unsigned streams[3];
+  unsigned long long seed, goff;
+  const long long* step_dev;
+};
+
+__global__ void __launch_bounds__(256) reparam_hier_flat_kernel(ReparamArgs a, long long n_total, HierRng rng) {
+  const int D = a.out_cols;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const bool draw = rng.eps_out[0] != nullptr;
+  const unsigned long long step = draw ? (unsigned long long)*rng.step_dev : 0ull;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n_total; i4 += stride) {
+    const long long b = i4 * 4;
+    const float4 m4 = reinterpret_cast<const float4*>(a.lv[0].loc + b)[0];
+    const float4 l4 = reinterpret_cast<const float4*>(a.lv[0].log_scale + b)[0];
+    float4 e4[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      if (l < a.n_levels) {
+        if (draw) {
+          e4[l] = philox_normal4((unsigned long long)i4 + rng.goff, rng.streams[l], step, rng.seed);
+          reinterpret_cast<float4*>(rng.eps_out[l] + b)[0] = e4[l];
+        } else {
+          e4[l] = reinterpret_cast<const float4*>(a.lv[l].eps + b)[0];
+        }
+      }
+    }
+    int n = (int)(b / D), d = (int)(b - (long long)n * D);
+    float o[4];
+    const float* mv = &m4.x;
+    const float* lv = &l4.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float acc = add_rn(mv[k], mul_rn(st_f32(lv[k]), (&e4[0].x)[k]));
+#pragma unroll
+      for (int l = 1; l < 3; ++l) {
+        if (l < a.n_levels) {
+          const rcb_level& L = a.lv[l];
+          const long long off = (long long)(L.row_map ? L.row_map[n] : n) * D + d;
+          acc = add_rn(acc, add_rn(L.loc[off], mul_rn(st_f32(L.log_scale[off]), (&e4[l].x)[k])));
+        }
+      }
+      o[k] = acc;
+      if (++d == D) {
+        d = 0;
+        ++n;
+      }
+    }
+    reinterpret_cast<float4*>(a.out + b)[0] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -471,7 +488,9 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
       const long long n = (long long)n_inr * out_cols;
       int blocks = cdiv(n >> 2, 256);
       if (blocks > 16384) blocks = 16384;
-      reparam_hier_flat_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, n);
+      HierRng no_rng;
+      memset(&no_rng, 0, sizeof(no_rng));
+      reparam_hier_flat_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, n, no_rng);
       RCB_LAUNCH_CHECK();
       return RCB_OK;
     }
@@ -479,6 +498,44 @@ extern "C" int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_
   dim3 grid(n_inr, cdiv(out_cols, 256));
   RCB_REQUIRE(grid.y <= 65535, RCB_ERR_SHAPE, "reparam_fwd: too many columns");
   reparam_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  RCB_LAUNCH_CHECK();
+  return RCB_OK;
+}
+
+extern "C" int rcb_reparam_hier_rng_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t out_cols,
+                                        float* const* eps_out, float* out, uint64_t seed, const uint32_t* rng_streams,
+                                        const int64_t* step_dev, uint64_t group_offset, rcb_stream_t stream) {
+  RCB_REQUIRE(levels && eps_out && out && rng_streams && step_dev, RCB_ERR_ARG, "reparam_hier_rng_fwd: null pointer");
+  RCB_REQUIRE(n_levels >= 1 && n_levels <= 3 && n_inr > 0 && out_cols > 0, RCB_ERR_ARG, "reparam_hier_rng_fwd: n_levels=%d", n_levels);
+  RCB_REQUIRE(((long long)n_inr * out_cols) % 4 == 0, RCB_ERR_SHAPE, "reparam_hier_rng_fwd: n_inr * out_cols must be a multiple of 4");
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  ReparamArgs a;
+  memset(&a, 0, sizeof(a));
+  HierRng rng;
+  memset(&rng, 0, sizeof(rng));
+  for (int l = 0; l < n_levels; ++l) {
+    a.lv[l] = levels[l];
+    const rcb_level& L = a.lv[l];
+    RCB_REQUIRE(L.loc && L.log_scale && eps_out[l] && al16(eps_out[l]), RCB_ERR_ARG, "reparam_hier_rng_fwd: level %d null / unaligned", l);
+    RCB_REQUIRE(!L.enc_mask && !L.enc_sample && !L.row_perm && !L.col_map && !L.scale_is_sigma && L.cols == out_cols && L.cols_out == out_cols,
+                RCB_ERR_UNSUPPORTED, "reparam_hier_rng_fwd: level %d is not plain (row map only, every column produced)", l);
+    rng.eps_out[l] = eps_out[l];
+    rng.streams[l] = rng_streams[l];
+  }
+  RCB_REQUIRE(!a.lv[0].row_map && a.lv[0].rows == n_inr && al16(a.lv[0].loc) && al16(a.lv[0].log_scale) && al16(out), RCB_ERR_ARG,
+              "reparam_hier_rng_fwd: level 0 is one 16-byte aligned row per INR");
+  a.n_levels = n_levels;
+  a.n_inr = n_inr;
+  a.samples = 1;
+  a.out_cols = out_cols;
+  a.out = out;
+  rng.seed = seed;
+  rng.goff = group_offset;
+  rng.step_dev = reinterpret_cast<const long long*>(step_dev);
+  const long long n = (long long)n_inr * out_cols;
+  int blocks = cdiv(n >> 2, 256);
+  if (blocks > 16384) blocks = 16384;
+  reparam_hier_flat_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, n, rng);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }

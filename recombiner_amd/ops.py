@@ -375,6 +375,33 @@ def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], sample
     return out
 
 
+def hier_rng_eligible(levels: Sequence[LevelSpec]):
+    """the levels of a patched preset in training: level 0 one plain row per INR, the coarser ones behind row maps only"""
+    if len(levels) < 2 or not rng_eligible(levels[0]):
+        return False
+    return all(lv.row_perm is None and lv.col_map is None and lv.enc_mask is None and not lv.scale_is_sigma
+               and lv.cols_out == lv.cols == levels[0].cols for lv in levels[1:])
+
+
+def reparam_hier_rng(levels: Sequence[LevelSpec], eps_out: Sequence[torch.Tensor], seed: int, rng_streams: Sequence[int], step,
+                     group_offset=0):
+    """-> out [N, 1, cols]: the multi-level training sample with every level's noise drawn in the kernel
+    (rcb_reparam_hier_rng_fwd); eps_out[l] ([N, 1, cols], fp32) receives level l's noise for the posterior update.  `step` is the
+    device-resident int64 step counter; level l draws from Philox stream rng_streams[l] at element index n * cols + d."""
+    lib = _lib.load()
+    n, cols = levels[0].n_inr, levels[0].cols_out
+    for e in eps_out:
+        if tuple(e.shape) != (n, 1, cols) or e.dtype != f32 or not e.is_contiguous():
+            raise RcbError(f"reparam_hier_rng: eps buffers must be contiguous fp32 [{n}, 1, {cols}]")
+    arr = (Level * len(levels))(*[lv.c_fwd(e) for lv, e in zip(levels, eps_out)])
+    outs = (C.c_void_p * len(levels))(*[e.data_ptr() for e in eps_out])
+    streams = (C.c_uint32 * len(levels))(*[int(v) for v in rng_streams])
+    out = torch.empty(n, 1, cols, device=levels[0].loc.device, dtype=f32)
+    check(lib.rcb_reparam_hier_rng_fwd(arr, len(levels), n, cols, outs, ptr(out), C.c_uint64(seed & (2 ** 64 - 1)), streams,
+                                       ptr(step, torch.int64), C.c_uint64(group_offset), stream_ptr()), "rcb_reparam_hier_rng_fwd")
+    return out
+
+
 class Planes:
     """A [rows, cols] fp32 matrix held as its two bf16 PLANES, x = hi + lo: hi = bf16(x), lo = bf16(x - hi) -- what the
     A-transform kernels split a row into, written by the PRODUCER of the row instead (rcb_reparam_rng_fwd, the fused next

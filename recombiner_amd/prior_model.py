@@ -134,6 +134,8 @@ class PriorBNNmodel(nn.Module):
         # with fuse_next_sample: the posterior update re-draws its step's noise from the counter instead of reading the copy
         # the sampler stored (rcb_level_bwd.eps_from_rng: same bits, 8 bytes per element less traffic)
         self.redraw_noise = os.environ.get("RCB_REDRAW_EPS", "1") != "0"
+        # three-level presets: the latent weights' noise drawn in the sampling kernel (RCB_HIER_RNG=0: three randn launches; A/B)
+        self.hier_rng = os.environ.get("RCB_HIER_RNG", "1") != "0"
         # concurrent streams inside the captured step (bit mask, see train(); 0 = one stream).  Measured on MI355X, same-box A/B of
         # the 4096-INR CIFAR step (gpurun_out r04_ab5): one stream 1.162 ms; A-transform backward beside the upsampling net's
         # backward (2) 1.125; + the net's weight-gradient side on a third stream (6) 1.109; + the network level's posterior
@@ -305,7 +307,7 @@ class PriorBNNmodel(nn.Module):
         key = (N, P, Cc, x.data_ptr(), tuple(x.shape), tuple(x.stride()), y.data_ptr(), float(lr), bool(training_mappings),
                world, id(linear_transform), id(upsample_net), self.precision, self.lowp_gemm, self.split_gemm, self.split_terms, self.split_dgrad_terms,
                self.wgrad_bf16, self.stage1_bf16, self.pe_bf16, self.fused_noise, self.fuse_next_sample, self.patch,
-               self.operand_planes, self.redraw_noise, self.rng_row_offset, self.rng_seed_override,
+               self.operand_planes, self.redraw_noise, self.hier_rng, self.rng_row_offset, self.rng_seed_override,
                os.environ.get("RCB_FORK", str(self.stream_forks)), self.force_segments, self.capture_collectives,
                tuple(None if q is None else tuple(q.shape) for q in priors),
                # the captured kernels read and Adam-update these STORAGES: Module.cpu()/.to() (a checkpoint written the
@@ -385,7 +387,12 @@ class PriorBNNmodel(nn.Module):
         rng_lpe = bool(self.fused_noise and self.noise_source is None and ops.rng_eligible(lpe_lv))
         use_rng = rng_lpe and len(net) == 1 and ops.rng_eligible(net[0])
         rng_seed = ws["seed"] if self.rng_seed_override is None else int(self.rng_seed_override) & (2 ** 64 - 1)
-        goff_net = ops.rng_group_offset(self.rng_row_offset, D) if use_rng else 0
+        # three levels of latent weights (patched presets): every level's noise drawn in the sampling kernel (Philox streams 0, 2, 3
+        # at the element index of the [N, D] noise arrays: independent of torch's generator and of how the rows are sharded) and
+        # written for the posterior updates, instead of three randn launches read back by the kernel
+        rng_hier = bool(self.hier_rng and rng_lpe and not use_rng and ops.hier_rng_eligible(net) and (N * D) % 4 == 0
+                        and (self.rng_row_offset * D) % 4 == 0)
+        goff_net = ops.rng_group_offset(self.rng_row_offset, D) if (use_rng or rng_hier) else 0
         goff_lpe = ops.rng_group_offset(self.rng_row_offset, self._d_lpe) if rng_lpe else 0
 
         want16 = split is not None and training_mappings and self.wgrad_bf16     # bf16 operands of the weight gradient
@@ -487,6 +494,11 @@ class PriorBNNmodel(nn.Module):
                     else:
                         h_w, e0 = ops.reparam_rng(net[0], rng_seed, 0, rng_ctr, group_offset=goff_net)
                     eps, h_w = [e0], h_w.view(N, D)
+                elif rng_hier:
+                    if "hier_eps" not in ws:
+                        ws["hier_eps"] = [torch.empty(N, 1, D, device=dev, dtype=torch.float32) for _ in net]
+                    eps = ws["hier_eps"]
+                    h_w = ops.reparam_hier_rng(net, eps, rng_seed, (0, 2, 3)[:len(net)], rng_ctr, goff_net).view(N, D)
                 else:
                     eps = [self._noise((N, 1, D)) for _ in net]
                     h_w = ops.reparam_fwd(net, eps, 1).view(N, D)

@@ -779,6 +779,39 @@ def test_posterior_flat_fast_path_equals_generic_kernel():
     assert k0 == pytest.approx(k1, rel=1e-9) and k0 > 0       # (each workgroup's partial sum is rounded to 2^-24 nats once)
 
 
+def test_three_level_sample_with_noise_drawn_in_the_kernel():
+    """rcb_reparam_hier_rng_fwd: every level's noise is the Philox stream rcb_philox_normal materialises (streams 0, 2, 3 at the
+    element index of the [N, D] arrays, group offset honoured), written out for the posterior update, and the sample equals
+    rcb_reparam_fwd on that noise bit for bit; a launch over a row range with its group offset draws the rows' own noise."""
+    gen = torch.Generator().manual_seed(31)
+    n, D = 24, 3201                              # n * D is a multiple of 4; rows are not 16-byte aligned
+    maps = [None, np.repeat(np.arange(n // 4), 4).astype(np.int32), np.repeat(np.arange(n // 12), 12).astype(np.int32)]
+    levels = []
+    for mp in maps:
+        rows = n if mp is None else int(mp.max()) + 1
+        levels.append(LevelSpec(g(0.02 * torch.randn(rows, D, generator=gen)), g(-4 + 0.5 * torch.randn(rows, D, generator=gen)), D, n,
+                                row_map=mp))
+    assert ops.hier_rng_eligible(levels)
+    step = torch.tensor([7], device=DEV, dtype=torch.long)
+    seed, streams = 0x1234_5678_9ABC_DEF0, (0, 2, 3)
+    eps = [torch.empty(n, 1, D, device=DEV) for _ in levels]
+    out = ops.reparam_hier_rng(levels, eps, seed, streams, step)
+    want_eps = [ops.philox_normal(n * D, seed, st_, step).view(n, 1, D) for st_ in streams]
+    for e, w in zip(eps, want_eps):
+        assert torch.equal(e, w)
+    assert torch.equal(out, ops.reparam_fwd(levels, want_eps, 1))
+    assert float(torch.stack([e.flatten() for e in eps]).std()) == pytest.approx(1.0, abs=0.02)
+    assert not torch.equal(eps[0], eps[1]) and not torch.equal(eps[1], eps[2])
+    # rows 8 .. 23 as a launch of their own (a shard): the same noise and the same sample
+    r0 = 8
+    sub = [LevelSpec(levels[0].loc[r0:], levels[0].log_scale[r0:], D, n - r0)]
+    for lv, mp in zip(levels[1:], maps[1:]):
+        sub.append(LevelSpec(lv.loc, lv.log_scale, D, n - r0, row_map=mp[r0:].copy()))
+    eps_s = [torch.empty(n - r0, 1, D, device=DEV) for _ in levels]
+    out_s = ops.reparam_hier_rng(sub, eps_s, seed, streams, step, group_offset=ops.rng_group_offset(r0, D))
+    assert torch.equal(out_s, out[r0:]) and all(torch.equal(a_, b_[r0:]) for a_, b_ in zip(eps_s, eps))
+
+
 def test_four_column_member_kernel_equals_generic_kernel():
     """training update of a coarse level (members behind a row map, one sample, rows of 3201 floats: only 4-byte aligned): the
     four-columns-per-thread kernel against the generic one (rcb_debug_generic_kernels_only): identical bits; the KL log differs
