@@ -179,6 +179,41 @@ def test_whole_step_at_configs1_size_is_reproducible_and_batch_invariant():
     assert torch.isfinite(m1.loc).all() and abs(mse8 - mse1) < 0.2 * mse1        # (eight INRs against the mean over 4096)
 
 
+def test_a_clip_of_the_audio_preset_trains_the_same_alone_and_inside_a_batch():
+    """Three-level preset (audio: 60 patches per clip, levels of 4 and 60 patches): with every level's noise and the lpe's drawn
+    in the kernels at the element index of the unsharded arrays (rng_row_offset), clip 5 of a batch of 8 trained alone (frozen
+    mappings) follows the batch's rows for that clip -- a rank's shard sees the noise of the unsharded run.  The hand-written
+    kernels are row-local; the A transform cuts its contraction differently for 60 and 480 rows, so the comparison is held to
+    fp32 rounding like the CIFAR one."""
+    from golden_util import assert_close_mostly
+    from recombiner_amd import utils
+    steps, lr, per, clips, pick = 8, 2e-4, 60, 8, 5
+    n_all = per * clips
+    cfg, m_all, lt, up, pri = _preset_model("audio", n_all)
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n_all, cfg["output_dim"], seed=0)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    rows = slice(pick * per, (pick + 1) * per)
+    _, m_one, _, _, _ = _preset_model("audio", per)
+    r2, r3 = per // 4, 1                                   # rows of the coarser levels per clip
+    with torch.no_grad():
+        for k in ("loc", "log_scale", "lpe_loc", "lpe_log_scale"):
+            getattr(m_one, k).copy_(getattr(m_all, k)[rows])
+        for k in ("h_loc", "h_log_scale"):
+            getattr(m_one, k).copy_(getattr(m_all, k)[pick * r2:(pick + 1) * r2])
+        for k in ("hh_loc", "hh_log_scale"):
+            getattr(m_one, k).copy_(getattr(m_all, k)[pick * r3:(pick + 1) * r3])
+    m_one.rng_row_offset = rows.start
+    for m_, n_, y_ in ((m_all, n_all, Yd), (m_one, per, Yd[rows].contiguous())):
+        m_.rng_seed_override = 0xBEEF
+        m_.train(steps, lr, Xd[None].expand(n_, -1, -1), y_, *pri, lt, up, 1e-8, training_mappings=False)
+        assert m_._ws is not None and m_._ws["graphs"] is not None and "hier_eps" in m_._ws and "smp_lpe" in m_._ws
+    for k, sl in (("loc", rows), ("log_scale", rows), ("lpe_loc", rows), ("lpe_log_scale", rows),
+                  ("h_loc", slice(pick * r2, (pick + 1) * r2)), ("hh_loc", slice(pick * r3, (pick + 1) * r3))):
+        assert_close_mostly(getattr(m_one, k), getattr(m_all, k)[sl].detach().cpu().numpy(), rtol=0, atol=2e-6, max_frac=2e-3,
+                            hard_atol=2.5 * lr * steps, what=k)
+        assert float((getattr(m_one, k) - getattr(m_all, k)[sl]).abs().max()) < 2.5 * lr * steps
+
+
 def test_whole_step_at_configs3_shard_size_captures_replays_and_stays_finite():
     """BASELINE configs[3] per-GPU shard: LibriSpeech-shaped 1-D INRs, 1024 clips x 60 patches = 61 440 INRs with the
     three-level hierarchy, bf16 mode: the step captures as one HIP graph, replays on the second call, the ELBO improves and
