@@ -5,6 +5,8 @@
 // CPU ops it replaces.
 #include <stdarg.h>
 
+#include <type_traits>
+
 #include "rcb_common.h"
 
 #pragma clang fp contract(off)
@@ -795,10 +797,13 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
 // the audio preset.  Same per-element operations in the same member order: the updated parameters are bit-identical.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
-__global__ void __launch_bounds__(256) posterior_members4_kernel(PostBwdArgs a) {
+// NT threads per workgroup: 256, or 64 when the level has so few rows that 1024-column workgroups would leave the chip empty
+// (the coarsest level of two photos: 2 rows x 96 members each -- the kernel is then a chain of member loads, eight in flight)
+template <int NT>
+__global__ void __launch_bounds__(NT) posterior_members4_kernel(PostBwdArgs a) {
   const rcb_level_bwd& L = a.L;
   const int r = blockIdx.x;
-  const int j0 = 4 * (blockIdx.y * 256 + threadIdx.x);
+  const int j0 = 4 * (blockIdx.y * NT + threadIdx.x);
   const int nv = L.cols - j0 >= 4 ? 4 : (L.cols - j0 > 0 ? L.cols - j0 : 0);      // valid columns of this thread
   const bool full = nv == 4;
   const int jb = nv > 0 ? j0 : 0;                   // (idle tail lanes stay alive for the wave reduction: they re-read column 0)
@@ -829,26 +834,45 @@ __global__ void __launch_bounds__(256) posterior_members4_kernel(PostBwdArgs a) 
 #pragma unroll
   for (int k = 0; k < 4; ++k) g_mu[k] = g_sig[k] = 0.f;
   const int mb = L.member_ptr[r], me = L.member_ptr[r + 1];
-  for (int q0 = mb; q0 < me; q0 += 4) {             // four members = eight 16-byte loads in flight
-    float go[4][4], ep[4][4];
+  // (the full / partial distinction is made ONCE around the whole member loop: a branch inside every load would keep the sixteen
+  // loads of a batch from being in flight together)
+  auto member_sums = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    for (int q0 = mb; q0 < me; q0 += 8) {           // eight members = sixteen 16-byte loads in flight
+      float go[8][4], ep[8][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = q0 + u < me ? q0 + u : me - 1;
-      const long long e = (long long)L.member_idx[q] * L.cols + jb;
-      ld(L.d_out + e, go[u]);
-      ld(L.eps + e, ep[u]);
-    }
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u < me ? q0 + u : me - 1;
+        const long long e = (long long)L.member_idx[q] * L.cols + jb;
+        if (FULL) {
+          const f4u tg = *reinterpret_cast<const f4u*>(L.d_out + e), te = *reinterpret_cast<const f4u*>(L.eps + e);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (q0 + u < me) {
+          for (int k = 0; k < 4; ++k) {
+            go[u][k] = tg[k];
+            ep[u][k] = te[k];
+          }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          g_mu[k] = add_rn(g_mu[k], go[u][k]);
-          g_sig[k] = add_rn(g_sig[k], mul_rn(go[u][k], ep[u][k]));
+          for (int k = 0; k < 4; ++k) {
+            go[u][k] = L.d_out[e + (k < nv ? k : 0)];
+            ep[u][k] = L.eps[e + (k < nv ? k : 0)];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (q0 + u < me) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            g_mu[k] = add_rn(g_mu[k], go[u][k]);
+            g_sig[k] = add_rn(g_sig[k], mul_rn(go[u][k], ep[u][k]));
+          }
         }
       }
     }
-  }
+  };
+  if (full) member_sums(std::true_type{});
+  else member_sums(std::false_type{});
   float pl[4], psc[4];
   ld(L.p_loc + jb, pl);
   ld(L.p_scale + jb, psc);
@@ -873,9 +897,13 @@ __global__ void __launch_bounds__(256) posterior_members4_kernel(PostBwdArgs a) 
   if (L.kl_accum) {   // unweighted KL of the parameters *before* this update (ELBO logging)
     __shared__ double s_kl[4];
     const double kv = wave_sum(kl);
-    if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
-    __syncthreads();
-    if (threadIdx.x == 0) fx_add_kl(L.kl_accum, blockIdx.x * 7 + blockIdx.y, (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
+    if (NT == 64) {
+      if (threadIdx.x == 0) fx_add_kl(L.kl_accum, blockIdx.x * 7 + blockIdx.y, kv);
+    } else {
+      if ((threadIdx.x & 63) == 0) s_kl[threadIdx.x >> 6] = kv;
+      __syncthreads();
+      if (threadIdx.x == 0) fx_add_kl(L.kl_accum, blockIdx.x * 7 + blockIdx.y, (s_kl[0] + s_kl[1]) + (s_kl[2] + s_kl[3]));
+    }
   }
   if (nv == 0) return;
   st(L.loc + o, loc);
@@ -1118,8 +1146,11 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
   }
   if (!g_generic_only && adam && lv->d_out && lv->eps && lv->samples == 1 && lv->cols_out == lv->cols && !lv->enc_mask && !lv->beta &&
       lv->member_ptr && !lv->row_perm_inv && !lv->col_inv && !lv->g_loc && !lv->g_log_scale && !lv->eps_from_rng && !want_next) {
-    dim3 grid4(lv->rows, cdiv(lv->cols, 1024));
-    posterior_members4_kernel<<<grid4, 256, 0, (hipStream_t)stream>>>(a);
+    if ((long long)lv->rows * cdiv(lv->cols, 1024) >= 1024) {
+      posterior_members4_kernel<256><<<dim3(lv->rows, cdiv(lv->cols, 1024)), 256, 0, (hipStream_t)stream>>>(a);
+    } else {
+      posterior_members4_kernel<64><<<dim3(lv->rows, cdiv(lv->cols, 256)), 64, 0, (hipStream_t)stream>>>(a);
+    }
     RCB_LAUNCH_CHECK();
     return RCB_OK;
   }

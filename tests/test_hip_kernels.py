@@ -819,8 +819,8 @@ def test_four_column_member_kernel_equals_generic_kernel():
     from recombiner_amd import _lib
     lib = _lib.load()
     gen = torch.Generator().manual_seed(29)
-    n, D = 36, 3201
-    for group in (4, 12):                                 # members per coarse row (a partial batch of four, three full ones)
+    D = 3201
+    for n, group in ((36, 4), (36, 12), (1024, 4)):       # members per coarse row; few rows (64-thread workgroups) and many (256)
         rows = n // group
         row_map = np.repeat(np.arange(rows), group).astype(np.int32)
         loc = 0.02 * torch.randn(rows, D, generator=gen)
