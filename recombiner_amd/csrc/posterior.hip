@@ -704,15 +704,22 @@ __device__ __forceinline__ void kl_grad_add(float loc, float sig, float pl, floa
 __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   const rcb_level_bwd& L = a.L;
   int r = blockIdx.x;
-  int j = blockIdx.y * blockDim.x + threadIdx.x;
-  const bool act = j < L.cols;     // tail lanes stay alive (clamped) so that the wave reduction is convergent
-  if (!act) j = L.cols - 1;
+  int t = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool act = t < L.cols;     // tail lanes stay alive (clamped) so that the wave reduction is convergent
+  if (!act) t = L.cols - 1;
+  // col_map set (coarse levels of the test-time layout, every column produced): the thread index is the PRODUCED column d,
+  // the contiguous axis of d_out / eps, and the thread finds its parameter column j = col_map[d].  A row of a coarse level
+  // gathers members x samples (80 ... 480) gradient elements per parameter: indexed by j those were scattered 4-byte reads
+  // (a 64-byte sector each), indexed by d they are coalesced and only the dozen parameter accesses scatter.  Which thread
+  // owns which element changes no arithmetic: bit-identical parameters.
+  const bool by_d = L.col_map != nullptr;
+  const int j = by_d ? L.col_map[t] : t;
   long long o = (long long)r * L.cols + j;
   float loc = L.loc[o];
   float ls = L.log_scale[o];
   float sig = st_f32(ls);
   float g_mu = 0.f, g_sig = 0.f;
-  int d = L.col_inv ? L.col_inv[j] : j;
+  int d = by_d ? t : (L.col_inv ? L.col_inv[j] : j);
   if (L.d_out && d < L.cols_out) {
     int r0 = L.row_perm_inv ? L.row_perm_inv[o] : r;
     int mb = L.member_ptr ? L.member_ptr[r0] : r0;
@@ -1154,6 +1161,8 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
     RCB_LAUNCH_CHECK();
     return RCB_OK;
   }
+  // (the generic kernel indexes its threads by the produced column only where that pays: see the kernel)
+  if (g_generic_only || !(lv->col_map && lv->col_inv && lv->member_ptr && lv->cols_out == lv->cols && lv->d_out)) a.L.col_map = nullptr;
   RCB_REQUIRE(!want_next && !lv->eps_from_rng, RCB_ERR_UNSUPPORTED,
               "posterior_bwd: the fused next sample / re-drawn noise need the plain (flat) case");
   dim3 grid(lv->rows, cdiv(lv->cols, 256));

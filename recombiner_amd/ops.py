@@ -536,6 +536,7 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  lv.cols_out, int(samples), addr(g_loc, f32), addr(g_ls, f32), addr(s.get("m_loc"), f32),
                  addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, torch.int64),
                  addr(kl_scalar_dev, f32))
+    b.col_map = addr(lv.col_map, i32)           # (a hint: threads indexed by the produced column where that pays, rcb.h)
     if next_sample is not None:
         ns = next_sample
         for t_ in (ns.out, ns.eps):

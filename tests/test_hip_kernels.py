@@ -812,6 +812,47 @@ def test_three_level_sample_with_noise_drawn_in_the_kernel():
     assert torch.equal(out_s, out[r0:]) and all(torch.equal(a_, b_[r0:]) for a_, b_ in zip(eps_s, eps))
 
 
+def test_coarse_level_of_the_test_time_layout_indexed_by_produced_column():
+    """test-time layout of a coarse level (column permutation, encode mask, per-group beta, S = 5, members behind a row map): with
+    rcb_level_bwd.col_map the threads are indexed by the produced column (coalesced gradient gathers) -- the same bits as with the
+    threads indexed by the parameter column (rcb_debug_generic_kernels_only drops the hint)."""
+    from recombiner_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(37)
+    n, D, S, G, group = 24, 3201, 5, 300, 6
+    rows = n // group
+    row_map = np.repeat(np.arange(rows), group).astype(np.int32)
+    perm = torch.randperm(D, generator=gen).numpy()
+    loc = 0.02 * torch.randn(rows, D, generator=gen)
+    ls = -4 + 0.5 * torch.randn(rows, D, generator=gen)
+    mask = (torch.rand(rows, D, generator=gen) < 0.3).float()
+    samp = 0.02 * torch.randn(rows, D, generator=gen)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    pls = -3 + 0.2 * torch.randn(D, generator=gen)
+    gidx = torch.sort(torch.randint(0, G, (D,), generator=gen)).values.int()
+    beta = torch.rand(rows, G, generator=gen) * 1e-3
+    eps = g(torch.randn(n, S, D, generator=gen))
+    Gm = g(torch.randn(n, S, D, generator=gen) * 1e-3)
+    outs = []
+    for generic in (1, 0):
+        lib.rcb_debug_generic_kernels_only(generic)
+        try:
+            dl, ds = g(loc.clone()), g(ls.clone())
+            lv = LevelSpec(dl, ds, D, n, row_map=row_map, col_map=perm, enc_sample=g(samp), enc_mask=g(mask))
+            state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+            slots = torch.zeros(1024, device=DEV, dtype=torch.int64)
+            for step in (1, 2):
+                ops.posterior_bwd(lv, g(pl), g(pls), True, 1.0, Gm, eps, S, beta=g(beta), group_idx=g(gidx), n_groups=G,
+                                  adam=ops.adam_cfg(2e-4, step), state=state, kl_accum=slots)
+            outs.append((dl, ds, state, float(slots[:-1].sum()) / ops.KL_FX))
+        finally:
+            lib.rcb_debug_generic_kernels_only(0)
+    (l0, s0, st0, k0), (l1, s1, st1, k1) = outs
+    assert torch.equal(l0, l1) and torch.equal(s0, s1) and all(torch.equal(st0[k], st1[k]) for k in st0)
+    assert k0 == pytest.approx(k1, rel=1e-9) and k0 > 0
+    assert float((l0 - g(loc)).abs().max()) > 0
+
+
 def test_four_column_member_kernel_equals_generic_kernel():
     """training update of a coarse level (members behind a row map, one sample, rows of 3201 floats: only 4-byte aligned): the
     four-columns-per-thread kernel against the generic one (rcb_debug_generic_kernels_only): identical bits; the KL log differs
