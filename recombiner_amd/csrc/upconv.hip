@@ -300,12 +300,14 @@ __device__ __forceinline__ void dgrad3_body(const __bf16* img, const uint4* frag
                                             int h, int lane, int wave, int q) {
   constexpr int G = 16, HO = 34, RS = 24;
   const long long xpix = ((long long)b * G * G + wave * 32 + q) * CIN;
-  bf16x4 xs[2][4];
+  // (lane (q, h) ends up with the 16 consecutive channels 32 mt + 16 h .. + 15 of its pixel -- the lane halves swap below --
+  // so the sign source is two 16-byte loads per block and the result two 16-byte stores, not four 8-byte pieces each)
+  Frag xs[2][2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      xs[mt][g4] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + 32 * mt + 8 * g4 + 4 * h);
+    for (int hf = 0; hf < 2; ++hf)
+      xs[mt][hf].u = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.x) + xpix + 32 * mt + 16 * h)[hf];
   __builtin_amdgcn_sched_barrier(0);
   f32x16 acc[2];
 #pragma unroll
@@ -327,12 +329,19 @@ __device__ __forceinline__ void dgrad3_body(const __bf16* img, const uint4* frag
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int ci = 32 * mt + 8 * g4 + 4 * h;
-      bf16x4 ob;
+    for (int hf = 0; hf < 2; ++hf) {
+      float o[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)xs[mt][g4][k] > 0.f ? 1.0f : SLOPE));
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + ci) = ob;
+      for (int k = 0; k < 4; ++k) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mt][4 * hf + k]), __float_as_uint(acc[mt][8 + 4 * hf + k]),
+                                                   false, false);
+        o[k] = __uint_as_float(sw[0]);
+        o[4 + k] = __uint_as_float(sw[1]);
+      }
+      Frag ob;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ob.v[k] = (__bf16)(o[k] * ((float)xs[mt][hf].v[k] > 0.f ? 1.0f : SLOPE));
+      reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.dx) + xpix + 32 * mt + 16 * h)[hf] = ob.u;
     }
   }
 }
