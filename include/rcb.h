@@ -24,7 +24,7 @@ extern "C" {
 /* major * 100 + minor; bumped with every change of a signature or of a structure layout (100: rounds 1-3; 400: round 4 --
  * rcb_level.scale_is_sigma, rcb_struct_bytes, the hi / lo operand planes of the A transform).  A binding compares
  * rcb_version() with the RCB_VERSION it was written against and rcb_struct_bytes() with the size of each of its mirrors. */
-#define RCB_VERSION 403
+#define RCB_VERSION 404
 #define RCB_OK 0
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
@@ -292,6 +292,9 @@ typedef struct {
   uint64_t rng_group_offset; /* Philox group of element 0 (rcb_reparam_rng_fwd's group_offset), for the next sample and eps_from_rng */
   void* next_out_lo;       /* nullable, with next_out_bf16: the LOW plane bf16(sample - high plane), same layout.  With both
                             * planes next_out may be NULL: rcb_atrans_apply reads the planes (x_hi / x_lo)          */
+  float* sample_sum_ws;    /* nullable scratch [2 * rows * cols_out]: levels without members, samples > 1 and col_inv (the
+                            * test-time layout of level 1) first form their sums over the samples there, contiguously, and the
+                            * update gathers two values per parameter instead of 2 * samples -- same results bit for bit  */
   const int32_t* col_map;  /* nullable [cols_out]: the map col_inv inverts (j = col_map[d]).  A performance hint only: with it
                             * (levels with members, every column produced) threads are indexed by d, the contiguous axis of
                             * d_out / eps, instead of by the parameter column -- same results bit for bit           */

@@ -74,12 +74,12 @@ class LevelBwd(C.Structure):
                 ("next_out", C.c_void_p), ("next_eps", C.c_void_p), ("next_out_bf16", C.c_void_p),
                 ("next_ld_bf16", C.c_int64), ("rng_seed", C.c_uint64), ("rng_step_dev", C.c_void_p),
                 ("rng_step_add", C.c_int64), ("rng_stream", C.c_uint32), ("eps_from_rng", C.c_uint32),
-                ("rng_group_offset", C.c_uint64), ("next_out_lo", C.c_void_p), ("col_map", C.c_void_p)]
+                ("rng_group_offset", C.c_uint64), ("next_out_lo", C.c_void_p), ("sample_sum_ws", C.c_void_p), ("col_map", C.c_void_p)]
 
 
 _lib = None
 # the header these mirrors were written against (include/rcb.h: RCB_VERSION) and the structures load() verifies by size
-ABI_VERSION = 403
+ABI_VERSION = 404
 _MIRRORS = {0: SirenDesc, 1: Level, 2: LevelBwd, 3: AdamCfg, 4: AdamTensor, 5: RecDesc}
 
 

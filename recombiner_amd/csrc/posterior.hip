@@ -701,6 +701,28 @@ __device__ __forceinline__ void kl_grad_add(float loc, float sig, float pl, floa
   g_sig = add_rn(g_sig, mul_rn(w, sub_rn(mul_rn(sig, inv_var_p), div_fast(1.0f, sig))));
 }
 
+// Levels WITHOUT members in the test-time layout (one parameter row per INR behind the reference's per-column row permutation
+// and the group-order column map, S samples): the update kernel gathers d_out and eps of (n, s, d) for every sample -- 2 S
+// scattered 4-byte reads per parameter, a 64-byte sector each.  This pass forms the sums over the samples where they are
+// contiguous, in the update's order (g = 0; g += d_out[s]; ge += d_out[s] * eps[s], s ascending): the update then gathers two
+// values.  Bit-identical: for a level without members the chain over the samples IS the whole sum.
+__global__ void __launch_bounds__(256) sample_sums_kernel(const float* __restrict__ d_out, const float* __restrict__ eps, int samples,
+                                                          long long row_elems, long long n_rows, float* __restrict__ ws) {
+  const long long total = n_rows * row_elems, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long n = i / row_elems, d = i - n * row_elems;
+    float g = 0.f, ge = 0.f;
+    for (int sidx = 0; sidx < samples; ++sidx) {
+      const long long e = (n * samples + sidx) * row_elems + d;
+      const float go = d_out[e];
+      g = add_rn(g, go);
+      ge = add_rn(ge, mul_rn(go, eps[e]));
+    }
+    ws[i] = g;
+    ws[total + i] = ge;
+  }
+}
+
 __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   const rcb_level_bwd& L = a.L;
   int r = blockIdx.x;
@@ -720,7 +742,17 @@ __global__ void __launch_bounds__(256) posterior_bwd_kernel(PostBwdArgs a) {
   float sig = st_f32(ls);
   float g_mu = 0.f, g_sig = 0.f;
   int d = by_d ? t : (L.col_inv ? L.col_inv[j] : j);
-  if (L.d_out && d < L.cols_out) {
+  if (L.sample_sum_ws && L.d_out && d < L.cols_out) {
+    // sums over the samples formed by sample_sums_kernel (levels without members): two gathers instead of 2 S
+    const long long e = (long long)(L.row_perm_inv ? L.row_perm_inv[o] : r) * L.cols_out + d;
+    g_mu = L.sample_sum_ws[e];
+    g_sig = L.sample_sum_ws[(long long)L.rows * L.cols_out + e];
+    if (L.enc_mask) {
+      float keep = 1.0f - L.enc_mask[o];
+      g_mu = mul_rn(g_mu, keep);
+      g_sig = mul_rn(g_sig, keep);
+    }
+  } else if (L.d_out && d < L.cols_out) {
     int r0 = L.row_perm_inv ? L.row_perm_inv[o] : r;
     int mb = L.member_ptr ? L.member_ptr[r0] : r0;
     int me = L.member_ptr ? L.member_ptr[r0 + 1] : r0 + 1;
@@ -1160,6 +1192,15 @@ extern "C" int rcb_posterior_bwd(const rcb_level_bwd* lv, const rcb_adam_cfg* ad
     }
     RCB_LAUNCH_CHECK();
     return RCB_OK;
+  }
+  // levels without members, several samples, gathered columns: the sums over the samples in a pass of their own (see
+  // sample_sums_kernel) when the caller gave the workspace
+  if (g_generic_only || lv->member_ptr || lv->samples < 2 || !lv->col_inv || !lv->d_out || !lv->eps) a.L.sample_sum_ws = nullptr;
+  if (a.L.sample_sum_ws) {
+    const long long tot = (long long)lv->rows * lv->cols_out;
+    int blocks = cdiv(tot, 256);
+    if (blocks > 16384) blocks = 16384;
+    sample_sums_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(lv->d_out, lv->eps, lv->samples, lv->cols_out, lv->rows, a.L.sample_sum_ws);
   }
   // (the generic kernel indexes its threads by the produced column only where that pays: see the kernel)
   if (g_generic_only || !(lv->col_map && lv->col_inv && lv->member_ptr && lv->cols_out == lv->cols && lv->d_out)) a.L.col_map = nullptr;

@@ -537,6 +537,12 @@ def posterior_bwd(lv: LevelSpec, p_loc, p_scale, p_is_log: bool, kl_scalar: floa
                  addr(s.get("v_loc"), f32), addr(s.get("m_ls"), f32), addr(s.get("v_ls"), f32), addr(kl_accum, torch.int64),
                  addr(kl_scalar_dev, f32))
     b.col_map = addr(lv.col_map, i32)           # (a hint: threads indexed by the produced column where that pays, rcb.h)
+    sums_ws = None
+    if (d_out is not None and eps is not None and samples > 1 and lv.col_inv is not None and lv.member_ptr is None
+            and lv.rows == lv.n_inr):
+        # test-time level 1 behind the per-column row permutation: sums over the samples in a contiguous pass first (rcb.h)
+        sums_ws = torch.empty(2 * lv.rows * lv.cols_out, device=lv.loc.device, dtype=f32)
+        b.sample_sum_ws = sums_ws.data_ptr()
     if next_sample is not None:
         ns = next_sample
         for t_ in (ns.out, ns.eps):

@@ -853,6 +853,47 @@ def test_coarse_level_of_the_test_time_layout_indexed_by_produced_column():
     assert float((l0 - g(loc)).abs().max()) > 0
 
 
+def test_level_one_of_the_patched_test_time_layout_with_presummed_samples():
+    """level 1 of a patched preset at test time: per-column row permutation, group-order column map, encode mask, per-group beta,
+    S = 5, and a row too long for the LDS-staged kernel (the lpe is part of it): the sums over the samples are formed in a contiguous
+    pass first (rcb_level_bwd.sample_sum_ws) -- the same bits as the generic kernel's 2 S gathers per parameter."""
+    from recombiner_amd import _lib
+    from recombiner_amd.test_model import _column_row_perms
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(41)
+    n, D, S, G = 12, 9601, 5, 500
+    perm = torch.randperm(D, generator=gen).numpy()
+    rperm = _column_row_perms(n, D)
+    loc = 0.02 * torch.randn(n, D, generator=gen)
+    ls = -4 + 0.5 * torch.randn(n, D, generator=gen)
+    mask = (torch.rand(n, D, generator=gen) < 0.3).float()
+    samp = 0.02 * torch.randn(n, D, generator=gen)
+    pl = 0.01 * torch.randn(D, generator=gen)
+    pls = -3 + 0.2 * torch.randn(D, generator=gen)
+    gidx = torch.sort(torch.randint(0, G, (D,), generator=gen)).values.int()
+    beta = torch.rand(n, G, generator=gen) * 1e-3
+    eps = g(torch.randn(n, S, D, generator=gen))
+    Gm = g(torch.randn(n, S, D, generator=gen) * 1e-3)
+    outs = []
+    for generic in (1, 0):
+        lib.rcb_debug_generic_kernels_only(generic)
+        try:
+            dl, ds = g(loc.clone()), g(ls.clone())
+            lv = LevelSpec(dl, ds, D, n, row_perm=rperm, col_map=perm, enc_sample=g(samp), enc_mask=g(mask))
+            state = {k: torch.zeros_like(dl) for k in ("m_loc", "v_loc", "m_ls", "v_ls")}
+            slots = torch.zeros(1024, device=DEV, dtype=torch.int64)
+            for step in (1, 2):
+                ops.posterior_bwd(lv, g(pl), g(pls), True, 1.0, Gm, eps, S, beta=g(beta), group_idx=g(gidx), n_groups=G,
+                                  adam=ops.adam_cfg(2e-4, step), state=state, kl_accum=slots)
+            outs.append((dl, ds, state, float(slots[:-1].sum()) / ops.KL_FX))
+        finally:
+            lib.rcb_debug_generic_kernels_only(0)
+    (l0, s0, st0, k0), (l1, s1, st1, k1) = outs
+    assert torch.equal(l0, l1) and torch.equal(s0, s1) and all(torch.equal(st0[k], st1[k]) for k in st0)
+    assert k0 == k1 and k0 > 0                   # (the same kernel, the same workgroups: the KL log is the same too)
+    assert float((l0 - g(loc)).abs().max()) > 0
+
+
 def test_four_column_member_kernel_equals_generic_kernel():
     """training update of a coarse level (members behind a row map, one sample, rows of 3201 floats: only 4-byte aligned): the
     four-columns-per-thread kernel against the generic one (rcb_debug_generic_kernels_only): identical bits; the KL log differs
