@@ -24,7 +24,7 @@ extern "C" {
 /* major * 100 + minor; bumped with every change of a signature or of a structure layout (100: rounds 1-3; 400: round 4 --
  * rcb_level.scale_is_sigma, rcb_struct_bytes, the hi / lo operand planes of the A transform).  A binding compares
  * rcb_version() with the RCB_VERSION it was written against and rcb_struct_bytes() with the size of each of its mirrors. */
-#define RCB_VERSION 404
+#define RCB_VERSION 405
 #define RCB_OK 0
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
@@ -163,6 +163,9 @@ typedef struct {
   int32_t scale_is_sigma;  /* 0: `log_scale` holds log-scales, sigma = softplus(.)/6 (the models' parameters).  1: it holds
                             * sigma itself -- the argument convention of utils.py:122-137, whose callers apply st() and the
                             * encoded-group masks first (prior_model.py:140-145, test_model.py:289-298); generic kernel only */
+  float* mu_sigma_ws;      /* nullable scratch [2 * rows * cols]: gathered levels (col_map / row_perm) first pack the effective
+                            * (mu, sigma) of every element as one 8-byte record there, contiguously; the sampler then gathers one
+                            * record per level and element instead of up to four 4-byte values -- same samples bit for bit   */
 } rcb_level;
 
 int rcb_reparam_fwd(const rcb_level* levels, int32_t n_levels, int32_t n_inr, int32_t samples,

@@ -42,7 +42,7 @@ class Level(C.Structure):
     _fields_ = [("loc", C.c_void_p), ("log_scale", C.c_void_p), ("enc_sample", C.c_void_p),
                 ("enc_mask", C.c_void_p), ("row_map", C.c_void_p), ("row_perm", C.c_void_p),
                 ("col_map", C.c_void_p), ("eps", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("cols_out", C.c_int32), ("scale_is_sigma", C.c_int32)]
+                ("cols_out", C.c_int32), ("scale_is_sigma", C.c_int32), ("mu_sigma_ws", C.c_void_p)]
 
 
 class RecDesc(C.Structure):
@@ -79,7 +79,7 @@ class LevelBwd(C.Structure):
 
 _lib = None
 # the header these mirrors were written against (include/rcb.h: RCB_VERSION) and the structures load() verifies by size
-ABI_VERSION = 404
+ABI_VERSION = 405
 _MIRRORS = {0: SirenDesc, 1: Level, 2: LevelBwd, 3: AdamCfg, 4: AdamTensor, 5: RecDesc}
 
 

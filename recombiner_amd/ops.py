@@ -353,12 +353,14 @@ class LevelSpec:
             inv[cm] = np.arange(cm.shape[0])
             self.col_inv = dev_i32(inv)
 
-    def c_fwd(self, eps):
+    def c_fwd(self, eps, ws=None):
+        """ws: optional scratch [2 * rows * cols] for the packed (mu, sigma) records of a gathered level (rcb_level.mu_sigma_ws)"""
         if tuple(eps.shape[-1:]) != (self.cols_out,):
             raise RcbError("eps last dim must equal cols_out")
         return Level(addr(self.loc.detach(), f32), addr(self.log_scale.detach(), f32), addr(self.enc_sample, f32),
                      addr(self.enc_mask, f32), addr(self.row_map, i32), addr(self.row_perm, i32),
-                     addr(self.col_map, i32), addr(eps, f32), self.rows, self.cols, self.cols_out, int(self.scale_is_sigma))
+                     addr(self.col_map, i32), addr(eps, f32), self.rows, self.cols, self.cols_out, int(self.scale_is_sigma),
+                     addr(ws, f32))
 
 
 def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], samples: int):
@@ -366,7 +368,12 @@ def reparam_fwd(levels: Sequence[LevelSpec], eps: Sequence[torch.Tensor], sample
     lib = _lib.load()
     n = levels[0].n_inr
     cols = levels[0].cols_out
-    arr = (Level * len(levels))(*[lv.c_fwd(e) for lv, e in zip(levels, eps)])
+    # gathered levels (test-time layout) of several INRs per launch: scratch for their packed (mu, sigma) records (rcb.h)
+    staged = (len(levels) == 1 and levels[0].col_map is not None and levels[0].row_map is None and levels[0].row_perm is None
+              and levels[0].cols * 16 <= 150 * 1024)                 # (the one-level LDS-staged kernel needs none)
+    scratch = [torch.empty(2 * lv.rows * lv.cols, device=lv.loc.device, dtype=f32)
+               if ((lv.col_map is not None or lv.row_perm is not None) and n * samples >= 8 and not staged) else None for lv in levels]
+    arr = (Level * len(levels))(*[lv.c_fwd(e, w_) for lv, e, w_ in zip(levels, eps, scratch)])
     for e, lv in zip(eps, levels):
         if tuple(e.shape) != (n, samples, lv.cols_out) or not e.is_contiguous():
             raise RcbError(f"eps must be contiguous [{n},{samples},{lv.cols_out}], got {tuple(e.shape)}")

@@ -894,6 +894,36 @@ def test_level_one_of_the_patched_test_time_layout_with_presummed_samples():
     assert float((l0 - g(loc)).abs().max()) > 0
 
 
+def test_three_gathered_levels_sampled_from_packed_mu_sigma_records():
+    """test-time sample of a patched preset (three levels, group-order column maps, per-column row permutations on levels 1 and 2,
+    encode masks, S = 5): with the (mu, sigma) records packed in a contiguous pass first (rcb_level.mu_sigma_ws) the sampler
+    gathers one 8-byte record per level and element -- the same samples bit for bit as the generic kernel's 4-byte gathers."""
+    from recombiner_amd import _lib
+    from recombiner_amd.test_model import _column_row_perms
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(43)
+    n, D, S = 24, 3301, 5
+    maps = [None, np.repeat(np.arange(n // 4), 4).astype(np.int32), np.repeat(np.arange(n // 12), 12).astype(np.int32)]
+    outs = []
+    for generic in (1, 0):
+        lib.rcb_debug_generic_kernels_only(generic)
+        try:
+            gen.manual_seed(43)
+            levels, eps = [], []
+            for li, mp in enumerate(maps):
+                rows = n if mp is None else int(mp.max()) + 1
+                levels.append(LevelSpec(g(0.02 * torch.randn(rows, D, generator=gen)), g(-4 + 0.5 * torch.randn(rows, D, generator=gen)), D, n,
+                                        row_map=mp, row_perm=_column_row_perms(rows, D) if li < 2 else None,
+                                        col_map=torch.randperm(D, generator=gen).numpy(),
+                                        enc_sample=g(0.02 * torch.randn(rows, D, generator=gen)),
+                                        enc_mask=g((torch.rand(rows, D, generator=gen) < 0.3).float())))
+                eps.append(g(torch.randn(n, S, D, generator=gen)))
+            outs.append(ops.reparam_fwd(levels, eps, S))
+        finally:
+            lib.rcb_debug_generic_kernels_only(0)
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+
+
 def test_four_column_member_kernel_equals_generic_kernel():
     """training update of a coarse level (members behind a row map, one sample, rows of 3201 floats: only 4-byte aligned): the
     four-columns-per-thread kernel against the generic one (rcb_debug_generic_kernels_only): identical bits; the KL log differs
