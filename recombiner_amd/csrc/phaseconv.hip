@@ -508,6 +508,160 @@ __global__ void __launch_bounds__(256) pc_dgrad_kernel(PcArgs p) {
   }
 }
 
+// The 64-channel stage (stage 2: dy has 64 channels): the kernel above stages ONE 16-channel block of the dy segment per pass,
+// i.e. 4 x 4^(ND-1) passes of eight MFMAs per wave with a barrier each (16 passes per tile group on the photo grids, 64 on the
+// video grids).  Here a pass stages whole 128-byte pixels of a segment: 4^(ND-1) passes of 32 MFMAs, the weight fragments of
+// the next 16-channel block requested while the current block is multiplied.  One image set (34 KB: four workgroups per CU), the
+// next pass's loads in flight during the MFMAs; adjacent pixels swapped where bit 1 of the pixel index is set and the chunk index
+// XORed with (pixel >> 2) & 7: the lanes' stride-2 gather covers all 64 banks once per 16-lane group (tools/lds_banks.py model).
+__device__ __forceinline__ int dg64_slot(int P, int chunk) { return (P ^ ((P >> 1) & 1)) * 8 + (chunk ^ ((P >> 2) & 7)); }
+
+template <int ND>
+__global__ void __launch_bounds__(256) pc_dgrad64_kernel(PcArgs p) {
+  constexpr int COUT = 64, CB = 4, NU = 1 << (2 * ND), NLEAD = 1 << (2 * (ND - 1)), PWD = 66, TCH = PWD * 8, NCH = 4 * TCH;
+  constexpr int NIT = (NCH + 255) / 256;
+  __shared__ uint4 img[NCH];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
+  const int mb = wave & 1, pair = wave >> 1;
+  const int g[3] = {p.g0, p.g1, p.g2};
+  const int gl = g[ND - 1];
+  const uint4* __restrict__ fr = p.frags + (long long)mb * NU * CB * 64 + lane;
+  const int n_groups = (p.n_tiles + 3) / 4;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // the four tiles of the group (uniform): batch index, leading source indices, first pixel
+    long long t_base[4];
+    int t_l0[4], t_l1[4], t_j0[4];
+    bool t_on[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int tile = grp * 4 + sl;
+      t_on[sl] = tile < p.n_tiles;
+      const int tc = t_on[sl] ? tile : p.n_tiles - 1;
+      int rest = tc / p.tiles_per_row;
+      t_j0[sl] = 32 * (tc - rest * p.tiles_per_row);
+      int l0 = 0, l1 = 0;
+      if (ND == 3) {
+        l1 = rest % g[1];
+        rest /= g[1];
+        l0 = rest % g[0];
+        rest /= g[0];
+      } else if (ND == 2) {
+        l0 = rest % g[0];
+        rest /= g[0];
+      }
+      t_l0[sl] = l0;
+      t_l1[sl] = l1;
+      t_base[sl] = rest;
+    }
+    uint4 stg[NIT];
+    auto fetch = [&](int ld) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (e < NCH) {
+          const int sl = e / TCH, rem = e - sl * TCH, pp = rem >> 3, c = rem & 7;
+          // (the tile of the chunk is one of four uniform records: selected, not indexed)
+          const long long base = sl == 0 ? t_base[0] : (sl == 1 ? t_base[1] : (sl == 2 ? t_base[2] : t_base[3]));
+          const int l0 = sl == 0 ? t_l0[0] : (sl == 1 ? t_l0[1] : (sl == 2 ? t_l0[2] : t_l0[3]));
+          const int l1 = sl == 0 ? t_l1[0] : (sl == 1 ? t_l1[1] : (sl == 2 ? t_l1[2] : t_l1[3]));
+          const int j0 = sl == 0 ? t_j0[0] : (sl == 1 ? t_j0[1] : (sl == 2 ? t_j0[2] : t_j0[3]));
+          bool inb = sl == 0 ? t_on[0] : (sl == 1 ? t_on[1] : (sl == 2 ? t_on[2] : t_on[3]));
+          long long off = base;
+          if (ND == 3) {
+            const int s0 = 2 * l0 + ((ld >> 2) & 3) - 1, s1 = 2 * l1 + (ld & 3) - 1;
+            inb = inb && s0 >= 0 && s0 < 2 * g[0] && s1 >= 0 && s1 < 2 * g[1];
+            off = (off * (2 * g[0]) + s0) * (2 * g[1]) + s1;
+          } else if (ND == 2) {
+            const int s0 = 2 * l0 + (ld & 3) - 1;
+            inb = inb && s0 >= 0 && s0 < 2 * g[0];
+            off = off * (2 * g[0]) + s0;
+          }
+          const int px = 2 * j0 - 1 + pp;
+          if (inb && px >= 0 && px < 2 * gl) v = reinterpret_cast<const uint4*>(p.x + (off * (2 * gl) + px) * COUT)[c];
+        }
+        stg[it] = v;
+      }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    Frag wnext[4];
+    auto fetch_w = [&](int ld, int cb) {
+#pragma unroll
+      for (int dl = 0; dl < 4; ++dl) wnext[dl].u = fr[((ld * 4 + dl) * CB + cb) * 64];
+    };
+    fetch(0);
+    fetch_w(0, 0);
+#pragma unroll 1
+    for (int ld = 0; ld < NLEAD; ++ld) {
+      __syncthreads();                             // every wave is done reading the previous pass's image
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        if (e < NCH) {
+          const int sl = e / TCH, rem = e - sl * TCH;
+          img[sl * TCH + dg64_slot(rem >> 3, rem & 7)] = stg[it];
+        }
+      }
+      __syncthreads();
+      if (ld + 1 < NLEAD) fetch(ld + 1);
+#pragma unroll 1
+      for (int cb = 0; cb < CB; ++cb) {             // (rolled: unrolled, the compiler hoists all 32 image reads of the pass -- 128 registers)
+        Frag w[4];
+#pragma unroll
+        for (int dl = 0; dl < 4; ++dl) w[dl] = wnext[dl];
+        if (cb + 1 < CB) fetch_w(ld, cb + 1);
+        else if (ld + 1 < NLEAD) fetch_w(ld + 1, 0);
+#pragma unroll
+        for (int dl = 0; dl < 4; ++dl) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            Frag f;
+            f.u = img[(2 * pair + k) * TCH + dg64_slot(2 * q + dl, 2 * cb + h)];
+            acc[k] = mfma16(w[dl].v, f.v, acc[k]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int tile = grp * 4 + 2 * pair + k;
+      if (tile >= p.n_tiles) continue;               // (uniform over the wave)
+      int rest = tile / p.tiles_per_row;
+      const int il = 32 * (tile - rest * p.tiles_per_row) + q;
+      const long long e0 = ((long long)rest * gl + il) * CIN + 32 * mb + 16 * h;      // (lane halves swap: see pc_dgrad_kernel)
+      const bool on = il < gl;
+      Frag xa[2];
+      if (p.xact && on) {
+        xa[0].u = reinterpret_cast<const uint4*>(p.xact + e0)[0];
+        xa[1].u = reinterpret_cast<const uint4*>(p.xact + e0)[1];
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float o[8];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[k][4 * hf + kk]), __float_as_uint(acc[k][8 + 4 * hf + kk]),
+                                                     false, false);
+          o[kk] = __uint_as_float(sw[0]);
+          o[4 + kk] = __uint_as_float(sw[1]);
+        }
+        Frag ob;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          float v = o[kk];
+          if (p.xact) v *= ((float)xa[hf].v[kk] > 0.f ? 1.0f : SLOPE);
+          ob.v[kk] = (__bf16)v;
+        }
+        if (on) reinterpret_cast<uint4*>(p.y + e0)[hf] = ob.u;
+      }
+    }
+  }
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------------------
 //   dWeff[a][t][ci][co] = sum_{b, i} x[b, i + a + t - 1, ci] dy[b, 2 i + a, co]        dbias[co] = sum dy
 // The contraction runs over positions, i.e. over the lanes' axis of both operands: the [pixel][channel] images of a tile
@@ -1115,9 +1269,17 @@ extern "C" int rcb_phaseconv_dgrad(const void* dy, const void* dgrad_frags, cons
   const int groups = (p.n_tiles + 3) / 4;             // four consecutive tiles per workgroup
   int gx = groups < 4096 ? groups : 4096;
   hipStream_t s = (hipStream_t)stream;
+  // RCB_PC_DGRAD64=0: the 16-channel-block kernel also at 64 channels (same-box A/B)
+  static const bool whole_pixels = [] { const char* e = getenv("RCB_PC_DGRAD64"); return !(e && e[0] == '0'); }();
 #define RCB_DG(NDv, Cv) \
   if (nd == NDv && cout == Cv) pc_dgrad_kernel<NDv, Cv><<<gx, 256, 0, s>>>(p);
-  RCB_DG(1, 64) RCB_DG(1, 16) RCB_DG(2, 64) RCB_DG(2, 16) RCB_DG(3, 64) RCB_DG(3, 16)
+  if (cout == 64 && whole_pixels) {
+    if (nd == 1) pc_dgrad64_kernel<1><<<gx, 256, 0, s>>>(p);
+    if (nd == 2) pc_dgrad64_kernel<2><<<gx, 256, 0, s>>>(p);
+    if (nd == 3) pc_dgrad64_kernel<3><<<gx, 256, 0, s>>>(p);
+  } else {
+    RCB_DG(1, 64) RCB_DG(1, 16) RCB_DG(2, 64) RCB_DG(2, 16) RCB_DG(3, 64) RCB_DG(3, 16)
+  }
 #undef RCB_DG
   RCB_LAUNCH_CHECK();
   return RCB_OK;
