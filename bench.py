@@ -363,13 +363,17 @@ def presets_table(dev):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             run(6)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            _, _, elbo = run(steps)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / steps
+            # best of three timed calls: the first replays after another workload have shown launch gaps inside the replayed graph
+            # (a 192-INR step at twice its usual time with unchanged kernel times) that a second call no longer has
+            ms = float("inf")
+            for _rep in range(3 if steps >= 20 else 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                _, _, elbo = run(steps)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = min(ms, e0.elapsed_time(e1) / steps)
             nprof = max(2, min(10, steps // 2))
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 run(nprof)
