@@ -252,6 +252,33 @@ def test_patched_2d_prior_training_checkpoint_and_compression_in_the_bf16_mode(t
         assert float((y_dec - model.predict(Xd)).abs().max()) < 1e-5
 
 
+def test_patched_1d_prior_training_checkpoint_and_compression_in_the_bf16_mode(tmp_path):
+    """the same on a (reduced) patched 1-D preset: the audio geometry with 8 patches of 64 samples per clip.  Prior training runs
+    the direct stage-1 kernels, the 1-D weight-gradient kernels, every level's noise drawn in the kernels and the lpe sample fused
+    into its update; compression runs the test-time layout (pre-summed samples, packed (mu, sigma) records); the bitstream decodes
+    to the encoder's reconstruction."""
+    from recombiner_amd import bitstream
+    cfg = dict(config.configs["audio"], pixel_sizes=[64], patch_nums=[8], hierarchical_patch_nums={"level2": [2], "level3": [8]})
+    n = 16                                                  # two clips of 8 patches
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], n, 1, seed=2)
+    path = os.path.join(tmp_path, "PRIOR1D.pkl")
+    out = drivers.train_prior(cfg, "audio", X.to(DEV)[None].expand(n, -1, -1), Y, max_bitrate=0.5, device=DEV, n_em_iter=2,
+                              first_epochs=12, epochs=12, lr=2e-3, checkpoint_path=path, checkpoint_every=1, precision=1,
+                              log=lambda *a: None)
+    assert np.isfinite(out["elbo"]).all() and np.mean(out["elbo"][-6:]) > np.mean(out["elbo"][:6])
+    ws = out["model"]._ws
+    assert ws is not None and "hier_eps" in ws and "smp_lpe" in ws               # the in-kernel noise paths were taken
+    ck = drivers.load_checkpoint(path)
+    assert len(ck) == 8 and type(ck[7]).__name__ == "Upsample"
+    Xd = X.to(DEV)[None].expand(8, -1, -1)
+    dist, model = drivers.compress(cfg, "audio", ck, Xd, Y[:8], device=DEV, n_epochs=10, finetune_epochs=1, precision=1)
+    assert np.isfinite(dist).all()
+    blob = bitstream.encode(model)
+    y_dec = bitstream.decode(cfg, "audio", ck, blob, Xd, 8, device=DEV, precision=1)
+    with torch.no_grad():
+        assert float((y_dec - model.predict(Xd)).abs().max()) < 1e-5
+
+
 def test_dropin_modules_drive_the_reference_call_sequence(tmp_path):
     """`dropin/` first on the path: `import config, prior_model, test_model, utils` resolve to the MI355X classes and the
     call sequence of main_prior_training.py:53-73,114-172,186-338 and main_compression.py:37-167 runs unchanged -- incl. the
