@@ -26,6 +26,11 @@ run audio python3 tools/prof_preset.py audio 8 32 1
 run video python3 tools/prof_preset.py video 4 32 1
 run kodak_w48 python3 tools/prof_preset.py kodak 2 48 1
 run video_w64_f16 python3 tools/prof_preset.py video 4 64 2
+# the presets at a rank's shard (BASELINE configs[2..4]) and the test-time step of a batch of 8 photos
+run audio_1024clips python3 tools/prof_preset.py audio 1024 32 1
+run kodak_w48_24photos python3 tools/prof_preset.py kodak 24 48 1
+run video_w64_f16_32clips python3 tools/prof_preset.py video 32 64 2
+run testtime_kodak_w48_8photos python3 tools/prof_testtime.py kodak 8 48 20
 pmc pmc_siren_fetch FETCH_SIZE python3 tools/run_siren.py bf16 4096 3 pe16 32 step
 pmc pmc_siren_write WRITE_SIZE python3 tools/run_siren.py bf16 4096 3 pe16 32 step
 pmc pmc_atrans_fetch FETCH_SIZE python3 tools/run_atrans.py 4096 2 4
