@@ -150,7 +150,9 @@ class PriorBNNmodel(nn.Module):
         self.force_segments = False
         # sharded step: None = capture the all-reduces inside the step graph when the backend is RCCL ("nccl"), else four
         # segments around host-enqueued collectives; True / False force one form
-        self.capture_collectives = None
+        # None: automatic (inside the step graph when the backend is RCCL); RCB_CAPTURE_COLLECTIVES=0 / 1 forces the four-segment
+        # form / the captured form without a code change (the escape hatch of a multi-GPU run)
+        self.capture_collectives = {"0": False, "1": True}.get(os.environ.get("RCB_CAPTURE_COLLECTIVES", ""), None)
         # in-kernel noise: first row of this model's INRs inside a larger (virtual) batch.  Row r of the model draws the noise of
         # row rng_row_offset + r of that batch (ops.rng_group_offset): a shard or a sub-batch trained on its own then sees
         # exactly the noise of the unsharded run, given the same seed (`rng_seed_override`, else derived per model and rank)
