@@ -31,6 +31,11 @@ run audio_1024clips python3 tools/prof_preset.py audio 1024 32 1
 run kodak_w48_24photos python3 tools/prof_preset.py kodak 24 48 1
 run video_w64_f16_32clips python3 tools/prof_preset.py video 32 64 2
 run testtime_kodak_w48_8photos python3 tools/prof_testtime.py kodak 8 48 20
+# the stand-alone benchmarks of the round's new phase-conv / stage-1 kernels at the shard shapes (their printed TB/s are from
+# these durations)
+run kernels_stage1 python3 tools/bench_stage1.py
+run kernels_wgrad1d python3 tools/bench_wgrad1d.py
+run kernels_phaseconv python3 tools/bench_phaseconv.py
 pmc pmc_siren_fetch FETCH_SIZE python3 tools/run_siren.py bf16 4096 3 pe16 32 step
 pmc pmc_siren_write WRITE_SIZE python3 tools/run_siren.py bf16 4096 3 pe16 32 step
 pmc pmc_atrans_fetch FETCH_SIZE python3 tools/run_atrans.py 4096 2 4
