@@ -93,8 +93,14 @@ struct Geo {
   static constexpr int LDS_BYTES = cmax(LDS_MAIN, 4 * RED_WAVE * 4 + 16);   // + the four waves' loss sums
 };
 
+// Waves per SIMD the register allocation aims at.  The loss / backward instances need their 231 registers: at three waves (<= 168)
+// they spill 142 of them and run 3.4 x slower (0.92 vs 0.27 ms; -DRCB_SIREN_WAVES=3 builds that variant).  The forward-only
+// instances (prediction, decoding) use ~130 and are 12 % faster when the allocator is TOLD three waves fit (0.136 -> 0.119 ms).
+#ifndef RCB_SIREN_WAVES
+#define RCB_SIREN_WAVES 2
+#endif
 template <typename T, int NH, int F, int E, int C, int MODE, bool IN16>
-__global__ void __launch_bounds__(256, 2) siren_bf16_kernel(SirenArgs a) {
+__global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) siren_bf16_kernel(SirenArgs a) {
   using G = Geo<NH, F, E, C>;
   using bf16x8 = typename Op16<T>::v8;
   using bf16x4 = typename Op16<T>::v4;
