@@ -118,6 +118,12 @@ typedef struct {
                               * under matrix / vector load, peak-clock rooflines overstate what such kernels can reach      */
 } rcb_siren_desc;
 
+/* Test hook: which kernel family runs the width-32 bf16 loss / backward launches whose inputs arrive as 16-bit rows (pe_bf16,
+ * xf_bf16): tiles > 0 = one wave per row with that many (2 or 4) 32-pixel tiles in flight (siren_mlp_wave.hip, the default: 4),
+ * 0 = one workgroup per row (siren_mlp_bf16.hip); tiles < 0 only queries.  Returns the previous setting.  Both families
+ * evaluate the same products with fp32 accumulation; they differ in the order in which the pixel tiles of a row are summed. */
+int rcb_debug_siren_wave_tiles(int32_t tiles);
+
 /* y_out[G, P, C] = MLP(x)                                                           */
 int rcb_siren_fwd(const rcb_siren_desc* d, const float* xf, const void* pe, const float* wvec,
                   float* y_out, rcb_stream_t stream);

@@ -21,7 +21,7 @@ EXPORTS = ["rcb_version", "rcb_last_error_string", "rcb_struct_bytes", "rcb_sire
            "rcb_phase_bigweight", "rcb_phase_bigweight_grad", "rcb_atrans_pack_elems", "rcb_atrans_pack", "rcb_atrans_plan",
            "rcb_atrans_apply", "rcb_atrans_workspace_floats", "rcb_atrans_wgrad_narrow_workspace", "rcb_atrans_wgrad_narrow",
            "rcb_stage1_1d_fwd", "rcb_stage1_1d_dgrad", "rcb_stage1_1d_wgrad", "rcb_stage1_1d_wgrad_workspace",
-           "rcb_reparam_hier_rng_fwd"]
+           "rcb_reparam_hier_rng_fwd", "rcb_debug_siren_wave_tiles"]
 
 
 class RcbError(RuntimeError):

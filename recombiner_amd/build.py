@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librcb_hip.so")
 SOURCES = ["atrans.hip", "phase_weight.hip", "phaseconv.hip", "posterior.hip", "rec_score.hip", "siren_mlp.hip",
-           "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_mlp_generic.hip", "stage1.hip", "tiles.hip", "upconv.hip",
+           "siren_mlp_bf16.hip", "siren_mlp_wave.hip", "siren_mlp_wide.hip", "siren_mlp_generic.hip", "stage1.hip", "tiles.hip", "upconv.hip",
            "upconv_weff.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

@@ -76,6 +76,10 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);
 int siren_wide_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // hidden width 48 / 64
 int siren_generic_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // fp32, widths other than 32
+// width 32, loss / backward, one wave per row with `variant` (2 or 4) pixel tiles in flight (siren_mlp_wave.hip); *taken = false
+// when that family has no instance for the request
+int& siren_wave_tiles();      // tiles in flight per wave (0: the workgroup kernel everywhere; rcb_debug_siren_wave_tiles)
+int siren_wave_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st, int variant, bool* taken);
 
 // the 16-bit kernel family of a descriptor: width 32 (siren_mlp_bf16.hip) or the kernel with dealt gradient tiles for widths
 // 48 / 64 (siren_mlp_wide.hip; in a -DRCB_SIREN_DEALT32 build RCB_SIREN_W32_DEALT=1 sends the width-32 loss / backward
@@ -85,7 +89,14 @@ inline int siren_16bit_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a,
   static const bool dealt32 = getenv("RCB_SIREN_W32_DEALT") != nullptr;
   if (dealt32 && mode != MODE_FWD) return siren_wide_dispatch(mode, d, a, st);
 #endif
-  return d->hidden > HID ? siren_wide_dispatch(mode, d, a, st) : siren_bf16_dispatch(mode, d, a, st);
+  if (d->hidden > HID) return siren_wide_dispatch(mode, d, a, st);
+  const int wave_variant = siren_wave_tiles();
+  if (wave_variant > 0 && mode != MODE_FWD) {
+    bool taken = false;
+    const int rc = siren_wave_dispatch(mode, d, a, st, wave_variant, &taken);
+    if (taken) return rc;
+  }
+  return siren_bf16_dispatch(mode, d, a, st);
 }
 
 }  // namespace rcb
