@@ -76,9 +76,8 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 int siren_bf16_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);
 int siren_wide_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // hidden width 48 / 64
 int siren_generic_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st);   // fp32, widths other than 32
-// width 32, loss / backward, one wave per row with `variant` (2 or 4) pixel tiles in flight (siren_mlp_wave.hip); *taken = false
-// when that family has no instance for the request
-int& siren_wave_tiles();      // tiles in flight per wave (0: the workgroup kernel everywhere; rcb_debug_siren_wave_tiles)
+// width 32, loss / backward, one wave per row (siren_mlp_wave.hip); *taken = false when that family has no instance for the request
+int& siren_wave_tiles();      // 1: one wave per row where instantiated, 0: the workgroup kernel everywhere (rcb_debug_siren_wave_tiles)
 int siren_wave_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st, int variant, bool* taken);
 
 // the 16-bit kernel family of a descriptor: width 32 (siren_mlp_bf16.hip) or the kernel with dealt gradient tiles for widths

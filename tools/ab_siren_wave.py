@@ -1,6 +1,6 @@
 """Same-process A/B of the two width-32 bf16 SIREN loss / backward families (rcb_debug_siren_wave_tiles):
     python tools/ab_siren_wave.py [N=4096] [rounds=5] [reps=20]
-0 = one workgroup per row (siren_mlp_bf16.hip), 2 / 4 = one wave per row with that many tiles in flight (siren_mlp_wave.hip).
+0 = one workgroup per row (siren_mlp_bf16.hip), 1 = one wave per row (siren_mlp_wave.hip).
 Checks each against the fp32 kernel (exact fp32 products) on the same inputs, then times them interleaved, launched as the
 training step launches them (rows on 128-byte lines, bf16 copy of the gradient, bf16 pe / dpe, bf16 coordinate grid)."""
 import os
@@ -15,7 +15,7 @@ from recombiner_amd.ops import SirenMeta
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-variants = [int(v) for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else ["0", "2", "4"])]
+variants = [int(v) for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else ["0", "1"])]
 grid = [int(v) for v in (sys.argv[5].split("x") if len(sys.argv) > 5 else ["32", "32"])]
 P = grid[0] * grid[1]
 dev = "cuda"
@@ -70,4 +70,4 @@ for r in range(rounds):
 for v in variants:
     t = sorted(times[v])
     print(f"variant {v}: us per launch median {t[len(t) // 2]:.1f} min {t[0]:.1f} max {t[-1]:.1f}  ({n} rows, {P} pixels)")
-lib.rcb_debug_siren_wave_tiles(4)
+lib.rcb_debug_siren_wave_tiles(0)
