@@ -365,7 +365,7 @@ def presets_table(dev):
             run(6)
             # best of three timed calls: the first replays after another workload have shown launch gaps inside the replayed graph
             # (a 192-INR step at twice its usual time with unchanged kernel times) that a second call no longer has
-            ms = float("inf")
+            calls = []
             for _rep in range(3 if steps >= 20 else 1):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
@@ -373,7 +373,8 @@ def presets_table(dev):
                 _, _, elbo = run(steps)
                 e1.record()
                 torch.cuda.synchronize()
-                ms = min(ms, e0.elapsed_time(e1) / steps)
+                calls.append(e0.elapsed_time(e1) / steps)
+            ms = sorted(calls)[len(calls) // 2]            # the MEDIAN call is what the record reports; all calls are kept beside it
             nprof = max(2, min(10, steps // 2))
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 run(nprof)
@@ -384,7 +385,9 @@ def presets_table(dev):
         top_us, top = rows[0]
         px, C, E, D = int(np.prod(cfg["pixel_sizes"])), cfg["output_dim"], 16, m._d_net
         rec = {"preset": label, "datapoints": n_data, "inrs": n, "pixels_per_inr": px, "hidden": width,
-               "operands": "bf16" if prec == 1 else "f16", "ms_per_step": round(ms, 4), "inr_steps_per_sec": round(n / (ms * 1e-3)),
+               "operands": "bf16" if prec == 1 else "f16", "ms_per_step": round(ms, 4),
+               "timing": "median of %d timed call(s) of %d steps" % (len(calls), steps), "ms_per_step_calls": [round(c, 4) for c in calls],
+               "inr_steps_per_sec": round(n / (ms * 1e-3)),
                "pixel_steps_per_sec": round(n * px / (ms * 1e-3)), "graph_replay": m._ws is not None and m._ws["graphs"] is not None,
                "finite": bool(np.isfinite(elbo).all()), "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "dominant_kernel": top[:80], "dominant_kernel_us": round(top_us, 1), "dominant_kernel_share": round(top_us / total, 3)}
@@ -469,7 +472,8 @@ def comm_report(m, lt, up, dev):
     hi, lo = chk.clone(), chk.clone()
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    rep = {"mappings_identical_across_ranks": bool(torch.equal(hi, lo)), "backend": dist.get_backend()}
+    rep = {"mappings_identical_across_ranks": bool(torch.equal(hi, lo)), "backend": dist.get_backend(),
+           "step_form_choice": os.environ.get("RCB_STEP_FORM_CHOICE", "model default (captured on one rank, four segments on more)")}
     if flat is not None and w["graphs"] is not None and w["graphs"][0] == "one":
         # RCCL: both all-reduces are captured INSIDE the one step graph (issued from the forked streams, overlapped by the
         # graph's own dependencies): no host work between segments; what can be timed from outside is the collective alone
@@ -606,9 +610,45 @@ def launch_ranks(a):
                  f"needs {a.gpus} devices (RCB_DIST_BACKEND=gloo rehearses the sharded code path on fewer; never for numbers)")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     # --standalone: torchrun picks AND holds the rendezvous port itself (no bind / close / reuse race with other jobs on the box)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
-           "--nproc-per-node", str(a.gpus), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.run(cmd, env=env).returncode)
+    run = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus)]
+    probe_capture_form(a, env, run, rehearsal)
+    sys.exit(subprocess.run(run + [os.path.abspath(__file__)] + sys.argv[1:], env=env).returncode)
+
+
+def probe_capture_form(a, env, run, rehearsal):
+    """Which form of the sharded step the ranks will run (recorded in comm.step_form_choice).  The form with both all-reduces
+    captured inside the step graph has only ever executed on one-rank communicators; a hang of RCCL under capture on N ranks
+    would take the measured run with it.  So the launcher first runs tools/rccl_capture_probe.py on the same N ranks as a
+    child with a hard timeout, and only a clean RCCL_CAPTURE_OK from every rank selects the captured form
+    (RCB_CAPTURE_COLLECTIVES=1); a failure, a timeout or a gloo rehearsal select the four-segment form (=0).  An explicit
+    RCB_CAPTURE_COLLECTIVES in the environment is left alone."""
+    import subprocess
+    if "RCB_CAPTURE_COLLECTIVES" in os.environ:
+        env["RCB_STEP_FORM_CHOICE"] = "RCB_CAPTURE_COLLECTIVES=%s given by the caller" % os.environ["RCB_CAPTURE_COLLECTIVES"]
+        return
+    if rehearsal:
+        env["RCB_CAPTURE_COLLECTIVES"], env["RCB_STEP_FORM_CHOICE"] = "0", "four segments (gloo rehearsal: no probe)"
+        return
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rccl_capture_probe.py")
+    timeout_s = float(os.environ.get("RCB_PROBE_TIMEOUT_S", "180"))
+    try:
+        # (own session: on a timeout the whole process group of the probe -- torchrun and its ranks -- is ended, by its id)
+        p = subprocess.Popen(run + [probe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+            ok = p.returncode == 0 and out.count("RCCL_CAPTURE_OK") >= a.gpus and "RCCL_CAPTURE_NOT_OK" not in out
+            why = "probe ok on %d ranks" % a.gpus if ok else "probe failed (exit code %s)" % p.returncode
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            ok, why = False, "probe timed out after %.0f s" % timeout_s
+    except Exception as e:                       # (no torchrun, no probe file ...)
+        ok, why = False, "probe could not run: %r" % (e,)
+    env["RCB_CAPTURE_COLLECTIVES"] = "1" if ok else "0"
+    env["RCB_STEP_FORM_CHOICE"] = ("collectives captured inside the step graph: " if ok else "four segments around host-enqueued collectives: ") + why
+    print("bench.py: sharded step form -- " + env["RCB_STEP_FORM_CHOICE"], file=sys.stderr, flush=True)
 
 
 def main():

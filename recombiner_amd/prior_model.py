@@ -434,8 +434,14 @@ class PriorBNNmodel(nn.Module):
         # all-reduce captures and replays correctly from the capturing stream and from a forked one, tools/rccl_capture_probe.py;
         # the four-segment form costs 142 us of host work per 1.09 ms step, bench.py `sharded_step_host_cost`); other
         # backends (gloo: the CPU rehearsals) keep the four captured segments around host-enqueued collectives
+        # Default (capture_collectives None): captured on a ONE-rank RCCL communicator only -- that is all this form has ever
+        # run on (the pool has one GPU per box).  With more ranks the four-segment form runs unless RCB_CAPTURE_COLLECTIVES=1
+        # (or capture_collectives=True) opts in; bench.py's launcher sets it after an N-rank tools/rccl_capture_probe.py run
+        # succeeded within its timeout, so that the first N > 1 execution of the captured form is never the measured one.
         capture_coll = bool(flat is not None and self.capture_collectives is not False
-                            and (self.capture_collectives is True or torch.distributed.get_backend(self.dp_group) == "nccl"))
+                            and (self.capture_collectives is True
+                                 or (torch.distributed.get_backend(self.dp_group) == "nccl"
+                                     and torch.distributed.get_world_size(self.dp_group) == 1)))
         # stream forks inside the (captured) step -- bit mask, same kernels on the same operands, so results are identical:
         #   1: the A transform's forward beside the upsampling net's forward;  2: the A transform's backward beside the
         #   upsampling net's backward;  4: the weight-gradient side of the upsampling net's backward beside its data path
@@ -802,10 +808,15 @@ class PriorBNNmodel(nn.Module):
                 except Exception as exc:     # capture is an optimisation: fall back to eager stepping
                     failure = exc
                     torch.cuda.synchronize()
+                    # a body that aborted in mid-capture leaves its per-step state behind (pending fork / side-stream
+                    # flags, the Work handles of collectives that were only RECORDED): an eager step that found them would
+                    # skip its own all-reduce and wait on a handle of the dead capture
+                    st.clear()
                 if flat is not None:
                     # every rank must take the same route from here on: replayed segments and eager steps issue the same
                     # collectives, but a rank that alone drops to eager would also alone flip `use_graph` for later calls.
-                    # No collective was issued during the capture attempt (they sit between the segments), so the ranks are
+                    # No collective has EXECUTED during the capture attempt -- in the four-segment form they sit between the
+                    # segments, in the captured form they were recorded into a graph that is dropped -- so the ranks are
                     # still aligned and can agree here.
                     ok = torch.tensor([0 if failure is not None else 1], device=dev, dtype=torch.int32)
                     torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.dp_group)
@@ -828,6 +839,7 @@ class PriorBNNmodel(nn.Module):
                 it = tqdm(it)
             for _ in it:
                 body()
+        _uf.WEIGHT_SIDE_STREAM = None       # (a module-level switch: never left set behind this call)
         mse_buf, kl_buf = mse_buf[:n_epoch], kl_buf[:n_epoch]
         kl_final = self._kl_value(priors)
         # one transfer (one synchronisation) for everything the call returns: [elbo per step ..., last MSE, final KL]

@@ -484,6 +484,8 @@ class _UpsampleCifarFn(torch.autograd.Function):
         # the library GEMMs (160 macro-tiles) leave a third of the chip idle on their own.  Same kernels, same operands:
         # identical results.
         side = WEIGHT_SIDE_STREAM if (need_w and fused3) else None
+        if side is not None and side.device != dz2.device:      # (a stream left behind by a model on another device)
+            side = None
         main = torch.cuda.current_stream() if side is not None else None
         if side is not None:
             side.wait_stream(main)                       # dz2 is complete

@@ -419,6 +419,11 @@ def test_bench_two_ranks_over_rccl():
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0
     assert rec["comm"]["backend"] == "nccl" and rec["comm"]["mappings_identical_across_ranks"] is True
+    # the launcher probed the captured form on the same two ranks first; whichever form that selected is the one that ran
+    choice = rec["comm"]["step_form_choice"]
+    assert choice.startswith(("collectives captured", "four segments")), choice
+    if choice.startswith("collectives captured"):
+        assert rec["comm"]["step_form"].startswith("one captured graph"), rec["comm"]
 
 
 @pytest.mark.parametrize("n", [1, 3, 5, 258])

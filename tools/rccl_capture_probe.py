@@ -1,18 +1,26 @@
-"""Can an RCCL all-reduce sit INSIDE a captured HIP graph on this stack (PyTorch ProcessGroupNCCL on ROCm)?  One rank, one GPU:
-capture [kernel, all_reduce(async), kernel on the main stream, wait, kernel], replay it, check the values; also with the
-collective issued from a side stream (the forked step's structure).   python tools/rccl_capture_probe.py"""
+"""Can an RCCL all-reduce sit INSIDE a captured HIP graph on this stack (PyTorch ProcessGroupNCCL on ROCm)?  Captures
+[kernel, all_reduce(async), kernel on the main stream, wait, kernel], replays it three times and checks the values; also with the
+collective issued from a side stream (the forked training step's structure).
+    python tools/rccl_capture_probe.py                      one rank, one GPU
+    python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N tools/rccl_capture_probe.py
+bench.py's launcher runs the N-rank form under a hard timeout before the measured run and lets the training step capture its
+collectives (RCB_CAPTURE_COLLECTIVES=1) only if every rank printed RCCL_CAPTURE_OK; exit code 0 = ok."""
 import os
 import sys
 import torch
 import torch.distributed as dist
 
+rank = int(os.environ.get("RANK", "0"))
+ws = int(os.environ.get("WORLD_SIZE", "1"))
+local = int(os.environ.get("LOCAL_RANK", "0"))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29713")
-dev = torch.device("cuda", 0)
+dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
 torch.cuda.set_device(dev)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-x = torch.ones(1 << 20, device=dev)
-y = torch.zeros(1 << 20, device=dev)
+dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=dev)
+n = 1 << 20
+x = torch.ones(n, device=dev)
+y = torch.zeros(n, device=dev)
 dist.all_reduce(x)                       # communicator set-up outside the capture
 torch.cuda.synchronize()
 side = torch.cuda.Stream()
@@ -39,12 +47,18 @@ for variant in ("same-stream", "side-stream"):
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
-        # x: 1 -> 2 -> 4 -> 8;  y: (1 + 2) + (1 + 4) + (1 + 8) = 17
-        print(variant, "captured and replayed:", float(x[0]), float(y[0]), "expected 8.0 17.0", flush=True)
-        ok = ok and float(x[0]) == 8.0 and float(y[0]) == 17.0
+        # per replay x -> 2 x summed over the ranks;  y += 1 + x
+        f = 2.0 * ws
+        ex, ey = f ** 3, 3.0 + f + f ** 2 + f ** 3
+        print(f"rank {rank}/{ws} {variant} captured and replayed: {float(x[0])} {float(y[0])} expected {ex} {ey}", flush=True)
+        ok = ok and float(x[0]) == ex and float(y[0]) == ey and float(x[n - 1]) == ex and float(y[n - 1]) == ey
     except Exception as e:
         ok = False
-        print(variant, "FAILED:", repr(e)[:300], flush=True)
+        print(f"rank {rank}/{ws} {variant} FAILED:", repr(e)[:300], flush=True)
         torch.cuda.synchronize()
-print("RCCL_CAPTURE_OK" if ok else "RCCL_CAPTURE_NOT_OK")
+flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+ok = bool(int(flag.item()))
+print("RCCL_CAPTURE_OK" if ok else "RCCL_CAPTURE_NOT_OK", flush=True)
 dist.destroy_process_group()
+sys.exit(0 if ok else 1)
