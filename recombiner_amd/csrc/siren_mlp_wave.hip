@@ -23,6 +23,8 @@
 // against the workgroup kernel's 226 -- one wave cannot issue more than one vector instruction per 4 cycles, half of what the
 // SIMD takes from two.  It is in the history of this file.)
 // Matches prior_model.py:168-179,237 and test_model.py:347-355,625-627 like the kernels it stands beside.
+#include <type_traits>
+
 #include "siren_op16.h"
 
 using namespace rcb;
@@ -575,46 +577,74 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
       const bool vec4 = (dst == nullptr || (((a.w_stride & 3) == 0) && ((reinterpret_cast<size_t>(a.dwvec) & 15) == 0))) &&
                         (d16 == nullptr || (((a.dw16_stride & 3) == 0) && ((reinterpret_cast<size_t>(a.dw16) & 7) == 0) &&
                                             (dlo == nullptr || (reinterpret_cast<size_t>(a.dwlo) & 7) == 0)));
+      // one wave-uniform decision in front of the stores instead of a branch around every one of them (a branch per store
+      // made the compiler park the accumulators in scratch and reload one per block behind a full vmcnt drain: 20 k cycles per
+      // row by the stamps): STEP = the training step's form (fp32 gradient + its bf16 copy, 16-byte rows)
+      auto emit = [&](auto step_form) {
+        constexpr bool STEP = decltype(step_form)::value;
 #pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        const int ol = G::off(l), no = G::lout(l);
-        const float bt = (gb[l] + __shfl_xor(gb[l], 32, 64)) * (1.0f / GS);
-        if (h == 0 && q < no) put(ol + q, bt);
+        for (int l = 0; l < NL; ++l) {
+          const int ol = G::off(l), no = G::lout(l);
+          const float bt = (gb[l] + __shfl_xor(gb[l], 32, 64)) * (1.0f / GS);
+          if (h == 0 && q < no) {
+            if (STEP) {
+              dst[ol + q] = bt;
+              d16[ol + q] = (__bf16)bt;
+            } else {
+              put(ol + q, bt);
+            }
+          }
 #pragma unroll
-        for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
-          const int gi = (l == 0) ? blk : (l + NB0 - 1);
-          const f32x16 gv = gW[gi];
-          const int i = 32 * blk + q;
-          if (i < G::lin(l)) {
-            if (no == HID && (ol + no) % 4 == 0 && vec4) {
+          for (int blk = 0; blk < ((l == 0) ? NB0 : 1); ++blk) {
+            const int gi = (l == 0) ? blk : (l + NB0 - 1);
+            const f32x16 gv = gW[gi];
+            const int i = 32 * blk + q;
+            if (i < G::lin(l)) {
+              if (no == HID && (ol + no) % 4 == 0 && (STEP || vec4)) {
 #pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) {
-                const int idx = ol + no + i * no + 8 * r4 + 4 * h;
-                const float v0 = gv[4 * r4] * (1.0f / GS), v1 = gv[4 * r4 + 1] * (1.0f / GS), v2 = gv[4 * r4 + 2] * (1.0f / GS),
-                            v3 = gv[4 * r4 + 3] * (1.0f / GS);
-                if (dst) *reinterpret_cast<float4*>(dst + idx) = make_float4(v0, v1, v2, v3);
-                if (d16) {
+                for (int r4 = 0; r4 < 4; ++r4) {
+                  const int idx = ol + no + i * no + 8 * r4 + 4 * h;
+                  const float v0 = gv[4 * r4] * (1.0f / GS), v1 = gv[4 * r4 + 1] * (1.0f / GS), v2 = gv[4 * r4 + 2] * (1.0f / GS),
+                              v3 = gv[4 * r4 + 3] * (1.0f / GS);
                   const typename Op16<__bf16>::v4 hb = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-                  *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + idx) = hb;
-                  if (dlo) {
-                    const typename Op16<__bf16>::v4 lb = {(__bf16)(v0 - (float)hb[0]), (__bf16)(v1 - (float)hb[1]),
-                                                          (__bf16)(v2 - (float)hb[2]), (__bf16)(v3 - (float)hb[3])};
-                    *reinterpret_cast<typename Op16<__bf16>::v4*>(dlo + idx) = lb;
+                  if (STEP) {
+                    *reinterpret_cast<float4*>(dst + idx) = make_float4(v0, v1, v2, v3);
+                    *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + idx) = hb;
+                  } else {
+                    if (dst) *reinterpret_cast<float4*>(dst + idx) = make_float4(v0, v1, v2, v3);
+                    if (d16) {
+                      *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + idx) = hb;
+                      if (dlo) {
+                        const typename Op16<__bf16>::v4 lb = {(__bf16)(v0 - (float)hb[0]), (__bf16)(v1 - (float)hb[1]),
+                                                              (__bf16)(v2 - (float)hb[2]), (__bf16)(v3 - (float)hb[3])};
+                        *reinterpret_cast<typename Op16<__bf16>::v4*>(dlo + idx) = lb;
+                      }
+                    }
                   }
                 }
-              }
-            } else {
+              } else {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                if (rho(r, 0) < no || rho(r, 1) < no) {
-                  const int o = rho(r, h);
-                  if (o < no) put(ol + no + i * no + o, gv[r] * (1.0f / GS));
+                for (int r = 0; r < 16; ++r) {
+                  if (rho(r, 0) < no || rho(r, 1) < no) {
+                    const int o = rho(r, h);
+                    if (o < no) {
+                      const float v = gv[r] * (1.0f / GS);
+                      if (STEP) {
+                        dst[ol + no + i * no + o] = v;
+                        d16[ol + no + i * no + o] = (__bf16)v;
+                      } else {
+                        put(ol + no + i * no + o, v);
+                      }
+                    }
+                  }
                 }
               }
             }
           }
         }
-      }
+      };
+      if (vec4 && dst != nullptr && d16 != nullptr && dlo == nullptr) emit(std::true_type{});
+      else emit(std::false_type{});
     }
     RCB_WSTAMP(3);
 #ifdef RCB_WAVE_STAMPS
@@ -649,8 +679,10 @@ int launch_wave(const SirenArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace rcb {
-// RCB_SIREN_WAVE in the environment sets the initial value (A/B runs): 0 = the workgroup kernel everywhere (default: the two
-// families measure the same, 236 vs 238 us at 4096 rows x 1024 pixels), 1 = one wave per row
+// RCB_SIREN_WAVE in the environment sets the initial value (A/B runs): 0 = the workgroup kernel everywhere (default: stand-alone
+// the wave family is 1-4 % faster, 226 vs 236 us at 4096 rows x 1024 pixels; inside the training step the two measure the same,
+// 1.077-1.088 vs 1.082-1.085 ms), 1 = one wave per row.  Raising a wave's issue priority on one of a CU's two workgroups
+// (s_setprio 1 / 3) changes nothing.
 int& siren_wave_tiles() {
   static int v = [] {
     const char* e = getenv("RCB_SIREN_WAVE");

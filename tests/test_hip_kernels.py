@@ -9,7 +9,7 @@ from golden_util import GOLDEN, O, cfg_of, check, load, prior_inputs, regen_nois
 
 pytestmark = pytest.mark.gpu
 
-from recombiner_amd import ops  # noqa: E402
+from recombiner_amd import _lib, ops  # noqa: E402
 from recombiner_amd.ops import LevelSpec, SirenMeta  # noqa: E402
 
 DEV = "cuda"
@@ -479,12 +479,63 @@ def test_siren_stitched_pe_layout_is_bit_identical(pn, ps, S, width, prec):
     assert torch.equal(_unstitch(st, S, list(pn), list(ps)), pe16)
     assert torch.equal(ops.siren_fwd(g(xf), st, g(wv), meta, pe_layout=lay), ops.siren_fwd(g(xf), pe16, g(wv), meta))
     scale = 1.0 / (S * P * 3)
-    s1, w1, d1 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta)
-    s2, w2, d2 = ops.siren_loss_bwd(g(xf), st, g(wv), g(y), scale, meta, pe_layout=lay)
+    # (bit identity holds inside one kernel family: the stitched layouts run on the workgroup kernel, so the patch-major launch
+    # is pinned to it as well; the two families against each other: test_siren_wave_family_against_the_workgroup_family)
+    lib = _lib.load()
+    fam = lib.rcb_debug_siren_wave_tiles(0)
+    try:
+        s1, w1, d1 = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta)
+        s2, w2, d2 = ops.siren_loss_bwd(g(xf), st, g(wv), g(y), scale, meta, pe_layout=lay)
+    finally:
+        lib.rcb_debug_siren_wave_tiles(fam)
     assert d2.shape == st.shape and torch.equal(s1, s2) and torch.equal(w1, w2)
     assert torch.equal(_unstitch(d2, S, list(pn), list(ps)), d1)
     with pytest.raises(ops.RcbError):
         ops.siren_loss_bwd(g(xf), st.float(), g(wv), g(y), scale, SirenMeta(S, P, 16, 16, 3, 32, 3, precision=0), pe_layout=lay)
+
+
+@pytest.mark.parametrize("N,S,P,dpe", [(37, 1, 1024, True), (6, 5, 1024, True), (9, 1, 96, False), (3, 2, 4096, True)])
+def test_siren_wave_family_against_the_workgroup_family(N, S, P, dpe):
+    """The two width-32 bf16 loss / backward families (siren_mlp_wave.hip: one wave per row, siren_mlp_bf16.hip: one workgroup
+    per row; rcb_debug_siren_wave_tiles) evaluate the same bf16 products with fp32 accumulation: loss to 1e-5, weight gradient
+    to 5e-4 of its largest entry (tile order, bias as two bf16 halves), input gradient to one bf16 ulp (1 / 128 of the largest
+    entry), each also against the fp32 kernel at the 16-bit-operand tolerance; the wave family is bitwise reproducible, takes
+    pixel-chunked launches and rows that are not on 16-byte boundaries, and leaves what it has no instance for (rows of
+    partial tiles, fp32 pe) to the workgroup family."""
+    lib = _lib.load()
+    case = dict(F=16, E=16, n_hidden=3, C=3, P=P, N=N, S=S)
+    dims, D, xf, pe, wv, y = _siren_case(seed=23, **case)
+    wv = wv / 3.0
+    meta = SirenMeta(S, P, 16, 16, 3, 32, 3, precision=1)
+    pe16, xf16 = g(pe).bfloat16(), ops.xf_bf16(g(xf))
+    scale = 1.0 / (S * P * 3)
+    ref = ops.siren_loss_bwd(g(xf), pe16.float(), g(wv), g(y), scale, SirenMeta(S, P, 16, 16, 3, 32, 3, precision=0), want_dpe=dpe)
+    out = {}
+    fam = lib.rcb_debug_siren_wave_tiles(-1)
+    try:
+        for f in (0, 1):
+            lib.rcb_debug_siren_wave_tiles(f)
+            out[f] = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_dpe=dpe, want_bf16=True, xf16=xf16)
+        again = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_dpe=dpe, want_bf16=True, xf16=xf16)
+        ch = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_dpe=dpe, xf16=xf16, pixel_chunks=2 if P >= 128 else 1)
+    finally:
+        lib.rcb_debug_siren_wave_tiles(fam)
+    for a_, b_ in zip(out[1], again):                      # bitwise reproducible
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
+    wmax = float(ref[1].abs().max())
+    for f in (0, 1):
+        s_, w_, d_, w16 = out[f]
+        torch.testing.assert_close(s_, ref[0], rtol=3e-3, atol=0)
+        assert float((w_ - ref[1]).abs().max()) < 2e-2 * wmax
+        assert float((w16.float() - w_).abs().max()) <= 2.0 ** -8 * wmax
+        if dpe:
+            assert float((d_.float() - ref[2]).abs().max()) < 3e-2 * float(ref[2].abs().max())
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=1e-5, atol=0)
+    assert float((out[1][1] - out[0][1]).abs().max()) < 5e-4 * wmax
+    if dpe:
+        assert float((out[1][2].float() - out[0][2].float()).abs().max()) <= 2.0 ** -7 * float(out[0][2].float().abs().max())
+    # chunked launch (partials summed in chunk order) == the unchunked one to fp32 rounding
+    assert float((ch[1] - out[1][1]).abs().max()) < 1e-5 * wmax and torch.allclose(ch[0], out[1][0], rtol=1e-5)
 
 
 def test_siren_rejects_bad_arguments():
