@@ -1153,6 +1153,23 @@ def stage1_1d_fwd(x, wbig, bias):
     return x1
 
 
+_SCRATCH = {}
+
+
+def _scratch(tag, n_floats, device):
+    """Per-(device, stream) fp32 scratch of a kernel family, allocated once: the slab workspaces are sized for the largest
+    grid (100 MB for the stage-1 weight gradient) and were allocated on every backward call -- inside a captured step that
+    pinned one such buffer in the graph's private pool per model.  Work on one stream is ordered, so one buffer per stream is
+    enough; a buffer first needed during a capture is taken from that capture's pool and not cached."""
+    key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(n_floats, device=device, dtype=f32)
+        if not torch.cuda.is_current_stream_capturing():
+            _SCRATCH[key] = buf
+    return buf
+
+
 def stage1_1d_dgrad(dz, wbig):
     """dz [B, 4 g, 64] bf16 (gradient of the stage's PRE-activation) -> dx [B, g, 128] fp32 (rcb_stage1_1d_dgrad)"""
     if dz.dim() != 3 or dz.shape[-1] != 64 or dz.shape[1] % 4 or dz.dtype != bf16 or not dz.is_cuda or not dz.is_contiguous():
@@ -1170,7 +1187,7 @@ def stage1_1d_wgrad(x, dz):
         raise RcbError("stage1_1d_wgrad: dz must be contiguous bf16 [B, 4 g, 64]")
     lib = _lib.load()
     n_ws = int(lib.rcb_stage1_1d_wgrad_workspace())
-    ws = torch.empty(n_ws, device=x.device, dtype=f32)
+    ws = _scratch("stage1_1d_wgrad", n_ws, x.device)
     dwbig = torch.empty(384, 256, device=x.device, dtype=f32)
     db = torch.empty(64, device=x.device, dtype=f32)
     check(lib.rcb_stage1_1d_wgrad(ptr(x, f32), ptr(dz), ptr(dwbig, f32), ptr(db, f32), ptr(ws, f32), C.c_int64(n_ws), x.shape[0],
@@ -1237,7 +1254,7 @@ def phaseconv_wgrad(x_act, dy):
     if list(dy.shape[1:-1]) != [2 * v for v in x_act.shape[1:-1]] or dy.shape[0] != x_act.shape[0]:
         raise RcbError("phaseconv_wgrad: dy grid must be twice the input grid")
     n_ws = int(lib.rcb_phaseconv_wgrad_workspace(nd, cout))
-    ws = torch.empty(n_ws, device=dy.device, dtype=f32)
+    ws = _scratch("phaseconv_wgrad_%d_%d" % (nd, cout), n_ws, dy.device)
     dW = torch.empty([cout, 64] + [3] * nd, device=dy.device, dtype=f32)
     db = torch.empty(cout, device=dy.device, dtype=f32)
     check(lib.rcb_phaseconv_wgrad(ptr(x_act), ptr(dy), ptr(dW), ptr(db), ptr(ws), C.c_int64(n_ws), x_act.shape[0], g[0], g[1], g[2],

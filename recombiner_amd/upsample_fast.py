@@ -214,7 +214,9 @@ class _WindowGemmFn(torch.autograd.Function):
                 dW = torch.mm(cols.t(), dy, out_dtype=torch.float32).to(Wbig.dtype)
         else:
             dW = cols.t() @ dy
-        db = _column_sum(dy, torch.float32 if lowp else dy.dtype).to(dy.dtype)
+        # (the two-step sum only in the 16-bit mode: its association follows the row count, and the fp32 parity mode keeps the
+        # single reduction its goldens were made with)
+        db = (_column_sum(dy, torch.float32) if lowp else dy.sum(0, dtype=dy.dtype)).to(dy.dtype)
         dx = None
         if ctx.needs_input_grad[0] and ctx.hip:
             from . import ops
