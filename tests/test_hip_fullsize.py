@@ -265,3 +265,125 @@ def test_forked_step_equals_one_stream_step_at_full_size():
     for other in outs[1:]:
         for a_, b_ in zip(outs[0], other):
             assert torch.equal(a_, b_)
+
+
+def _variant_model(name, n, width, prec, seed=42):
+    """a preset at another hidden width / operand type (BASELINE's "width-48" and "width-64 fp16" variants: the reference
+    builds its INR from any hidden_dims, prior_model.py:84-85)"""
+    from recombiner_amd import config
+    from recombiner_amd import prior_model as PM
+    cfg = dict(config.configs[name])
+    cfg["hidden_dims"] = [width] * len(cfg["hidden_dims"])
+    m = PM.PriorBNNmodel(cfg["input_dim"], cfg["hidden_dims"], cfg["output_dim"], n, cfg["data_dim"], cfg["pixel_sizes"],
+                         cfg["upsample_factors"], cfg["latent_dim"], cfg["patch"], cfg["patch_nums"],
+                         cfg["hierarchical_patch_nums"], random_seed=seed, device=DEV)
+    m.precision = prec
+    torch.manual_seed(123)
+    lt = PM.LinearTransform(m.dims).to(DEV)
+    torch.manual_seed(124)
+    up = PM.Upsample(cfg["data_dim"], cfg["paddings"], cfg["layerwise_scale_factors"]).to(DEV)
+    D, s0, lat = m._d_net, 0.0211547, list(m.lpe_loc.shape[1:])
+    pri = [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV), torch.zeros(lat, device=DEV), torch.full(lat, s0, device=DEV)]
+    pri += [torch.zeros(D, device=DEV), torch.full((D,), s0, device=DEV)] * 2
+    return cfg, m, lt, up, pri
+
+
+def test_one_kodak_photo_at_full_geometry_width48():
+    """BASELINE configs[2] at its FULL geometry (config.py:50-70 with hidden_dims = [48] * 3): one Kodak-sized photo = 8 x 12
+    patches of 64 x 64 pixels = 96 INRs of 4096 pixels, stitched 2-D positional encodings, three-level hierarchy, bf16
+    operands (the golden-vector tests run this preset on 2 x 2 patches of 32 x 32).  The prior-training step captures as one
+    HIP graph, replays on the second call, stays finite and improves the ELBO; and photo 1 of a batch of two trained ALONE
+    (frozen mappings, the batch's noise for its rows) follows the batch's rows for that photo to fp32 rounding -- the
+    stitched upsampling couples the patches of a photo, never two photos."""
+    import warnings
+    from golden_util import assert_close_mostly
+    from recombiner_amd import utils
+    per, steps, lr = 96, 6, 2e-4
+    cfg, m_all, lt, up, pri = _variant_model("kodak", 2 * per, 48, 1)
+    assert cfg["pixel_sizes"] == [64, 64] and int(np.prod(cfg["patch_nums"])) == per and m_all.dims == [32, 48, 48, 48, 3]
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], 2 * per, cfg["output_dim"], seed=0)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    # (1) one photo with the mappings trained: capture, replay, finite, improving
+    _, m1, lt1, up1, _ = _variant_model("kodak", per, 48, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, _, e1 = m1.train(5, 1e-3, Xd[None].expand(per, -1, -1), Yd[:per].contiguous(), *pri, lt1, up1, 1e-8, training_mappings=True)
+        ws = m1._ws
+        assert ws is not None and ws["graphs"] is not None
+        _, _, e2 = m1.train(5, 1e-3, Xd[None].expand(per, -1, -1), Yd[:per].contiguous(), *pri, lt1, up1, 1e-8, training_mappings=True)
+    assert m1._ws is ws and np.isfinite(e1).all() and np.isfinite(e2).all() and np.mean(e2) > np.mean(e1)
+    for k in ("loc", "log_scale", "h_loc", "hh_loc", "lpe_loc"):
+        assert torch.isfinite(getattr(m1, k)).all(), k
+    # (2) photo 1 alone == photo 1 inside the batch of two
+    rows = slice(per, 2 * per)
+    r2 = per // int(np.prod(cfg["hierarchical_patch_nums"]["level2"]))
+    _, m_one, _, _, _ = _variant_model("kodak", per, 48, 1)
+    with torch.no_grad():
+        for k in ("loc", "log_scale", "lpe_loc", "lpe_log_scale"):
+            getattr(m_one, k).copy_(getattr(m_all, k)[rows])
+        for k in ("h_loc", "h_log_scale"):
+            getattr(m_one, k).copy_(getattr(m_all, k)[r2:2 * r2])
+        for k in ("hh_loc", "hh_log_scale"):
+            getattr(m_one, k).copy_(getattr(m_all, k)[1:2])
+    m_one.rng_row_offset = rows.start
+    for m_, n_, y_ in ((m_all, 2 * per, Yd), (m_one, per, Yd[rows].contiguous())):
+        m_.rng_seed_override = 0xC0DA
+        m_.train(steps, lr, Xd[None].expand(n_, -1, -1), y_, *pri, lt, up, 1e-8, training_mappings=False)
+        assert m_._ws is not None and m_._ws["graphs"] is not None
+    for k, sl in (("loc", rows), ("log_scale", rows), ("lpe_loc", rows), ("h_loc", slice(r2, 2 * r2)), ("hh_loc", slice(1, 2))):
+        assert_close_mostly(getattr(m_one, k), getattr(m_all, k)[sl].detach().cpu().numpy(), rtol=0, atol=2e-6, max_frac=2e-3,
+                            hard_atol=2.5 * lr * steps, what=k)
+
+
+def test_one_video_clip_at_full_geometry_width64_f16():
+    """BASELINE configs[4] at its FULL geometry (config.py:94-114 with hidden_dims = [64] * 3, f16 operands): one clip = 1 x 8 x 8
+    patches of 24 x 16 x 16 pixels = 64 INRs of 6144 pixels, stitched 3-D positional encodings.  Prior training: the step
+    captures, replays, stays finite, improves.  Test time (main_compression.py:87-162): a prior from those steps, one clip
+    optimised with five samples per step (finite, improving), then ONE A* encode round of level 1 -- every row's
+    largest-KL group, 65 536 candidates, the certified fast scorer -- whose indices must be those of the exact scorer
+    (the reference's arithmetic op for op, test_model.py:501-533) for every one of the 64 jobs."""
+    import contextlib
+    import io
+    import warnings
+    from recombiner_amd import drivers, utils
+    per = 64
+    cfg, m, lt, up, pri = _variant_model("video", 2 * per, 64, 2)
+    assert cfg["pixel_sizes"] == [24, 16, 16] and int(np.prod(cfg["patch_nums"])) == per and m.dims == [34, 64, 64, 64, 3]
+    X, Y = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], 2 * per, cfg["output_dim"], seed=0)
+    Xd, Yd = X.to(DEV)[None].expand(2 * per, -1, -1), Y.to(DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, _, e1 = m.train(6, 1e-3, Xd, Yd, *pri, lt, up, 1e-6, training_mappings=True)
+        ws = m._ws
+        assert ws is not None and ws["graphs"] is not None
+        _, _, e2 = m.train(6, 1e-3, Xd, Yd, *pri, lt, up, 1e-6, training_mappings=True)
+    assert m._ws is ws and np.isfinite(e1).all() and np.isfinite(e2).all() and np.mean(e2) > np.mean(e1)
+    ck = drivers.build_checkpoint(m, lt, up, *pri, 1e-6)
+    del m
+    Xn, Yn = utils.synthetic_inputs(cfg["pixel_sizes"], cfg["fourier_dim"], per, cfg["output_dim"], seed=3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tm = drivers.build_test_model(cfg, "video", ck, per, DEV, 42)
+    tm.precision = 2
+    Xt, Yt = Xn.to(DEV)[None].expand(per, -1, -1), Yn.to(DEV)
+
+    def loss():
+        with torch.no_grad():
+            return float(((tm.predict(Xt, random_seed=7, sample_size=1) - Yt) ** 2).mean())
+    l0 = loss()
+    tm.train(Xt, Yt, 12, torch.optim.Adam(tm.parameters(), lr=2e-3), False, sample_size=5)
+    l1 = loss()
+    assert np.isfinite(l1) and l1 < l0
+    for k in ("loc", "log_scale", "h_loc", "hh_loc"):
+        assert torch.isfinite(getattr(tm, k)).all(), k
+    # one encode round of level 1 through the batched driver path, against the exact scorer job by job
+    lv = tm._l1
+    LN2 = float(np.log(2.0))
+    bits = tm._group_kls(lv) / LN2
+    groups = torch.argmax(torch.where(lv.d_done.bool(), torch.full_like(bits, -1e10), bits), dim=1)
+    rows = torch.arange(lv.rows, device=DEV)
+    K = int(np.ceil(2 ** tm.bit_per_group))
+    order = torch.sort(lv.d_glen[groups], stable=True)[1]
+    exact = [tm._sample_group(lv, int(r), int(g_), K)[0] for r, g_ in zip(rows[order].tolist(), groups[order].tolist())]
+    idx, _ = tm._encode_jobs(lv, rows, groups, K)
+    assert lv.rows == per and K == 65536 and idx.cpu().tolist() == exact
+    assert int(lv.d_done.sum()) == per                     # one group per row committed
