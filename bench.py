@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # PMC traffic of the SIREN training kernel per launch (4096 INRs), by pe/dpe storage type (True: bf16)
-PMC_FILE = {True: "r04_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
+PMC_FILE = {True: "r05_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
 STEPS_PER_INR = 200 + 549 * 100   # reference schedule
 
 
@@ -35,7 +35,7 @@ def siren_source_sha16():
     """hash of the sources of the width-32 16-bit SIREN kernel: stamps the committed PMC traffic summary (see roofline)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("siren_mlp_bf16.hip", "siren_common.h", "siren_op16.h"):
+    for f in ("siren_mlp_wave.hip", "siren_mlp_bf16.hip", "siren_common.h", "siren_op16.h"):
         with open(os.path.join(ROOT, "recombiner_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -830,28 +830,44 @@ def main():
             # (the higher of the HBM and MFMA fractions); `limiter` names the real one.
             valu = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r04_siren_isa_census.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r05_siren_isa_census.json")) as f:
                     cen = json.load(f)
                 if cen.get("source_sha16") == siren_source_sha16():
-                    n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                    n_simd = 4 * n_cu
                     tiles = n * (1024 // 32)
                     cyc = cen["vector_issue_cycles_per_tile"]
-                    floor_ms = tiles / n_simd * cyc / (siren_clock_ghz * 1e9) * 1e3
-                    floor_peak_ms = tiles / n_simd * cyc / 2.4e9 * 1e3
+                    per = tiles / n_simd / (siren_clock_ghz * 1e9) * 1e3          # ms per (cycle per tile and SIMD)
+                    fl = cen["floors_per_tile"]
+                    # every SIMD holds two tiles (two waves); per tile and SIMD: the matrix pipe and the transcendental unit
+                    # serve both waves, the CU's one LDS serves the four SIMDs, one wave's vector issue stream is the upper
+                    # end of the vector-issue cost (two waves interleave)
+                    floors = {"matrix_pipe_ms": round(fl["matrix_pipe_per_simd"] * per, 4),
+                              "transcendental_unit_ms": round(fl["transcendental_unit_per_simd"] * per, 4),
+                              "lds_ms": round(fl["lds_per_cu_for_one_tile_on_each_simd"] * per, 4),
+                              "vector_issue_one_stream_ms": round(cyc * per, 4)}
+                    floor_ms = cyc * per
                     valu = {"instructions_per_tile": cen["instructions"], "by_class": cen["by_class"],
                             "vector_issue_cycles_per_tile": cyc, "transcendental_cycles_per_tile": cen["transcendental_cycles_per_tile"],
+                            "mfma_pipe_cycles_per_tile": cen["mfma_pipe_cycles_per_tile"],
+                            "lds_cycles_per_tile_and_wave": cen["lds_cycles_per_tile_and_wave"],
+                            "scratch_instructions_in_tile_loop": cen["scratch_instructions_in_tile_loop"],
                             "tiles_per_launch": tiles, "simds": n_simd, "shader_clock_ghz_measured": round(siren_clock_ghz, 3),
-                            "issue_floor_ms_at_measured_clock": round(floor_ms, 4), "issue_floor_ms_at_2.4ghz": round(floor_peak_ms, 4),
+                            "floors_at_measured_clock": floors,
+                            "issue_floor_ms_at_measured_clock": round(floor_ms, 4),
+                            "issue_floor_ms_at_2.4ghz": round(tiles / n_simd * cyc / 2.4e9 * 1e3, 4),
                             "frac_of_issue_floor": round(floor_ms / ms, 4),
-                            "source": "profiles/r04_siren_isa_census.json (tools/siren_census.py)"}
+                            "frac_of_largest_pipe_floor": round(max(floors["matrix_pipe_ms"], floors["transcendental_unit_ms"], floors["lds_ms"]) / ms, 4),
+                            "source": "profiles/r05_siren_isa_census.json (tools/siren_census.py)"}
                 else:
                     valu = {"note": "stale census: the SIREN kernel sources changed since tools/siren_census.py ran"}
             except (OSError, KeyError, ValueError):
                 valu = None
             busy = (valu or {}).get("frac_of_issue_floor")
             limiter = ("vector issue" if (busy is not None and busy >= 0.8) else
-                       "dependency latency at two waves per SIMD (MFMA -> sin/cos -> conversion chains and LDS round trips); "
-                       "vector issue is the nearest roofline" if busy is not None else "unknown (no census)")
+                       "no single pipe: two waves per SIMD share a matrix pipe, a transcendental unit and (with the other three SIMDs) "
+                       "the LDS, each 30-50 % busy, and the phases of the two waves overlap only partly (profiles/r05_siren_sq_pmc.json)"
+                       if busy is not None else "unknown (no census)")
             roof = {"kernel": "fused SIREN fwd+MSE+bwd, bf16 MFMA (rcb_siren_loss_bwd)", "bound": "hbm", "limiter": limiter,
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" % PMC_FILE[pe16],

@@ -37,6 +37,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef RCB_WAVE_FSB
 #define RCB_WAVE_FSB 1       // scheduling barrier behind every forward layer (A/B builds)
 #endif
+#ifndef RCB_WAVE_PIPE_FWD
+#define RCB_WAVE_PIPE_FWD 1  // forward pass software-pipelined across the layers by hand (0: layer by layer, the compiler's order)
+#endif
 #ifndef RCB_WAVE_BSB
 #define RCB_WAVE_BSB 1       // ... behind every backward layer
 #endif
@@ -214,6 +217,10 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
   int lfr_lane = lane * 16;
   auto LFR = [&](int ls) -> i32x4 { return *(const RCB_LDS(i32x4)*)(wlds + G::LFR_OFF + ls * 1024 + lfr_lane); };
 
+  if (a.clock_probe != nullptr && blockIdx.x < 256 && threadIdx.x == 0) {      // measurement aid: rcb_siren_desc.clock_probe
+    a.clock_probe[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   for (int u = blockIdx.x * 4 + wave; u < nunits; u += gridDim.x * 4) {
     RCB_WSTAMP(0);
 #ifdef RCB_WAVE_STAMPS
@@ -396,6 +403,70 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
       // ================= forward ==================================================================================================
       bf16x8 S[2];                           // sines of the layer just finished: the next layer's B operand
       bf16x8 dzb[2];                         // packed gradient of the layer being processed
+#if RCB_WAVE_PIPE_FWD
+      // Software-pipelined across the layers: the sines of a layer are evaluated in two halves and each half's packed
+      // fragment goes straight into the next layer's k-step, so that k-step 0 runs on the matrix pipe under the second half's
+      // sines; the next layer's bias term (an MFMA that depends on nothing) is issued under the first half's.  Order pinned
+      // with scheduling barriers: left alone the compiler puts all sixteen sines behind the three chained MFMAs and an s_nop.
+      put_x(xin);
+      f32x16 c = mfma_i4<T>(BFR[0], ONES, zero16());
+#pragma unroll
+      for (int s = 0; s < K0S; ++s) c = mfma_i4<T>(FR[s], as_i4(xin[s]), c);
+      f32x16 cb = mfma_i4<T>(BFR[NH > 1 ? 1 : 0], ONES, zero16());          // bias term of layer 1 (of nothing when NH == 1)
+#pragma unroll
+      for (int l = 0; l < NH; ++l) {
+        f32x16 cn;
+        const bool last = (l + 1 == NH);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          bf16x8 pk;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) pk[jj] = (T)__builtin_amdgcn_sinf((WS == 1.0f) ? c[8 * hf + jj] : c[8 * hf + jj] * (1.0f / WS));
+          S[hf] = pk;
+          __builtin_amdgcn_sched_barrier(0);
+          const i32x4 fr = last ? LFR(hf) : FR[K0S + 2 * l + hf];
+          cn = mfma_i4<T>(fr, as_i4(pk), hf == 0 ? (last ? zero16() : cb) : cn);
+          if (hf == 0 && l + 2 < NH) cb = mfma_i4<T>(BFR[l + 2 < NH ? l + 2 : 0], ONES, zero16());
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        put_img(s_img(l), S);
+        c = cn;
+#ifdef RCB_WAVE_STAMPS
+        RCB_WSTAMP(ts + 1 + l);
+#endif
+      }
+      {
+        // output layer: loss gradient (or the upstream gradient) on the C rows that exist, packed with literal zeros
+        f32x16 dzo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.f;
+          if (rho(r, 0) < C || rho(r, 1) < C) {
+            const bool ok = valid && rho(r, h) < C;
+            if (MODE == MODE_LOSS) {
+              const float y = (WS != 1.0f) ? (c[r] * (1.0f / WS) + bout[r]) : (c[r] + bout[r]);
+              const float diff = ok ? (y - yv[r]) : 0.f;
+              sse_local += diff * diff;
+              v = (2.0f * GS) * a.dy_scale * diff;
+            } else {
+              v = ok ? yv[r] * GS : 0.f;
+            }
+          }
+          dzo[r] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const int r = 8 * s + jj;
+            dzb[s][jj] = (rho(r, 0) < C || rho(r, 1) < C) ? (T)dzo[r] : (T)0.0f;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef RCB_WAVE_STAMPS
+        RCB_WSTAMP(ts + 1 + NH);
+#endif
+      }
+#else
       put_x(xin);
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
@@ -453,6 +524,8 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
         RCB_WSTAMP(ts + 1 + l);
 #endif
       }
+
+#endif
 
       // ================= backward ===============================================================================================
       // per layer: dz image written; data-gradient MFMAs; the pre-activation of layer l - 1 recomputed from its input rows (read
@@ -651,6 +724,10 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) g_wave_stamps[5] = __builtin_amdgcn_s_memrealtime();
 #endif
   }
+  if (a.clock_probe != nullptr && blockIdx.x < 256 && threadIdx.x == 0) {      // (wave 0 of the workgroup: its own rows)
+    a.clock_probe[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 #ifdef RCB_WAVE_STAMPS
@@ -679,14 +756,14 @@ int launch_wave(const SirenArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace rcb {
-// RCB_SIREN_WAVE in the environment sets the initial value (A/B runs): 0 = the workgroup kernel everywhere (default: stand-alone
-// the wave family is 1-4 % faster, 226 vs 236 us at 4096 rows x 1024 pixels; inside the training step the two measure the same,
-// 1.077-1.088 vs 1.082-1.085 ms), 1 = one wave per row.  Raising a wave's issue priority on one of a CU's two workgroups
+// RCB_SIREN_WAVE in the environment sets the initial value (A/B runs): 1 = one wave per row where this family has an instance
+// (default: stand-alone 221 vs 236 us at 4096 rows x 1024 pixels, same box; inside the training step the gain is within the
+// run-to-run spread), 0 = the workgroup kernel everywhere.  Raising a wave's issue priority on one of a CU's two workgroups
 // (s_setprio 1 / 3) changes nothing.
 int& siren_wave_tiles() {
   static int v = [] {
     const char* e = getenv("RCB_SIREN_WAVE");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 1;
   }();
   return v;
 }
