@@ -119,10 +119,12 @@ typedef struct {
 } rcb_siren_desc;
 
 /* Test hook: which kernel family runs the width-32 bf16 loss / backward launches whose inputs arrive as 16-bit rows (pe_bf16,
- * xf_bf16, [G][P][E] pe, rows of whole 32-pixel tiles): tiles = 1 -> one WAVE per row (siren_mlp_wave.hip, the default:
- * 221 vs 236 us per launch at BASELINE configs[1] size), 0 -> one workgroup per row (siren_mlp_bf16.hip); tiles < 0 only queries.  Returns the previous
- * setting.  Both families evaluate the same products with fp32 accumulation; they differ in the order in which the pixel tiles
- * of a row are summed and in how the bias enters the accumulator (fp32 value / two bf16 halves through the matrix pipe). */
+ * xf_bf16, [G][P][E] pe, rows of whole 32-pixel tiles): 1 (default) -> one WAVE per row (siren_mlp_wave.hip: 221 vs 236 us per
+ * launch at BASELINE configs[1] size) where the rows fill the resident waves to 90 % in the last round, else -- and for
+ * everything that family has no instance for -- one workgroup per row (siren_mlp_bf16.hip); 2 -> the wave family whatever
+ * the number of rows (tests); 0 -> the workgroup family everywhere; < 0 only queries.  Returns the previous setting.  Both
+ * families evaluate the same products with fp32 accumulation; they differ in the order in which the pixel tiles of a row are
+ * summed and in how the bias enters the accumulator (fp32 value / two bf16 halves through the matrix pipe). */
 int rcb_debug_siren_wave_tiles(int32_t tiles);
 
 /* y_out[G, P, C] = MLP(x)                                                           */

@@ -738,6 +738,18 @@ extern "C" int rcb_debug_wave_stamps(unsigned long long* dst, int n_entries) {
 namespace {
 #endif
 
+// compute units of the current device (cached per device: a process may drive several)
+int cu_count() {
+  static int n_cu[64];
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) dev_id = 0;
+  if (n_cu[dev_id] == 0) {
+    hipDeviceProp_t prop;
+    n_cu[dev_id] = (hipGetDeviceProperties(&prop, dev_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n_cu[dev_id];
+}
+
 template <typename T, int NH, int F, int E, int C, int MODE, bool DPE>
 int launch_wave(const SirenArgs& a, hipStream_t st) {
   using G = WGeo<NH, F, E, C>;
@@ -746,7 +758,9 @@ int launch_wave(const SirenArgs& a, hipStream_t st) {
   if (e != hipSuccess) return fail((int)e, "siren(wave): hipFuncSetAttribute: %s", hipGetErrorString(e));
   const long long units = (long long)a.G * a.chunks;
   long long blocks = (units + 3) / 4;
-  static const long long cap = getenv("RCB_WAVE_BLOCKS") ? atoll(getenv("RCB_WAVE_BLOCKS")) : 512;   // (A/B runs)
+  const int cus = cu_count();
+  static const long long cap_env = getenv("RCB_WAVE_BLOCKS") ? atoll(getenv("RCB_WAVE_BLOCKS")) : 0;   // (A/B runs)
+  const long long cap = cap_env > 0 ? cap_env : 2ll * cus;
   if (blocks > cap) blocks = cap;                       // two workgroups (four independent waves each) per CU
   kfn<<<(unsigned)blocks, 256, G::LDS_BYTES, st>>>(a);
   RCB_LAUNCH_CHECK();
@@ -771,9 +785,16 @@ int& siren_wave_tiles() {
 // kernel (siren_mlp_bf16.hip) runs it
 int siren_wave_dispatch(int mode, const rcb_siren_desc* d, SirenArgs& a, hipStream_t st, int variant, bool* taken) {
   *taken = false;
-  (void)variant;
   if (mode == MODE_FWD || d->precision != 1 || !a.pe_bf16 || a.xf16 == nullptr || d->hidden != HID || (a.P & 31) != 0 || a.pe_nd != 0)
     return RCB_OK;
+  {
+    // A wave walks whole rows: the launch is as long as the wave with the most rows.  Unless the (row, chunk) units fill the
+    // resident waves (two 4-wave workgroups per CU) to 90 % in the last round, the workgroup family -- four waves per row,
+    // any number of rows -- is the better fit (the test-time batches: 500 images x 5 samples = 2500 rows on 2048 waves).
+    const long long units = (long long)a.G * a.chunks, waves = 8ll * cu_count();
+    const long long rounds = (units + waves - 1) / waves;
+    if (variant != 2 && units * 10 < rounds * waves * 9) return RCB_OK;      // (2: forced, tests)
+  }
 #define RCB_CASE(NHv, Fv, Ev, Cv)                                                                               \
   if (d->n_hidden == NHv && d->fourier_dim == Fv && d->pe_dim == Ev && d->out_dim == Cv) {                      \
     *taken = true;                                                                                              \

@@ -514,7 +514,7 @@ def test_siren_wave_family_against_the_workgroup_family(N, S, P, dpe):
     fam = lib.rcb_debug_siren_wave_tiles(-1)
     try:
         for f in (0, 1):
-            lib.rcb_debug_siren_wave_tiles(f)
+            lib.rcb_debug_siren_wave_tiles(2 * f)          # 2: the wave family whatever the number of rows
             out[f] = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_dpe=dpe, want_bf16=True, xf16=xf16)
         again = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_dpe=dpe, want_bf16=True, xf16=xf16)
         ch = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_dpe=dpe, xf16=xf16, pixel_chunks=2 if P >= 128 else 1)

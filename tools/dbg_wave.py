@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recombiner_amd import _lib, ops, utils
 from recombiner_amd.ops import SirenMeta
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-kt = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+kt = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # 2: the wave family whatever the number of rows
 dev = "cuda"
 lib = _lib.load()
 P = 1024
