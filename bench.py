@@ -764,7 +764,7 @@ def main():
         wv = torch.empty(n, ld, device=dev)[:, :D]
         wv.copy_((torch.rand(n, D, device=dev) * 2 - 1) * 0.02)
         want16 = bool(m.precision != 0 and m.split_gemm and not m.lowp_gemm and m.wgrad_bf16)
-        xf16 = ops.xf_bf16(Xd) if m.precision == 1 else None
+        xf16 = ops.xf_bf16(Xd, m.precision) if m.precision in (1, 2) else None
 
         probe = torch.zeros(256, 4, device=dev, dtype=torch.int64)     # per-workgroup clock stamps of the LAST launch
 

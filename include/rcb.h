@@ -24,7 +24,7 @@ extern "C" {
 /* major * 100 + minor; bumped with every change of a signature or of a structure layout (100: rounds 1-3; 400: round 4 --
  * rcb_level.scale_is_sigma, rcb_struct_bytes, the hi / lo operand planes of the A transform).  A binding compares
  * rcb_version() with the RCB_VERSION it was written against and rcb_struct_bytes() with the size of each of its mirrors. */
-#define RCB_VERSION 405
+#define RCB_VERSION 406
 #define RCB_OK 0
 #define RCB_ERR_ARG (-1)
 #define RCB_ERR_SHAPE (-2)
@@ -89,10 +89,13 @@ typedef struct {
                           * otherwise leave most of the 256 CUs idle).  y_out / dpe are unaffected; dwvec and sse then
                           * receive PARTIAL results: dwvec [c][n_rows][w_row_stride], sse [c][n_rows], to be summed in
                           * chunk order by rcb_siren_reduce_chunks; dw_bf16 must be NULL (the reduction emits it)   */
-  const void* xf_bf16;   /* nullable, bf16 operand mode with pe_bf16 = 1: a bf16 copy of xf (same shape, same strides in
-                          * elements).  The coordinate grid is constant for a whole run and the kernel rounds it to bf16 for
-                          * its MFMA operand anyway: given the copy, both input halves are loaded as operand bits (no
-                          * unpack / re-round per tile).  Results are bit-identical with and without it.            */
+  const void* xf_bf16;   /* nullable, 16-bit operand modes with pe_bf16 = 1: a 16-bit copy of xf IN THE OPERAND FORMAT (bf16 for
+                          * precision 1, IEEE f16 for precision 2), rows padded with zeros to a multiple of 8 features
+                          * ([P][8 * ceil(F / 8)], 16-byte rows; the per-row stride is xf_row_stride / F * that; since version
+                          * 406 -- before, bf16 only, unpadded, and ignored unless F % 8 == 0).  The coordinate grid is constant
+                          * for a whole run and the kernel rounds it to its operand format anyway: given the copy, both input
+                          * halves are loaded as 16-bit rows (no widening to fp32 / re-rounding per tile, a third of the input
+                          * registers).  The rounding of the inputs is the same with and without it.                 */
   int32_t pe_grid_dims;  /* 0: pe / dpe are [G][P][E].  1..3 (16-bit kernels): the rows are the PATCHES of stitched grids, as the
                           * reference's patched presets build them (utils.py:60-116: the latent grids of a datapoint's patches
                           * are stitched, upsampled together and cut back into patches): pe / dpe are the upsampling net's own

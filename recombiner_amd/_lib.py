@@ -79,7 +79,7 @@ class LevelBwd(C.Structure):
 
 _lib = None
 # the header these mirrors were written against (include/rcb.h: RCB_VERSION) and the structures load() verifies by size
-ABI_VERSION = 405
+ABI_VERSION = 406
 _MIRRORS = {0: SirenDesc, 1: Level, 2: LevelBwd, 3: AdamCfg, 4: AdamTensor, 5: RecDesc}
 
 

@@ -33,7 +33,7 @@ struct SirenArgs {
   __bf16* dwlo;       // nullable (with dw16): the low plane bf16(dwvec - dw16), same layout; dwvec may then be NULL
   long long dw16_stride;
   int chunks;         // >= 1: workgroups per row of wvec (pixel tiles split; dwvec / sse hold per-chunk partials)
-  const void* xf16;   // nullable: bf16 copy of xf, same shape and strides (rcb_siren_desc.xf_bf16)
+  const void* xf16;   // nullable: 16-bit copy of xf in the operand format, rows padded to 8 features (rcb_siren_desc.xf_bf16)
   unsigned long long* clock_probe;   // nullable: rcb_siren_desc.clock_probe
   // pe / dpe layout (rcb_siren_desc.pe_grid_dims): 0 = [G][P][E]; else the rows are the patches of stitched grids
   // [images][G0][G1][G2][E], G_i = pe_pn[i] * pe_ps[i] (unused leading axes are 1), image = sample * pe_ndc + datapoint

@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
   constexpr bool VEC4 = (F % 4 == 0) && (E % 4 == 0) && (F % 8 == 0) && (E % 8 == 0);
   // raw fp32 input rows of the NEXT tile are fetched while the current tile computes (HBM/L2 latency
   // is otherwise exposed at only 2 waves per SIMD)
-  // IN16 (chosen by the launcher: bf16 operands, pe stored as bf16, a bf16 copy of xf supplied, 16-byte rows): both input
+  // IN16 (chosen by the launcher: pe stored as bf16, a 16-bit copy of xf in the operand format supplied, 16-byte rows): both input
   // halves arrive as 16-bit rows and the loaded bits ARE the tile's B operand -- no widening to fp32 and re-rounding per
   // tile (24 VALU instructions and 8 registers less; same-box A/B: -15 % kernel time)
   float4 raw[IN16 ? 1 : 2 * K0S];
@@ -320,9 +320,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
     const int pp = tile * 32 + q;
     const int pcl = pp < P ? pp : P - 1;
     if constexpr (IN16) {
-      const __bf16* s16 = (h == 0) ? (reinterpret_cast<const __bf16*>(a.xf16) + (long long)n * a.xf_stride + (long long)pcl * F)
-                                   : (reinterpret_cast<const __bf16*>(a.pe) + (pe_row + pe_pix_off(a, pcl)) * E);
-      const int kh16 = (h == 0) ? KH0 : KH1;
+      // (16-bit elements either way: the xf copy is in T's format with rows of FP = F rounded up to 8, zero padded; pe is bf16)
+      constexpr int FP = (F + 7) / 8 * 8;
+      const unsigned short* s16 = (h == 0) ? (reinterpret_cast<const unsigned short*>(a.xf16) + (long long)n * (a.xf_stride / F * FP) + (long long)pcl * FP)
+                                           : (reinterpret_cast<const unsigned short*>(a.pe) + (pe_row + pe_pix_off(a, pcl)) * E);
+      const int kh16 = (h == 0) ? FP : KH1;
 #pragma unroll
       for (int s = 0; s < K0S; ++s) {
         uint4 u = make_uint4(0, 0, 0, 0);
@@ -409,9 +411,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
 #pragma unroll
     for (int s = 0; s < K0S; ++s) {
       if constexpr (IN16) {
-        union { uint4 u; bf16x8 v; } cv;
-        cv.u = raw16[s];
-        xin[s] = cv.v;
+        xin[s] = rcb::op16::in16_operand<T>(raw16[s], h);
       } else {
         const float4 v0 = raw[2 * s], v1 = raw[2 * s + 1];
         xin[s][0] = (T)v0.x; xin[s][1] = (T)v0.y; xin[s][2] = (T)v0.z; xin[s][3] = (T)v0.w;
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
     // cosines: packed bf16 (8 registers per layer; unpacked again for dz = dh * cos) or, in the IN16 variant whose register
     // budget allows it, the fp32 values themselves (16 per layer, no pack / unpack: -72 VALU instructions per tile; the
     // product then uses the unrounded cosine)
-    constexpr bool COS32 = IN16;
+    constexpr bool COS32 = IN16 && NB0 == 1;      // (two input blocks, F = 18: a second layer-0 gradient tile takes those registers)
     bf16x8 S[NH][2], Cs[COS32 ? 1 : NH][2];
     f32x16 Cf[COS32 ? NH : 1];
     f32x16 acc;
@@ -695,8 +695,8 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
 
 template <typename T, int NH, int F, int E, int C>
 int launch_mode(int mode, const SirenArgs& a, hipStream_t st) {
-  // both input halves as operand bits: bf16 operands, pe stored as bf16, a bf16 copy of xf supplied, 16-byte rows
-  constexpr bool can16 = Op16<T>::IS_BF16 && (E % 8 == 0) && (F % 8 == 0) && E > 0;
+  // both input halves as 16-bit rows: pe stored as bf16, a 16-bit copy of xf in the operand format supplied (rows padded to 8 features)
+  constexpr bool can16 = (E % 8 == 0) && E > 0;
   if (can16 && a.pe_bf16 && a.xf16 != nullptr && mode == MODE_LOSS) return launch_one<T, NH, F, E, C, MODE_LOSS, can16>(a, st);
   if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, MODE_FWD, false>(a, st);
   if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, MODE_BWD, false>(a, st);

@@ -308,9 +308,11 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
     const int pp = tile * 32 + q;
     const int pcl = pp < P ? pp : P - 1;
     if constexpr (IN16) {
-      const __bf16* s16 = (h == 0) ? (reinterpret_cast<const __bf16*>(a.xf16) + (long long)n * a.xf_stride + (long long)pcl * F)
-                                   : (reinterpret_cast<const __bf16*>(a.pe) + (pe_row + pe_pix_off(a, pcl)) * E);
-      const int kh16 = (h == 0) ? KH0 : KH1;
+      // (16-bit elements either way: the xf copy is in T's format with rows of FP = F rounded up to 8, zero padded; pe is bf16)
+      constexpr int FP = (F + 7) / 8 * 8;
+      const unsigned short* s16 = (h == 0) ? (reinterpret_cast<const unsigned short*>(a.xf16) + (long long)n * (a.xf_stride / F * FP) + (long long)pcl * FP)
+                                           : (reinterpret_cast<const unsigned short*>(a.pe) + (pe_row + pe_pix_off(a, pcl)) * E);
+      const int kh16 = (h == 0) ? FP : KH1;
 #pragma unroll
       for (int s = 0; s < K0S; ++s) {
         uint4 u = make_uint4(0, 0, 0, 0);
@@ -460,9 +462,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
 #pragma unroll
       for (int s = 0; s < K0S; ++s) {
         if constexpr (IN16) {
-          union { uint4 u; bf16x8 v; } cv;
-          cv.u = raw16[s];
-          xin[s] = cv.v;
+          xin[s] = rcb::op16::in16_operand<T>(raw16[s], h);
         } else {
           xin[s] = xnext[s];
         }
@@ -914,7 +914,7 @@ int launch_one(const SirenArgs& a, hipStream_t st) {
 
 template <typename T, int NH, int F, int E, int C, int W>
 int launch_mode(int mode, const SirenArgs& a, hipStream_t st) {
-  constexpr bool can16 = Op16<T>::IS_BF16 && (E % 8 == 0) && (F % 8 == 0) && E > 0;
+  constexpr bool can16 = (E % 8 == 0) && E > 0;
   if (can16 && a.pe_bf16 && a.xf16 != nullptr && mode == MODE_LOSS) return launch_one<T, NH, F, E, C, W, MODE_LOSS, can16>(a, st);
   if (mode == MODE_FWD) return launch_one<T, NH, F, E, C, W, MODE_FWD, false>(a, st);
   if (mode == MODE_BWD) return launch_one<T, NH, F, E, C, W, MODE_BWD, false>(a, st);

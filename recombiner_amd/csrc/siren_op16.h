@@ -36,6 +36,31 @@ namespace op16 {
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ constexpr int fk(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
+// 16-bit input rows as operand bits (IN16 instances).  Half-wave 0 loads the coordinate features from the caller's 16-bit copy of
+// xf, which is already in the operand format T (rows padded to a multiple of 8 features: rcb_siren_desc.xf_bf16); half-wave 1
+// loads the upsampled features, stored as bf16 by their producer: operand bits as they are when T is bf16, widened and rounded
+// to f16 otherwise (the value the fp32-input path produces: (T)(float)bf16).
+template <typename T>
+__device__ __forceinline__ typename Op16<T>::v8 in16_operand(uint4 u, int h) {
+  union { uint4 u; typename Op16<T>::v8 v; } bits, cv;
+  bits.u = u;
+  if constexpr (Op16<T>::IS_BF16) {
+    return bits.v;
+  } else {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cv.v[2 * i] = (T)__uint_as_float(w[i] << 16);
+      cv.v[2 * i + 1] = (T)__uint_as_float(w[i] & 0xffff0000u);
+    }
+    cv.u.x = h ? cv.u.x : bits.u.x;
+    cv.u.y = h ? cv.u.y : bits.u.y;
+    cv.u.z = h ? cv.u.z : bits.u.z;
+    cv.u.w = h ? cv.u.w : bits.u.w;
+    return cv.v;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ float sum8_16(typename Op16<T>::v8 v, float acc) {
   const typename Op16<T>::v2 ones = {(T)1.0f, (T)1.0f};

@@ -94,18 +94,21 @@ def siren_pixel_chunks(G, meta: SirenMeta):
 _XF16_CACHE = collections.OrderedDict()
 
 
-def xf_bf16(xf):
-    """bf16 copy of the coordinate features with the same shape / strides in elements (rcb_siren_desc.xf_bf16); None for
-    grids that are not shared ([P, F] or a stride-0 expansion of one).  A caller that records kernel launches (HIP graph)
-    must OWN the copy it passes on (`xf16=` of the siren_* wrappers; the models keep it in their graph workspace): the
-    cache below only serves eager calls and may drop its entries."""
+def xf_bf16(xf, precision=1):
+    """16-bit copy of the coordinate features in the operand format of `precision` (1: bf16, 2: f16), rows zero-padded to a
+    multiple of 8 features (rcb_siren_desc.xf_bf16); None for grids that are not shared ([P, F] or a stride-0 expansion of
+    one).  A caller that records kernel launches (HIP graph) must OWN the copy it passes on (`xf16=` of the siren_* wrappers;
+    the models keep it in their graph workspace): the cache below only serves eager calls and may drop its entries."""
     if xf.dim() == 3 and xf.stride(0) != 0:
         return None
     base = xf if xf.dim() == 2 else xf[0]
-    return base.to(bf16).contiguous()
+    F = base.shape[-1]
+    out = torch.zeros(base.shape[0], (F + 7) // 8 * 8, dtype=bf16 if precision == 1 else torch.float16, device=base.device)
+    out[:, :F] = base
+    return out
 
 
-def _xf_bf16_cached(xf):
+def _xf_bf16_cached(xf, precision=1):
     """xf_bf16 through a small LRU cache for eager calls: the grid is constant for a whole run.  An entry keeps a
     reference to its source tensor (while it is held the allocator cannot hand the address to other data, so (address,
     shape, version counter) identifies the contents); the least recently used entry is dropped beyond 16 -- a copy is only
@@ -113,12 +116,12 @@ def _xf_bf16_cached(xf):
     if xf.dim() == 3 and xf.stride(0) != 0:
         return None
     base = xf if xf.dim() == 2 else xf[0]
-    key = (base.data_ptr(), tuple(base.shape), base._version, str(base.device))
+    key = (base.data_ptr(), tuple(base.shape), base._version, str(base.device), precision)
     hit = _XF16_CACHE.get(key)
     if hit is not None:
         _XF16_CACHE.move_to_end(key)
         return hit[1]
-    copy = base.to(bf16).contiguous()
+    copy = xf_bf16(base, precision)
     if not torch.cuda.is_current_stream_capturing():      # (a copy made inside a capture lives in that graph's memory pool)
         _XF16_CACHE[key] = (base, copy)
         while len(_XF16_CACHE) > 16:
@@ -167,9 +170,13 @@ def _siren_desc(meta: SirenMeta, wvec, xf, pe=None, dw_bf16=None, chunks=1, pe_l
         for i in range(nd):
             d.pe_patch_nums[i] = pe_layout.patch_nums[i]
             d.pe_patch_size[i] = pe_layout.patch_size[i]
-    if meta.precision == 1 and pe is not None and pe.dtype == bf16 and not _os.environ.get("RCB_SIREN_NO_XF16"):   # (A/B switch)
-        x16 = xf16 if xf16 is not None else _xf_bf16_cached(xf)
+    if meta.precision in (1, 2) and pe is not None and pe.dtype == bf16 and not _os.environ.get("RCB_SIREN_NO_XF16"):   # (A/B switch)
+        x16 = xf16 if xf16 is not None else _xf_bf16_cached(xf, meta.precision)
         if x16 is not None:
+            want = (xf.shape[-2], (meta.fourier_dim + 7) // 8 * 8)
+            if tuple(x16.shape) != want or x16.dtype != (bf16 if meta.precision == 1 else torch.float16) or not x16.is_contiguous():
+                raise RcbError(f"xf16: expected a contiguous {want} copy of xf in the operand format (ops.xf_bf16(xf, precision)), "
+                               f"got {tuple(x16.shape)} {x16.dtype}")
             d.xf_bf16 = x16.data_ptr()
             d._keep = x16
     return d, G

@@ -352,7 +352,7 @@ class PriorBNNmodel(nn.Module):
                             if (training_mappings and (world > 1 or (self.force_segments and self.dp_group is not None))) else None),
                       # the bf16 copy of the coordinate grid the captured SIREN launches read: owned by the workspace,
                       # i.e. alive exactly as long as the graphs that reference its address
-                      xf16=ops.xf_bf16(x) if (self.precision == 1 and dev.type == "cuda") else None)
+                      xf16=ops.xf_bf16(x, self.precision) if (self.precision in (1, 2) and dev.type == "cuda") else None)
             # 16-bit modes: the A transform on the hand-written kernels of atrans.hip (every geometry)
             ws["split"] = (ops.ATransform(slices, dev, self.split_terms, self.split_dgrad_terms)
                            if (self.split_gemm and self.precision != 0 and not self.lowp_gemm) else None)

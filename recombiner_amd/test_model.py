@@ -518,7 +518,7 @@ class TestBNNmodel(nn.Module):
                       states=[{k: next(views) for k in ("m_loc", "v_loc", "m_ls", "v_ls")} for lv in self._levels],
                       graphs={}, warm=0,
                       # bf16 copy of the coordinate grid: owned by the workspace that owns the graphs reading its address
-                      xf16=ops.xf_bf16(x) if (self.precision == 1 and dev.type == "cuda") else None)
+                      xf16=ops.xf_bf16(x, self.precision) if (self.precision in (1, 2) and dev.type == "cuda") else None)
             self._ws = ws
         else:
             ws["state_flat"].zero_()

@@ -178,8 +178,8 @@ def test_siren_bf16_pe_storage_is_bit_identical(prec, F):
     y16 = ops.siren_fwd(g(xf), pe16, g(wv), meta)
     assert torch.equal(y32, y16)
     s32, w32, d32 = ops.siren_loss_bwd(g(xf), pe32, g(wv), g(y), scale, meta)
-    # (bf16 operands + bf16 pe + a shared grid with F % 8 == 0 select the variant that loads both input halves as operand
-    # bits and keeps the cosines unrounded in fp32 -- same forward, slightly MORE accurate gradients; the storage statement
+    # (bf16 pe + a shared grid select the variant that loads both input halves as 16-bit rows and, with one input block
+    # (F % 8 == 0), keeps the cosines unrounded in fp32 -- same forward, slightly MORE accurate gradients; the storage statement
     # is about one arithmetic, so that variant is switched off here and compared separately below)
     os.environ["RCB_SIREN_NO_XF16"] = "1"
     try:
@@ -188,7 +188,16 @@ def test_siren_bf16_pe_storage_is_bit_identical(prec, F):
         del os.environ["RCB_SIREN_NO_XF16"]
     assert d16.dtype == torch.bfloat16
     assert torch.equal(s32, s16) and torch.equal(w32, w16) and torch.equal(d32.bfloat16(), d16)
-    if prec == 1 and F % 8 == 0:
+    if F % 8 != 0:
+        # two input blocks (F = 18): the 16-bit-row variant (xf copy padded to 24 features, in the operand format) keeps the packed
+        # cosines -- the same arithmetic on the same operand bits
+        s16b, w16b, d16b = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta)
+        assert torch.equal(s16b, s16) and torch.equal(w16b, w16) and torch.equal(d16b, d16)
+        x16 = ops.xf_bf16(g(xf), prec)
+        assert x16.shape == (1000, 24) and x16.dtype == (torch.bfloat16 if prec == 1 else torch.float16) and not x16[:, F:].any()
+        with pytest.raises(ops.RcbError):                              # an unpadded copy is refused, not read out of bounds
+            ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, xf16=g(xf).to(x16.dtype))
+    else:
         s16b, w16b, d16b = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta)
         assert torch.equal(s16b, s16)                                     # the forward pass is the same arithmetic
         assert not torch.equal(w16b, w16)                                 # (the variant really ran)
@@ -391,6 +400,28 @@ def test_siren_wide_bf16_pe_storage_and_split_output():
     assert torch.equal(s32, s16) and torch.equal(w32, w16) and torch.equal(d32.bfloat16(), d16)
     assert ops.siren_wide_layers(meta) == (2, 64 * 65)
     assert wcopy.shape == w32.shape and wcopy.stride(0) % 8 == 0 and torch.equal(wcopy, w32.bfloat16())
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_siren_wide_16bit_input_rows_equal_fp32_input_rows(case, prec):
+    """width 48 / 64, both operand formats, one and two input blocks: the instances that load both input halves as 16-bit rows
+    (a copy of the coordinate grid in the operand format, rows padded to 8 features; bf16 pe converted to f16 in registers) run
+    the arithmetic of the instances that load fp32 rows and round them per tile -- bit for bit."""
+    S, P, C, W = case["S"], case["P"], case["C"], case["hidden"]
+    dims, D, xf, pe, wv, y = _siren_case(seed=23, **case)
+    meta = SirenMeta(samples=S, n_pix=P, fourier_dim=case["F"], pe_dim=case["E"], n_hidden=case["n_hidden"], hidden=W,
+                     out_dim=C, precision=prec)
+    pe16, scale = g(pe).bfloat16(), 1.0 / (S * P * C)
+    os.environ["RCB_SIREN_NO_XF16"] = "1"
+    try:
+        ref = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_bf16=True)
+    finally:
+        del os.environ["RCB_SIREN_NO_XF16"]
+    out = ops.siren_loss_bwd(g(xf), pe16, g(wv), g(y), scale, meta, want_bf16=True, xf16=ops.xf_bf16(g(xf), prec))
+    for a_, b_ in zip(out, ref):
+        assert torch.equal(a_, b_)
+    assert torch.isfinite(out[1]).all() and float(out[1].abs().max()) > 0
 
 
 @pytest.mark.parametrize("width,prec", [(32, 1), (32, 2), (48, 1), (64, 2)])

@@ -25,7 +25,7 @@ if as_step:
     wv_p = torch.empty(n, (meta.d_net + 31) // 32 * 32, device=dev)[:, :meta.d_net]
     wv_p.copy_(wv)
     wv = wv_p
-    kw = dict(want_bf16=True, xf16=ops.xf_bf16(Xd) if prec == 1 else None)
+    kw = dict(want_bf16=True, xf16=ops.xf_bf16(Xd, prec) if prec in (1, 2) else None)
 if len(sys.argv) > 4 and sys.argv[4] == "pe16":
     pe = pe.bfloat16()
 
