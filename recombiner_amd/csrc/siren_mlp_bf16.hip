@@ -570,19 +570,27 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
 #pragma unroll
         for (int s = 0; s < 2; ++s) dx = Op16<T>::mfma(FA(base + s), dzb[s], dx);
         if (valid) {
+          // (the lane half enters the address through an opaque copy: the row base then stays a scalar pair -- hoisted as a
+          // per-lane 64-bit pointer it was spilled and reloaded once per tile behind a full vmcnt drain)
+          int ln = threadIdx.x;
+          asm volatile("" : "+v"(ln));
+          const int hs = (ln >> 5) & 1;
           float* dst = a.dpe + (pe_row + pe_pix_off(a, p)) * E;
           if (E % 8 == 0 && a.pe_bf16) {
-            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + (pe_row + pe_pix_off(a, p)) * E;
+            __bf16* d16 = reinterpret_cast<__bf16*>(a.dpe) + pe_row * E;
+            const int off16 = pe_pix_off(a, p) * E + 4 * hs;
 #pragma unroll
             for (int g4 = 0; g4 < E / 8; ++g4) {
               typename Op16<__bf16>::v4 ob = {(__bf16)(dx[4 * g4] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 1] * (1.0f / (GS * WS))),
                                               (__bf16)(dx[4 * g4 + 2] * (1.0f / (GS * WS))), (__bf16)(dx[4 * g4 + 3] * (1.0f / (GS * WS)))};
-              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + 8 * g4 + 4 * h) = ob;
+              *reinterpret_cast<typename Op16<__bf16>::v4*>(d16 + off16 + 8 * g4) = ob;
             }
           } else if (E % 8 == 0) {
+            float* d32 = a.dpe + pe_row * E;
+            const int off32 = pe_pix_off(a, p) * E + 4 * hs;
 #pragma unroll
             for (int g4 = 0; g4 < E / 8; ++g4)
-              *reinterpret_cast<float4*>(dst + 8 * g4 + 4 * h) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
+              *reinterpret_cast<float4*>(d32 + off32 + 8 * g4) = make_float4(dx[4 * g4] * (1.0f / (GS * WS)), dx[4 * g4 + 1] * (1.0f / (GS * WS)),
                                                                              dx[4 * g4 + 2] * (1.0f / (GS * WS)), dx[4 * g4 + 3] * (1.0f / (GS * WS)));
           } else {
 #pragma unroll
