@@ -31,14 +31,57 @@ PMC_FILE = {True: "r05_siren_bf16_pmc.json", False: "r01_siren_bf16_pmc.json"}
 STEPS_PER_INR = 200 + 549 * 100   # reference schedule
 
 
-def siren_source_sha16():
-    """hash of the sources of the width-32 16-bit SIREN kernel: stamps the committed PMC traffic summary (see roofline)"""
+def _sha16(files):
     import hashlib
     h = hashlib.sha256()
-    for f in ("siren_mlp_wave.hip", "siren_mlp_bf16.hip", "siren_common.h", "siren_op16.h"):
+    for f in files:
         with open(os.path.join(ROOT, "recombiner_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def siren_source_sha16():
+    """hash of the sources of the headline SIREN kernel (one wave per INR): stamps the committed PMC traffic summary (see roofline)"""
+    return _sha16(("siren_mlp_wave.hip", "siren_common.h", "siren_op16.h"))
+
+
+def siren_census_sha16():
+    """hash of every source tools/siren_census.py reads (the three 16-bit SIREN kernel families): stamps its JSON"""
+    return _sha16(("siren_mlp_wave.hip", "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_common.h", "siren_op16.h"))
+
+
+def siren_instance_census(kernel_name, prec, dims_in, n_hidden, hidden, C, n_inrs, px, clock_ghz, n_cu, us):
+    """-> the `valu` object of one preset's SIREN kernel: the census row (tools/siren_census.py) of the instance the step selected
+    (family read off the profiled kernel name, template arguments from the preset) priced per pipe like the headline kernel's:
+    floors = 32-pixel tiles per SIMD x cycles per tile / clock (the clock measured in the headline kernel's launches)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_siren_isa_census.json")) as f:
+            cen = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if cen.get("source_sha16") != siren_census_sha16():
+        return {"note": "stale census: the SIREN kernel sources changed since tools/siren_census.py ran"}
+    F, E = dims_in
+    T = "DF16b" if prec == 1 else "DF16_"
+    fam = "siren_wave_kernel" if "siren_wave" in kernel_name else "siren_wide_kernel" if "siren_wide" in kernel_name else "siren_bf16_kernel"
+    args = "I%sLi%dELi%dELi%dELi%dE" % (T, n_hidden, F, E, C) + ("Li%dE" % hidden if fam == "siren_wide_kernel" else "") + "Li2ELb1E"
+    row = next((r for r in cen["instances"] if (fam + args) in r["kernel"]), None)
+    if row is None:
+        return {"note": "no census row for %s%s" % (fam, args)}
+    tiles = n_inrs * ((px + 31) // 32)
+    per = tiles / (4 * n_cu) / (clock_ghz * 1e9) * 1e3                     # ms per (cycle per tile and SIMD)
+    floors = {"matrix_pipe_ms": round(row["mfma_pipe_cycles_per_tile"] * per, 4),
+              "transcendental_unit_ms": round(row["transcendental_cycles_per_tile"] * per, 4),
+              "lds_ms": round(4 * row["lds_cycles_per_tile_and_wave"] * per, 4),
+              "vector_issue_one_stream_ms": round(row["vector_issue_cycles_per_tile"] * per, 4)}
+    ms = us * 1e-3
+    return {"instance": fam + args, "vgprs": row["vgprs"], "scratch_bytes_per_lane": row["scratch_bytes_per_lane"],
+            "scratch_instructions_in_tile_loop": row["scratch_instructions_in_tile_loop"],
+            "instructions_per_tile": row["tile_loop_instructions"], "by_class": row["by_class"],
+            "tiles_per_launch": tiles, "shader_clock_ghz_assumed": round(clock_ghz, 3), "floors_ms": floors,
+            "frac_of_issue_floor": round(floors["vector_issue_one_stream_ms"] / ms, 4),
+            "frac_of_largest_pipe_floor": round(max(floors["matrix_pipe_ms"], floors["transcendental_unit_ms"], floors["lds_ms"]) / ms, 4),
+            "source": "profiles/r05_siren_isa_census.json (tools/siren_census.py)"}
 
 
 def parse():
@@ -139,6 +182,7 @@ def kernel_table(run, steps, n, D):
     P, E, Dl = 1024, 16, 512
     per_inr = {   # algorithmic HBM bytes per INR and step
         "siren_bf16_kernel": ("hbm", 2 * P * E * 2 + P * 3 * 4 + 2 * D * 4 + 4),
+        "siren_wave_kernel": ("hbm", 2 * P * E * 2 + P * 3 * 4 + 2 * D * 4 + 4),
         # both launches (net parameters + latent grid): loc, log_scale, 4 Adam moments read + written (48 B), the gradient read,
         # the next sample written (fp32; its bf16 copy and the noise, re-drawn since round 4, are not counted)
         "posterior_flat_kernel": ("hbm", 56 * (D + Dl)),
@@ -307,7 +351,7 @@ def rd_trained(dev, precision, runs_per_rate=3):
                        sched["finetune_epochs"])}
 
 
-def presets_table(dev):
+def presets_table(dev, clock_ghz=None):
     """BASELINE configs[2..4] (and the reference presets they vary) plus the test-time path on this box, untimed by the
     driver's step clock but inside its run.
     prior_training: the training step of each preset in its 16-bit mode (production path: device noise, graph replay) at the
@@ -400,6 +444,10 @@ def presets_table(dev):
             rec.update(siren_us=round(s_us, 1), siren_share=round(s_us / total, 3), siren_alg_bytes=bts,
                        siren_hbm_frac=round(bts / (s_us * 1e-6) / 8e12, 4), siren_alg_flops=fl,
                        siren_mfma_frac=round(fl / (s_us * 1e-6) / 2.5e15, 4))
+            lb = max(siren, key=lambda r: r[0])                     # the loss / backward instance (the step has no other SIREN launch)
+            ck = clock_ghz if (clock_ghz and clock_ghz == clock_ghz) else 2.1
+            rec["valu"] = siren_instance_census(lb[1], prec, (cfg["fourier_dim"], E), len(cfg["hidden_dims"]), width, C, n, px, ck,
+                                                torch.cuda.get_device_properties(dev).multi_processor_count, lb[0])
         out.append(rec)
         del m, lt, up, Xd, Yd, X, pri
         torch.cuda.empty_cache()
@@ -832,7 +880,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r05_siren_isa_census.json")) as f:
                     cen = json.load(f)
-                if cen.get("source_sha16") == siren_source_sha16():
+                if cen.get("source_sha16") == siren_census_sha16():
                     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
                     n_simd = 4 * n_cu
                     tiles = n * (1024 // 32)
@@ -888,15 +936,23 @@ def main():
             os.environ["RCB_FORK"] = "0"
             try:
                 run(6)
-                return kernel_table(run, 10, n, D)
+                tab = kernel_table(run, 10, n, D)
             finally:
                 if keep is None:
                     del os.environ["RCB_FORK"]
                 else:
                     os.environ["RCB_FORK"] = keep
                 run(6)
+            # the same sum for the SHIPPED (three-stream) form: kernels stretch while they run beside each other, so this total
+            # against the step time says how much of the co-running is time-slicing rather than overlap
+            shipped = kernel_table(run, 10, n, D)
+            tab["shipped_form"] = {"kernel_us_per_step_total": shipped["kernel_us_per_step_total"],
+                                   "kernels_per_step": shipped["kernels_per_step"],
+                                   "sum_over_step_time": round(shipped["kernel_us_per_step_total"] / (el / a.steps * 1e6), 3),
+                                   "one_stream_sum_over_step_time": round(tab["kernel_us_per_step_total"] / (el / a.steps * 1e6), 3)}
+            return tab
         for key, fn in (("kernels", one_stream_table), ("rec", lambda: rec_roofline(dev)),
-                        ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision)), ("presets", lambda: presets_table(dev)),
+                        ("psnr_bpp", lambda: psnr_at_bpp(dev, m.precision)), ("presets", lambda: presets_table(dev, siren_clock_ghz)),
                         ("sharded_step_cost_captured", lambda: segment_host_cost(dev, cfg, n, tm, el / a.steps * 1e3, True)),
                         ("sharded_step_cost_segments", lambda: segment_host_cost(dev, cfg, n, tm, el / a.steps * 1e3, False))):
             try:

@@ -40,6 +40,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef RCB_WAVE_PIPE_FWD
 #define RCB_WAVE_PIPE_FWD 1  // forward pass software-pipelined across the layers by hand (0: layer by layer, the compiler's order)
 #endif
+#ifndef RCB_WAVE_ZPIPE
+#define RCB_WAVE_ZPIPE 1    // backward: the recomputed pre-activation one layer ahead (see compute_z)
+#endif
 #ifndef RCB_WAVE_BSB
 #define RCB_WAVE_BSB 1       // ... behind every backward layer
 #endif
@@ -531,13 +534,34 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
       // per layer: dz image written; data-gradient MFMAs; the pre-activation of layer l - 1 recomputed from its input rows (read
       // back from the tile's image) -> cosine x data gradient -> packed dz of the layer below; weight-gradient MFMAs on the
       // transposed reads of the dz image and of the layer's input image, one k-step in front of the vector work and one behind.
+      // (RCB_WAVE_ZPIPE) the recomputed pre-activation is taken one layer ahead: z of sine layer l - 2 is issued at the END of layer l
+      // (behind its cosine work, where d and the product are dead) and consumed by layer l - 1 -- its three MFMAs and its row
+      // re-reads then sit beside vector work instead of in front of it, and the data-gradient chain d -> cos x d -> pack no
+      // longer queues behind them in the matrix pipe
+      auto compute_z = [&](int lm) -> f32x16 {              // lm = 0 .. NH - 1 (compile-time after unrolling)
+        f32x16 zz = mfma_i4<T>(BFR[lm], ONES, zero16());
+        if (lm == 0) {
+          bf16x8 tx[K0S];
+          get_x(tx);
+#pragma unroll
+          for (int s = 0; s < K0S; ++s) zz = mfma_i4<T>(FR[s], as_i4(tx[s]), zz);
+        } else {
+          bf16x8 ts[2];
+          get_img(s_img(lm - 1), ts);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) zz = mfma_i4<T>(FR[K0S + 2 * (lm - 1) + s], as_i4(ts[s]), zz);
+        }
+        return zz;
+      };
+      f32x16 zc = zero16();
+      if (RCB_WAVE_ZPIPE) zc = compute_z(NL - 2);
 #pragma unroll
       for (int l = NL - 1; l >= 0; --l) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         put_img(dz_img, dzb);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         bf16x8 rin[cmax(K0S, 2)];
-        if (l >= 1) {
+        if (!RCB_WAVE_ZPIPE && l >= 1) {
           if (l - 1 == 0) {
             bf16x8 tx[K0S];
             get_x(tx);
@@ -562,7 +586,9 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
           for (int s = 0; s < 2; ++s) d = mfma_i4<T>(LFR(3 + s), as_i4(dzb[s]), d);
         }
         f32x16 z;
-        if (l > 0) {
+        if (RCB_WAVE_ZPIPE) {
+          z = zc;
+        } else if (l > 0) {
           z = mfma_i4<T>(BFR[l - 1], ONES, zero16());
           if (l - 1 == 0) {
 #pragma unroll
@@ -613,6 +639,7 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
           dzb[0] = dzn[0];
           dzb[1] = dzn[1];
         }
+        if (RCB_WAVE_ZPIPE && l >= 2) zc = compute_z(l - 2);
 #if RCB_WAVE_BSB
         __builtin_amdgcn_sched_barrier(0);
 #endif

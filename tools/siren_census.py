@@ -2,7 +2,8 @@
 per-pipe costs of MI355X_MICROARCH.md.  Runs in the build container (hipcc cross-compiles):
 
     python tools/siren_census.py            -> profiles/r05_siren_isa_census.json, stamped with the hash of the kernel sources
-    python tools/siren_census.py --check    -> exit code 1 if the headline instance has a scratch instruction inside its tile loop
+    python tools/siren_census.py --check    -> exit code 1 if an instance the training step selects (wave family, 16-bit-input-row
+                                               instances) has a scratch instruction inside its tile loop; __graft_entry__.build() runs it
 
 Per wave and 32-pixel tile (one trip of the innermost loop that holds the transcendentals):
   * vector issue  : transcendental 8 cycles, v_cvt_pk 4.5, other VALU 4, an MFMA holds the issue for 8 of its 32 -- the cost of ONE
@@ -33,7 +34,7 @@ LDS_COST = (("ds_write_b64", 6), ("ds_write_b128", 13), ("ds_write2", 13), ("ds_
 
 def source_sha16():
     h = hashlib.sha256()
-    for f in ("siren_mlp_wave.hip", "siren_mlp_bf16.hip", "siren_common.h", "siren_op16.h"):
+    for f in ("siren_mlp_wave.hip", "siren_mlp_bf16.hip", "siren_mlp_wide.hip", "siren_common.h", "siren_op16.h"):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -138,8 +139,10 @@ def main():
     check = "--check" in sys.argv
     instances, headline = [], None
     with tempfile.TemporaryDirectory() as td:
-        for src in FILES:
-            lines, res = compile_asm(src, td)
+        import concurrent.futures
+        with concurrent.futures.ThreadPoolExecutor(len(FILES)) as pool:       # (three hipcc processes side by side)
+            compiled = list(pool.map(lambda f: compile_asm(f, td), FILES))
+        for src, (lines, res) in zip(FILES, compiled):
             for name, body in kernel_bodies(lines).items():
                 if "siren" not in name:
                     continue
@@ -152,7 +155,12 @@ def main():
                 instances.append({"file": src, "kernel": name, "vgprs": r.get("vgprs"), "scratch_bytes_per_lane": r.get("scratch_bytes"),
                                   "waves_per_simd": r.get("occupancy"), "tile_loop_instructions": c["instructions"],
                                   "scratch_instructions_in_tile_loop": c["scratch_instructions_in_tile_loop"],
-                                  "mfma_per_trip": c["by_class"].get("mfma", 0)})
+                                  "mfma_per_trip": c["by_class"].get("mfma", 0), "by_class": c["by_class"],
+                                  # one trip = one 32-pixel tile of one wave, in all three families
+                                  "vector_issue_cycles_per_tile": c["vector_issue_cycles_per_tile"],
+                                  "mfma_pipe_cycles_per_tile": c["mfma_pipe_cycles_per_tile"],
+                                  "transcendental_cycles_per_tile": c["transcendental_cycles_per_tile"],
+                                  "lds_cycles_per_tile_and_wave": c["lds_cycles_per_tile_and_wave"]})
                 if src == HEADLINE[0] and HEADLINE[1] in name:
                     headline = c
     assert headline is not None, "headline instance not found"
@@ -169,15 +177,20 @@ def main():
            "note": "floors: a SIMD works on two tiles at a time (two waves); per tile and SIMD the matrix pipe needs "
                    "mfma_pipe_cycles, the transcendental unit its cycles, the CU's LDS 4 x lds_cycles for the four tiles its SIMDs "
                    "hold; the vector issue of ONE wave's stream is vector_issue_cycles (two waves interleave)"}
-    path = os.path.join(ROOT, "profiles", "r05_siren_isa_census.json")
-    json.dump(out, open(path, "w"), indent=1)
+    if "--no-write" not in sys.argv:
+        path = os.path.join(ROOT, "profiles", "r05_siren_isa_census.json")
+        json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "instances"}, indent=1))
     bad = [r for r in instances if r["scratch_instructions_in_tile_loop"]]
     print("%d instances; scratch inside the tile loop in %d:" % (len(instances), len(bad)))
     for r in bad:
         print("  ", r["file"], r["kernel"][:90], r["scratch_instructions_in_tile_loop"], "per trip,", r["scratch_bytes_per_lane"], "B")
-    if check and headline["scratch_instructions_in_tile_loop"]:
-        print("FAIL: scratch inside the headline kernel's tile loop")
+    # the instances the models' training step selects in the 16-bit modes: the wave family and the 16-bit-input-row (IN16)
+    # instances of the two workgroup families (template argument Lb1 behind MODE_LOSS = Li2); the fp32-input-row instances
+    # (Lb0) remain for callers that hold pe in fp32 or have no shared coordinate grid
+    shipped_bad = [r for r in bad if r["file"] == "siren_mlp_wave.hip" or r["kernel"].endswith(("Li2ELb1EEEvN3rcb9SirenArgsE",))]
+    if check and (headline["scratch_instructions_in_tile_loop"] or shipped_bad):
+        print("FAIL: scratch inside the tile loop of an instance the training step selects:", [r["kernel"] for r in shipped_bad] or "headline")
         return 1
     return 0
 
