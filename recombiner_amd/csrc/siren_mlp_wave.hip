@@ -40,6 +40,18 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef RCB_WAVE_PIPE_FWD
 #define RCB_WAVE_PIPE_FWD 1  // forward pass software-pipelined across the layers by hand (0: layer by layer, the compiler's order)
 #endif
+#ifndef RCB_WAVE_FAIR
+#define RCB_WAVE_FAIR 0     // time-sliced issue priority between the two workgroups of a CU (see the tile loop): measured, off
+#endif
+#ifndef RCB_WAVE_FAIR_SHIFT
+#define RCB_WAVE_FAIR_SHIFT 14
+#endif
+#ifndef RCB_WAVE_PROBE_BLOCK0
+#define RCB_WAVE_PROBE_BLOCK0 0
+#endif
+#ifndef RCB_WAVE_PROBE_WAVE
+#define RCB_WAVE_PROBE_WAVE 0
+#endif
 #ifndef RCB_WAVE_ZPIPE
 #define RCB_WAVE_ZPIPE 1    // backward: the recomputed pre-activation one layer ahead (see compute_z)
 #endif
@@ -220,10 +232,17 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
   int lfr_lane = lane * 16;
   auto LFR = [&](int ls) -> i32x4 { return *(const RCB_LDS(i32x4)*)(wlds + G::LFR_OFF + ls * 1024 + lfr_lane); };
 
-  if (a.clock_probe != nullptr && blockIdx.x < 256 && threadIdx.x == 0) {      // measurement aid: rcb_siren_desc.clock_probe
-    a.clock_probe[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    a.clock_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  // measurement aid: rcb_siren_desc.clock_probe (diagnostic builds move the window: -DRCB_WAVE_PROBE_BLOCK0=256 -DRCB_WAVE_PROBE_WAVE=3)
+  const int pblk = (int)blockIdx.x - RCB_WAVE_PROBE_BLOCK0;
+  const bool probing = a.clock_probe != nullptr && pblk >= 0 && pblk < 256 && threadIdx.x == 64 * RCB_WAVE_PROBE_WAVE;
+  if (probing) {
+    a.clock_probe[4 * pblk + 0] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[4 * pblk + 1] = __builtin_amdgcn_s_memrealtime();
   }
+#if RCB_WAVE_FAIR
+  const unsigned young = (blockIdx.x >= (gridDim.x >> 1)) ? 1u : 0u;      // the second workgroup of a CU (dispatch order)
+  unsigned long long fair_clk = __builtin_amdgcn_s_memtime();
+#endif
   for (int u = blockIdx.x * 4 + wave; u < nunits; u += gridDim.x * 4) {
     RCB_WSTAMP(0);
 #ifdef RCB_WAVE_STAMPS
@@ -380,6 +399,19 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
 #ifdef RCB_WAVE_STAMPS
       const int ts = 10 + 12 * (t - t0);          // stamps of the first tiles of the row
       RCB_WSTAMP(ts);
+#endif
+#if RCB_WAVE_FAIR
+      // The two waves of a SIMD are arbitrated by priority, then AGE: the wave of the workgroup that was dispatched first runs
+      // nearly unimpeded and finishes its two rows at ~176 us, the other one gets the leftover issue slots and finishes at ~212 us,
+      // the last 36 of them alone on its SIMD (rcb_siren_desc.clock_probe on both halves of the grid, tools/wave_spread.py).
+      // This switch hands the high priority to the two halves of the grid in alternating time slices of the shader clock
+      // (2^RCB_WAVE_FAIR_SHIFT cycles; the clock is read one tile ahead, so its wait is one that happens anyway).  Measured: the
+      // halves then finish at ~200 / ~210 us -- and the kernel still ends at 218-222 us: the pole-and-filler arrangement the
+      // hardware falls into is as productive as equal shares, and the end is set by the slowest XCD (their clocks differ by 5 %
+      // under this kernel: 1.93 ... 2.04 GHz).  Off.
+      if ((((unsigned)(fair_clk >> RCB_WAVE_FAIR_SHIFT)) & 1u) != young) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      fair_clk = __builtin_amdgcn_s_memtime();
 #endif
       bf16x8 xin[K0S];
       float yv[16];
@@ -751,9 +783,9 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) g_wave_stamps[5] = __builtin_amdgcn_s_memrealtime();
 #endif
   }
-  if (a.clock_probe != nullptr && blockIdx.x < 256 && threadIdx.x == 0) {      // (wave 0 of the workgroup: its own rows)
-    a.clock_probe[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    a.clock_probe[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  if (probing) {                                                                // (one wave of the workgroup: its own rows)
+    a.clock_probe[4 * pblk + 2] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[4 * pblk + 3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
