@@ -145,6 +145,16 @@ __device__ __forceinline__ f32x16 zero16() {
 // under a per-lane condition sits in a branch, and the compiler then counts no store when it waits for the NEXT tile's inputs
 // (requested before the stores were issued, vmcnt being in order) -- the wave would wait for the stores' completion, ~1.5 k
 // cycles per tile by the in-kernel stamps.
+// [pixel][feature] image swizzle of this kernel: the 8-byte chunk index (f >> 2) has its low 3 bits XORed with (pix >> 2) & 7.
+// A lane half writes (and re-reads) 32 pixel rows of 64 bytes at one chunk index: pixel bits 0-1 pick the bank quarter, bits 2-4
+// the chunk position -- 32 distinct bank pairs; with the (pix >> 1) key of siren_op16.h's swz(), built for 16-pixel row groups,
+// pixels q and q + 16 share their banks and every image store / row re-read of this kernel took two passes (tools/lds_banks.py;
+// PMC: 15 % of the LDS cycles were conflicts).  The transposed reads (4 pixels x 8 chunks per 32 lanes) stay conflict-free.
+__device__ __forceinline__ int wswz(int pix, int f, int stride) {
+  const int c = f >> 2;
+  return pix * stride + ((((c & 7) ^ ((pix >> 2) & 7)) | (c & ~7)) << 2) + (f & 3);
+}
+
 template <typename T, int NH, int F, int E, int C, int MODE, bool DPE>
 __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
   using G = WGeo<NH, F, E, C>;
@@ -170,8 +180,8 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
   int po[2][2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    po[s][0] = swz(q, 16 * s + 4 * h, G::TSA);
-    po[s][1] = swz(q, 16 * s + 8 + 4 * h, G::TSA);
+    po[s][0] = wswz(q, 16 * s + 4 * h, G::TSA);
+    po[s][1] = wswz(q, 16 * s + 8 + 4 * h, G::TSA);
   }
   auto put_img = [&](RCB_LDS(T)* img, const bf16x8 (&v)[2]) {
 #pragma unroll
@@ -199,8 +209,8 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
       union { bf16x8 v; bf16x4 hlf[2]; } uu;
       uu.v = v[s];
       if (8 * s + 8 <= xkh) {
-        *(RCB_LDS(bf16x4)*)(x_img + swz(q, xbase + 8 * s, G::TSX)) = uu.hlf[0];
-        *(RCB_LDS(bf16x4)*)(x_img + swz(q, xbase + 8 * s + 4, G::TSX)) = uu.hlf[1];
+        *(RCB_LDS(bf16x4)*)(x_img + wswz(q, xbase + 8 * s, G::TSX)) = uu.hlf[0];
+        *(RCB_LDS(bf16x4)*)(x_img + wswz(q, xbase + 8 * s + 4, G::TSX)) = uu.hlf[1];
       }
     }
   };
@@ -211,8 +221,8 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) uu.v[j] = (T)0.f;
       if (8 * s + 8 <= xkh) {
-        uu.hlf[0] = *(const RCB_LDS(bf16x4)*)(x_img + swz(q, xbase + 8 * s, G::TSX));
-        uu.hlf[1] = *(const RCB_LDS(bf16x4)*)(x_img + swz(q, xbase + 8 * s + 4, G::TSX));
+        uu.hlf[0] = *(const RCB_LDS(bf16x4)*)(x_img + wswz(q, xbase + 8 * s, G::TSX));
+        uu.hlf[1] = *(const RCB_LDS(bf16x4)*)(x_img + wswz(q, xbase + 8 * s + 4, G::TSX));
       }
       v[s] = uu.v;
     }
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
     union { s16x4 v[2]; bf16x8 b; } u;
 #pragma unroll
     for (int w = 0; w < 2; ++w)
-      u.v[w] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RCB_LDS(s16x4)*)(img + swz(16 * s + 8 * h + 4 * w + q4, fcol + 16 * fb + 4 * p4, stride)));
+      u.v[w] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RCB_LDS(s16x4)*)(img + wswz(16 * s + 8 * h + 4 * w + q4, fcol + 16 * fb + 4 * p4, stride)));
     return u.b;
   };
   // a fragment kept in LDS.  `lfr_lane` is laundered once per tile (an empty asm the compiler cannot see through): the reads
