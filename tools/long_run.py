@@ -11,7 +11,8 @@ from recombiner_amd import config, tuning, utils
 from recombiner_amd import prior_model as PM
 
 tuning.enable_tuned_gemms()
-RUNS = [("cifar", "cifar", 512, 32, 1), ("protein", "protein", 512, 32, 1), ("kodak", "kodak", 1, 32, 1), ("audio", "audio", 4, 32, 1),
+RUNS = [("cifar-4096", "cifar", 4096, 32, 1),      # (the batch size at which the one-wave-per-INR SIREN family runs)
+        ("cifar", "cifar", 512, 32, 1), ("protein", "protein", 512, 32, 1), ("kodak", "kodak", 1, 32, 1), ("audio", "audio", 4, 32, 1),
         ("video", "video", 2, 32, 1), ("kodak-w48", "kodak", 1, 48, 1), ("video-w64-f16", "video", 2, 64, 2)]
 only = sys.argv[1:]
 bad = 0
