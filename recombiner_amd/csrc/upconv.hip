@@ -897,6 +897,9 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
 #ifndef RCB_B3_STAMPS
 #define RCB_B3_STAMPS 0
 #endif
+#ifndef RCB_B3_WG16
+#define RCB_B3_WG16 1        // weight-gradient part on v_mfma_f32_16x16x32_bf16 (0: the 32 x 32 x 16 form of the separate kernel)
+#endif
 #ifndef RCB_B3_DIAG
 #define RCB_B3_DIAG 0      // ablations (wrong results): 1 no dx stores, 2 one fragment read per tap pair, 3 one dy read for all taps,
                            // 4 dx stores land in the workgroup's first INR (L2-resident target)
@@ -951,6 +954,17 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     frags[e] = f.u;
   }
   for (int e = tid; e < (HO * HO * RS + HG * HG * XRS) / 8; e += 512) reinterpret_cast<uint4*>(dyimg)[e] = make_uint4(0, 0, 0, 0);
+#if RCB_B3_WG16
+  // weight gradient on v_mfma_f32_16x16x32_bf16: [combo slot][16-channel block of cin] tiles of 16 cin x 16 cout (the 32 x 32 x 16
+  // form has 32 columns for the 16 output channels: half of every MFMA, and this phase ran at 90 % of the matrix pipe)
+  f32x4v wacc[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wacc[c][cb][r] = 0.f;
+#else
   f32x16 wacc[2][2];   // weight gradient: [combo slot][mt]
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -958,6 +972,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) wacc[c][mt][r] = 0.f;
+#endif
   float dbsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
@@ -1069,6 +1084,32 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     // depends on the phase only: one transposed read feeds both combos (10 reads per 4 MFMAs instead of 12)
     __builtin_amdgcn_sched_barrier(0);
     B3_T(3);
+#if RCB_B3_WG16
+    {
+      // per 32 positions (two rows of the 16 x 16 grid) and combo: four MFMAs of K = 32, one per 16-channel block of cin; a lane
+      // group g = lane >> 4 supplies positions 8 g .. 8 g + 7 of both operands (two transposed 8-byte reads each)
+      const int p = wave >> 1, pa = p >> 1, pb = p & 1, ty = wave & 1, kg = lane >> 4;
+#pragma unroll 2
+      for (int pt = 0; pt < G * G / 32; ++pt) {       // partly unrolled: the prefetch registers must stay in registers
+        union { s16x4 s[2]; bf16x8 v; } av[2][4], bv;
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const int pos = 32 * pt + 8 * kg + 4 * w2 + q4;
+          const int i = pos >> 4, j = pos & 15;
+          const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb)) * XRS + 4 * p4;
+#pragma unroll
+          for (int c = 0; c < 2; ++c)               // tx = c: the neighbouring column
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) av[c][cb].s[w2] = tr_read(xr + c * XRS + 16 * cb);
+          bv.s[w2] = tr_read(dyimg + ((2 * i + pa + 1) * HO + (2 * j + pb + 1)) * RS + 4 * p4);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) wacc[c][cb] = mfma16x32(av[c][cb].v, bv.v, wacc[c][cb]);
+      }
+    }
+#else
     {
       const int p = wave >> 1, pa = p >> 1, pb = p & 1, ty = wave & 1;
 #pragma unroll 2
@@ -1094,6 +1135,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
         }
       }
     }
+#endif
     B3_T(4);
   }
 #if RCB_B3_STAMPS
@@ -1119,6 +1161,13 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   for (int c = 0; c < 2; ++c) {
     const int combo = 2 * wave + c;
     const int p = combo >> 2, t = combo & 3;
+#if RCB_B3_WG16
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)       // 16 x 16 accumulator: column (cout) = lane & 15, rows (cin) 4 (lane >> 4) + r
+        slab[weff_index(t >> 1, t & 1, 16 * cb + 4 * (lane >> 4) + r, p >> 1, p & 1, lane & 15, COUT)] = wacc[c][cb][r];
+#else
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int co = lane & 31;
@@ -1130,6 +1179,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
         }
       }
     }
+#endif
   }
 }
 

@@ -291,8 +291,9 @@ def test_phase_form_routing_for_other_geometries(name):
 
 
 def test_fused_stage3_backward_equals_separate_kernels():
-    """rcb_upconv_bwd_fused == rcb_upconv_dgrad + rcb_upconv_wgrad on the same inputs: dx bit-identical (same MFMA
-    sequence), weight / bias gradients identical up to the order of the bf16-exact image sums (also bit-identical)."""
+    """rcb_upconv_bwd_fused == rcb_upconv_dgrad + rcb_upconv_wgrad on the same inputs: dx and the bias gradient bit-identical
+    (same MFMA sequence / same sums), the weight gradient equal to fp32 summation order (the fused kernel uses the 16 x 16 x 32
+    MFMA since round 5) and both within fp32 rounding of the fp64 definition."""
     from recombiner_amd import ops
     torch.manual_seed(9)
     for B in (5, 300):
@@ -302,8 +303,21 @@ def test_fused_stage3_backward_equals_separate_kernels():
         dx0 = ops.upconv_dgrad(dpe, W3, h2, 16, 16)
         dw0, db0 = ops.upconv_wgrad(h2, dpe, 16, 16)
         dx1, dw1, db1 = ops.upconv_bwd_fused(dpe, W3, h2, 16, 16)
-        assert torch.equal(dx0, dx1)
-        assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+        assert torch.equal(dx0, dx1) and torch.equal(db0, db1)
+        # weight gradient: the fused kernel contracts 32 positions per v_mfma_f32_16x16x32_bf16, the separate one 16 per
+        # 32 x 32 x 16 MFMA -- the same bf16-exact products in another fp32 association.  Both against the fp64 definition
+        # dW[ty, tx, ci, pa, pb, co] = sum_{b, i, j} x[b, i + pa + ty - 1, j + pb + tx - 1, ci] dy[b, 2 i + pa, 2 j + pb, co]
+        xp = torch.nn.functional.pad(h2.double(), (0, 0, 1, 1, 1, 1))                       # zero halo
+        ref = torch.zeros(2, 2, 64, 2, 2, 16, dtype=torch.float64, device=DEV)
+        for ty in range(2):
+            for tx in range(2):
+                for pa in range(2):
+                    for pb in range(2):
+                        xs = xp[:, pa + ty:pa + ty + 16, pb + tx:pb + tx + 16, :]
+                        ref[ty, tx, :, pa, pb, :] = torch.einsum("bijc,bijo->co", xs, dpe.double()[:, pa::2, pb::2, :])
+        tol = 3e-6 * float(ref.abs().max())
+        assert float((dw0.double() - ref).abs().max()) < tol and float((dw1.double() - ref).abs().max()) < tol
+        assert torch.equal(dw1, ops.upconv_bwd_fused(dpe, W3, h2, 16, 16)[1])                 # fixed order: reproducible
 
 
 @pytest.mark.parametrize("n,grid", [(2, (5, 7)), (1, (8, 12)), (2, (32, 48))])
