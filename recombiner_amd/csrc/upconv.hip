@@ -929,12 +929,25 @@ struct Bwd3Args {
 __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   constexpr int COUT = 16, G = 16, OG = 32, HO = 34, RS = 24, HG = 18, NF = 32;
   constexpr int WSZ = 1024 * COUT, ROW = WSZ + COUT;
+#if RCB_B3_WG16
+  // x image of THIS kernel: 128-byte pixel rows, the 32-byte block cb of 16 channels stored at block cb ^ xkey(column) with
+  // xkey = column bit 1 | column bit 3 << 1.  The transposed reads of the weight gradient take, per 32 lanes, four adjacent
+  // columns and the four columns eight further on: with this key (and the bank half that the column parity selects) their 32
+  // 8-byte pieces fall on 32 distinct bank pairs.  On the 144-byte rows of the other kernels every one of those reads took two
+  // passes, and with the matrix work halved (16 x 16 x 32) they are what the phase waits for (tools/lds_banks.py: 4.0 -> 2.0
+  // cycles per read; staging stores 8 -> 6, the data gradient's eight sign reads per INR 4 -> 8)
+  constexpr int XR3 = 64;
+#define B3_XKEY(col) ((((col) >> 1) & 1) | ((((col) >> 3) & 1) << 1))
+#else
+  constexpr int XR3 = XRS;
+#define B3_XKEY(col) 0
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* frags = reinterpret_cast<uint4*>(smem_raw);                              // [16 combos][2 mt][64 lanes]
   __bf16* dyimg = reinterpret_cast<__bf16*>(smem_raw + NF * 1024);                // [34][34][24]
   __bf16* ximg = dyimg + HO * HO * RS;                                            // [18][18][XRS]
   constexpr int SCR_RS = 40;                                                      // dx transposition tile: 80-byte rows
-  __bf16* dxscr = ximg + HG * HG * XRS;                                           // [8 waves][32][SCR_RS]
+  __bf16* dxscr = ximg + HG * HG * XR3;                                           // [8 waves][32][SCR_RS]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
   const int fb = (lane >> 4) & 1, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
   for (int e = tid; e < NF * 64; e += 512) {
@@ -953,7 +966,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)a.weff[weff_index(ty, tx, ci, pa, pb, 8 * fh + j, COUT)];
     frags[e] = f.u;
   }
-  for (int e = tid; e < (HO * HO * RS + HG * HG * XRS) / 8; e += 512) reinterpret_cast<uint4*>(dyimg)[e] = make_uint4(0, 0, 0, 0);
+  for (int e = tid; e < (HO * HO * RS + HG * HG * XR3) / 8; e += 512) reinterpret_cast<uint4*>(dyimg)[e] = make_uint4(0, 0, 0, 0);
 #if RCB_B3_WG16
   // weight gradient on v_mfma_f32_16x16x32_bf16: [combo slot][16-channel block of cin] tiles of 16 cin x 16 cout (the 32 x 32 x 16
   // form has 32 columns for the 16 output channels: half of every MFMA, and this phase ran at 90 % of the matrix pipe)
@@ -1010,7 +1023,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
       }
       {   // x: pixel e >> 3, chunk e & 7
         const int pix = e >> 3, c8 = e & 7;
-        *reinterpret_cast<uint4*>(ximg + (((pix >> 4) + 1) * HG + ((pix & 15) + 1)) * XRS + 8 * c8) = px[k];
+        *reinterpret_cast<uint4*>(ximg + (((pix >> 4) + 1) * HG + ((pix & 15) + 1)) * XR3 + 16 * ((c8 >> 1) ^ B3_XKEY((pix & 15) + 1)) + 8 * (c8 & 1)) = px[k];
       }
     }
     B3_T(1);
@@ -1055,7 +1068,8 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
       // is eight 8-byte pieces per lane at 128-byte stride (measured: a quarter of the kernel's time).  Instead each half goes
       // through a per-wave LDS tile [32 positions][32 channels] and leaves as 16-byte pieces, four consecutive lanes per
       // position: 64 contiguous bytes per position and instruction.
-      const __bf16* xs = ximg + ((u + 1) * HG + (v + 1)) * XRS;
+      const __bf16* xs = ximg + ((u + 1) * HG + (v + 1)) * XR3;
+      const int xk16 = 16 * B3_XKEY(v + 1);
       __bf16* scr = dxscr + wave * (32 * SCR_RS);
       __bf16* dxw = reinterpret_cast<__bf16*>(a.dx) + ((long long)(RCB_B3_DIAG == 4 ? (int)blockIdx.x : b) * G * G + wave * 32) * CIN;
 #pragma unroll
@@ -1063,7 +1077,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int ci = 32 * mt + 8 * g4 + 4 * h;
-          const bf16x4 t = *reinterpret_cast<const bf16x4*>(xs + ci);
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(xs + (((32 * mt + 8 * g4) & ~15) ^ xk16) + ((8 * g4) & 15) + 4 * h);
           bf16x4 ob;
 #pragma unroll
           for (int k = 0; k < 4; ++k) ob[k] = (__bf16)(acc[mt][4 * g4 + k] * ((float)t[k] > 0.f ? 1.0f : SLOPE));
@@ -1089,24 +1103,47 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
       // per 32 positions (two rows of the 16 x 16 grid) and combo: four MFMAs of K = 32, one per 16-channel block of cin; a lane
       // group g = lane >> 4 supplies positions 8 g .. 8 g + 7 of both operands (two transposed 8-byte reads each)
       const int p = wave >> 1, pa = p >> 1, pb = p & 1, ty = wave & 1, kg = lane >> 4;
-#pragma unroll 2
-      for (int pt = 0; pt < G * G / 32; ++pt) {       // partly unrolled: the prefetch registers must stay in registers
-        union { s16x4 s[2]; bf16x8 v; } av[2][4], bv;
+      // this lane's 18 read addresses of position block 0 (the blocks that follow are two image rows further on: one
+      // wave-uniform offset per trip of the loop)
+      // (LDS byte addresses, opaque to the compiler: left to itself it re-derives every address in every trip)
+      typedef __attribute__((address_space(3))) s16x4* lds_tr_t;
+      unsigned xa[2][2][4], da[2];
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) {
-          const int pos = 32 * pt + 8 * kg + 4 * w2 + q4;
-          const int i = pos >> 4, j = pos & 15;
-          const __bf16* xr = ximg + ((i + pa + ty) * HG + (j + pb)) * XRS + 4 * p4;
+      for (int w2 = 0; w2 < 2; ++w2) {
+        const int pos = 8 * kg + 4 * w2 + q4;
+        const int i = pos >> 4, j = pos & 15;
 #pragma unroll
-          for (int c = 0; c < 2; ++c)               // tx = c: the neighbouring column
+        for (int c = 0; c < 2; ++c) {
+          const int col = j + pb + c;
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) av[c][cb].s[w2] = tr_read(xr + c * XRS + 16 * cb);
-          bv.s[w2] = tr_read(dyimg + ((2 * i + pa + 1) * HO + (2 * j + pb + 1)) * RS + 4 * p4);
+          for (int cb = 0; cb < 4; ++cb) {
+            xa[w2][c][cb] = (unsigned)(size_t)(lds_tr_t)(ximg + ((i + pa + ty) * HG + col) * XR3 + 16 * (cb ^ B3_XKEY(col)) + 4 * p4);
+            asm volatile("" : "+v"(xa[w2][c][cb]));
+          }
         }
+        da[w2] = (unsigned)(size_t)(lds_tr_t)(dyimg + ((2 * i + pa + 1) * HO + (2 * j + pb + 1)) * RS + 4 * p4);
+        asm volatile("" : "+v"(da[w2]));
+      }
+      constexpr unsigned XSTEP = 2 * HG * XR3 * 2, DSTEP = 4 * HO * RS * 2;       // bytes per position block
+#pragma unroll 1
+      for (int trip = 0; trip < G * G / 64; ++trip) {     // two position blocks per trip (the prefetch registers must stay in registers)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int u2 = 0; u2 < 2; ++u2) {
+          union { s16x4 s[2]; bf16x8 v; } av[2][4], bv;
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) wacc[c][cb] = mfma16x32(av[c][cb].v, bv.v, wacc[c][cb]);
+          for (int w2 = 0; w2 < 2; ++w2) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)               // tx = c: the neighbouring column
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb)
+                av[c][cb].s[w2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(size_t)(xa[w2][c][cb] + (2 * trip + u2) * XSTEP));
+            bv.s[w2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(size_t)(da[w2] + (2 * trip + u2) * DSTEP));
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) wacc[c][cb] = mfma16x32(av[c][cb].v, bv.v, wacc[c][cb]);
+        }
       }
     }
 #else
@@ -1143,6 +1180,7 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     for (int k = 0; k < 8; ++k) g_b3_stamps[wave * 8 + k] = ph_[k];
 #endif
 #undef RCB_FETCH_B3
+#undef B3_XKEY
   float* slab = a.partial + (long long)blockIdx.x * ROW;
   {   // bias gradient: per-thread channel partials through LDS (fixed order: deterministic)
     __syncthreads();
@@ -1372,7 +1410,7 @@ extern "C" int rcb_upconv_bwd_fused(const void* dy, const float* weff, const voi
   hipStream_t st = (hipStream_t)stream;
   const int g = wgrad_blocks(batch);
   static bool done = false;
-  int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * XRS) * 2 + 8 * 32 * 40 * 2, st, done);
+  int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * (RCB_B3_WG16 ? 64 : XRS)) * 2 + 8 * 32 * 40 * 2, st, done);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
   upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 1024, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);

@@ -345,12 +345,14 @@ def test_reference_written_checkpoint_and_psnr_at_bpp(precision):
     # Over 400 + 311 x 6 Adam steps at lr 2e-3 two runs that differ by fp32 rounding drift apart and pick different A*
     # candidates (each index is a random draw from the posterior), so one image's final PSNR scatters by ~0.3 dB between
     # equally valid runs -- the reference against itself would, too.  The rate-distortion point is the MEAN over the 32
-    # images: within 0.1 dB (fp32) / 0.25 dB (bf16) of the reference's at the identical rate; single images within 1.5 dB
+    # images: within 0.2 dB (fp32) / 0.25 dB (bf16) of the reference's at the identical rate; single images within 1.5 dB
     # (fp32) / 2.5 dB (bf16: measured 0.004 dB on the mean with one image 1.4 dB off mid-way).  Two runs of THIS test in the
     # fp32 mode on one box already differ by up to 0.5 dB on single images (its library GEMM / convolution kernels are not
     # bitwise reproducible from run to run, and the trajectory amplifies one ulp); 1.18 dB was seen once in ~15 runs.
     dist = np.asarray(dist, dtype=np.float64)
-    assert abs(dist.mean() - ref.mean()) < (0.1 if precision == 0 else 0.25), (dist.mean(), ref.mean())
+    # (fp32 mode: per-image scatter ~0.3 dB -> sigma of the mean of 32 images ~0.05 dB; the former 0.1 dB limit was a 2-sigma
+    # bound and tripped about once in 15 runs, e.g. +0.107 dB in round 5; 0.2 dB is 4 sigma)
+    assert abs(dist.mean() - ref.mean()) < (0.2 if precision == 0 else 0.25), (dist.mean(), ref.mean())
     assert np.abs(dist - ref).max() < (1.5 if precision == 0 else 2.5), np.abs(dist - ref).max()
     blob = bitstream.encode(m)
     assert bitstream.payload_bits(blob) / (n * 1024) == pytest.approx(float(d["bpp"]))           # identical rate
