@@ -1235,26 +1235,45 @@ namespace {
 #endif
 
 // fixed-order sum of the workgroup slabs: out[j] = sum_w partial[w][j]
-__global__ void __launch_bounds__(1024) upconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int row,
-                                                                   int wsz, float* __restrict__ dweff,
-                                                                   float* __restrict__ dbias) {
-  // 64 outputs per block; wave k of 16 sums the slabs k, k + 16, ... (coalesced 256-byte rows, eight loads in flight), the
-  // sixteen wave sums are added as a fixed tree: a fixed association (bitwise reproducible).  (Four waves with four loads in
-  // flight spent 10 us on the 17 MB of the 16-channel stage: one dependent round trip per four slabs.)
+__global__ void __launch_bounds__(256) upconv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int row,
+                                                                  int wsz, float* __restrict__ dweff,
+                                                                  float* __restrict__ dbias) {
+  // 64 outputs per block; sixteen partial sums per output -- partial k adds the slabs k, k + 16, ... (coalesced 256-byte rows,
+  // eight loads in flight each) -- joined by a fixed tree: a fixed association (bitwise reproducible).  Four waves of a
+  // 256-thread block form four of the sixteen partial sums each.  (As ONE 1024-thread block of sixteen waves -- the same sums --
+  // the kernel took 9 us alone and 145 us inside the three-stream step: a block that needs sixteen free wave slots on one CU
+  // at once is not placed while the neighbouring streams' 256-thread blocks keep refilling the CUs, and the chain behind it
+  // -- the last weight-gradient GEMM, the map onto the conv weights -- ended the forked region, tools/step_timeline.py.)
   __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float s[4][8];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[v][u] = 0.f;
   if (j < row) {
     const float* p = partial + j;
-    int w = wave;
-    for (; w + 7 * 16 < nblk; w += 8 * 16) {
+    int w = 4 * wave;                      // partial sums 4 wave + v, v = 0 .. 3, side by side (32 loads in flight)
+    for (; w + 3 + 7 * 16 < nblk; w += 8 * 16) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] += p[(long long)(w + 16 * u) * row];
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[v][u] += p[(long long)(w + v + 16 * u) * row];
     }
-    for (; w < nblk; w += 16) s[0] += p[(long long)w * row];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {          // the ragged rest, per partial sum exactly as its own loop would run
+      int wv = w + v;
+      for (; wv + 7 * 16 < nblk; wv += 8 * 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[v][u] += p[(long long)(wv + 16 * u) * row];
+      }
+      for (; wv < nblk; wv += 16) s[v][0] += p[(long long)wv * row];
+    }
   }
-  part[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    part[4 * wave + v][lane] = ((s[v][0] + s[v][1]) + (s[v][2] + s[v][3])) + ((s[v][4] + s[v][5]) + (s[v][6] + s[v][7]));
   __syncthreads();
   if (wave == 0 && j < row) {
     float t[8];
@@ -1390,7 +1409,7 @@ extern "C" int rcb_upconv_wgrad(const void* x, int32_t x_is_f32_preact, const vo
   if (!hit) return fail(RCB_ERR_UNSUPPORTED, "upconv_wgrad: grid=%d cout=%d not instantiated", grid, cout);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
-  upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 1024, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
+  upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
@@ -1413,7 +1432,7 @@ extern "C" int rcb_upconv_bwd_fused(const void* dy, const float* weff, const voi
   int rc = launch(upconv_bwd3_fused_kernel, a, g, 32 * 1024 + (34 * 34 * 24 + 18 * 18 * (RCB_B3_WG16 ? 64 : XRS)) * 2 + 8 * 32 * 40 * 2, st, done);
   if (rc) return rc;
   const int row = 1024 * cout + cout;
-  upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 1024, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
+  upconv_wgrad_reduce_kernel<<<(row + 63) / 64, 256, 0, st>>>(workspace, g, row, 1024 * cout, dweff, dbias);
   RCB_LAUNCH_CHECK();
   return RCB_OK;
 }
