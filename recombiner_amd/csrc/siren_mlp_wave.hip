@@ -145,14 +145,18 @@ __device__ __forceinline__ f32x16 zero16() {
 // under a per-lane condition sits in a branch, and the compiler then counts no store when it waits for the NEXT tile's inputs
 // (requested before the stores were issued, vmcnt being in order) -- the wave would wait for the stores' completion, ~1.5 k
 // cycles per tile by the in-kernel stamps.
-// [pixel][feature] image swizzle of this kernel: the 8-byte chunk index (f >> 2) has its low 3 bits XORed with (pix >> 2) & 7.
-// A lane half writes (and re-reads) 32 pixel rows of 64 bytes at one chunk index: pixel bits 0-1 pick the bank quarter, bits 2-4
-// the chunk position -- 32 distinct bank pairs; with the (pix >> 1) key of siren_op16.h's swz(), built for 16-pixel row groups,
-// pixels q and q + 16 share their banks and every image store / row re-read of this kernel took two passes (tools/lds_banks.py;
-// PMC: 15 % of the LDS cycles were conflicts).  The transposed reads (4 pixels x 8 chunks per 32 lanes) stay conflict-free.
+// [pixel][feature] image swizzle of this kernel: the 8-byte chunk index (f >> 2) has its low 3 bits XORed with
+// ((pix >> 1) & 7) ^ ((pix >> 4) & 1).  Stores go through the LDS in groups of 16 consecutive lanes on 32 banks: within a group pixel
+// bit 0 picks the bank half and bits 1-3 (through the key) the chunk position -- conflict-free, as with the plain (pix >> 1) key
+// of siren_op16.h's swz().  The row re-reads of the backward pass (ds_read_b64: 32-lane groups on 64 banks) also need pixels q and
+// q + 16 apart: bit 4 flips the key's low bit, which keeps the stores' bijection (bit 4 is constant inside a 16-lane group) and
+// separates the two.  With swz() every row re-read took two passes (PMC: 15 % of the LDS cycles were conflicts); a first attempt
+// keyed on pixel bits 2-4 fixed the reads and made every STORE two-way (36 % conflicts by the counters, 32 instead of 16 cycles
+// per four stores once the store grouping is modelled: tools/lds_banks.py `w64`) -- at an unchanged kernel time either way: the
+// LDS is not what this kernel waits for.  The transposed reads (4 pixels x 8 chunks per 32 lanes) are conflict-free with all three.
 __device__ __forceinline__ int wswz(int pix, int f, int stride) {
   const int c = f >> 2;
-  return pix * stride + ((((c & 7) ^ ((pix >> 2) & 7)) | (c & ~7)) << 2) + (f & 3);
+  return pix * stride + ((((c & 7) ^ (((pix >> 1) & 7) ^ ((pix >> 4) & 1))) | (c & ~7)) << 2) + (f & 3);
 }
 
 template <typename T, int NH, int F, int E, int C, int MODE, bool DPE>
