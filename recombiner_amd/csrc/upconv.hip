@@ -425,6 +425,20 @@ __global__ void __launch_bounds__(512) upconv_dgrad3_lds_kernel(DgradArgs a) {
 // halves of the 64 output channels: 32 fragments in registers, 16 image reads feed 32 MFMAs per tile.  Two INRs per
 // pass halve the barriers per INR; LeakyReLU of the pre-activation input is applied once, when the image is staged.
 // ------------------------------------------------------------------------------------------------
+#ifndef RCB_F2_STAMPS
+#define RCB_F2_STAMPS 0    // diagnostic build: ticks per phase of workgroup 0's waves (rcb_debug_f2_stamps, tools/f2_stamps.py)
+#endif
+#if RCB_F2_STAMPS
+__device__ unsigned long long g_f2_stamps[8 * 8];
+#define F2_T(k)                                                     \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    ph_[k] += now_ - last_;                                         \
+    last_ = now_;                                                   \
+  } while (0)
+#else
+#define F2_T(k) do { } while (0)
+#endif
 template <int IN_MODE>   // 1: fp32 pre-activation, 3: bf16 pre-activation
 __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
   constexpr int G = 8, HG = 10, RS = 72, COUT = 64, IMG = HG * HG * RS;
@@ -468,8 +482,12 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
   const int gs = gridDim.x;
   int p = blockIdx.x;
   if (p < npair) RCB_FETCH2(p)
+#if RCB_F2_STAMPS
+  unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (; p < npair; p += gs) {
     __syncthreads();
+    F2_T(0);
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int e_ = tid + 512 * k, pix = (e_ >> 3) & 63, c8 = e_ & 7;
@@ -477,7 +495,9 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
       f.v = raw_frag<IN_MODE>(pre[k], true);
       *reinterpret_cast<uint4*>(img + (e_ >> 9) * IMG + (((pix >> 3) + 1) * HG + ((pix & 7) + 1)) * RS + 8 * c8) = f.u;
     }
+    F2_T(1);
     __syncthreads();
+    F2_T(2);
     if (p + gs < npair) RCB_FETCH2(p + gs)
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {         // (INR of this wave, tile) pairs, one after the other
@@ -506,6 +526,8 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
                 acc[mt] = mfma16(fa.v, bf.v, acc[mt]);
               }
             }
+        __builtin_amdgcn_sched_barrier(0);
+        F2_T(3);
         // bias + LeakyReLU on the original channels, then the lane halves swap so that lane (q, h) owns the 16
         // consecutive channels 32 mt + 16 h .. + 15 of its pixel
         const long long opix = ((long long)b * (2 * G) + 2 * i + pa) * (2 * G) + 2 * j + pb;
@@ -539,9 +561,15 @@ __global__ void __launch_bounds__(512) upconv_fwd2_reg_kernel(FwdArgs a) {
             dst[1] = o1.u;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        F2_T(4);
       }
     }
   }
+#if RCB_F2_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_f2_stamps[wave * 8 + k] = ph_[k];
+#endif
 #undef RCB_FETCH2
 }
 
@@ -1226,6 +1254,11 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
 #if RCB_D2_STAMPS
 extern "C" int rcb_debug_d2_stamps(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_d2_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+#if RCB_F2_STAMPS
+extern "C" int rcb_debug_f2_stamps(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_f2_stamps), sizeof(unsigned long long) * n);
 }
 #endif
 extern "C" int rcb_debug_b3_stamps(unsigned long long* dst, int n) {

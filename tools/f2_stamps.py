@@ -1,0 +1,40 @@
+"""Where the stage-2 forward kernel spends its time (diagnostic build):
+   python -m recombiner_amd.build --variant f2 --only upconv.hip -DRCB_B3_STAMPS=1 -DRCB_F2_STAMPS=1
+   RCB_LIB=.../librcb_f2.so python tools/f2_stamps.py
+Per wave of workgroup 0, s_memtime ticks summed over its passes (4 INRs each): first barrier, staging, second barrier,
+gathers + MFMAs of its four (INR, tile) pairs, their epilogues (bias, LeakyReLU, lane swap, stores)."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from recombiner_amd import ops, _lib
+
+B = 4096
+x = torch.randn(B, 8, 8, 64, device="cuda").bfloat16()
+weff = torch.randn(2, 2, 64, 2, 2, 64, device="cuda") * 0.05
+bias = torch.randn(64, device="cuda") * 0.1
+for _ in range(5):
+    ops.upconv_fwd(x, weff, bias, 8, 64, False, preact=True)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.upconv_fwd(x, weff, bias, 8, 64, False, preact=True)
+e1.record()
+torch.cuda.synchronize()
+print("avg us per launch:", e0.elapsed_time(e1) * 100)
+lib = _lib.load()
+try:
+    f = lib.rcb_debug_f2_stamps
+except AttributeError:
+    sys.exit("not a stamps build")
+buf = (C.c_uint64 * 64)()
+assert f(buf, 64) == 0
+st = np.array(buf, dtype=np.int64).reshape(8, 8)[:, :5]
+np.set_printoptions(linewidth=200)
+print("ticks per wave [barrier1, staging, barrier2, gathers + MFMAs, epilogues], summed over the workgroup's passes:")
+print(st)
+print("share of the wave's time:", (st / st.sum(1, keepdims=True)).round(3).mean(0))
+print("ticks total per wave:", st.sum(1))
