@@ -598,9 +598,18 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
   // all 64 banks once per ds_read_b128 lane group (tools/lds_banks.py; the plain padded image cost 4 cycles per group)
   constexpr int G = 8, OG = 16, HO = 18, RS = 64, ROWS = HO * RS + 32, COUT = 64, IMG = HO * ROWS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                               // [IMG]
-  float* red = reinterpret_cast<float*>(smem_raw + ((IMG * 2 + 15) / 16) * 16);   // [4 waves][16][64]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 31, h = lane >> 5;
+  // Two image buffers and two exchange buffers (118 KB): INR n + 1 is staged into the other image while INR n is contracted,
+  // and ONE barrier per INR remains -- between the exchange write of the kh = 1 waves and its read by the kh = 0 waves, which
+  // then finish INR n (add, LeakyReLU', stores) while the kh = 1 waves -- the younger wave of every SIMD, which needs 42 k ticks
+  // for the MFMA loops the kh = 0 waves do in 31 k (tools/d2_stamps.py) -- are already in the MFMA loop of INR n + 1.  With one
+  // image the loop had three barriers per INR.  Measured: 76 k -> 66 k ticks per wave, 57 -> 55 us (the denser kernel sustains
+  // a lower clock: 1.3 -> 1.2 GHz).  Splitting the epilogue between the two halves as well made it slower again (72 k ticks): the
+  // kh = 1 waves are the slow ones already.
+  constexpr int IMGB = ((IMG * 2 + 15) / 16) * 16;                                 // bytes of one image buffer
+  __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                               // [2][IMG]
+  float* red = reinterpret_cast<float*>(smem_raw + 2 * IMGB);                      // [2][4 waves][16][64]
+  // (the wave index as a scalar: branches on mt / tile / kh are then scalar branches, not exec masks and select chains)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q = lane & 31, h = lane >> 5;
   const int mt = wave & 1, tile = (wave >> 1) & 1, kh = wave >> 2;
   uint4 fr[8][4];   // [combo of this half][kb]
 #pragma unroll
@@ -622,7 +631,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
       pin(fr[c][kb]);
     }
   }
-  for (int e = tid; e < IMG / 8; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  for (int e = tid; e < 2 * IMGB / 16; e += 512) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
   float dbsum[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) dbsum[k] = 0.f;
@@ -643,18 +652,28 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
 #if RCB_D2_STAMPS
   unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (; b < a.batch; b += gs) {
-    __syncthreads();
+#define RCB_STAGED2(dst)                                                                                                   \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                          \
+    const int e_ = tid + 512 * k, pix = e_ >> 3, c8 = e_ & 7, xx = (pix & 15) + 1;                                          \
+    *reinterpret_cast<uint4*>((dst) + ((pix >> 4) + 1) * ROWS + xx * RS + 8 * (c8 ^ ((xx >> 1) & 7))) = pre[k];            \
+  }
+  if (b < a.batch) {                 // the first INR's image; the second one's rows are requested behind it
+    RCB_STAGED2(img)
+    if (b + gs < a.batch) RCB_FETCHD2(b + gs)
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; b < a.batch; b += gs, cur ^= 1) {
+    const __bf16* im = img + cur * (IMGB / 2);
     D2_T(0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e_ = tid + 512 * k, pix = e_ >> 3, c8 = e_ & 7, xx = (pix & 15) + 1;
-      *reinterpret_cast<uint4*>(img + ((pix >> 4) + 1) * ROWS + xx * RS + 8 * (c8 ^ ((xx >> 1) & 7))) = pre[k];
+    // INR n + 1 into the other buffer (every wave is past the barrier of INR n - 1, i.e. past its reads of that buffer), then
+    // the rows of INR n + 2 are requested: in flight during the MFMA loop
+    if (b + gs < a.batch) {
+      __bf16* nx = img + (cur ^ 1) * (IMGB / 2);
+      RCB_STAGED2(nx)
+      if (b + 2 * gs < a.batch) RCB_FETCHD2(b + 2 * gs)
     }
     D2_T(1);
-    __syncthreads();
-    D2_T(2);
-    if (b + gs < a.batch) RCB_FETCHD2(b + gs)
     // sign source of this lane's 16 output channels, requested before the MFMA loop
     const long long xoff = ((long long)b * G * G + pos) * CIN + 32 * mt + 16 * h;
     float xf[16];     // fp32 sign source
@@ -680,14 +699,14 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
     for (int c = 0; c < 8; ++c) {
       const int n = 8 * kh + c, ry = (n >> 2) - 1, rx = (n & 3) - 1;
       const int xx = 2 * v + rx + 1, sw = (xx >> 1) & 7;
-      const __bf16* px = img + (2 * u + ry + 1) * ROWS + xx * RS;
-      uint4 cur[4];
+      const __bf16* px = im + (2 * u + ry + 1) * ROWS + xx * RS;
+      uint4 curf[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) cur[kb] = *reinterpret_cast<const uint4*>(px + 8 * ((2 * kb + h) ^ sw));
+      for (int kb = 0; kb < 4; ++kb) curf[kb] = *reinterpret_cast<const uint4*>(px + 8 * ((2 * kb + h) ^ sw));
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         Frag bf, fa;
-        bf.u = cur[kb];
+        bf.u = curf[kb];
         fa.u = fr[c][kb];
         acc = mfma16(fa.v, bf.v, acc);
       }
@@ -695,7 +714,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
     }
     D2_T(3);
     // add the two combo halves (register-major layout: conflict-free)
-    float* rw = red + (wave & 3) * 16 * 64;
+    float* rw = red + (cur * 4 + (wave & 3)) * 16 * 64;
     if (kh == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) rw[r * 64 + lane] = acc[r];
@@ -745,6 +764,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
     for (int k = 0; k < 8; ++k) g_d2_stamps[wave * 8 + k] = ph_[k];
 #endif
 #undef RCB_FETCHD2
+#undef RCB_STAGED2
   if (dbias_partial) {   // fixed-order reduction over the 32 pixels of a lane half, then over the two tiles
     __syncthreads();
 #pragma unroll
@@ -1376,7 +1396,7 @@ extern "C" int32_t rcb_upconv_dgrad_partial_rows(int32_t batch) { return batch >
 
 template <int X_F32>
 static int launch_dgrad2(const DgradArgs& a, float* dbias_partial, hipStream_t st) {
-  constexpr int kSmem = ((18 * (18 * 64 + 32) * 2 + 15) / 16) * 16 + 4 * 16 * 64 * 4;
+  constexpr int kSmem = 2 * (((18 * (18 * 64 + 32) * 2 + 15) / 16) * 16) + 2 * 4 * 16 * 64 * 4;      // two images, two exchange buffers
   auto kfn = upconv_dgrad2_reg_kernel<X_F32>;
   // (per launch: the attribute belongs to the (function, device) pair)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
