@@ -42,7 +42,18 @@ struct WeffArgs {
 
 template <int COUT>
 __device__ __forceinline__ void build_stage(const float* __restrict__ W, float* __restrict__ out, int ci, float* w, int tid) {
-  for (int e = tid; e < COUT * 9; e += 256) w[e] = W[((e / 9) * 64 + ci) * 9 + e % 9];
+  {   // (loads first, then stores: see the stage-1 branch)
+    constexpr int NT = (COUT * 9 + 255) / 256;
+    float t3[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int e = tid + 256 * k;
+      t3[k] = e < COUT * 9 ? W[((e / 9) * 64 + ci) * 9 + e % 9] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+      if (tid + 256 * k < COUT * 9) w[tid + 256 * k] = t3[k];
+  }
   __syncthreads();
   for (int e = tid; e < 16 * COUT; e += 256) {
     const int co = e % COUT, ab = (e / COUT) & 3, tt = e / (4 * COUT);
@@ -64,7 +75,17 @@ __global__ void __launch_bounds__(256) weff_build_kernel(WeffArgs a) {
   const int blk = blockIdx.x, tid = threadIdx.x;
   if (blk < 512) {
     const int i = blk >> 2, st = blk & 3, s = st >> 1, t = st & 1;
-    for (int e = tid; e < 64 * 25; e += 256) w[e] = a.W1[((e / 25) * 128 + i) * 25 + e % 25];
+    {   // all loads first, then the stores (a load-store loop waits one memory round trip per trip: seven here)
+      float t7[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int e = tid + 256 * k;
+        t7[k] = e < 64 * 25 ? a.W1[((e / 25) * 128 + i) * 25 + e % 25] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        if (tid + 256 * k < 64 * 25) w[tid + 256 * k] = t7[k];
+    }
     __syncthreads();
     for (int rem = 2 * tid; rem < 4096; rem += 512) {         // two neighbouring output channels per thread: 4-byte bf16 stores
       const int y = rem >> 9, x = (rem >> 6) & 7, o = rem & 63;

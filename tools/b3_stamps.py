@@ -32,9 +32,13 @@ if hasattr(lib, "rcb_debug_b3_stamps") or True:
         sys.exit("not a stamps build")
     buf = (C.c_uint64 * 64)()
     assert f(buf, 64) == 0
-    st = np.array(buf, dtype=np.int64).reshape(8, 8)[:, :5]
+    raw = np.array(buf, dtype=np.int64).reshape(8, 8)
+    st = raw[:, :5]
+    wall_us = (raw[:, 6] - raw[:, 5]) / 100.0        # s_memrealtime: 100 MHz
+    print("INR loop of workgroup 0: %.1f us by the 100 MHz wall clock -> s_memtime ticks at %.2f GHz" % (
+        wall_us.mean(), float(st.sum(1).mean() / (wall_us.mean() * 1e3))))
     np.set_printoptions(linewidth=200)
     print("ticks per wave [barrier1, staging, barrier2, dgrad, wgrad], summed over the workgroup's INRs:")
     print(st)
     print("share of the wave's time:", (st / st.sum(1, keepdims=True)).round(3).mean(0))
-    print("ticks total per wave:", st.sum(1), "(s_memtime runs at 100 MHz: x 10 ns)")
+    print("ticks total per wave:", st.sum(1))

@@ -32,7 +32,12 @@ except AttributeError:
     sys.exit("not a stamps build")
 buf = (C.c_uint64 * 64)()
 assert f(buf, 64) == 0
-st = np.array(buf, dtype=np.int64).reshape(8, 8)[:, :5]
+raw = np.array(buf, dtype=np.int64).reshape(8, 8)
+st = raw[:, :5]
+wall_us = (raw[:, 6] - raw[:, 5]) / 100.0        # s_memrealtime: 100 MHz
+print("workgroup 0: prologue (weights, LDS clear, first fetch issued) %.1f us;" % ((raw[:, 5] - raw[:, 7]).mean() / 100.0), end=" ")
+print("pass loop %.1f us by the 100 MHz wall clock -> s_memtime ticks at %.2f GHz" % (
+    wall_us.mean(), float(st.sum(1).mean() / (wall_us.mean() * 1e3))))
 np.set_printoptions(linewidth=200)
 print("ticks per wave [barrier1, staging, barrier2, gathers + MFMAs, epilogues], summed over the workgroup's passes:")
 print(st)
