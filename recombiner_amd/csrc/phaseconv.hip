@@ -60,18 +60,37 @@ __device__ __forceinline__ float weff_elem(const float* __restrict__ W, int cout
   float s = 0.f;
   constexpr int KK = ND == 1 ? 3 : (ND == 2 ? 9 : 27);
   const float* w = W + ((long long)co * CIN + ci) * KK;
+  // Per axis the taps of (phase bit, source-tap bit) are {0}, {1, 2}, {0, 1} or {2}: at most two.  The 2^ND candidate index
+  // tuples are loaded without a branch (a missing second candidate repeats the first and is dropped by a select): 2 / 4 / 8
+  // independent loads per element.  Under a branch per kernel tap the loads went out one at a time, each behind its own wait
+  // (tools/serial_loads.py: 420 serialised pairs in the 3-D pack kernel); loading all 3^ND taps unconditionally was slower in 3-D.
+  int k0[ND], k1[ND];
+  bool two[ND];
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) {
-    bool on = true;
-    int rem = kk;
-#pragma unroll
-    for (int ax = ND - 1; ax >= 0; --ax) {
-      const int k = rem % 3;
-      rem /= 3;
-      on = on && tap_hits((a >> (ND - 1 - ax)) & 1, (t >> (ND - 1 - ax)) & 1, k);
-    }
-    if (on) s += w[kk];
+  for (int ax = 0; ax < ND; ++ax) {
+    const int ab = (a >> (ND - 1 - ax)) & 1, tb = (t >> (ND - 1 - ax)) & 1;
+    k0[ax] = ab == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2);
+    two[ax] = (ab == 0 && tb == 1) || (ab == 1 && tb == 0);
+    k1[ax] = two[ax] ? k0[ax] + 1 : k0[ax];
   }
+  float wv[1 << ND];
+  bool on[1 << ND];
+#pragma unroll
+  for (int c = 0; c < (1 << ND); ++c) {
+    int idx = 0;
+    bool ok = true;
+#pragma unroll
+    for (int ax = 0; ax < ND; ++ax) {
+      const int pick = (c >> (ND - 1 - ax)) & 1;
+      idx = idx * 3 + (pick ? k1[ax] : k0[ax]);
+      ok = ok && (pick == 0 || two[ax]);
+    }
+    wv[c] = w[idx];
+    on[c] = ok;
+  }
+  // (candidates in ascending tap order: the order in which the taps were summed before)
+#pragma unroll
+  for (int c = 0; c < (1 << ND); ++c) s += on[c] ? wv[c] : 0.f;
   return s;
 }
 

@@ -18,12 +18,15 @@ __device__ __forceinline__ int tap_of(int a, int k) { return a == 0 ? (k == 0 ? 
 // one effective weight straight from the 3x3 taps: Weff[ty][tx][ci][a][b][co] = sum_{k in K(a,ty), l in K(b,tx)} W[co][ci][k][l]
 __device__ __forceinline__ float weff_of(const float* __restrict__ W, int ty, int tx, int ci, int a, int b, int co) {
   const float* w = W + (co * 64 + ci) * 9;
+  // (all nine taps loaded, the ones outside (a, ty) x (b, tx) dropped by a select: a branch per tap serialises the loads)
+  float wv[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wv[k] = w[k];
   float acc = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
-      if (tap_of(a, k) == ty && tap_of(b, l) == tx) acc += w[k * 3 + l];
+    for (int l = 0; l < 3; ++l) acc += (tap_of(a, k) == ty && tap_of(b, l) == tx) ? wv[k * 3 + l] : 0.f;
   return acc;
 }
 
