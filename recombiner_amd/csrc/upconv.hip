@@ -826,6 +826,35 @@ __device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
+// Bias gradient of a persistent weight-gradient kernel: the 512 threads' private partial sums (8 channels each; thread t holds
+// channels 8 (t % (COUT / 8)) .. + 7) are joined in a FIXED order -- 512 / COUT groups of eight threads' values per channel
+// (each group summed by one thread, ascending), then the groups ascending: deterministic, and 8 + 512 / COUT dependent LDS reads
+// instead of the 512 * 8 / COUT of a single thread per channel (stamps: 10.5 us of epilogue per launch in the fused stage-3
+// backward, most of it this chain of 256 reads).  `red`: at least 512 * 8 + 512 floats of LDS.
+template <int COUT>
+__device__ __forceinline__ void bias_partials_join(const float (&dbsum)[8], float* red, int tid, float* dst) {
+  constexpr int C8 = COUT / 8, NG = 512 / COUT;           // NG groups of eight values per channel
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dbsum[j];
+  __syncthreads();
+  {
+    const int ch = tid % COUT, grp = tid / COUT;           // every thread: one (channel, group)
+    const int c8 = ch >> 3, j = ch & 7;
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sacc += red[(c8 + C8 * (8 * grp + k)) * 8 + j];
+    red[512 * 8 + grp * COUT + ch] = sacc;
+  }
+  __syncthreads();
+  if (tid < COUT) {
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) tot += red[512 * 8 + g * COUT + tid];
+    dst[tid] = tot;
+  }
+}
+
 // One persistent workgroup per CU walks its INRs: the x / dy images of the NEXT INR are fetched into registers
 // while the matrix cores consume the current ones from LDS (a CU needs tens of KB in flight to keep its share of
 // HBM busy), and the workgroup's sums go to its own slab: no atomics, bitwise reproducible after the fixed-order
@@ -924,20 +953,7 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   }
 #undef RCB_WG_FETCH
   float* slab = a.partial + (long long)blockIdx.x * ROW;
-  {   // bias gradient: per-thread channel partials through LDS (fixed order: deterministic)
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem_raw);      // [512][8]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dbsum[j];
-    __syncthreads();
-    if (tid < COUT) {
-      constexpr int C8 = COUT / 8;                        // thread t holds channels 8 * (t % C8) .. + 7
-      const int c8 = tid >> 3, j = tid & 7;
-      float sacc = 0.f;
-      for (int t = c8; t < 512; t += C8) sacc += red[t * 8 + j];
-      slab[WSZ + tid] = sacc;
-    }
-  }
+  bias_partials_join<COUT>(dbsum, reinterpret_cast<float*>(smem_raw), tid, slab + WSZ);
   // D[m = ci, n = co]: rows in registers, column on the lane
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -1005,6 +1021,9 @@ struct Bwd3Args {
 
 __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   constexpr int COUT = 16, G = 16, OG = 32, HO = 34, RS = 24, HG = 18, NF = 32;
+#if RCB_B3_STAMPS
+  const unsigned long long t_entry_ = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int WSZ = 1024 * COUT, ROW = WSZ + COUT;
 #if RCB_B3_WG16
   // x image of THIS kernel: 128-byte pixel rows, the 32-byte block cb of 16 channels stored at block cb ^ xkey(column) with
@@ -1258,25 +1277,14 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
   }
 #if RCB_B3_STAMPS
   ph_[6] = __builtin_amdgcn_s_memrealtime();
+  ph_[7] = t_entry_;
   if (blockIdx.x == 0 && lane == 0)
     for (int k = 0; k < 8; ++k) g_b3_stamps[wave * 8 + k] = ph_[k];
 #endif
 #undef RCB_FETCH_B3
 #undef B3_XKEY
   float* slab = a.partial + (long long)blockIdx.x * ROW;
-  {   // bias gradient: per-thread channel partials through LDS (fixed order: deterministic)
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem_raw);      // [512][8]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dbsum[j];
-    __syncthreads();
-    if (tid < COUT) {
-      const int c8 = tid >> 3, j = tid & 7;              // thread t holds channels 8 * (t & 1) .. + 7
-      float sacc = 0.f;
-      for (int t = c8; t < 512; t += 2) sacc += red[t * 8 + j];
-      slab[WSZ + tid] = sacc;
-    }
-  }
+  bias_partials_join<COUT>(dbsum, reinterpret_cast<float*>(smem_raw), tid, slab + WSZ);
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int combo = 2 * wave + c;
@@ -1301,6 +1309,10 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
     }
 #endif
   }
+#if RCB_B3_STAMPS
+  if (blockIdx.x == 0 && lane == 0) g_b3_stamps[wave * 8 + 4 + 60 - 60] = g_b3_stamps[wave * 8 + 4];   // (keeps slot 4)
+  if (blockIdx.x == 0 && lane == 0 && wave == 0) g_b3_stamps[63] = __builtin_amdgcn_s_memrealtime();   // kernel end of workgroup 0 (slot 7 of wave 7)
+#endif
 }
 
 #if RCB_B3_STAMPS

@@ -35,7 +35,10 @@ if hasattr(lib, "rcb_debug_b3_stamps") or True:
     raw = np.array(buf, dtype=np.int64).reshape(8, 8)
     st = raw[:, :5]
     wall_us = (raw[:, 6] - raw[:, 5]) / 100.0        # s_memrealtime: 100 MHz
-    print("INR loop of workgroup 0: %.1f us by the 100 MHz wall clock -> s_memtime ticks at %.2f GHz" % (
+    end_wg = raw[7, 7]
+    print("workgroup 0: prologue %.1f us, epilogue (bias sums, slab stores) %.1f us;" % (
+        (raw[:7, 5] - raw[:7, 7]).mean() / 100.0, (end_wg - raw[0, 6]) / 100.0), end=" ")
+    print("INR loop %.1f us by the 100 MHz wall clock -> s_memtime ticks at %.2f GHz" % (
         wall_us.mean(), float(st.sum(1).mean() / (wall_us.mean() * 1e3))))
     np.set_printoptions(linewidth=200)
     print("ticks per wave [barrier1, staging, barrier2, dgrad, wgrad], summed over the workgroup's INRs:")
