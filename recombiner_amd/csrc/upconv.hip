@@ -621,13 +621,15 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
   // c ^ ((x >> 1) & 7): every gather below (lane = output position, pixels two apart, one chunk per instruction) then covers
   // all 64 banks once per ds_read_b128 lane group (tools/lds_banks.py; the plain padded image cost 4 cycles per group)
   constexpr int G = 8, OG = 16, HO = 18, RS = 64, ROWS = HO * RS + 32, COUT = 64, IMG = HO * ROWS;
+#if RCB_D2_STAMPS
+  const unsigned long long t_entry_ = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // Two image buffers and two exchange buffers (118 KB): INR n + 1 is staged into the other image while INR n is contracted,
   // and ONE barrier per INR remains -- between the exchange write of the kh = 1 waves and its read by the kh = 0 waves, which
   // then finish INR n (add, LeakyReLU', stores) while the kh = 1 waves -- the younger wave of every SIMD, which needs 42 k ticks
   // for the MFMA loops the kh = 0 waves do in 31 k (tools/d2_stamps.py) -- are already in the MFMA loop of INR n + 1.  With one
-  // image the loop had three barriers per INR.  Measured: 76 k -> 66 k ticks per wave, 57 -> 55 us (the denser kernel sustains
-  // a lower clock: 1.3 -> 1.2 GHz).  Splitting the epilogue between the two halves as well made it slower again (72 k ticks): the
+  // image the loop had three barriers per INR.  Measured: 76 k -> 66 k ticks per wave in the loop.  Splitting the epilogue between the two halves as well made it slower again (72 k ticks): the
   // kh = 1 waves are the slow ones already.
   constexpr int IMGB = ((IMG * 2 + 15) / 16) * 16;                                 // bytes of one image buffer
   __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                               // [2][IMG]
@@ -680,6 +682,7 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
   const int pos = tile * 32 + q, u = pos >> 3, v = pos & 7;
 #if RCB_D2_STAMPS
   unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_loop_ = __builtin_amdgcn_s_memrealtime();
 #endif
 #define RCB_STAGED2(dst)                                                                                                   \
   _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                          \
@@ -789,6 +792,8 @@ __global__ void __launch_bounds__(512) upconv_dgrad2_reg_kernel(DgradArgs a, flo
     D2_T(6);
   }
 #if RCB_D2_STAMPS
+  ph_[7] = __builtin_amdgcn_s_memrealtime() - t_loop_;      // wall clock (100 MHz) of the INR loop; slot 2 (unused): the prologue
+  ph_[2] = t_loop_ - t_entry_;
   if (blockIdx.x == 0 && lane == 0)
     for (int k = 0; k < 8; ++k) g_d2_stamps[wave * 8 + k] = ph_[k];
 #endif

@@ -13,14 +13,19 @@ from recombiner_amd import ops, _lib
 B = 4096
 dy = (torch.randn(B, 32, 32, 16, device="cuda") * 1e-3).bfloat16()
 x = torch.randn(B, 16, 16, 64, device="cuda").bfloat16()
-weff = torch.randn(2, 2, 64, 2, 2, 16, device="cuda") * 0.05
+# the production path: effective weights and their pre-ordered MFMA fragments from the conv weights (rcb_upconv_weff_build)
+W1 = torch.randn(64, 128, 5, 5, device="cuda") * 0.02
+W2c = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+W3c = torch.randn(16, 64, 3, 3, device="cuda") * 0.05
+_, _, weff2_, weff3_, pack = ops.upconv_weff_build(W1, torch.zeros(64, device="cuda"), W2c, W3c, True)
+weff = weff3_
 for _ in range(5):
-    out = ops.upconv_bwd_fused(dy, weff, x, 16, 16)
+    out = ops.upconv_bwd_fused(dy, weff, x, 16, 16, pack=pack)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
-    ops.upconv_bwd_fused(dy, weff, x, 16, 16)
+    ops.upconv_bwd_fused(dy, weff, x, 16, 16, pack=pack)
 e1.record()
 torch.cuda.synchronize()
 print("avg us per launch (incl. slab reduction):", e0.elapsed_time(e1) * 100)

@@ -14,14 +14,19 @@ from recombiner_amd import ops, _lib
 B = 4096
 dy = (torch.randn(B, 16, 16, 64, device="cuda") * 1e-3).bfloat16()
 x = torch.randn(B, 8, 8, 64, device="cuda").bfloat16()
-weff = torch.randn(2, 2, 64, 2, 2, 64, device="cuda") * 0.05
+# the production path: effective weights and their pre-ordered MFMA fragments from the conv weights (rcb_upconv_weff_build)
+W1 = torch.randn(64, 128, 5, 5, device="cuda") * 0.02
+W2c = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+W3c = torch.randn(16, 64, 3, 3, device="cuda") * 0.05
+_, _, weff2_, weff3_, pack = ops.upconv_weff_build(W1, torch.zeros(64, device="cuda"), W2c, W3c, True)
+weff = weff2_
 for _ in range(5):
-    out = ops.upconv_dgrad(dy, weff, x, 8, 64, preact=True)
+    out = ops.upconv_dgrad(dy, weff, x, 8, 64, preact=True, pack=pack)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
-    ops.upconv_dgrad(dy, weff, x, 8, 64, preact=True)
+    ops.upconv_dgrad(dy, weff, x, 8, 64, preact=True, pack=pack)
 e1.record()
 torch.cuda.synchronize()
 print("avg us per launch:", e0.elapsed_time(e1) * 100)
@@ -32,7 +37,12 @@ except AttributeError:
     sys.exit("not a stamps build")
 buf = (C.c_uint64 * 64)()
 assert f(buf, 64) == 0
-st = np.array(buf, dtype=np.int64).reshape(8, 8)[:, :7]
+raw = np.array(buf, dtype=np.int64).reshape(8, 8)
+st = raw[:, :7].copy()
+prologue_us, loop_us = raw[:, 2].mean() / 100.0, raw[:, 7].mean() / 100.0       # s_memrealtime: 100 MHz (slot 2: no barrier B any more)
+st[:, 2] = 0
+print("workgroup 0: prologue %.1f us, INR loop %.1f us by the 100 MHz wall clock -> s_memtime ticks at %.2f GHz" % (
+    prologue_us, loop_us, float(st.sum(1).mean() / (loop_us * 1e3))))
 np.set_printoptions(linewidth=200)
 print("ticks per wave [barrier A, staging, barrier B, MFMA loop, exchange write, barrier C, epilogue]:")
 print(st)

@@ -13,15 +13,20 @@ from recombiner_amd import ops, _lib
 
 B = 4096
 x = torch.randn(B, 8, 8, 64, device="cuda").bfloat16()
-weff = torch.randn(2, 2, 64, 2, 2, 64, device="cuda") * 0.05
+# the production path: effective weights and their pre-ordered MFMA fragments from the conv weights (rcb_upconv_weff_build)
+W1 = torch.randn(64, 128, 5, 5, device="cuda") * 0.02
+W2c = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+W3c = torch.randn(16, 64, 3, 3, device="cuda") * 0.05
+_, _, weff2_, weff3_, pack = ops.upconv_weff_build(W1, torch.zeros(64, device="cuda"), W2c, W3c, True)
+weff = weff2_
 bias = torch.randn(64, device="cuda") * 0.1
 for _ in range(5):
-    ops.upconv_fwd(x, weff, bias, 8, 64, False, preact=True)
+    ops.upconv_fwd(x, weff, bias, 8, 64, False, preact=True, pack=pack)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
-    ops.upconv_fwd(x, weff, bias, 8, 64, False, preact=True)
+    ops.upconv_fwd(x, weff, bias, 8, 64, False, preact=True, pack=pack)
 e1.record()
 torch.cuda.synchronize()
 print("avg us per launch:", e0.elapsed_time(e1) * 100)
