@@ -61,6 +61,19 @@ union Frag {
 // (where their operands would stay live, and spill, across it)
 __device__ __forceinline__ void pin(uint4& u) { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
 
+#ifndef RCB_WC_STAMPS
+#define RCB_WC_STAMPS 0    // diagnostic build: s_memrealtime (100 MHz) of workgroup 0 at kernel entry / loop start / loop end / kernel end
+#endif
+#if RCB_WC_STAMPS
+__device__ unsigned long long g_wc_stamps[2][4];      // [0]: upconv_wgrad_kernel, [1]: upconv_fwd3_lds_kernel (last launch of each)
+#define WC_T(which, k)                                                                            \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_wc_stamps[which][k] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define WC_T(which, k) do { } while (0)
+#endif
+
 // raw (unconverted) 8-channel loads: the next INR's image is requested into registers while the current one is
 // consumed, and converted (mode 1/3: with LeakyReLU) only when it is committed to LDS
 template <int MODE> struct Raw8;
@@ -229,6 +242,7 @@ __device__ __forceinline__ void fwd3_body(const __bf16* img, const uint4 (&fr)[2
 template <int COUT, int OUT_BF16, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) upconv_fwd3_lds_kernel(FwdArgs a) {
   static_assert(COUT == 16, "epilogue lane swap is written for 16 output channels");
+  WC_T(1, 0);
   static_assert(NW == 8 || NW == 4, "8 or 4 waves");
   // image [18][18][64] in LDS, the 16-byte chunk c of pixel column x stored at c ^ ((x >> 1) & 7): the gathers of fwd3_body
   // (lane = source position, consecutive pixels, one chunk per instruction) cover all 64 banks once per ds_read_b128 lane
@@ -288,6 +302,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) upconv_fwd3_lds_kern
   const int gs = gridDim.x;
   int b = blockIdx.x;
   if (b < a.batch) RCB_FETCH3(b)
+  WC_T(1, 1);
   for (; b < a.batch; b += gs) {
     __syncthreads();          // everyone is done with the previous image (and with the halo setup)
 #pragma unroll
@@ -300,6 +315,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) upconv_fwd3_lds_kern
 #pragma unroll 1
     for (int t2 = 0; t2 < 8 / NW; ++t2) fwd3_body<COUT, OUT_BF16>(img, fr, a, b, pa, tp + (NW / 2) * t2, lane, bia);
   }
+  WC_T(1, 2);
+  WC_T(1, 3);
 #undef RCB_FETCH3
 }
 
@@ -867,6 +884,7 @@ __device__ __forceinline__ void bias_partials_join(const float (&dbsum)[8], floa
 template <int COUT, int G, int X_MODE, int DY_F32>
 __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = (COUT + 31) / 32;
+  WC_T(0, 0);
   constexpr int HG = G + 2;             // halo grid
   constexpr int OG = 2 * G;             // output grid
   constexpr int DM = DY_F32 ? 2 : 0;
@@ -903,6 +921,7 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
   }
   int b = blockIdx.x;
   if (b < a.batch) RCB_WG_FETCH(b)
+  WC_T(0, 1);
   for (; b < a.batch; b += gridDim.x) {
     __syncthreads();   // previous INR fully consumed (also orders the halo clear)
 #pragma unroll
@@ -957,6 +976,7 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
     }
   }
 #undef RCB_WG_FETCH
+  WC_T(0, 2);
   float* slab = a.partial + (long long)blockIdx.x * ROW;
   bias_partials_join<COUT>(dbsum, reinterpret_cast<float*>(smem_raw), tid, slab + WSZ);
   // D[m = ci, n = co]: rows in registers, column on the lane
@@ -978,6 +998,7 @@ __global__ void __launch_bounds__(512) upconv_wgrad_kernel(WgradArgs a) {
         }
       }
   }
+  WC_T(0, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1325,6 +1346,11 @@ __global__ void __launch_bounds__(512) upconv_bwd3_fused_kernel(Bwd3Args a) {
 #if RCB_D2_STAMPS
 extern "C" int rcb_debug_d2_stamps(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_d2_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+#if RCB_WC_STAMPS
+extern "C" int rcb_debug_wc_stamps(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wc_stamps), sizeof(unsigned long long) * n);
 }
 #endif
 #if RCB_F2_STAMPS
