@@ -266,6 +266,9 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
     const int n = g / a.S;
     const long long pe_row = (long long)g * a.P;          // pe / dpe as [G][P][E] (the stitched layouts stay with the workgroup kernel)
     const float* __restrict__ wsrc = a.wvec + (long long)g * a.w_stride;
+    static_assert(G::off(G::SPLIT) % 4 == 0, "the second half of the row starts on a 16-byte boundary");
+    const int rowcap = (int)a.w_stride;                  // floats readable from the row's start (the array holds whole strides)
+    const bool dma16 = (a.w_stride & 3) == 0 && (reinterpret_cast<size_t>(wsrc) & 15) == 0 && rowcap >= ((G::DNET + 3) & ~3);
 
     // ---- the row's weights as MFMA A fragments ------------------------------------------------------------------------------
     // fragment k order: the chained accumulator's (siren_mlp_bf16.hip): k-slot (step s, lane half h, element j) = row fk(s,h,j).
@@ -280,16 +283,29 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
       for (int half = 0; half < 2; ++half) {
         const int f0 = half == 0 ? 0 : G::off(G::SPLIT), f1 = half == 0 ? G::off(G::SPLIT) : G::DNET;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // 16-byte pieces (1 KB per instruction: 7 instead of 26 per half -- an LDS-DMA instruction costs the issuing wave 60-180
+        // cycles) where the row allows them: 16-byte aligned rows whose stride covers the last piece's overrun of <= 3 floats
+        // (the training step's rows sit on 128-byte lines); 4-byte pieces otherwise
+        if (dma16) {
 #pragma unroll
-        for (int c0 = f0; c0 < f1; c0 += 64) {
-          const int idx = c0 + lane < G::DNET ? c0 + lane : G::DNET - 1;        // (never beyond the row)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + idx),
-                                           (RCB_LDS(void)*)(wl + (c0 - f0)), 4, 0, 0);
+          for (int c0 = f0; c0 < f1; c0 += 256) {
+            const int idx = c0 + 4 * lane + 3 < rowcap ? c0 + 4 * lane : rowcap - 4;      // (never beyond the row's stride)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + idx),
+                                             (RCB_LDS(void)*)(wl + (c0 - f0)), 16, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int c0 = f0; c0 < f1; c0 += 64) {
+            const int idx = c0 + lane < G::DNET ? c0 + lane : G::DNET - 1;        // (never beyond the row)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + idx),
+                                             (RCB_LDS(void)*)(wl + (c0 - f0)), 4, 0, 0);
+          }
         }
         // (the builtin, not inline assembly: the compiler tracks LDS-DMA as vector-memory operations that write LDS and, unless
         // it SEES them retired, drains vmcnt in front of every LDS access of the tile loop -- including the input prefetch)
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        RCB_WSTAMP(6 + 2 * half);
         auto W = [&](int idx) -> float { return wl[idx - f0]; };
 #pragma unroll
         for (int slot = 0; slot < NFA + NFB; ++slot) {
@@ -345,6 +361,7 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
           f8[1] = (h == 0) ? bl : (T)0.f;
           BFR[l] = as_i4(f8);
         }
+        RCB_WSTAMP(7 + 2 * half);
         if (half == 1) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {

@@ -29,6 +29,7 @@ assert raw.rcb_debug_wave_stamps(buf, 256) == 0
 st = np.array(buf[:], dtype=np.int64)
 print("shader clock GHz", (st[3] - st[0]) / ((st[5] - st[4]) * 10.0), " row us", (st[5] - st[4]) / 100.0)
 print("prologue", st[1] - st[0], " tile loop", st[2] - st[1], " epilogue", st[3] - st[2], " row", st[3] - st[0])
+print("   prologue phases: DMA of the first half issued + landed", st[6] - st[0], " its fragments", st[7] - st[6], " second half landed", st[8] - st[7], " its fragments", st[9] - st[8], " rest (accumulators, first fetch)", st[1] - st[9])
 for k in range(6):
     b = st[10 + 12 * k: 10 + 12 * k + 9]
     print(f"tile {k}: forward layers", np.diff(b[:5]), " backward layers", np.diff(b[4:9]), " tile", b[8] - b[0], " to next", st[10 + 12 * (k + 1)] - b[0])
