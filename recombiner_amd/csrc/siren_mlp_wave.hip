@@ -317,22 +317,28 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
             if (slot < K0S) {
               const int kk = 8 * slot + j;
               const int row = (h == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
-              if (row >= 0) w = W(G::off(0) + HID + row * HID + q);
+              const float v = W(G::off(0) + HID + (row >= 0 ? row : 0) * HID + q);
+              w = row >= 0 ? v : 0.f;
             } else if (slot < NFA) {
               const int l = 1 + (slot - K0S) / 2, st = (slot - K0S) & 1;
               const int no = (l == NL - 1) ? C : HID;
-              if (q < no) w = W(G::off(l) + no + fk(st, h, j) * no + q);
+              // (every gather below reads unconditionally from a clamped position and drops the value by a select: a read under a
+              // lane-dependent condition is an exec-masked branch per element, and the gathers then go out one behind the other)
+              const float v = W(G::off(l) + no + fk(st, h, j) * no + (q < no ? q : 0));
+              w = q < no ? v : 0.f;
             } else {
               const int b = slot - NFA;
               if (b == 0) {
                 const int oo = fk(0, h, j);
-                if (oo < C) w = W(G::off(NL - 1) + C + q * C + oo);
+                const float v = W(G::off(NL - 1) + C + q * C + (oo < C ? oo : 0));
+                w = oo < C ? v : 0.f;
               } else if (b < 1 + 2 * (NH - 1)) {
                 const int l = (NH - 1) - (b - 1) / 2, st = (b - 1) & 1;
                 w = W(G::off(l) + HID + q * HID + fk(st, h, j));
               } else {
                 const int st = (b - 1 - 2 * (NH - 1));
-                if (q < E) w = W(G::off(0) + HID + (F + q) * HID + fk(st, h, j));
+                const float v = W(G::off(0) + HID + (F + (q < E ? q : 0)) * HID + fk(st, h, j));
+                w = q < E ? v : 0.f;
               }
             }
             w8[j] = w;
@@ -366,7 +372,10 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             bout[r] = 0.f;
-            if (rho(r, 0) < C || rho(r, 1) < C) bout[r] = (rho(r, h) < C) ? W(G::off(NL - 1) + (rho(r, h) < C ? rho(r, h) : 0)) : 0.f;
+            if (rho(r, 0) < C || rho(r, 1) < C) {
+              const float v = W(G::off(NL - 1) + (rho(r, h) < C ? rho(r, h) : 0));
+              bout[r] = (rho(r, h) < C) ? v : 0.f;
+            }
           }
         }
       }
