@@ -193,18 +193,23 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
         if (slot < K0S) {
           int kk = 8 * slot + j;
           int row = (fh == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
-          if (row >= 0) w = wsrc[G::off(0) + HID + row * HID + fq];
+          // (every read below comes from a position that is valid for all lanes and is dropped by a select: under a
+          // lane-dependent condition each read is an exec-masked branch of its own, 125 of them in this prologue)
+          const float v = wsrc[G::off(0) + HID + (row >= 0 ? row : 0) * HID + fq];
+          w = row >= 0 ? v : 0.f;
         } else if (slot < NFA) {
           int l = 1 + (slot - K0S) / 2, st = (slot - K0S) & 1;
           int no = (l == NL - 1) ? C : HID;
           int o = 0;
           for (int i = 0; i < l; ++i) o += G::lout(i) * (G::lin(i) + 1);
-          if (fq < no) w = wsrc[o + no + fk(st, fh, j) * no + fq];
+          const float v = wsrc[o + no + fk(st, fh, j) * no + (fq < no ? fq : 0)];
+          w = fq < no ? v : 0.f;
         } else {
           int b = slot - NFA;
           if (b == 0) {
             int oo = fk(0, fh, j);
-            if (oo < C) w = wsrc[G::off(NL - 1) + C + fq * C + oo];
+            const float v = wsrc[G::off(NL - 1) + C + fq * C + (oo < C ? oo : 0)];
+            w = oo < C ? v : 0.f;
           } else if (b < 1 + 2 * (NH - 1)) {
             int l = (NH - 1) - (b - 1) / 2, st = (b - 1) & 1;
             int o = 0;
@@ -212,7 +217,8 @@ __global__ void __launch_bounds__(256, MODE == MODE_FWD ? 3 : RCB_SIREN_WAVES) s
             w = wsrc[o + HID + fq * HID + fk(st, fh, j)];
           } else {
             int st = (b - 1 - 2 * (NH - 1));
-            if (fq < E) w = wsrc[G::off(0) + HID + (F + fq) * HID + fk(st, fh, j)];
+            const float v = wsrc[G::off(0) + HID + (F + (fq < E ? fq : 0)) * HID + fk(st, fh, j)];
+            w = fq < E ? v : 0.f;
           }
         }
         // forward fragments of the sine layers carry w0 / 2 pi; the transposed fragments that produce a hidden layer's

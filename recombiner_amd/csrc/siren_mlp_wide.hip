@@ -118,6 +118,11 @@ struct GeoW {
   static_assert(LSPLIT >= 1 && DNET - off(LSPLIT) <= CAP, "weights stage in two parts");
 };
 
+// a staged weight read from a position that is valid for EVERY lane, dropped by a select where the lane has no element there.
+// (`cond ? wl[idx] : 0.f` with a lane-dependent condition compiles to an exec-masked branch around each read: 150-300 of them
+// in this kernel's prologue, each read waited for on its own.)
+__device__ __forceinline__ float sel_ld(bool keep, float v) { return keep ? v : 0.f; }
+
 // Two workgroups of four waves per CU (two waves per SIMD, 256 registers each).  The weight-gradient tiles are DEALT to the
 // waves instead of every wave accumulating all of them: per layer each wave stores the dZ / input images of its pixel tile,
 // the workgroup synchronises, and the owner of gradient tile (ob, ib) contracts it over the images of all four pixel tiles.
@@ -199,7 +204,8 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
             put(G::FA0 + mb * K0S + s, [&](int j) {
               const int kk = 8 * s + j, out = 32 * mb + fq;
               const int row = (fh == 0) ? (kk < F ? kk : -1) : (kk < E ? F + kk : -1);
-              return (row >= 0 && out < W) ? wl[G::off(0) + W + row * W + out] : 0.f;
+              const bool ok = row >= 0 && out < W;      // (read from a clamped position, dropped by a select: see sel_ld)
+              return sel_ld(ok, wl[G::off(0) + W + (ok ? row : 0) * W + (ok ? out : 0)]);
             });
           }
         // data gradient through layer 0 onto the E upsampled features: 16 rows stored
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
           if (!mine()) continue;
           union { bf16x8 v; uint4 u; } fr;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) fr.v[j] = (T)((fq < E ? wl[G::off(0) + W + (F + fq) * W + featk(ks, fh, j)] : 0.f) * WS);
+          for (int j = 0; j < 8; ++j) fr.v[j] = (T)(sel_ld(fq < E, wl[G::off(0) + W + (F + (fq < E ? fq : 0)) * W + featk(ks, fh, j)]) * WS);
           if (fq < 16) fragsx[ks * 32 + fh * 16 + fq] = fr.u;
         }
       }
@@ -222,7 +228,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
             if (!mine()) continue;
             put(G::FAH + ((l - 1) * HB + mb) * KSH + ks, [&](int j) {
               const int out = 32 * mb + fq;
-              return out < W ? wl[G::off(l) + W + featk(ks, fh, j) * W + out] : 0.f;
+              return sel_ld(out < W, wl[G::off(l) + W + featk(ks, fh, j) * W + (out < W ? out : 0)]);
             });
           }
         // data gradient through hidden layer l
@@ -233,7 +239,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
             if (!mine()) continue;
             put(G::FBH + (((NH - 1) - l) * HB + ib) * KSH + ks, [&](int j) {
               const int m = 32 * ib + fq;
-              return m < W ? wl[G::off(l) + W + m * W + featk(ks, fh, j)] : 0.f;
+              return sel_ld(m < W, wl[G::off(l) + W + (m < W ? m : 0) * W + featk(ks, fh, j)]);
             });
           }
       }
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
 #pragma unroll
         for (int ks = 0; ks < KSH; ++ks) {
           if (!mine()) continue;
-          put(G::FAO + ks, [&](int j) { return fq < C ? wl[G::off(NH) + C + featk(ks, fh, j) * C + fq] : 0.f; });
+          put(G::FAO + ks, [&](int j) { return sel_ld(fq < C, wl[G::off(NH) + C + featk(ks, fh, j) * C + (fq < C ? fq : 0)]); });
         }
         // data gradient through the output layer (k = output channel, one step)
 #pragma unroll
@@ -250,7 +256,8 @@ __global__ void __launch_bounds__(256, (GeoW<NH, F, E, C, W>::WG_PER_CU)) siren_
           if (!mine()) continue;
           put(G::FBO + ib, [&](int j) {
             const int m = 32 * ib + fq, k = fk(0, fh, j);
-            return (m < W && k < C) ? wl[G::off(NH) + C + m * C + k] : 0.f;
+            const bool ok = m < W && k < C;
+            return sel_ld(ok, wl[G::off(NH) + C + (ok ? m : 0) * C + (ok ? k : 0)]);
           });
         }
       }
