@@ -41,7 +41,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define RCB_WAVE_PIPE_FWD 1  // forward pass software-pipelined across the layers by hand (0: layer by layer, the compiler's order)
 #endif
 #ifndef RCB_WAVE_FAIR
-#define RCB_WAVE_FAIR 0     // time-sliced issue priority between the two workgroups of a CU (see the tile loop): measured, off
+#define RCB_WAVE_FAIR 2     // issue priority between the two workgroups of a CU: 0 none (age decides), 1 time-sliced (measured: no gain), 2 swapped per row
 #endif
 #ifndef RCB_WAVE_FAIR_SHIFT
 #define RCB_WAVE_FAIR_SHIFT 14
@@ -256,9 +256,25 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
 #if RCB_WAVE_FAIR
   const unsigned young = (blockIdx.x >= (gridDim.x >> 1)) ? 1u : 0u;      // the second workgroup of a CU (dispatch order)
   unsigned long long fair_clk = __builtin_amdgcn_s_memtime();
+  unsigned fair_row = 0;
 #endif
   for (int u = blockIdx.x * 4 + wave; u < nunits; u += gridDim.x * 4) {
     RCB_WSTAMP(0);
+#if RCB_WAVE_FAIR == 2
+    // Mode 2 (shipped): the roles swap per ROW.  The SIMD arbitrates its two waves by priority, then age: left alone the wave of
+    // the first-dispatched workgroup runs nearly unimpeded (88 us per row) and finishes its two rows at ~176 us, the other one
+    // gets the leftover issue slots (106 us per row) and ends the kernel at ~212-222 us, its last 36 us alone on the SIMD
+    // (rcb_siren_desc.clock_probe on both halves of the grid, tools/wave_spread.py).  Here the second workgroup of a CU takes the
+    // higher priority on its odd rows: each workgroup is the pole for one row and the filler for the other, both halves finish
+    // within 190-204 us and the kernel at ~210: 229.0 / 233.8 / 235.9 vs 237.6 / 237.8 / 237.5 us medians on one (slow) box.
+    // (Alternating the priority in time slices of 16 k cycles, mode 1, equalises the halves too -- at 200 / 210 us -- without
+    // moving the kernel's end: frequent flips cost what they gain.)
+    if (young) {
+      if (fair_row & 1u) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    ++fair_row;
+#endif
 #ifdef RCB_WAVE_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) g_wave_stamps[4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -440,7 +456,7 @@ __global__ void __launch_bounds__(256, 2) siren_wave_kernel(SirenArgs a) {
       const int ts = 10 + 12 * (t - t0);          // stamps of the first tiles of the row
       RCB_WSTAMP(ts);
 #endif
-#if RCB_WAVE_FAIR
+#if RCB_WAVE_FAIR == 1
       // The two waves of a SIMD are arbitrated by priority, then AGE: the wave of the workgroup that was dispatched first runs
       // nearly unimpeded and finishes its two rows at ~176 us, the other one gets the leftover issue slots and finishes at ~212 us,
       // the last 36 of them alone on its SIMD (rcb_siren_desc.clock_probe on both halves of the grid, tools/wave_spread.py).
