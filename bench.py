@@ -699,6 +699,40 @@ def probe_capture_form(a, env, run, rehearsal):
     print("bench.py: sharded step form -- " + env["RCB_STEP_FORM_CHOICE"], file=sys.stderr, flush=True)
 
 
+def probe_capture_form_in_rank(ws):
+    """The same probe for ranks that an EXTERNAL launcher started (torchrun ... bench.py --gpus N: bench.py's own launcher, and
+    with it probe_capture_form, never ran).  Before this process touches the GPU, every rank starts tools/rccl_capture_probe.py
+    as a child on its own rendezvous (MASTER_PORT + 1, the elastic agent's variables removed so that the child of rank 0 hosts
+    the store) with a hard timeout; -> True / False for THIS rank, or None when nothing was probed (an explicit
+    RCB_CAPTURE_COLLECTIVES, a choice already made by bench.py's launcher, a gloo rehearsal).  main() then agrees on the minimum
+    over the ranks through the real communicator.  Every failure mode -- no probe file, a busy port, a hang -- ends in the
+    four-segment form."""
+    import subprocess
+    if "RCB_CAPTURE_COLLECTIVES" in os.environ or "RCB_STEP_FORM_CHOICE" in os.environ:
+        return None
+    if os.environ.get("RCB_DIST_BACKEND", "nccl") != "nccl":
+        return None
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rccl_capture_probe.py")
+    timeout_s = float(os.environ.get("RCB_PROBE_TIMEOUT_S", "180"))
+    try:
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC", "TORCH_NCCL_ASYNC"))}
+        env["MASTER_ADDR"] = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = str(ws), os.environ.get("RANK", "0"), os.environ.get("LOCAL_RANK", "0")
+        p = subprocess.Popen([sys.executable, probe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                             start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+            return bool(p.returncode == 0 and "RCCL_CAPTURE_OK" in out and "RCCL_CAPTURE_NOT_OK" not in out)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            return False
+    except Exception:                            # noqa: BLE001 -- anything at all: the safe form
+        return False
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -713,6 +747,8 @@ def main():
     if ws > 1 and backend == "nccl" and ndev < ws:
         sys.exit(f"bench.py: {ws} RCCL ranks need {ws} GPUs, {ndev} visible")
     dev = torch.device("cuda", local % max(ndev, 1))
+    # (before anything touches the GPU: the probe runs as a child of this rank)
+    probed = probe_capture_form_in_rank(ws) if (ws > 1 or os.environ.get("RCB_RANK_PROBE_FORCE")) else None
     torch.cuda.set_device(dev)
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -728,6 +764,17 @@ def main():
         ws_seen = int(one.item())
         if ws_seen != a.gpus or torch.distributed.get_world_size() != a.gpus:
             sys.exit(f"bench.py: communicator has {ws_seen} ranks, --gpus {a.gpus}")
+        if probed is not None:                  # every rank probed (or none did): the captured form only if ALL of them passed
+            agree = torch.tensor([1.0 if probed else 0.0], device=dev)
+            torch.distributed.all_reduce(agree, op=torch.distributed.ReduceOp.MIN)
+            probed = bool(agree.item() > 0.5)
+    if probed is not None:
+        os.environ["RCB_CAPTURE_COLLECTIVES"] = "1" if probed else "0"
+        os.environ["RCB_STEP_FORM_CHOICE"] = (("collectives captured inside the step graph: " if probed else
+                                               "four segments around host-enqueued collectives: ")
+                                              + ("in-rank probe ok on %d ranks" % ws if probed else "in-rank probe failed or timed out"))
+        if rank == 0:
+            print("bench.py: sharded step form -- " + os.environ["RCB_STEP_FORM_CHOICE"], file=sys.stderr, flush=True)
 
     from recombiner_amd import config, ops, tuning, utils
     tuned = False if a.no_tuned_gemms else tuning.enable_tuned_gemms()

@@ -176,6 +176,35 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert out.returncode != 0 and "launcher started 1 rank" in out.stderr
 
 
+def test_in_rank_capture_probe_decisions(monkeypatch):
+    """bench.py under an external launcher (torchrun ... bench.py --gpus N): every rank probes the captured form of the sharded
+    step in a CHILD process before it touches the GPU.  Host logic only: nothing is probed when the caller or bench.py's own
+    launcher already chose, or on a gloo rehearsal; a probe that cannot run (here: no GPU for the child) selects the safe
+    four-segment form instead of raising."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules["bench_under_test"] = bench
+    spec.loader.exec_module(bench)
+    for k in ("RCB_CAPTURE_COLLECTIVES", "RCB_STEP_FORM_CHOICE", "RCB_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("RCB_CAPTURE_COLLECTIVES", "0")
+    assert bench.probe_capture_form_in_rank(2) is None
+    monkeypatch.delenv("RCB_CAPTURE_COLLECTIVES")
+    monkeypatch.setenv("RCB_STEP_FORM_CHOICE", "four segments (gloo rehearsal: no probe)")
+    assert bench.probe_capture_form_in_rank(2) is None
+    monkeypatch.delenv("RCB_STEP_FORM_CHOICE")
+    monkeypatch.setenv("RCB_DIST_BACKEND", "gloo")
+    assert bench.probe_capture_form_in_rank(2) is None
+    monkeypatch.delenv("RCB_DIST_BACKEND")
+    if not torch.cuda.is_available():                    # the child finds no GPU: exit code != 0 -> the safe form, no exception
+        monkeypatch.setenv("RCB_PROBE_TIMEOUT_S", "120")
+        monkeypatch.setenv("MASTER_PORT", "29931")
+        assert bench.probe_capture_form_in_rank(1) is False
+
+
 REF_DIR = "/root/reference"
 
 
