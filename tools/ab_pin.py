@@ -1,3 +1,5 @@
+"""Stage-2 forward / stage-2 data gradient / stage-3 forward, stand-alone launch times (non-pack weight path):
+    python tools/ab_pin.py        (RCB_LIB selects another build for a same-box A/B)"""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from recombiner_amd import ops
