@@ -14,7 +14,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "step_begin_kernel" in r["Kernel_Name"]]
 i0, i1 = starts[-back - 1], starts[-back]
 t0 = int(rows[i0]["Start_Timestamp"])
-print("step of %d kernels, %.1f us from first start to last end" % (i1 - i0, (max(int(r["End_Timestamp"]) for r in rows[i0:i1]) - t0) / 1e3))
+span = (max(int(r["End_Timestamp"]) for r in rows[i0:i1]) - t0) / 1e3
+periods = [(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3 for a, b in zip(starts[-12:-1], starts[-11:])]
+print("step of %d kernels, %.1f us from first start to last end; step period (start to start, last 11 steps) median %.1f us -> %.1f us between replays" % (
+    i1 - i0, span, sorted(periods)[len(periods) // 2], sorted(periods)[len(periods) // 2] - span))
 for r in rows[i0:i1]:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
